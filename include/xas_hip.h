@@ -1,0 +1,229 @@
+/*
+ * xas_hip.h - C ABI of libxas_hip.so: the MI355X (gfx950) kernels behind the
+ * X-as-Supervision training step.
+ *
+ * The reference (Charrrrrlie/X-as-Supervision) is pure Python/PyTorch and has no FFI of
+ * its own; the boundary a maintainer binds is "one call per fused op", replacing the
+ * chains of ATen/cuDNN kernels listed beside each entry (reference file:line).  The
+ * Python host side (x-as-supervision_amd/xas_amd) binds these with ctypes and wraps
+ * them in torch.autograd.Function; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless typed otherwise; buffers are
+ *     owned by the caller; the library allocates nothing and never synchronises;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it;
+ *   - activations are NHWC ("channels last"): x[n][h][w][c];
+ *   - return value 0 = enqueued; != 0 = rejected on the host before any launch
+ *     (bad shape / unsupported size), message via xas_last_error().
+ */
+#ifndef XAS_HIP_H
+#define XAS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* xas_last_error(void);
+int xas_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Soft-argmax ("integral") head.
+ * Replaces keypoint_detector_integral_multi.py:69-88 (softmax, six marginal sums, peak
+ * pick, topk, two avg_pool1d, two gathers) and keypoint_detector_integral.py:48-63.
+ *
+ * logits  [B][H][W][K*D] (NHWC storage of the reference's [B, K*D, H, W]); D==H==W.
+ * num_hypo >= 1 with neighbor > 0 : multi-hypothesis head; num_hypo == 1 and
+ * neighbor == 0 : single-hypothesis head (plain expectation along depth).
+ * kps      [B][num_hypo][K][3]   normalised to [-1,1)
+ * z_idx    [B][K][num_hypo] int64 (depth-peak bins, 1..D-2; ties: lower index first)
+ * depth_prob_map [K][D]          (depth marginal of sample 0)
+ * stats    [B][K][XAS_HEAD_STATS] saved for backward (lse, X, Y, Z_h, S_h ...)
+ * partial  workspace, xas_head_workspace_floats(B,K,D) floats
+ * ---------------------------------------------------------------------------------- */
+#define XAS_HEAD_STATS 16
+size_t xas_head_workspace_floats(int B, int K, int D);
+int xas_head_softargmax_fwd(const float* logits, int B, int K, int D, int num_hypo, int neighbor,
+                            float* kps, int64_t* z_idx, float* depth_prob_map, float* stats,
+                            float* partial, void* stream);
+/* grad_logits [B][H][W][K*D] = d loss / d logits given grad_kps [B][num_hypo][K][3].
+ * coef: workspace of B*K*(4+D) floats. */
+int xas_head_softargmax_bwd(const float* logits, const float* stats, const int64_t* z_idx,
+                            const float* grad_kps, int B, int K, int D, int num_hypo, int neighbor,
+                            float* grad_logits, float* coef, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Patch -> world geometry, all hypotheses in one launch.
+ * Replaces modules/util.py:128-152 -> :61-95 (clone/index_put chains + two batched
+ * torch.linalg.inv) called per camera per hypothesis at modules/model.py:72-84.
+ * kps [B][Hy][K][3]; trans_image [B][2][3]; k_mat [B][3][3]; pelvis [B][3];
+ * rot_world [B][3][3]; trans_world [B][3]; world [B][Hy][K][3].
+ * flags: bit0 is_norm, bit1 mono, bit2 patch (reference defaults: is_norm|patch).
+ * ---------------------------------------------------------------------------------- */
+#define XAS_GEO_NORM 1
+#define XAS_GEO_MONO 2
+#define XAS_GEO_PATCH 4
+int xas_patch_to_world_fwd(const float* kps, const float* trans_image, const float* k_mat,
+                           const float* pelvis, const float* rot_world, const float* trans_world,
+                           int B, int Hy, int K, float image_size, float rect_width, int flags,
+                           float* world, void* stream);
+int xas_patch_to_world_bwd(const float* kps, const float* grad_world, const float* trans_image,
+                           const float* k_mat, const float* pelvis, const float* rot_world,
+                           const float* trans_world, int B, int Hy, int K, float image_size,
+                           float rect_width, int flags, float* grad_kps, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Line-mask renderer fused with the max over lines.
+ * Replaces modules/util.py:21-59 (about 25 ATen kernels, 419 MB intermediates) plus
+ * torch.max(dim=1) at modules/model.py:94,96.
+ * kps: joints, (x,y) of joint j of sample b at kps[b*kp_stride_b + j*kp_stride_j + {0,1}].
+ * parents/children: L int32 each (device).  fine_mask: bit l set -> exponent x2
+ * (modules/util.py:50-53, applied by the host when L >= 21).
+ * mask [B][1][S][S].   partial: workspace B*nblk*K*2 floats, nblk = xas_lines_nblk(S).
+ * ---------------------------------------------------------------------------------- */
+int xas_lines_nblk(int S);
+int xas_draw_lines_max_fwd(const float* kps, long kp_stride_b, long kp_stride_j, int B, int K,
+                           const int* parents, const int* children, int L, unsigned fine_mask,
+                           float body_width, int S, float* mask, void* stream);
+int xas_draw_lines_max_bwd(const float* kps, long kp_stride_b, long kp_stride_j, int B, int K,
+                           const int* parents, const int* children, int L, unsigned fine_mask,
+                           float body_width, int S, const float* grad_mask, float* partial,
+                           float* grad_kps_xy /* [B][K][2] */, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Convolution family: fp32 MFMA implicit GEMM on NHWC activations.
+ * Replaces the cuDNN calls behind nn.Conv2d / nn.ConvTranspose2d / nn.Linear in
+ * integral_base_modules/resnet.py:16-47, deconv_head.py:24-35, physique_network.py:15-50,
+ * discriminator.py:8-21 and torchvision's Bottleneck.
+ *
+ * x  [N][Hi][Wi][Cin]      w  packed [Cout][R][S][Cin] (see xas_pack_weight)
+ * y  [N][Ho][Wo][Cout]     Ho = (Hi + 2*pad - R)/stride + 1
+ * bias (Cout) may be NULL.  Optional fused input transform for xas_conv_fwd:
+ *   in_scale/in_shift (Cin) != NULL : x' = act(x*in_scale[c] + in_shift[c]),
+ *   act: 0 none, 1 relu, 2 leaky-relu(0.01)   (batch-norm + activation of the
+ *   producing layer folded into this conv's operand load).
+ * Optional fused statistics: stat_sum/stat_sqsum ([gridM][Cout] partials) != NULL.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  int N, Hi, Wi, Cin;
+  int Cout, R, S;
+  int stride, pad;
+  int Ho, Wo;
+} xas_conv_shape;
+
+int xas_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
+                 const xas_conv_shape* s, void* stream);
+/* dx = conv_transpose(dy, w): also the FORWARD of nn.ConvTranspose2d (deconv_head.py:27-29)
+ * with roles swapped.  w_packed_t: [Cin][R][S][Cout] (xas_pack_weight transposed=1). */
+int xas_conv_dgrad(const float* dy, const float* w_packed_t, float* dx,
+                   const xas_conv_shape* s, void* stream);
+/* dw_packed [Cout][R][S][Cin] (+)= sum_n,ho,wo dy * x ; workspace for split-K partials. */
+size_t xas_conv_wgrad_workspace_floats(const xas_conv_shape* s);
+int xas_conv_wgrad(const float* x, const float* dy, float* dw_packed, float* workspace,
+                   const xas_conv_shape* s, void* stream);
+/* OIHW [Cout][Cin][R][S] <-> packed.  transposed=0: [Cout][R][S][Cin];
+ * transposed=1: [Cin][R][S][Cout].  unpack adds nothing: it overwrites dst. */
+int xas_pack_weight(const float* oihw, float* packed, int Cout, int Cin, int R, int S,
+                    int transposed, void* stream);
+int xas_unpack_weight(const float* packed, float* oihw, int Cout, int Cin, int R, int S,
+                      int transposed, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Batch normalisation (training mode), activation, residual; NHWC, M = N*H*W rows.
+ * Replaces ATen batch_norm_stats / batch_norm_elemt / batch_norm_backward_{reduce,elemt}
+ * behind nn.BatchNorm2d and nn.SyncBatchNorm (resnet.py:18,40, deconv_head.py:30,
+ * physique_network.py:18,25,33).
+ * stats step : per-channel (mean, M2) partials -> mean, biased var (Chan combine).
+ * The host may all-gather (mean, var, count) across ranks between the two steps for
+ * SyncBatchNorm (one coalesced message per layer).
+ * act: 0 none, 1 relu, 2 leaky-relu(0.01).
+ * ---------------------------------------------------------------------------------- */
+size_t xas_bn_workspace_floats(long M, int C);
+int xas_bn_stats(const float* x, long M, int C, float* mean, float* var_biased,
+                 float* workspace, void* stream);
+/* y = act(gamma*(x-mean)*rsqrt(var+eps)+beta [+ residual]) */
+int xas_bn_apply(const float* x, const float* mean, const float* var_biased, const float* gamma,
+                 const float* beta, const float* residual, float eps, int act, long M, int C,
+                 float* y, void* stream);
+/* running = (1-momentum)*running + momentum*stat; var uses the unbiased estimate n/(n-1). */
+int xas_bn_update_running(const float* mean, const float* var_biased, float* running_mean,
+                          float* running_var, float momentum, long count, int C, void* stream);
+/* backward, step 1: dz = dy * act'(y); sum_dz[c], sum_dz_xhat[c]  (and dresidual = dz) */
+int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy, const float* mean,
+                      const float* var_biased, float eps, int act, long M, int C,
+                      float* sum_dz, float* sum_dz_xhat, float* workspace, void* stream);
+/* step 2: dx = gamma*invstd*(dz - sum_dz/cnt - xhat*sum_dz_xhat/cnt); dres = dz if != NULL */
+int xas_bn_bwd_apply(const float* x, const float* y, const float* dy, const float* mean,
+                     const float* var_biased, const float* gamma, const float* sum_dz,
+                     const float* sum_dz_xhat, float eps, int act, long M, int C, double count,
+                     float* dx, float* dresidual, void* stream);
+
+/* 3x3 stride-2 pad-1 max pool (resnet.py:20), NHWC. idx: int8 argmax tap 0..8 for backward */
+int xas_maxpool3x3s2_fwd(const float* x, int N, int H, int W, int C, float* y, int8_t* idx, void* stream);
+int xas_maxpool3x3s2_bwd(const float* dy, const int8_t* idx, int N, int H, int W, int C, float* dx, void* stream);
+
+/* bilinear x2 upsample, align_corners=False (physique_network.py:31), NHWC */
+int xas_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, void* stream);
+int xas_upsample2x_bwd(const float* dy, int N, int H, int W, int C, float* dx, void* stream);
+
+/* elementwise: y = sigmoid(x) ; dx = dy*y*(1-y) */
+int xas_sigmoid_fwd(const float* x, long n, float* y, void* stream);
+int xas_sigmoid_bwd(const float* y, const float* dy, long n, float* dx, void* stream);
+/* NCHW -> NHWC and back (input images arrive NCHW: dataloader.py:166) */
+int xas_nchw_to_nhwc(const float* x, int N, int C, int H, int W, float* y, void* stream);
+int xas_nhwc_to_nchw(const float* x, int N, int C, int H, int W, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Mask losses (modules/base_losses/loss_func.py:4-16), fused clip * weight * MSE.
+ * mode bit0: use_clip (mask > 0.1), bit1: has weight.
+ *   weight given : out[0] = mean(e * clip * weight)
+ *   no weight    : out[0] = mean((m-gt)^2), out[1] = mean(clip)   (the reference returns the
+ *                  tensor mse*clip; its later .mean() equals out[0]*out[1])
+ * partial: workspace of xas_loss_nblk(n) * 2 floats.
+ * bwd: dm = grad_scalar * d(out)/dm for the weighted form; for the unweighted+clip form
+ *      dm = grad_scalar * out[1] * 2(m-gt)/n.
+ * ---------------------------------------------------------------------------------- */
+int xas_loss_nblk(long n);
+int xas_mask_loss_fwd(const float* m, const float* gt, const float* weight, long n, int mode,
+                      float* partial, float* out, void* stream);
+int xas_mask_loss_bwd(const float* m, const float* gt, const float* weight, long n, int mode,
+                      const float* out, const float* grad_scalar, float* dm, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * GCN discriminator building blocks (discriminator.py:180-238, gcn.py:79-110 with
+ * torch_geometric SAGEConv(mean) / graph LayerNorm semantics).  Node features [B*N][C].
+ * ---------------------------------------------------------------------------------- */
+/* y[b,i,:] = sum_j adj[i][j] * x[b,j,:]  (adj: N x N row-normalised, device) */
+int xas_graph_aggregate(const float* x, const float* adj, int B, int N, int C, float* y, void* stream);
+/* graph LayerNorm over the WHOLE tensor + per-channel affine + relu (+ residual):
+ * stats[0]=mean, stats[1]=std  ; workspace xas_gln_workspace_floats(n) */
+size_t xas_gln_workspace_floats(long n);
+int xas_gln_fwd(const float* x, const float* gamma, const float* beta, const float* residual,
+                long rows, int C, float eps, float* y, float* stats, float* workspace, void* stream);
+int xas_gln_bwd(const float* x, const float* y_pre_res, const float* dy, const float* gamma,
+                const float* stats, long rows, int C, float eps, float* dx, float* dgamma,
+                float* dbeta, float* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * SMPL linear blend skinning (modules/smplpytorch/pytorch/smpl_layer.py:63-156).
+ * ---------------------------------------------------------------------------------- */
+int xas_smpl_lbs_fwd(const float* pose /*[B][72]*/, const float* betas /*[B][10]*/,
+                     const float* v_template /*[V][3]*/, const float* shapedirs /*[V][3][10]*/,
+                     const float* posedirs /*[V][3][207]*/, const float* j_regressor /*[24][V]*/,
+                     const float* weights /*[V][24]*/, const int* parents /*[24]*/, int B, int V,
+                     int center_idx, float* verts /*[B][V][3]*/, float* joints /*[B][24][3]*/,
+                     float* workspace /* B*(24*3 + 24*16 + 207) floats */, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused multi-tensor Adam (train.py:257-264: betas (0.5, 0.999), eps 1e-8, no decay).
+ * One launch updates a flat parameter arena: p, g, m, v are arenas of n floats.
+ * ---------------------------------------------------------------------------------- */
+int xas_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                  float beta2, float eps, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'x-as-supervision_amd')
+for p in (ROOT, PKG, os.path.join(ROOT, 'tests', 'golden')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def golden(name):
+    import numpy as np
+    return np.load(os.path.join(ROOT, 'tests', 'golden', name + '.npz'), allow_pickle=False)
+
+
+@pytest.fixture(scope='session')
+def load_golden():
+    return golden

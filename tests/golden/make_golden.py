@@ -1,0 +1,354 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference's own
+Python modules from /root/reference (build container only; the reference never
+travels to the GPU box).  Run:  python tests/golden/make_golden.py
+
+What is imported untouched: modules.model, modules.util, modules.base_losses.loss_func,
+modules.physique_network, modules.smplpytorch.pytorch.{smpl_layer,rodrigues_layer,tensutils}.
+modules.keypoint_detector_integral{,_multi} and modules.integral_base_modules.* import
+`easydict` and `torchvision`, neither of which is installed: inert module objects are
+registered for those two names (an attribute dict; a Bottleneck block restated from
+torchvision 0.17.2's published definition) and the ImageNet download in
+network.init_pose_net is skipped.  The Bottleneck arithmetic is therefore NOT pinned by
+this import ("parity unpinned" list).  modules.gcn / modules.discriminator
+need torch_geometric (absent): only the pure-torch function my_batched_dense_to_sparse is
+extracted from the source file and executed on the file's own __main__ example.
+
+Outputs are data only (inputs come from tests/golden/inputs.py generators).
+"""
+import ast
+import os
+import sys
+import types
+
+os.environ.setdefault('PYTHONDONTWRITEBYTECODE', '1')
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import numpy as np
+import torch
+import torch.nn as nn
+import yaml
+
+import inputs as gi
+
+torch.set_num_threads(8)
+
+
+# ----------------------------------------------------------------- import shims
+class _AttrDict(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+class _TVBottleneck(nn.Module):
+    """torchvision 0.17.2 Bottleneck (v1.5) restated: 1x1 -> 3x3(stride) -> 1x1(x4)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + (x if self.downsample is None else self.downsample(x)))
+
+
+def _install_shims():
+    ed = types.ModuleType('easydict')
+    ed.EasyDict = _AttrDict
+    sys.modules['easydict'] = ed
+    tv = types.ModuleType('torchvision')
+    tvm = types.ModuleType('torchvision.models')
+    tvr = types.ModuleType('torchvision.models.resnet')
+    tvr.Bottleneck = _TVBottleneck
+    tvr.BasicBlock = type('BasicBlock', (nn.Module,), {'expansion': 1})
+    tv.models, tvm.resnet = tvm, tvr
+    sys.modules.update({'torchvision': tv, 'torchvision.models': tvm, 'torchvision.models.resnet': tvr})
+
+
+_install_shims()
+import modules.integral_base_modules.network as ref_network            # noqa: E402
+ref_network.init_pose_net = lambda net, cfg: net                         # no ImageNet download
+from modules.keypoint_detector_integral_multi import KPDetector3DMulti   # noqa: E402
+from modules.keypoint_detector_integral import KPDetector3D              # noqa: E402
+from modules import util as ref_util                                     # noqa: E402
+from modules import model as ref_model                                   # noqa: E402
+from modules.base_losses import loss_func as ref_loss                    # noqa: E402
+from modules.physique_network import PhysiqueMaskGenerator               # noqa: E402
+from modules.smplpytorch.pytorch.smpl_layer import SMPL_Layer            # noqa: E402
+
+from oracle import nets as onets                                         # noqa: E402  (weights/key check only)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def save(name, **arrays):
+    out = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()}
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('wrote', name, {k: v.shape for k, v in out.items()})
+
+
+def bare(cls, **attrs):
+    obj = cls.__new__(cls)
+    nn.Module.__init__(obj)
+    for k, v in attrs.items():
+        setattr(obj, k, v)
+    return obj
+
+
+def ref_head_multi(logits, K, num_hypo, nb):
+    """Replays KPDetector3DMulti.forward after `heatmap = self.net(x)` (multi.py:69-88)
+    by giving the reference class an identity network."""
+    det = bare(KPDetector3DMulti, num_kp=K, num_hypo=num_hypo, neighbor_size=nb, name='resnet_multi')
+    det.net = nn.Identity()
+    captured = {}
+    orig = det.find_peak
+    det.find_peak = lambda hm: captured.setdefault('idx', orig(hm))
+    kps, dmap = det(logits)
+    return kps, dmap, captured['idx']
+
+
+def ref_head_single(logits, K):
+    det = bare(KPDetector3D, num_kp=K, name='resnet')
+    det.net = nn.Identity()
+    return det(logits)
+
+
+# ----------------------------------------------------------------- 1. heads
+def g_head():
+    lg, planted = gi.planted_logits(2, 2, 16, seed=11)
+    lt = T(lg).requires_grad_(True)
+    kps, dmap, idx = ref_head_multi(lt, 2, 3, 15)
+    gw = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).standard_normal(kps.shape).astype(np.float32))
+    (kps * gw).sum().backward()
+    k1, d1 = ref_head_single(T(lg), 2)
+    save('head_small', logits=lg, planted=planted, kps=kps, depth_prob_map=dmap, z_idx=idx,
+         grad_out=gw, grad_logits=lt.grad, kps_single=k1, depth_prob_map_single=d1)
+    # full size (K=18, D=64): inputs regenerated from the seed, outputs only are stored
+    lg, planted = gi.planted_logits(1, 18, 64, seed=12)
+    kps, dmap, idx = ref_head_multi(T(lg), 18, 3, 15)
+    k1, d1 = ref_head_single(T(lg), 18)
+    save('head_full', planted=planted, kps=kps, depth_prob_map=dmap, z_idx=idx, kps_single=k1)
+
+
+# ----------------------------------------------------------------- 2. draw_lines + max
+def g_lines():
+    parents, children = ref_model.cal_links(gi.HM36_PARENTS, gi.LINE_SELECT, use_root=False, extension=True)
+    p17, c17 = ref_model.cal_links(gi.HM36_PARENTS, gi.LINE_SELECT, use_root=False, extension=False)
+    save('links', parents25=parents, children25=children, parents17=p17, children17=c17)
+    for S in (64, 256):
+        kp = T(gi.skeleton_2d(2, seed=21)).requires_grad_(True)
+        hm = ref_util.draw_lines(kp, S, parents, children, 3.0e-3)
+        mx = torch.max(hm.clone(), dim=1, keepdim=True)[0]
+        gw = T(np.random.Generator(np.random.PCG64(6)).random((2, 1, S, S)).astype(np.float32))
+        (mx * gw).sum().backward()
+        step = 1 if S == 64 else 4
+        save('lines_%d' % S, kps=kp, mask=mx[:, :, ::step, ::step], checksum=mx.double().sum(),
+             sq_checksum=(mx.double() ** 2).sum(), grad_kps=kp.grad, n_lines=hm.shape[1])
+    # < 21 lines branch (no fine-line doubling)
+    kp = T(gi.skeleton_2d(2, seed=22))
+    hm = ref_util.draw_lines(kp, 64, p17, c17, 3.0e-3)
+    save('lines_17', kps=kp, mask=torch.max(hm, dim=1, keepdim=True)[0])
+
+
+# ----------------------------------------------------------------- 3. patch -> world
+def g_geometry():
+    B = 4
+    ti, km, pv, rw, tw = gi.camera_params(B, seed=31)
+    x = {'cam_0_trans_image': T(ti), 'cam_0_img': torch.zeros(B, 3, 256, 256), 'cam_0_pelvis': T(pv),
+         'cam_0_k_mat': T(km), 'cam_0_trans_world': T(tw), 'cam_0_rot_world': T(rw)}
+    rng = np.random.Generator(np.random.PCG64(32))
+    kp = T(rng.uniform(-0.9, 0.9, (B, 18, 3)).astype(np.float32)).requires_grad_(True)
+    w = ref_util.convert_patch_to_world(kp, x, 'cam_0', is_norm=True)
+    gw = T(rng.standard_normal((B, 18, 3)).astype(np.float32))
+    (w * gw).sum().backward()
+    px = T(rng.uniform(20, 230, (B, 18, 3)).astype(np.float32))
+    w_px = ref_util.convert_patch_to_world(px, x, 'cam_0', is_norm=False)
+    w_mono = ref_util.convert_patch_to_world(kp.detach(), x, 'cam_0', is_norm=True, RECT_WIDTH=256, mono=True, patch=False)
+    save('geometry', kps=kp, world=w, grad_out=gw, grad_kps=kp.grad, kps_px=px, world_px=w_px, world_mono=w_mono)
+
+
+# ----------------------------------------------------------------- 4. losses
+def g_losses():
+    rng = np.random.Generator(np.random.PCG64(41))
+    f = lambda *s: T(rng.standard_normal(s).astype(np.float32))
+    m, gt = T(rng.random((2, 1, 32, 32)).astype(np.float32)), T((rng.random((2, 1, 32, 32)) > 0.5).astype(np.float32))
+    w = T((1 + 24 * rng.random((2, 1, 32, 32))).astype(np.float32))
+    kp3 = f(4, 18, 3) * 500
+    kp2 = f(4, 18, 2)
+    lg3, lg2, gt2 = f(4, 3, 1), f(4, 1), f(4, 1)
+    save('losses', m=m, gt=gt, w=w, kp3=kp3, kp2=kp2, lg3=lg3, lg2=lg2, gt2=gt2,
+         recon_plain=ref_loss.compute_mask_reconstruction_loss(m, gt),
+         recon_w=ref_loss.compute_mask_reconstruction_loss(m, gt, weight=w),
+         recon_clip=ref_loss.compute_mask_reconstruction_loss(m, gt, use_clip=True),
+         recon_w_clip=ref_loss.compute_mask_reconstruction_loss(m, gt, weight=w, use_clip=True),
+         bone_sym=ref_loss.compute_bone_sym_loss(kp3), kp_sym3=ref_loss.compute_kp_sym_loss(kp3),
+         kp_sym2=ref_loss.compute_kp_sym_loss(kp2, is_3D=False),
+         sup=ref_loss.compute_supervision(kp3, kp3.flip(0)),
+         disc_gen3=ref_loss.compute_disc_loss(lg3, None), disc_gen2=ref_loss.compute_disc_loss(lg2, None),
+         disc_d=ref_loss.compute_disc_loss(lg3, gt2))
+
+
+# ----------------------------------------------------------------- 5. physique net
+def g_physique():
+    ref = PhysiqueMaskGenerator([32, 64, 128])
+    mine = gi.seeded_fill_(onets.PhysiqueNet([32, 64, 128]), seed=51)
+    ref.load_state_dict(mine.state_dict(), strict=True)
+    ref.train()
+    x = T(gi.blob_mask(2, 64, seed=52)) * 0.9
+    x.requires_grad_(True)
+    y = ref(x)
+    gw = T(np.random.Generator(np.random.PCG64(53)).standard_normal(y.shape).astype(np.float32))
+    (y * gw).sum().backward()
+    sd = ref.state_dict()
+    save('physique', keys=np.array(list(sd.keys())), x=x, y=y, grad_out=gw, grad_x=x.grad,
+         grad_enc0_w=ref.encoder[0][0].weight.grad, grad_dec4_b=ref.decoder[4].bias.grad,
+         grad_dec1_w_norm=ref.decoder[1][1].weight.grad.norm(),
+         run_mean_enc0=sd['encoder.0.1.running_mean'], run_var_enc0=sd['encoder.0.1.running_var'],
+         nbt=sd['encoder.0.1.num_batches_tracked'])
+
+
+# ----------------------------------------------------------------- 6. detector end to end
+def _ref_detector(multi=True):
+    torch.manual_seed(0)
+    if multi:
+        ref = KPDetector3DMulti('resnet_multi', 18, 64, 3, 15)
+    else:
+        ref = KPDetector3D('resnet', 18, 64)
+    mine = gi.seeded_fill_(onets.Detector(18, 64), seed=61)
+    sd = mine.state_dict()
+    sd['net.head.features.9.bias'] = T(gi.planted_depth_bias(18, 64, seed=62))
+    ref.load_state_dict(sd, strict=True)       # also proves key names / shapes are equal
+    return ref
+
+
+def g_detector():
+    ref = _ref_detector(True)
+    ref.train()
+    x = T(gi.synthetic_batch(2, [0], seed=63)['cam_0_img'])
+    heat = ref.net(x)
+    keys = list(ref.state_dict().keys())
+    shapes = [list(v.shape) for v in ref.state_dict().values()]
+    ref2 = _ref_detector(True)
+    ref2.train()
+    kps, dmap = ref2(x)
+    gw = T(np.random.Generator(np.random.PCG64(64)).standard_normal(kps.shape).astype(np.float32))
+    (kps * gw).sum().backward()
+    p = dict(ref2.named_parameters())
+    sd = ref2.state_dict()
+    save('detector', keys=np.array(keys), shapes=np.array([str(s) for s in shapes]),
+         heat_sub=heat[:, ::37, ::4, ::4], heat_sum=heat.double().sum(), heat_abs=heat.double().abs().sum(),
+         kps=kps, depth_prob_map=dmap, grad_out=gw,
+         g_conv1=p['net.backbone.conv1.weight'].grad, g_l1c2=p['net.backbone.layer1.0.conv2.weight'].grad[:8],
+         g_l4c3_norm=p['net.backbone.layer4.2.conv3.weight'].grad.norm(),
+         g_l2ds=p['net.backbone.layer2.0.downsample.0.weight'].grad[:4, :16],
+         g_dc0=p['net.head.features.0.weight'].grad[:4, :4], g_dc6_norm=p['net.head.features.6.weight'].grad.norm(),
+         g_fin_b=p['net.head.features.9.bias'].grad, g_bn1_w=p['net.backbone.bn1.weight'].grad,
+         rm_bn1=sd['net.backbone.bn1.running_mean'], rv_l3=sd['net.backbone.layer3.5.bn3.running_var'])
+    ref1 = _ref_detector(False)
+    ref1.train()
+    k1, _ = ref1(x)
+    save('detector_single', kps=k1)
+
+
+# ----------------------------------------------------------------- 7. SMPL
+def g_smpl():
+    buf = gi.smpl_buffers(seed=71)
+    lay = bare(SMPL_Layer, center_idx=0, gender='neutral', num_joints=24,
+               kintree_parents=[4294967295] + [0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21])
+    lay.register_buffer('th_betas', torch.zeros(1, 10))
+    lay.register_buffer('th_shapedirs', T(buf['shapedirs']))
+    lay.register_buffer('th_posedirs', T(buf['posedirs']))
+    lay.register_buffer('th_v_template', T(buf['v_template']))
+    lay.register_buffer('th_J_regressor', T(buf['J_regressor']))
+    lay.register_buffer('th_weights', T(buf['weights']))
+    rng = np.random.Generator(np.random.PCG64(72))
+    pose = T((0.4 * rng.standard_normal((3, 72))).astype(np.float32))
+    betas = T(rng.standard_normal((3, 10)).astype(np.float32))
+    verts, jtr = lay(pose, betas)
+    h36m = ref_util.smpl_to_h36m(verts, T(buf['h36m_regressor']))
+    save('smpl', pose=pose, betas=betas, verts_sub=verts[:, ::10], verts_sum=verts.double().sum(), joints=jtr, h36m=h36m)
+
+
+# ----------------------------------------------------------------- 8. model wiring
+class LinearDisc(nn.Module):
+    """Stand-in discriminator (the real one needs torch_geometric): [B,18,3] -> [B,1]."""
+    name = 'LinearStandIn'
+
+    def __init__(self):
+        super().__init__()
+        self.fc = nn.Linear(54, 1)
+
+    def forward(self, kp):
+        return self.fc(kp.reshape(kp.shape[0], -1))
+
+
+def g_model():
+    for tag in ('HM36_Multi_SurS1', 'HM36_Multi_SurS2'):
+        cfg = yaml.load(open(os.path.join(REF, 'config', tag + '.yaml')), Loader=yaml.FullLoader)
+        mp = cfg['model_params']
+        mp['cam_id_list'] = [0, 1]            # two cameras keep the CPU run short
+        reg = _ref_detector(True)
+        phys = PhysiqueMaskGenerator(mp['physique_mask_generator_params']['layers'])
+        phys.load_state_dict(gi.seeded_fill_(onets.PhysiqueNet([32, 64, 128]), seed=81).state_dict())
+        disc = gi.seeded_fill_(LinearDisc(), seed=82)
+        gen = ref_model.Counter3DModel(mp, reg, None, None, phys)
+        dis = ref_model.Counter3DDisc(mp, disc, None, None)
+        gen.train(), dis.train()
+        x = {k: T(v) for k, v in gi.synthetic_batch(2, [0, 1], seed=83).items()}
+        loss_d, _ = dis(x, gen.regressor)
+        loss_d.mean().backward()
+        gd = disc.fc.weight.grad.clone()
+        disc.zero_grad()
+        losses, out = gen(x, dis.smpl_discriminator)
+        tot = sum(v.mean() for v in losses.values())
+        tot.backward()
+        p = dict(reg.named_parameters())
+        arrays = {'loss_disc': loss_d, 'grad_disc_w': gd, 'total': tot,
+                  'g_conv1': p['net.backbone.conv1.weight'].grad, 'g_fin_b': p['net.head.features.9.bias'].grad,
+                  'g_phys_dec4_w': phys.decoder[4].weight.grad, 'g_disc_after_gen': disc.fc.weight.grad,
+                  'pose_3d_cam_0': out['pose_3d_depth_cam_0'], 'kp_gt_world': out['kp_gt_world'],
+                  'mask_line_sub': out['mask_heatmap_line_cam_1'][:, :, ::4, ::4]}
+        for k, v in losses.items():
+            arrays['loss_' + k] = v.mean()
+            arrays['shape_' + k] = np.array(list(v.shape), np.int64)
+        save('model_' + tag, **arrays)
+
+
+# ----------------------------------------------------------------- 9. dense -> sparse known answer
+def g_sparse():
+    src = open(os.path.join(REF, 'modules', 'gcn.py')).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == 'my_batched_dense_to_sparse'][0]
+    ns = {'torch': torch, 'Tensor': torch.Tensor, 'Tuple': tuple}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), 'gcn.py', 'exec'), ns)
+    adj = torch.tensor([[[3, 1], [2, 0]], [[0, 1], [0, 2]]])          # gcn.py:113
+    ei, ea = ns['my_batched_dense_to_sparse'](adj)
+    a18 = torch.eye(18).repeat(3, 1, 1)
+    p17, c17 = ref_model.cal_links(gi.HM36_PARENTS, gi.LINE_SELECT, use_root=False, extension=False)
+    a18[:, p17, c17] = 1.0
+    a18[:, c17, p17] = 1.0
+    ei18, ea18 = ns['my_batched_dense_to_sparse'](a18)
+    save('sparse', adj=adj, edge_index=ei, edge_attr=ea, edge_index18=ei18, edge_attr18=ea18)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['head', 'lines', 'geometry', 'losses', 'physique', 'detector', 'smpl', 'model', 'sparse']
+    for w in which:
+        globals()['g_' + w]()
