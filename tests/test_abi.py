@@ -1,0 +1,73 @@
+"""The C-ABI library loads and exports every symbol declared in include/xas_hip.h, and the ctypes
+signature table matches the header.  No compute calls (CPU-only test)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_prototypes():
+    src = open(os.path.join(ROOT, 'include', 'xas_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    src = re.sub(r'//[^\n]*', '', src)
+    protos = {}
+    for m in re.finditer(r'\b(int|size_t|const char\*)\s+(xas_\w+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S):
+        ret, name, args = m.groups()
+        codes = ''
+        args = args.strip()
+        if args and args != 'void':
+            for a in args.split(','):
+                a = a.strip()
+                if 'xas_conv_shape' in a:
+                    codes += 's'
+                elif '*' in a:
+                    codes += 'p'
+                elif re.match(r'(const\s+)?unsigned\b', a):
+                    codes += 'u'
+                elif re.match(r'(const\s+)?long\b', a):
+                    codes += 'l'
+                elif re.match(r'(const\s+)?int\b', a):
+                    codes += 'i'
+                elif re.match(r'(const\s+)?float\b', a):
+                    codes += 'f'
+                elif re.match(r'(const\s+)?double\b', a):
+                    codes += 'd'
+                elif re.match(r'(const\s+)?size_t\b', a):
+                    codes += 'z'
+                else:
+                    raise AssertionError('unparsed argument %r in %s' % (a, name))
+        protos[name] = (codes, {'int': 'i', 'size_t': 'z', 'const char*': 'c'}[ret])
+    return protos
+
+
+def test_library_is_built():
+    import __graft_entry__ as ge
+    if not os.path.exists(ge.LIB):
+        ge.build_lib(verbose=False)
+    assert os.path.exists(ge.LIB)
+
+
+def test_exports_and_signatures():
+    import ctypes
+    from xas_amd import _lib
+    lib = _lib.load()
+    protos = header_prototypes()
+    assert len(protos) > 30
+    for name, (codes, ret) in protos.items():
+        assert hasattr(lib, name), 'library does not export %s' % name
+        if name == 'xas_last_error':
+            continue
+        assert name in _lib.SIGNATURES, 'no ctypes signature for %s' % name
+        assert _lib.SIGNATURES[name] == (codes, ret), '%s: table %r vs header %r' % (name, _lib.SIGNATURES[name], (codes, ret))
+    assert set(_lib.SIGNATURES) <= set(protos)
+    assert ctypes.sizeof(_lib.ConvShape) == 11 * 4
+    assert lib.xas_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+    import torch
+    from xas_amd import ops_head
+    with pytest.raises(RuntimeError):
+        ops_head.softargmax_multi(torch.zeros(1, 32, 16, 16), 2, 3, 15)

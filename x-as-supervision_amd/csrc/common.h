@@ -1,0 +1,59 @@
+// Shared host/device helpers for libxas_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "xas_hip.h"
+
+namespace xas {
+
+void set_error(const char* fmt, ...);
+
+#define XAS_REQUIRE(cond, ...)        \
+  do {                                \
+    if (!(cond)) {                    \
+      ::xas::set_error(__VA_ARGS__);  \
+      return 1;                       \
+    }                                 \
+  } while (0)
+
+#define XAS_LAUNCH_CHECK()                                               \
+  do {                                                                   \
+    hipError_t e_ = hipGetLastError();                                   \
+    if (e_ != hipSuccess) {                                              \
+      ::xas::set_error("%s:%d launch failed: %s", __FILE__, __LINE__,    \
+                       hipGetErrorString(e_));                           \
+      return 2;                                                          \
+    }                                                                    \
+  } while (0)
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum over blockDim.x threads (multiple of 64, <= 1024); result valid in all threads
+__device__ __forceinline__ float block_sum(float v, float* smem /* >= 17 floats */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) smem[wid] = v;
+  __syncthreads();
+  float r = (lane < nw) ? smem[lane] : 0.f;
+  r = wave_sum(r);
+  return r;
+}
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+
+}  // namespace xas

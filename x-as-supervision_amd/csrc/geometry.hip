@@ -1,0 +1,305 @@
+// Patch->world geometry and the fused line-mask renderer (max over lines).  gfx950.
+//
+// patch_to_world : modules/util.py:128-152 -> :61-95, all hypotheses in one launch, with
+//                  closed-form 2x2 / 3x3 inverses instead of two batched LU solves.
+// draw_lines_max : modules/util.py:21-59 + torch.max(dim=1) at modules/model.py:94,96.
+//                  max_l exp(e_l) == exp(max_l e_l): one exp per pixel, nothing but the
+//                  [B,1,S,S] mask ever reaches HBM (the reference keeps ten 419 MB
+//                  intermediates for autograd).  Backward recomputes the winner line.
+#include "common.h"
+
+namespace xas {
+
+struct CamParams {
+  float i00, i01, i10, i11, t0, t1;   // inverse crop affine, translation
+  float fx, fy, cx, cy, pz;           // intrinsics, pelvis depth
+  float r[9];                         // R^-1 row-major
+  float tw[3];
+};
+
+__device__ __forceinline__ CamParams load_cam(const float* ti, const float* km, const float* pv, const float* rw,
+                                              const float* tw, int b) {
+  CamParams c;
+  const float* A = ti + b * 6;
+  const float a00 = A[0], a01 = A[1], a10 = A[3], a11 = A[4];
+  const float det = a00 * a11 - a01 * a10;
+  c.i00 = a11 / det; c.i01 = -a01 / det; c.i10 = -a10 / det; c.i11 = a00 / det;
+  c.t0 = A[2]; c.t1 = A[5];
+  const float* Kc = km + b * 9;
+  c.fx = Kc[0]; c.fy = Kc[4]; c.cx = Kc[2]; c.cy = Kc[5];
+  c.pz = pv[b * 3 + 2];
+  const float* R = rw + b * 9;
+  const float m00 = R[4] * R[8] - R[5] * R[7], m01 = R[2] * R[7] - R[1] * R[8], m02 = R[1] * R[5] - R[2] * R[4];
+  const float m10 = R[5] * R[6] - R[3] * R[8], m11 = R[0] * R[8] - R[2] * R[6], m12 = R[2] * R[3] - R[0] * R[5];
+  const float m20 = R[3] * R[7] - R[4] * R[6], m21 = R[1] * R[6] - R[0] * R[7], m22 = R[0] * R[4] - R[1] * R[3];
+  const float d3 = R[0] * m00 + R[1] * m10 + R[2] * m20;
+  c.r[0] = m00 / d3; c.r[1] = m01 / d3; c.r[2] = m02 / d3;
+  c.r[3] = m10 / d3; c.r[4] = m11 / d3; c.r[5] = m12 / d3;
+  c.r[6] = m20 / d3; c.r[7] = m21 / d3; c.r[8] = m22 / d3;
+  c.tw[0] = tw[b * 3]; c.tw[1] = tw[b * 3 + 1]; c.tw[2] = tw[b * 3 + 2];
+  return c;
+}
+
+__global__ void patch_to_world_fwd_kernel(const float* __restrict__ kps, const float* ti, const float* km,
+                                          const float* pv, const float* rw, const float* tw, int B, int HK,
+                                          float S, float rect, int flags, float* __restrict__ world) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * HK) return;
+  const int b = i / HK;
+  const CamParams c = load_cam(ti, km, pv, rw, tw, b);
+  float p0 = kps[i * 3], p1 = kps[i * 3 + 1], p2 = kps[i * 3 + 2];
+  if (flags & XAS_GEO_PATCH) {
+    if (flags & XAS_GEO_NORM) {
+      p0 = (p0 + 1.f) / 2.f * (S - 1.f);
+      p1 = (p1 + 1.f) / 2.f * (S - 1.f);
+      p2 = p2 * (S - 1.f);
+    }
+    const float du = p0 - c.t0, dv = p1 - c.t1;
+    p0 = c.i00 * du + c.i01 * dv;
+    p1 = c.i10 * du + c.i11 * dv;
+    p2 = p2 * (1.0f / S * rect) + c.pz;
+  }
+  float o0, o1, o2;
+  if (flags & XAS_GEO_MONO) {
+    o0 = -p0; o1 = -(p2 + 128.f); o2 = -p1;
+  } else {
+    const float q0 = (p0 - c.cx) / c.fx * p2 - c.tw[0];
+    const float q1 = (p1 - c.cy) / c.fy * p2 - c.tw[1];
+    const float q2 = p2 - c.tw[2];
+    o0 = c.r[0] * q0 + c.r[1] * q1 + c.r[2] * q2;
+    o1 = c.r[3] * q0 + c.r[4] * q1 + c.r[5] * q2;
+    o2 = c.r[6] * q0 + c.r[7] * q1 + c.r[8] * q2;
+  }
+  world[i * 3] = o0; world[i * 3 + 1] = o1; world[i * 3 + 2] = o2;
+}
+
+__global__ void patch_to_world_bwd_kernel(const float* __restrict__ kps, const float* __restrict__ gw, const float* ti,
+                                          const float* km, const float* pv, const float* rw, const float* tw, int B,
+                                          int HK, float S, float rect, int flags, float* __restrict__ gk) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * HK) return;
+  const int b = i / HK;
+  const CamParams c = load_cam(ti, km, pv, rw, tw, b);
+  float p0 = kps[i * 3], p1 = kps[i * 3 + 1], p2 = kps[i * 3 + 2];
+  if (flags & XAS_GEO_PATCH) {
+    if (flags & XAS_GEO_NORM) {
+      p0 = (p0 + 1.f) / 2.f * (S - 1.f);
+      p1 = (p1 + 1.f) / 2.f * (S - 1.f);
+      p2 = p2 * (S - 1.f);
+    }
+    const float du = p0 - c.t0, dv = p1 - c.t1;
+    p0 = c.i00 * du + c.i01 * dv;
+    p1 = c.i10 * du + c.i11 * dv;
+    p2 = p2 * (1.0f / S * rect) + c.pz;
+  }
+  const float g0 = gw[i * 3], g1 = gw[i * 3 + 1], g2 = gw[i * 3 + 2];
+  float d0, d1, d2;      // gradient w.r.t. (p0,p1,p2) after the patch stage
+  if (flags & XAS_GEO_MONO) {
+    d0 = -g0; d2 = -g1; d1 = -g2;
+  } else {
+    const float q0 = c.r[0] * g0 + c.r[3] * g1 + c.r[6] * g2;
+    const float q1 = c.r[1] * g0 + c.r[4] * g1 + c.r[7] * g2;
+    const float q2 = c.r[2] * g0 + c.r[5] * g1 + c.r[8] * g2;
+    d0 = q0 * p2 / c.fx;
+    d1 = q1 * p2 / c.fy;
+    d2 = q0 * (p0 - c.cx) / c.fx + q1 * (p1 - c.cy) / c.fy + q2;
+  }
+  if (flags & XAS_GEO_PATCH) {
+    const float e0 = c.i00 * d0 + c.i10 * d1;
+    const float e1 = c.i01 * d0 + c.i11 * d1;
+    d0 = e0; d1 = e1;
+    d2 = d2 * (1.0f / S * rect);
+    if (flags & XAS_GEO_NORM) {
+      d0 *= (S - 1.f) / 2.f; d1 *= (S - 1.f) / 2.f; d2 *= (S - 1.f);
+    }
+  }
+  gk[i * 3] = d0; gk[i * 3 + 1] = d1; gk[i * 3 + 2] = d2;
+}
+
+// ------------------------------------------------------------------ line renderer
+constexpr int kMaxLines = 32;
+constexpr int kLineThreads = 256;
+constexpr int kPixPerThread = 4;
+
+struct LineSeg { float ax, ay, bx, by, vx, vy, den, scale; };
+
+__device__ __forceinline__ void load_lines(LineSeg* segs, const float* kps, long sb, long sj, int b,
+                                           const int* parents, const int* children, int L, unsigned fine,
+                                           float body_width) {
+  if (threadIdx.x < L) {
+    const int l = threadIdx.x;
+    const float* a = kps + b * sb + children[l] * sj;   // start = child, end = parent (util.py:35-36)
+    const float* e = kps + b * sb + parents[l] * sj;
+    LineSeg s;
+    s.ax = a[0]; s.ay = a[1]; s.bx = e[0]; s.by = e[1];
+    s.vx = s.bx - s.ax; s.vy = s.by - s.ay;
+    s.den = 1e-8f + (s.vx * s.vx + s.vy * s.vy);
+    s.scale = ((fine >> l) & 1u) ? 2.f : 1.f;
+    segs[l] = s;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float seg_exponent(const LineSeg& s, float gx, float gy, float body_width, float* t_out) {
+  const float dax = gx - s.ax, day = gy - s.ay;
+  const float t = (dax * s.vx + day * s.vy) / s.den;
+  float d2;
+  if (t <= 0.f) {
+    d2 = dax * dax + day * day;
+  } else if (t >= 1.f) {
+    const float dbx = gx - s.bx, dby = gy - s.by;
+    d2 = dbx * dbx + dby * dby;
+  } else {
+    const float rx = gx - (s.ax + t * s.vx), ry = gy - (s.ay + t * s.vy);
+    d2 = rx * rx + ry * ry;
+  }
+  *t_out = t;
+  return (-d2 / body_width) * s.scale;
+}
+
+__global__ void draw_lines_max_fwd_kernel(const float* __restrict__ kps, long sb, long sj, const int* parents,
+                                          const int* children, int L, unsigned fine, float body_width, int S,
+                                          float* __restrict__ mask) {
+  __shared__ LineSeg segs[kMaxLines];
+  const int b = blockIdx.y;
+  load_lines(segs, kps, sb, sj, b, parents, children, L, fine, body_width);
+  const int pix0 = (blockIdx.x * kLineThreads + threadIdx.x) * kPixPerThread;
+  if (pix0 >= S * S) return;
+  const float fs = (float)(S - 1);
+  float out[kPixPerThread];
+#pragma unroll
+  for (int q = 0; q < kPixPerThread; ++q) {
+    const int pix = pix0 + q;
+    const float gx = 2.f * ((float)(pix % S) / fs) - 1.f, gy = 2.f * ((float)(pix / S) / fs) - 1.f;
+    float best = -INFINITY, t;
+    for (int l = 0; l < L; ++l) best = fmaxf(best, seg_exponent(segs[l], gx, gy, body_width, &t));
+    out[q] = __expf(best);
+  }
+  float* o = mask + (size_t)b * S * S + pix0;
+  if (pix0 + kPixPerThread <= S * S && ((S * S) % kPixPerThread) == 0) {
+    *reinterpret_cast<float4*>(o) = make_float4(out[0], out[1], out[2], out[3]);
+  } else {
+    for (int q = 0; q < kPixPerThread && pix0 + q < S * S; ++q) o[q] = out[q];
+  }
+}
+
+__global__ void draw_lines_max_bwd_kernel(const float* __restrict__ kps, long sb, long sj, const int* parents,
+                                          const int* children, int L, unsigned fine, float body_width, int S, int K,
+                                          const float* __restrict__ gmask, float* __restrict__ partial) {
+  __shared__ LineSeg segs[kMaxLines];
+  __shared__ float acc[64 * 2];
+  const int b = blockIdx.y;
+  load_lines(segs, kps, sb, sj, b, parents, children, L, fine, body_width);
+  for (int i = threadIdx.x; i < K * 2; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  const int pix0 = (blockIdx.x * kLineThreads + threadIdx.x) * kPixPerThread;
+  const float fs = (float)(S - 1);
+  for (int q = 0; q < kPixPerThread; ++q) {
+    const int pix = pix0 + q;
+    if (pix >= S * S) break;
+    const float go = gmask[(size_t)b * S * S + pix];
+    const float gx = 2.f * ((float)(pix % S) / fs) - 1.f, gy = 2.f * ((float)(pix / S) / fs) - 1.f;
+    float best = -INFINITY, bt = 0.f, t;
+    int bl = 0;
+    for (int l = 0; l < L; ++l) {
+      const float e = seg_exponent(segs[l], gx, gy, body_width, &t);
+      if (e > best) { best = e; bl = l; bt = t; }        // first maximum wins, as torch.max
+    }
+    const float ge = go * __expf(best);
+    if (ge == 0.f) continue;
+    const LineSeg s = segs[bl];
+    const float gd2 = -ge * s.scale / body_width;
+    float gax = 0.f, gay = 0.f, gbx = 0.f, gby = 0.f;
+    if (bt <= 0.f) {
+      gax = -2.f * (gx - s.ax) * gd2; gay = -2.f * (gy - s.ay) * gd2;
+    } else if (bt >= 1.f) {
+      gbx = -2.f * (gx - s.bx) * gd2; gby = -2.f * (gy - s.by) * gd2;
+    } else {
+      const float rx = gx - (s.ax + bt * s.vx), ry = gy - (s.ay + bt * s.vy);
+      const float grx = 2.f * rx * gd2, gry = 2.f * ry * gd2;
+      const float gt = -(grx * s.vx + gry * s.vy);
+      const float gnum = gt / s.den, gden = -gt * bt / s.den;
+      float gvx = -bt * grx + (gx - s.ax) * gnum + 2.f * s.vx * gden;
+      float gvy = -bt * gry + (gy - s.ay) * gnum + 2.f * s.vy * gden;
+      gax = -grx - s.vx * gnum - gvx; gay = -gry - s.vy * gnum - gvy;
+      gbx = gvx; gby = gvy;
+    }
+    const int ja = children[bl], jb = parents[bl];
+    atomicAdd(&acc[ja * 2], gax); atomicAdd(&acc[ja * 2 + 1], gay);
+    atomicAdd(&acc[jb * 2], gbx); atomicAdd(&acc[jb * 2 + 1], gby);
+  }
+  __syncthreads();
+  float* o = partial + ((size_t)b * gridDim.x + blockIdx.x) * K * 2;
+  for (int i = threadIdx.x; i < K * 2; i += blockDim.x) o[i] = acc[i];
+}
+
+__global__ void lines_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int K2, float* __restrict__ out) {
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < K2; i += blockDim.x) {
+    float s = 0.f;
+    for (int j = 0; j < nblk; ++j) s += partial[((size_t)b * nblk + j) * K2 + i];
+    out[(size_t)b * K2 + i] = s;
+  }
+}
+
+}  // namespace xas
+
+using namespace xas;
+
+extern "C" int xas_patch_to_world_fwd(const float* kps, const float* trans_image, const float* k_mat,
+                                      const float* pelvis, const float* rot_world, const float* trans_world, int B,
+                                      int Hy, int K, float image_size, float rect_width, int flags, float* world,
+                                      void* stream) {
+  XAS_REQUIRE(kps && world && trans_image && k_mat && pelvis && rot_world && trans_world, "patch_to_world: null buffer");
+  XAS_REQUIRE(B > 0 && Hy > 0 && K > 0, "patch_to_world: bad shape B=%d Hy=%d K=%d", B, Hy, K);
+  const int n = B * Hy * K;
+  hipLaunchKernelGGL(patch_to_world_fwd_kernel, dim3(cdiv(n, 128)), dim3(128), 0, as_stream(stream), kps, trans_image,
+                     k_mat, pelvis, rot_world, trans_world, B, Hy * K, image_size, rect_width, flags, world);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int xas_patch_to_world_bwd(const float* kps, const float* grad_world, const float* trans_image,
+                                      const float* k_mat, const float* pelvis, const float* rot_world,
+                                      const float* trans_world, int B, int Hy, int K, float image_size,
+                                      float rect_width, int flags, float* grad_kps, void* stream) {
+  XAS_REQUIRE(kps && grad_world && grad_kps && trans_image && k_mat && pelvis && rot_world && trans_world,
+              "patch_to_world bwd: null buffer");
+  XAS_REQUIRE(B > 0 && Hy > 0 && K > 0, "patch_to_world bwd: bad shape");
+  const int n = B * Hy * K;
+  hipLaunchKernelGGL(patch_to_world_bwd_kernel, dim3(cdiv(n, 128)), dim3(128), 0, as_stream(stream), kps, grad_world,
+                     trans_image, k_mat, pelvis, rot_world, trans_world, B, Hy * K, image_size, rect_width, flags,
+                     grad_kps);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int xas_lines_nblk(int S) { return (int)cdiv((long)S * S, kLineThreads * kPixPerThread); }
+
+extern "C" int xas_draw_lines_max_fwd(const float* kps, long kp_stride_b, long kp_stride_j, int B, int K,
+                                      const int* parents, const int* children, int L, unsigned fine_mask,
+                                      float body_width, int S, float* mask, void* stream) {
+  XAS_REQUIRE(kps && parents && children && mask, "draw_lines: null buffer");
+  XAS_REQUIRE(L >= 1 && L <= kMaxLines && K >= 1 && K <= 64 && S >= 2 && B >= 1, "draw_lines: bad shape L=%d K=%d S=%d", L, K, S);
+  XAS_REQUIRE(body_width > 0.f, "draw_lines: body_width must be > 0");
+  hipLaunchKernelGGL(draw_lines_max_fwd_kernel, dim3(xas_lines_nblk(S), B), dim3(kLineThreads), 0, as_stream(stream),
+                     kps, kp_stride_b, kp_stride_j, parents, children, L, fine_mask, body_width, S, mask);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int xas_draw_lines_max_bwd(const float* kps, long kp_stride_b, long kp_stride_j, int B, int K,
+                                      const int* parents, const int* children, int L, unsigned fine_mask,
+                                      float body_width, int S, const float* grad_mask, float* partial,
+                                      float* grad_kps_xy, void* stream) {
+  XAS_REQUIRE(kps && parents && children && grad_mask && partial && grad_kps_xy, "draw_lines bwd: null buffer");
+  XAS_REQUIRE(L >= 1 && L <= kMaxLines && K >= 1 && K <= 64 && S >= 2 && B >= 1, "draw_lines bwd: bad shape");
+  const int nblk = xas_lines_nblk(S);
+  hipLaunchKernelGGL(draw_lines_max_bwd_kernel, dim3(nblk, B), dim3(kLineThreads), 0, as_stream(stream), kps,
+                     kp_stride_b, kp_stride_j, parents, children, L, fine_mask, body_width, S, K, grad_mask, partial);
+  XAS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(lines_bwd_reduce_kernel, dim3(B), dim3(64), 0, as_stream(stream), partial, nblk, K * 2,
+                     grad_kps_xy);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}

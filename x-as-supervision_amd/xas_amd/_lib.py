@@ -1,0 +1,115 @@
+"""ctypes binding of libxas_hip.so (include/xas_hip.h)."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libxas_hip.so')
+_lib = None
+
+_T = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float, 'u': ctypes.c_uint,
+      'd': ctypes.c_double, 'z': ctypes.c_size_t}
+
+
+class ConvShape(ctypes.Structure):
+    """xas_conv_shape"""
+    _fields_ = [(n, ctypes.c_int) for n in ('N', 'Hi', 'Wi', 'Cin', 'Cout', 'R', 'S', 'stride', 'pad', 'Ho', 'Wo')]
+
+
+# name -> (argument codes, return code).  's' = pointer to ConvShape.  Last 'p' is the stream
+# for every launch function.
+SIGNATURES = {
+    'xas_abi_version': ('', 'i'),
+    'xas_head_workspace_floats': ('iii', 'z'),
+    'xas_head_softargmax_fwd': ('piiiiipppppp', 'i'),
+    'xas_head_softargmax_bwd': ('ppppiiiiippp', 'i'),
+    'xas_patch_to_world_fwd': ('ppppppiiiffipp', 'i'),
+    'xas_patch_to_world_bwd': ('pppppppiiiffipp', 'i'),
+    'xas_lines_nblk': ('i', 'i'),
+    'xas_draw_lines_max_fwd': ('plliippiufipp', 'i'),
+    'xas_draw_lines_max_bwd': ('plliippiufipppp', 'i'),
+    'xas_conv_fwd': ('ppppsp', 'i'),
+    'xas_conv_dgrad': ('pppsp', 'i'),
+    'xas_conv_wgrad_workspace_floats': ('s', 'z'),
+    'xas_conv_wgrad': ('ppppsp', 'i'),
+    'xas_pack_weight': ('ppiiiiip', 'i'),
+    'xas_unpack_weight': ('ppiiiiip', 'i'),
+    'xas_bn_workspace_floats': ('li', 'z'),
+    'xas_bn_stats': ('plipppp', 'i'),
+    'xas_bn_apply': ('ppppppfilipp', 'i'),
+    'xas_bn_update_running': ('ppppflip', 'i'),
+    'xas_bn_bwd_reduce': ('pppppfilipppp', 'i'),
+    'xas_bn_bwd_apply': ('ppppppppfilidppp', 'i'),
+    'xas_maxpool3x3s2_fwd': ('piiiippp', 'i'),
+    'xas_maxpool3x3s2_bwd': ('ppiiiipp', 'i'),
+    'xas_upsample2x_fwd': ('piiiipp', 'i'),
+    'xas_upsample2x_bwd': ('piiiipp', 'i'),
+    'xas_sigmoid_fwd': ('plpp', 'i'),
+    'xas_sigmoid_bwd': ('pplpp', 'i'),
+    'xas_nchw_to_nhwc': ('piiiipp', 'i'),
+    'xas_nhwc_to_nchw': ('piiiipp', 'i'),
+    'xas_loss_nblk': ('l', 'i'),
+    'xas_mask_loss_fwd': ('pppliPpp'.replace('P', 'p'), 'i'),
+    'xas_mask_loss_bwd': ('pppliPppp'.replace('P', 'p'), 'i'),
+    'xas_graph_aggregate': ('ppiiipp', 'i'),
+    'xas_gln_workspace_floats': ('l', 'z'),
+    'xas_gln_fwd': ('pppplifpppp', 'i'),
+    'xas_gln_bwd': ('ppppplifppppp', 'i'),
+    'xas_smpl_lbs_fwd': ('ppppppppiiipppp', 'i'),
+    'xas_adam_step': ('pppplffffip', 'i'),
+}
+
+
+def load():
+    """Load the library (idempotent).  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('libxas_hip.so is missing (%s): run `python __graft_entry__.py` to build the HIP '
+                           'library; the MI355X path has no CPU fallback' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.xas_last_error.restype = ctypes.c_char_p
+    lib.xas_last_error.argtypes = []
+    _lib = lib
+    return lib
+
+
+_bound = {}
+
+
+def fn(name):
+    """Bind one entry point (argtypes from SIGNATURES) on first use."""
+    f = _bound.get(name)
+    if f is None:
+        args, ret = SIGNATURES[name]
+        f = getattr(load(), name)      # AttributeError if the symbol is not exported
+        f.argtypes = [ctypes.POINTER(ConvShape) if c == 's' else _T[c] for c in args]
+        f.restype = _T[ret]
+        _bound[name] = f
+    return f
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('xas_amd ops run on the GPU only (got a %s tensor); there is no CPU fallback' % t.device)
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Launch wrapper: appends the current HIP stream and turns a non-zero status into RuntimeError."""
+    rc = fn(name)(*args, stream())
+    if rc != 0:
+        raise RuntimeError('%s failed (%d): %s' % (name, rc, load().xas_last_error().decode()))
+
+
+def query(name, *args):
+    return fn(name)(*args)
