@@ -100,11 +100,8 @@ int xas_draw_lines_max_bwd(const float* kps, long kp_stride_b, long kp_stride_j,
  *
  * x  [N][Hi][Wi][Cin]      w  packed [Cout][R][S][Cin] (see xas_pack_weight)
  * y  [N][Ho][Wo][Cout]     Ho = (Hi + 2*pad - R)/stride + 1
- * bias (Cout) may be NULL.  Optional fused input transform for xas_conv_fwd:
- *   in_scale/in_shift (Cin) != NULL : x' = act(x*in_scale[c] + in_shift[c]),
- *   act: 0 none, 1 relu, 2 leaky-relu(0.01)   (batch-norm + activation of the
- *   producing layer folded into this conv's operand load).
- * Optional fused statistics: stat_sum/stat_sqsum ([gridM][Cout] partials) != NULL.
+ * bias (Cout) may be NULL.  Shapes outside the MFMA tiles (Cin % 32 != 0 or Cout < 16:
+ * the 3-channel stem, the 1-channel mask convs) run a direct VALU kernel.
  * ---------------------------------------------------------------------------------- */
 typedef struct {
   int N, Hi, Wi, Cin;
@@ -143,6 +140,9 @@ int xas_unpack_weight(const float* packed, float* oihw, int Cout, int Cin, int R
 size_t xas_bn_workspace_floats(long M, int C);
 int xas_bn_stats(const float* x, long M, int C, float* mean, float* var_biased,
                  float* workspace, void* stream);
+/* out[c] = sum_m x[m][c]  (bias gradients: deconv_head.py:34, physique_network.py:17, discriminator.py:11);
+ * workspace: xas_bn_workspace_floats(M, C) */
+int xas_col_sum(const float* x, long M, int C, float* out, float* workspace, void* stream);
 /* y = act(gamma*(x-mean)*rsqrt(var+eps)+beta [+ residual]) */
 int xas_bn_apply(const float* x, const float* mean, const float* var_biased, const float* gamma,
                  const float* beta, const float* residual, float eps, int act, long M, int C,
@@ -178,9 +178,11 @@ int xas_nhwc_to_nchw(const float* x, int N, int C, int H, int W, float* y, void*
 /* ------------------------------------------------------------------------------------
  * Mask losses (modules/base_losses/loss_func.py:4-16), fused clip * weight * MSE.
  * mode bit0: use_clip (mask > 0.1), bit1: has weight.
- *   weight given : out[0] = mean(e * clip * weight)
+ * out: 3 floats.
+ *   weight given : out[0] = mean(e * clip * weight), out[1] = 1
  *   no weight    : out[0] = mean((m-gt)^2), out[1] = mean(clip)   (the reference returns the
  *                  tensor mse*clip; its later .mean() equals out[0]*out[1])
+ *   out[2] = out[0]*out[1] = the scalar the trainer reduces to (train.py:182)
  * partial: workspace of xas_loss_nblk(n) * 2 floats.
  * bwd: dm = grad_scalar * d(out)/dm for the weighted form; for the unweighted+clip form
  *      dm = grad_scalar * out[1] * 2(m-gt)/n.
@@ -202,7 +204,9 @@ int xas_graph_aggregate(const float* x, const float* adj, int B, int N, int C, f
 size_t xas_gln_workspace_floats(long n);
 int xas_gln_fwd(const float* x, const float* gamma, const float* beta, const float* residual,
                 long rows, int C, float eps, float* y, float* stats, float* workspace, void* stream);
-int xas_gln_bwd(const float* x, const float* y_pre_res, const float* dy, const float* gamma,
+/* backward of y = relu(ln(x)) (+ residual: pass-through handled by the caller); the relu mask is
+ * recomputed from x, gamma, beta. */
+int xas_gln_bwd(const float* x, const float* beta, const float* dy, const float* gamma,
                 const float* stats, long rows, int C, float eps, float* dx, float* dgamma,
                 float* dbeta, float* workspace, void* stream);
 

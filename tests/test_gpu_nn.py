@@ -1,0 +1,236 @@
+"""GPU parity of the layer kernels (through the C ABI) against plain PyTorch fp32 CPU references,
+and of the whole detector against the oracle / reference-import goldens."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+import inputs as gi
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def maxabs(a, b):
+    return float((a.detach().cpu() - b.detach().cpu()).abs().max())
+
+
+CONV_CASES = [
+    # n, cin, h, w, cout, k, stride, pad
+    (2, 64, 16, 16, 64, 1, 1, 0),
+    (2, 64, 16, 16, 64, 3, 1, 1),
+    (2, 128, 17, 13, 96, 3, 2, 1),      # odd sizes, N tile tail
+    (3, 256, 8, 8, 512, 1, 2, 0),       # strided 1x1 (downsample)
+    (2, 32, 12, 12, 32, 3, 1, 1),       # BN=32 tile
+    (2, 3, 32, 32, 64, 7, 2, 3),        # stem (direct path)
+    (2, 1, 16, 16, 32, 3, 1, 1),        # physique first conv
+    (2, 32, 16, 16, 1, 3, 1, 1),        # physique last conv
+    (1, 256, 8, 8, 1152, 1, 1, 0),      # final projection
+]
+
+
+@pytest.mark.parametrize('n,cin,h,w,cout,k,stride,pad', CONV_CASES)
+def test_conv2d_fwd_bwd(n, cin, h, w, cout, k, stride, pad):
+    from xas_amd import layers as L
+    g = torch.Generator().manual_seed(n * 1000 + cin + cout + k)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    xc, wc, bc = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yc = TF.conv2d(xc, wc, bc, stride, pad)
+    gy = torch.randn(yc.shape, generator=g)
+    (yc * gy).sum().backward()
+    m = L.Conv2d(cin, cout, k, stride, pad, bias=True).cuda()
+    with torch.no_grad():
+        m.weight.copy_(wt)
+        m.bias.copy_(b)
+    xg = x.cuda().requires_grad_(True)
+    yg = m(xg)
+    assert yg.shape == yc.shape
+    (yg * gy.cuda()).sum().backward()
+    assert rel(yg, yc) < 2e-6 and maxabs(yg, yc) < 2e-5
+    assert rel(xg.grad, xc.grad) < 2e-6
+    assert rel(m.weight.grad, wc.grad) < 3e-6
+    assert rel(m.bias.grad, bc.grad) < 3e-6
+
+
+@pytest.mark.parametrize('n,cin,h,cout', [(2, 2048, 4, 256), (2, 256, 8, 256), (1, 64, 5, 32)])
+def test_conv_transpose2d(n, cin, h, cout):
+    from xas_amd import layers as L
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, cin, h, h, generator=g)
+    wt = torch.randn(cin, cout, 4, 4, generator=g) / (cin * 4) ** 0.5
+    xc, wc = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    yc = TF.conv_transpose2d(xc, wc, None, 2, 1)
+    gy = torch.randn(yc.shape, generator=g)
+    (yc * gy).sum().backward()
+    m = L.ConvTranspose2d(cin, cout, 4, 2, 1).cuda()
+    with torch.no_grad():
+        m.weight.copy_(wt)
+    xg = x.cuda().requires_grad_(True)
+    yg = m(xg)
+    (yg * gy.cuda()).sum().backward()
+    assert yg.shape == yc.shape
+    assert rel(yg, yc) < 2e-6 and rel(xg.grad, xc.grad) < 2e-6 and rel(m.weight.grad, wc.grad) < 3e-6
+
+
+@pytest.mark.parametrize('rows,cin,cout', [(576, 6, 128), (576, 128, 128), (32, 4608, 512), (32, 512, 1)])
+def test_linear(rows, cin, cout):
+    from xas_amd import layers as L
+    g = torch.Generator().manual_seed(rows + cin)
+    x = torch.randn(rows, cin, generator=g)
+    m = L.Linear(cin, cout).cuda()
+    xc = x.clone().requires_grad_(True)
+    wc, bc = m.weight.detach().cpu().requires_grad_(True), m.bias.detach().cpu().requires_grad_(True)
+    yc = TF.linear(xc, wc, bc)
+    gy = torch.randn(yc.shape, generator=g)
+    (yc * gy).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    yg = m(xg)
+    (yg * gy.cuda()).sum().backward()
+    assert rel(yg, yc) < 2e-6 and rel(xg.grad, xc.grad) < 2e-6
+    assert rel(m.weight.grad, wc.grad) < 3e-6 and rel(m.bias.grad, bc.grad) < 3e-6
+
+
+@pytest.mark.parametrize('n,c,h,act,res', [(4, 64, 16, 1, False), (2, 256, 9, 1, True), (3, 32, 8, 2, False),
+                                           (2, 2048, 4, 0, False), (2, 128, 7, 0, True)])
+def test_batch_norm_train(n, c, h, act, res):
+    from xas_amd import layers as L
+    g = torch.Generator().manual_seed(c + h)
+    x = torch.randn(n, c, h, h, generator=g) * 2 + 3            # mean >> 0 exercises the pivoted variance
+    r = torch.randn(n, c, h, h, generator=g) if res else None
+    gam, bet = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    xc = x.clone().requires_grad_(True)
+    rc = r.clone().requires_grad_(True) if res else None
+    gc, bc = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    yc = TF.batch_norm(xc, rm, rv, gc, bc, True, 0.1, 1e-5)
+    if res:
+        yc = yc + rc
+    yc = {0: lambda t: t, 1: TF.relu, 2: lambda t: TF.leaky_relu(t, 0.01)}[act](yc)
+    gy = torch.randn(yc.shape, generator=g)
+    (yc * gy).sum().backward()
+    m = L.BatchNorm2d(c, act=act).cuda()
+    with torch.no_grad():
+        m.weight.copy_(gam)
+        m.bias.copy_(bet)
+    xg = x.cuda().requires_grad_(True)
+    rg = r.cuda().requires_grad_(True) if res else None
+    yg = m(xg, residual=rg)
+    (yg * gy.cuda()).sum().backward()
+    assert maxabs(yg, yc) < 2e-5
+    assert rel(xg.grad, xc.grad) < 2e-5
+    assert rel(m.weight.grad, gc.grad) < 1e-5 and rel(m.bias.grad, bc.grad) < 1e-5
+    if res:
+        assert rel(rg.grad, rc.grad) < 1e-6
+    assert maxabs(m.running_mean, rm) < 1e-6 and maxabs(m.running_var, rv) < 1e-5
+    assert int(m.num_batches_tracked) == 1
+    # eval mode uses the running statistics
+    m.eval()
+    ye = m(x.cuda(), residual=r.cuda() if res else None)
+    yr = TF.batch_norm(x, rm, rv, gam, bet, False, 0.1, 1e-5)
+    if res:
+        yr = yr + r
+    yr = {0: lambda t: t, 1: TF.relu, 2: lambda t: TF.leaky_relu(t, 0.01)}[act](yr)
+    assert maxabs(ye, yr) < 2e-5
+
+
+def test_pool_upsample_sigmoid():
+    from xas_amd import ops_nn as F
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 18, 14, generator=g)
+    xc = x.clone().requires_grad_(True)
+    yc = TF.max_pool2d(xc, 3, 2, 1)
+    gy = torch.randn(yc.shape, generator=g)
+    (yc * gy).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    yg = F.maxpool3x3s2(xg)
+    (yg * gy.cuda()).sum().backward()
+    assert maxabs(yg, yc) == 0 and maxabs(xg.grad, xc.grad) < 1e-6
+    x = torch.randn(2, 32, 7, 9, generator=g)
+    xc = x.clone().requires_grad_(True)
+    yc = TF.interpolate(xc, scale_factor=2, mode='bilinear')
+    gy = torch.randn(yc.shape, generator=g)
+    (yc * gy).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    yg = F.upsample2x(xg)
+    (yg * gy.cuda()).sum().backward()
+    assert maxabs(yg, yc) < 1e-6 and maxabs(xg.grad, xc.grad) < 1e-5
+    x = torch.randn(2, 1, 16, 16, generator=g)
+    xc = x.clone().requires_grad_(True)
+    yc = torch.sigmoid(xc)
+    (yc * yc).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    yg = F.sigmoid(xg)
+    (yg * yg).sum().backward()
+    assert maxabs(yg, yc) < 1e-6 and maxabs(xg.grad, xc.grad) < 1e-6
+
+
+def _hip_regressor(multi=True):
+    from modules.keypoint_detector_integral import KPDetector3D
+    from modules.keypoint_detector_integral_multi import KPDetector3DMulti
+    from oracle import step as ostep
+    ora = ostep.Regressor('resnet_multi', 18, 64, 3, 15) if multi else ostep.Regressor('resnet', 18, 64)
+    gi.seeded_fill_(ora, seed=61)
+    with torch.no_grad():
+        ora.net.head.features[9].bias.copy_(T(gi.planted_depth_bias(18, 64, seed=62)))
+    hip = KPDetector3DMulti('resnet_multi', 18, 64, 3, 15) if multi else KPDetector3D('resnet', 18, 64)
+    hip.load_state_dict(ora.state_dict(), strict=True)            # same key names / shapes as the reference
+    return hip.cuda(), ora
+
+
+def test_detector_vs_golden_and_oracle():
+    g = golden('detector')
+    hip, ora = _hip_regressor(True)
+    assert list(hip.state_dict().keys()) == g['keys'].tolist()
+    hip.train()
+    x = T(gi.synthetic_batch(2, [0], seed=63)['cam_0_img'])
+    kps, dmap = hip(x.cuda())
+    assert kps.shape == (2, 3, 18, 3) and dmap.shape == (18, 64)
+    assert maxabs(kps, T(g['kps'])) < 1e-4                      # north-star bar: 1e-4 in normalised space
+    assert maxabs(dmap, T(g['depth_prob_map'])) < 1e-5
+    (kps * T(g['grad_out']).cuda()).sum().backward()
+    p = dict(hip.named_parameters())
+    # Parameter gradients of this planted-peak case are ill conditioned in fp32: the CPU fp32 oracle and
+    # this path are BOTH ~1e-2 (relative) away from an fp64 evaluation of the same graph, and two CPU fp32
+    # runs with different thread counts differ by 6e-3 (tools/diag_detector_grads.py).  The bar
+    # below is therefore 3e-2 against the reference golden; the per-layer kernels are held to 3e-6
+    # above, where the comparison is well conditioned.
+    GT = 3e-2
+    assert rel(p['net.backbone.conv1.weight'].grad, T(g['g_conv1'])) < GT
+    assert rel(p['net.backbone.layer1.0.conv2.weight'].grad[:8], T(g['g_l1c2'])) < GT
+    assert rel(p['net.backbone.layer2.0.downsample.0.weight'].grad[:4, :16], T(g['g_l2ds'])) < GT
+    assert rel(p['net.head.features.0.weight'].grad[:4, :4], T(g['g_dc0'])) < GT
+    assert rel(p['net.head.features.9.bias'].grad, T(g['g_fin_b'])) < GT
+    assert rel(p['net.backbone.bn1.weight'].grad, T(g['g_bn1_w'])) < GT
+    assert abs(float(p['net.backbone.layer4.2.conv3.weight'].grad.norm()) / float(g['g_l4c3_norm']) - 1) < GT
+    assert abs(float(p['net.head.features.6.weight'].grad.norm()) / float(g['g_dc6_norm']) - 1) < GT
+    sd = hip.state_dict()
+    assert maxabs(sd['net.backbone.bn1.running_mean'], T(g['rm_bn1'])) < 1e-6
+    assert maxabs(sd['net.backbone.layer3.5.bn3.running_var'], T(g['rv_l3'])) < 1e-5
+    # depth-peak indices: bit exact against the oracle on the same weights/input
+    ora.train()
+    from oracle import head as ohead
+    _, _, idx = ohead.softargmax_multi(ora.net(x), 18, 3, 15)
+    assert np.array_equal(idx.numpy(), hip.last_peak_indices.cpu().numpy())
+    # heat-map (logits) against the golden sub-sample
+    hip2, _ = _hip_regressor(True)
+    hip2.train()
+    heat = hip2.net(x.cuda())
+    assert heat.shape == (2, 1152, 64, 64)
+    assert maxabs(heat[:, ::37, ::4, ::4], T(g['heat_sub'])) < 5e-4
+
+
+def test_detector_single_hypothesis():
+    hip, _ = _hip_regressor(False)
+    hip.train()
+    x = T(gi.synthetic_batch(2, [0], seed=63)['cam_0_img'])
+    k1, _ = hip(x.cuda())
+    assert k1.shape == (2, 1, 18, 3)
+    assert maxabs(k1, T(golden('detector_single')['kps'])) < 1e-4

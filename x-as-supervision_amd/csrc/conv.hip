@@ -1,0 +1,640 @@
+// fp32 MFMA implicit-GEMM convolution family for gfx950: forward, data gradient
+// (== ConvTranspose2d forward), weight gradient.  NHWC activations, packed weights
+// [rows][R][S][chan] so both GEMM operands are "row x K-contiguous".
+//
+//   fwd   : Y[m, co]  = sum_{r,s,c} X[pix(m,r,s), c] * W[co][r][s][c]          M = N*Ho*Wo
+//   dgrad : dX[p, ci] = sum_{r,s,co} dY[src(p,r,s), co] * Wt[ci][r][s][co]     per stride phase
+//   wgrad : dW[co, (r,s,c)] = sum_m dY[m, co] * X[pix(m,r,s), c]               split over m
+//
+// Block = 256 threads = 4 waves, tile BM x BN x 32, v_mfma_f32_32x32x2_f32 (exact fp32,
+// 64 FLOP/clk/SIMD).  Operands are staged global -> registers -> LDS (double buffered,
+// one barrier per K-step, the next K-step's global loads in flight during the MFMAs).
+// LDS rows are padded to 36 dwords: a lane reads 4 consecutive k as one ds_read_b128 and
+// feeds 4 MFMAs (MFMA j of a lane-half h consumes k = 4h + j on both operands), which is
+// bank-conflict free for the 16-lane b128 groups.
+//
+// Replaces the cuDNN conv kernels behind integral_base_modules/resnet.py:16-47,
+// deconv_head.py:24-35, physique_network.py:15-50 and torchvision's Bottleneck.
+#include "common.h"
+
+namespace xas {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BK = 32;        // K-step (channels of one tap)
+constexpr int LDK = BK + 4;   // padded LDS row, dwords
+
+struct FastDiv {              // n / d and n % d for 0 <= n < 2^31, d >= 1
+  unsigned d, mul, shift;
+  __host__ void init(unsigned dd) {
+    d = dd;
+    if (dd == 1) { mul = 0; shift = 0; return; }
+    unsigned s = 0;
+    while ((1ull << s) < dd) ++s;
+    unsigned long long m = ((1ull << (31 + s)) + dd - 1) / dd;   // ceil(2^(31+s)/d) fits 32 bits
+    mul = (unsigned)m; shift = s;
+  }
+  __device__ __forceinline__ unsigned div(unsigned n) const {
+    return d == 1 ? n : (unsigned)(((unsigned long long)n * mul) >> (31 + shift));
+  }
+};
+
+struct IgemmParams {
+  const float* src;    // activations that are gathered (x for fwd, dy for dgrad)
+  const float* wgt;    // packed weights [rows][R][S][Cs]
+  const float* bias;   // per output column or null
+  float* out;
+  int N;
+  int Hs, Ws, Cs;      // gathered tensor dims
+  int Hd, Wd, Cd;      // destination dims; Cd = number of GEMM columns
+  int R, S, stride, pad;
+  FastDiv div_hw, div_w;   // row -> (n, a, b) decode over the row grid
+  int Hrow, Wrow;          // row grid (fwd: Ho x Wo; dgrad: per-phase grid, set in kernel)
+};
+
+// ------------------------------------------------------------------------------------
+// shared MFMA core: As[BM][LDK], Bs[BN][LDK] -> acc
+// ------------------------------------------------------------------------------------
+template <int BM, int BN>
+struct TileCfg {
+  static constexpr int WAVES_N = (BN >= 64) ? 2 : 1;
+  static constexpr int WAVES_M = 4 / WAVES_N;
+  static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  static constexpr int MI = WM / 32, NI = WN / 32;
+  static_assert(MI >= 1 && NI >= 1, "tile too small");
+};
+
+template <int BM, int BN>
+__device__ __forceinline__ void mfma_tile(const float* __restrict__ As, const float* __restrict__ Bs,
+                                          f32x16 (&acc)[TileCfg<BM, BN>::MI][TileCfg<BM, BN>::NI], int wm, int wn,
+                                          int lane) {
+  using C = TileCfg<BM, BN>;
+  const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < BK / 8; ++kk) {
+    float4 a[C::MI], b[C::NI];
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+      a[mi] = *reinterpret_cast<const float4*>(As + (wm * C::WM + mi * 32 + i) * LDK + kk * 8 + h * 4);
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni)
+      b[ni] = *reinterpret_cast<const float4*>(Bs + (wn * C::WN + ni * 32 + i) * LDK + kk * 8 + h * 4);
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni) {
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// fwd (MODE 0) and dgrad (MODE 1)
+// ------------------------------------------------------------------------------------
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+  using C = TileCfg<BM, BN>;
+  constexpr int APASS = BM / 32, BPASS = BN / 32;
+  extern __shared__ __align__(16) float lds[];
+  float* As = lds;                       // [2][BM][LDK]
+  float* Bs = lds + 2 * BM * LDK;        // [2][BN][LDK]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+  const int kq = tid & 7, lrow = tid >> 3;          // float4 slot along k, row within a 32-row pass
+
+  // ---- per-mode geometry -----------------------------------------------------------
+  int Hrow = p.Hrow, Wrow = p.Wrow;
+  int ph = 0, pw = 0, base_r = 0, base_s = 0, nr = p.R, ns = p.S, off_h = -p.pad, off_w = -p.pad, rstep = 1;
+  int sa = p.stride;                                 // source step per row-grid step
+  if (MODE == 1) {
+    const int st = p.stride;
+    ph = blockIdx.z / st; pw = blockIdx.z % st;
+    Hrow = (p.Hd - ph + st - 1) / st; Wrow = (p.Wd - pw + st - 1) / st;
+    base_r = (ph + p.pad) % st; base_s = (pw + p.pad) % st;
+    nr = base_r < p.R ? (p.R - base_r + st - 1) / st : 0;
+    ns = base_s < p.S ? (p.S - base_s + st - 1) / st : 0;
+    off_h = (ph + p.pad - base_r) / st; off_w = (pw + p.pad - base_s) / st;
+    rstep = st; sa = 1;
+  }
+  const int Mrows = p.N * Hrow * Wrow;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  if (m0 >= Mrows) return;                           // uniform per block (uneven phases)
+  const int HW = Hrow * Wrow;
+
+  // rows this thread stages: lrow + 32*j
+  int rn[APASS], ra[APASS], rb[APASS];               // image, source base coords (already * sa + off)
+#pragma unroll
+  for (int j = 0; j < APASS; ++j) {
+    const int m = m0 + lrow + 32 * j;
+    if (m < Mrows) {
+      int n, a, b;
+      if (MODE == 0) { n = p.div_hw.div(m); const int rem = m - n * HW; a = p.div_w.div(rem); b = rem - a * Wrow; }
+      else { n = m / HW; const int rem = m - n * HW; a = rem / Wrow; b = rem - a * Wrow; }
+      rn[j] = n; ra[j] = a * sa + off_h; rb[j] = b * sa + off_w;
+    } else { rn[j] = -1; ra[j] = 0; rb[j] = 0; }
+  }
+  const int cchunks = p.Cs / BK;
+  const int nk = nr * ns * cchunks;
+  const size_t wrow_stride = (size_t)p.R * p.S * p.Cs;
+
+  f32x16 acc[C::MI][C::NI];
+#pragma unroll
+  for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  float4 ra4[APASS], rb4[BPASS];
+  auto load_step = [&](int ks) {
+    const int tap = ks / cchunks, c0 = (ks - tap * cchunks) * BK + kq * 4;
+    const int jr = tap / ns, js = tap - jr * ns;
+    // fwd: source = base + tap ; dgrad: source = base - tap index (transposed walk)
+    const int dh = (MODE == 0) ? jr : -jr, dw = (MODE == 0) ? js : -js;
+    const int wtap = (base_r + rstep * jr) * p.S + (base_s + rstep * js);
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) {
+      const int hs = ra[j] + dh, ws = rb[j] + dw;
+      const bool ok = rn[j] >= 0 && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
+      ra4[j] = ok ? *reinterpret_cast<const float4*>(p.src + (((size_t)rn[j] * p.Hs + hs) * p.Ws + ws) * p.Cs + c0)
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) {
+      const int n = n0 + lrow + 32 * j;
+      rb4[j] = n < p.Cd ? *reinterpret_cast<const float4*>(p.wgt + (size_t)n * wrow_stride + (size_t)wtap * p.Cs + c0)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_step = [&](int buf) {
+    float* a = As + buf * BM * LDK;
+    float* b = Bs + buf * BN * LDK;
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) *reinterpret_cast<float4*>(a + (lrow + 32 * j) * LDK + kq * 4) = ra4[j];
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) *reinterpret_cast<float4*>(b + (lrow + 32 * j) * LDK + kq * 4) = rb4[j];
+  };
+
+  if (nk > 0) load_step(0);
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks & 1;
+    store_step(buf);
+    __syncthreads();
+    if (ks + 1 < nk) load_step(ks + 1);
+    mfma_tile<BM, BN>(As + buf * BM * LDK, Bs + buf * BN * LDK, acc, wm, wn, lane);
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ---
+  const int col_l = lane & 31, rsub = 4 * (lane >> 5);
+#pragma unroll
+  for (int mi = 0; mi < C::MI; ++mi) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int m = m0 + wm * C::WM + mi * 32 + (reg & 3) + 8 * (reg >> 2) + rsub;
+      if (m >= Mrows) continue;
+      size_t orow;
+      if (MODE == 0) orow = (size_t)m;
+      else {
+        const int n = m / HW; const int rem = m - n * HW; const int a = rem / Wrow, b = rem - a * Wrow;
+        orow = ((size_t)n * p.Hd + (ph + p.stride * a)) * p.Wd + (pw + p.stride * b);
+      }
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni) {
+        const int n = n0 + wn * C::WN + ni * 32 + col_l;
+        if (n < p.Cd) {
+          float v = acc[mi][ni][reg];
+          if (MODE == 0 && p.bias) v += p.bias[n];
+          p.out[orow * p.Cd + n] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// wgrad: C[co][nn] = sum_m dY[m][co] * Xcol[m][nn],  nn = (r*S+s)*Cin + c
+// LDS tiles are [k = pixel][row] (row-contiguous, as they come from memory); MFMA operands
+// are read with ds_read_b32 (lanes walk rows: conflict free).
+// ------------------------------------------------------------------------------------
+struct WgradParams {
+  const float* x; const float* dy; float* out;      // out: [splits][Cout][KK] slabs
+  int N, Hi, Wi, Cin, Cout, R, S, stride, pad, Ho, Wo;
+  int KK;                                            // R*S*Cin
+  int M;                                             // N*Ho*Wo
+  int m_per_split;
+  FastDiv div_hw, div_w, div_cin, div_s;
+};
+
+constexpr int WBK = 32;       // pixels per K-step
+
+template <int BM, int BN, bool VEC>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+  using C = TileCfg<BM, BN>;
+  constexpr int LDA = BM + 4, LDB = BN + 4;          // +4 keeps float4 stores aligned
+  constexpr int AQ = BM / 4, BQ = BN / 4;            // float4 per pixel row
+  constexpr int AROWS = 256 / AQ, BROWS = 256 / BQ;  // pixel rows per pass
+  constexpr int APASS = WBK / AROWS, BPASS = WBK / BROWS;
+  extern __shared__ __align__(16) float lds[];
+  float* As = lds;                                   // [2][WBK][LDA]
+  float* Bs = lds + 2 * WBK * LDA;                   // [2][WBK][LDB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+  const int co0 = blockIdx.x * BM, nn0 = blockIdx.y * BN;
+  const int split = blockIdx.z;
+  const int mbeg = split * p.m_per_split, mend = min(p.M, mbeg + p.m_per_split);
+  const int HWo = p.Ho * p.Wo;
+
+  const int aq = tid % AQ, arow = tid / AQ;
+  const int bq = tid % BQ, brow = tid / BQ;
+  // column geometry of this thread's B float4 (VEC) : fixed tap and channel
+  const int nnb = nn0 + bq * 4;
+  int tap_r = 0, tap_s = 0, tap_c = 0;
+  bool bcol_ok = nnb < p.KK;
+  if (VEC && bcol_ok) {
+    const int tap = p.div_cin.div(nnb); tap_c = nnb - tap * p.Cin;
+    tap_r = p.div_s.div(tap); tap_s = tap - tap_r * p.S;
+  }
+
+  f32x16 acc[C::MI][C::NI];
+#pragma unroll
+  for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  float4 ra4[APASS], rb4[BPASS];
+  auto load_step = [&](int mk) {
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) {
+      const int m = mk + arow + AROWS * j, co = co0 + aq * 4;
+      ra4[j] = (m < mend && co < p.Cout) ? *reinterpret_cast<const float4*>(p.dy + (size_t)m * p.Cout + co)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) {
+      const int m = mk + brow + BROWS * j;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < mend && bcol_ok) {
+        const int n = p.div_hw.div(m); const int rem = m - n * HWo;
+        const int ho = p.div_w.div(rem), wo = rem - ho * p.Wo;
+        if (VEC) {
+          const int hi = ho * p.stride - p.pad + tap_r, wi = wo * p.stride - p.pad + tap_s;
+          if ((unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi)
+            v = *reinterpret_cast<const float4*>(p.x + (((size_t)n * p.Hi + hi) * p.Wi + wi) * p.Cin + tap_c);
+        } else {
+          float t[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int nn = nnb + e;
+            t[e] = 0.f;
+            if (nn < p.KK) {
+              const int tap = p.div_cin.div(nn); const int c = nn - tap * p.Cin;
+              const int r = p.div_s.div(tap), s = tap - r * p.S;
+              const int hi = ho * p.stride - p.pad + r, wi = wo * p.stride - p.pad + s;
+              if ((unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi)
+                t[e] = p.x[(((size_t)n * p.Hi + hi) * p.Wi + wi) * p.Cin + c];
+            }
+          }
+          v = make_float4(t[0], t[1], t[2], t[3]);
+        }
+      }
+      rb4[j] = v;
+    }
+  };
+  auto store_step = [&](int buf) {
+    float* a = As + buf * WBK * LDA;
+    float* b = Bs + buf * WBK * LDB;
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) *reinterpret_cast<float4*>(a + (arow + AROWS * j) * LDA + aq * 4) = ra4[j];
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) *reinterpret_cast<float4*>(b + (brow + BROWS * j) * LDB + bq * 4) = rb4[j];
+  };
+
+  const int i = lane & 31, h = lane >> 5;
+  const int nsteps = (mend > mbeg) ? (mend - mbeg + WBK - 1) / WBK : 0;
+  if (nsteps > 0) load_step(mbeg);
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1;
+    store_step(buf);
+    __syncthreads();
+    if (st + 1 < nsteps) load_step(mbeg + (st + 1) * WBK);
+    const float* a = As + buf * WBK * LDA + wm * C::WM + i;
+    const float* b = Bs + buf * WBK * LDB + wn * C::WN + i;
+#pragma unroll
+    for (int kk = 0; kk < WBK / 2; ++kk) {
+      float av[C::MI], bv[C::NI];
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi) av[mi] = a[(2 * kk + h) * LDA + mi * 32];
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni) bv[ni] = b[(2 * kk + h) * LDB + ni * 32];
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+    }
+  }
+  float* slab = p.out + (size_t)split * p.Cout * p.KK;
+  const int col_l = lane & 31, rsub = 4 * (lane >> 5);
+#pragma unroll
+  for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int co = co0 + wm * C::WM + mi * 32 + (reg & 3) + 8 * (reg >> 2) + rsub;
+      if (co >= p.Cout) continue;
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni) {
+        const int nn = nn0 + wn * C::WN + ni * 32 + col_l;
+        if (nn < p.KK) slab[(size_t)co * p.KK + nn] = acc[mi][ni][reg];
+      }
+    }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int splits, long n, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * n + i];
+  out[i] = s;
+}
+
+// ------------------------------------------------------------------------------------
+// direct (VALU) fallbacks for shapes the MFMA tiles do not cover (Cin = 1 / 3, Cout = 1)
+// ------------------------------------------------------------------------------------
+__global__ void direct_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                  const float* __restrict__ bias, float* __restrict__ y, xas_conv_shape s) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)s.N * s.Ho * s.Wo * s.Cout;
+  if (idx >= total) return;
+  const int co = idx % s.Cout;
+  long m = idx / s.Cout;
+  const int wo = m % s.Wo; m /= s.Wo;
+  const int ho = m % s.Ho; const int n = m / s.Ho;
+  float acc = bias ? bias[co] : 0.f;
+  for (int r = 0; r < s.R; ++r) {
+    const int hi = ho * s.stride - s.pad + r;
+    if ((unsigned)hi >= (unsigned)s.Hi) continue;
+    for (int q = 0; q < s.S; ++q) {
+      const int wi = wo * s.stride - s.pad + q;
+      if ((unsigned)wi >= (unsigned)s.Wi) continue;
+      const float* xp = x + (((size_t)n * s.Hi + hi) * s.Wi + wi) * s.Cin;
+      const float* wp = w + (((size_t)co * s.R + r) * s.S + q) * s.Cin;
+      for (int c = 0; c < s.Cin; ++c) acc = fmaf(xp[c], wp[c], acc);
+    }
+  }
+  y[idx] = acc;
+}
+
+// wt packed transposed [Cin][R][S][Cout]
+__global__ void direct_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ wt,
+                                    float* __restrict__ dx, xas_conv_shape s) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)s.N * s.Hi * s.Wi * s.Cin;
+  if (idx >= total) return;
+  const int ci = idx % s.Cin;
+  long m = idx / s.Cin;
+  const int wi = m % s.Wi; m /= s.Wi;
+  const int hi = m % s.Hi; const int n = m / s.Hi;
+  float acc = 0.f;
+  for (int r = 0; r < s.R; ++r) {
+    const int th = hi + s.pad - r;
+    if (th < 0 || th % s.stride) continue;
+    const int ho = th / s.stride;
+    if (ho >= s.Ho) continue;
+    for (int q = 0; q < s.S; ++q) {
+      const int tw = wi + s.pad - q;
+      if (tw < 0 || tw % s.stride) continue;
+      const int wo = tw / s.stride;
+      if (wo >= s.Wo) continue;
+      const float* gp = dy + (((size_t)n * s.Ho + ho) * s.Wo + wo) * s.Cout;
+      const float* wp = wt + (((size_t)ci * s.R + r) * s.S + q) * s.Cout;
+      for (int c = 0; c < s.Cout; ++c) acc = fmaf(gp[c], wp[c], acc);
+    }
+  }
+  dx[idx] = acc;
+}
+
+// Cout == 1 weight gradient (physique_network.py:50, the 32 -> 1 output conv): thread = column nn,
+// block walks a pixel chunk; slabs [chunks][KK] are summed by slab_reduce_kernel.
+__global__ void wgrad_cout1_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                   float* __restrict__ slabs, xas_conv_shape s, int m_per_chunk) {
+  const int KK = s.R * s.S * s.Cin;
+  const int nn = blockIdx.x * blockDim.x + threadIdx.x;
+  const long M = (long)s.N * s.Ho * s.Wo;
+  const long mbeg = (long)blockIdx.y * m_per_chunk, mend = min(M, mbeg + m_per_chunk);
+  if (nn >= KK) return;
+  const int tap = nn / s.Cin, c = nn % s.Cin, r = tap / s.S, q = tap % s.S;
+  float acc = 0.f;
+  for (long m = mbeg; m < mend; ++m) {
+    const int wo = m % s.Wo; const long t = m / s.Wo; const int ho = t % s.Ho; const int n = t / s.Ho;
+    const int hi = ho * s.stride - s.pad + r, wi = wo * s.stride - s.pad + q;
+    if ((unsigned)hi < (unsigned)s.Hi && (unsigned)wi < (unsigned)s.Wi)
+      acc = fmaf(dy[m], x[(((size_t)n * s.Hi + hi) * s.Wi + wi) * s.Cin + c], acc);
+  }
+  slabs[(size_t)blockIdx.y * KK + nn] = acc;
+}
+
+// OIHW <-> packed
+__global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int R,
+                                   int S, int transposed, int unpack) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)Cout * Cin * R * S;
+  if (idx >= total) return;
+  // idx enumerates the packed tensor
+  long t = idx;
+  int co, ci, r, q;
+  if (!transposed) { ci = t % Cin; t /= Cin; q = t % S; t /= S; r = t % R; co = t / R; }
+  else { co = t % Cout; t /= Cout; q = t % S; t /= S; r = t % R; ci = t / R; }
+  const long o = (((long)co * Cin + ci) * R + r) * S + q;
+  if (unpack) dst[o] = src[idx]; else dst[idx] = src[o];
+}
+
+static int check_shape(const xas_conv_shape* s, const char* who) {
+  XAS_REQUIRE(s != nullptr, "%s: null shape", who);
+  XAS_REQUIRE(s->N > 0 && s->Hi > 0 && s->Wi > 0 && s->Cin > 0 && s->Cout > 0 && s->R > 0 && s->S > 0 &&
+                  s->stride > 0 && s->pad >= 0, "%s: non-positive dimension", who);
+  XAS_REQUIRE((long)s->N * s->Hi * s->Wi * s->Cin < (1l << 31) && (long)s->N * s->Ho * s->Wo * s->Cout < (1l << 31),
+              "%s: tensor too large for 32-bit row indices", who);
+  return 0;
+}
+
+static int check_fwd_dims(const xas_conv_shape* s, const char* who) {
+  XAS_REQUIRE(s->Ho == (s->Hi + 2 * s->pad - s->R) / s->stride + 1 && s->Wo == (s->Wi + 2 * s->pad - s->S) / s->stride + 1,
+              "%s: Ho/Wo (%d,%d) inconsistent with Hi=%d Wi=%d R=%d S=%d stride=%d pad=%d", who, s->Ho, s->Wo, s->Hi,
+              s->Wi, s->R, s->S, s->stride, s->pad);
+  return 0;
+}
+
+template <int BM, int BN, int MODE>
+static int launch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
+  const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)cdiv(Mrows_max, BM), (unsigned)cdiv(p.Cd, BN), (unsigned)phases);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE>), grid, dim3(256), lds, st, p);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int MODE>
+static int dispatch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
+  if (p.Cd >= 96) return launch_igemm<128, 128, MODE>(p, Mrows_max, phases, st);
+  if (p.Cd >= 48) return launch_igemm<128, 64, MODE>(p, Mrows_max, phases, st);
+  return launch_igemm<128, 32, MODE>(p, Mrows_max, phases, st);
+}
+
+}  // namespace xas
+
+using namespace xas;
+
+extern "C" int xas_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
+                            const xas_conv_shape* s, void* stream) {
+  if (check_shape(s, "conv_fwd") || check_fwd_dims(s, "conv_fwd")) return 1;
+  XAS_REQUIRE(x && w_packed && y, "conv_fwd: null buffer");
+  hipStream_t st = as_stream(stream);
+  if (s->Cin % BK != 0 || s->Cout < 16) {
+    const long total = (long)s->N * s->Ho * s->Wo * s->Cout;
+    hipLaunchKernelGGL(direct_fwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, x, w_packed, bias, y, *s);
+    XAS_LAUNCH_CHECK();
+    return 0;
+  }
+  XAS_REQUIRE((((uintptr_t)x | (uintptr_t)w_packed) & 15) == 0, "conv_fwd: operands must be 16-byte aligned");
+  IgemmParams p{};
+  p.src = x; p.wgt = w_packed; p.bias = bias; p.out = y; p.N = s->N;
+  p.Hs = s->Hi; p.Ws = s->Wi; p.Cs = s->Cin; p.Hd = s->Ho; p.Wd = s->Wo; p.Cd = s->Cout;
+  p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.Hrow = s->Ho; p.Wrow = s->Wo;
+  p.div_hw.init((unsigned)(s->Ho * s->Wo)); p.div_w.init((unsigned)s->Wo);
+  return dispatch_igemm<0>(p, s->N * s->Ho * s->Wo, 1, st);
+}
+
+extern "C" int xas_conv_dgrad(const float* dy, const float* w_packed_t, float* dx, const xas_conv_shape* s,
+                              void* stream) {
+  if (check_shape(s, "conv_dgrad")) return 1;
+  XAS_REQUIRE(dy && w_packed_t && dx, "conv_dgrad: null buffer");
+  // valid for the conv (Hi -> Ho) and for ConvTranspose2d forward (Ho given, Hi = (Ho-1)*stride - 2*pad + R)
+  XAS_REQUIRE((s->Ho - 1) * s->stride - 2 * s->pad + s->R <= s->Hi && (s->Wo - 1) * s->stride - 2 * s->pad + s->S <= s->Wi,
+              "conv_dgrad: Hi/Wi (%d,%d) too small for Ho/Wo (%d,%d)", s->Hi, s->Wi, s->Ho, s->Wo);
+  hipStream_t st = as_stream(stream);
+  if (s->Cout % BK != 0 || s->Cin < 16) {
+    const long total = (long)s->N * s->Hi * s->Wi * s->Cin;
+    hipLaunchKernelGGL(direct_dgrad_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, dy, w_packed_t, dx, *s);
+    XAS_LAUNCH_CHECK();
+    return 0;
+  }
+  XAS_REQUIRE((((uintptr_t)dy | (uintptr_t)w_packed_t) & 15) == 0, "conv_dgrad: operands must be 16-byte aligned");
+  IgemmParams p{};
+  p.src = dy; p.wgt = w_packed_t; p.bias = nullptr; p.out = dx; p.N = s->N;
+  p.Hs = s->Ho; p.Ws = s->Wo; p.Cs = s->Cout; p.Hd = s->Hi; p.Wd = s->Wi; p.Cd = s->Cin;
+  p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad;
+  const int Hp = (s->Hi + s->stride - 1) / s->stride, Wp = (s->Wi + s->stride - 1) / s->stride;
+  return dispatch_igemm<1>(p, s->N * Hp * Wp, s->stride * s->stride, st);
+}
+
+static void wgrad_plan(const xas_conv_shape* s, int* bm, int* bn, int* splits, int* mps) {
+  const long KK = (long)s->R * s->S * s->Cin, M = (long)s->N * s->Ho * s->Wo;
+  *bm = s->Cout >= 96 ? 128 : 64;
+  *bn = 128;
+  const long tiles = cdiv(s->Cout, *bm) * cdiv(KK, *bn);
+  long sp = cdiv(1024, tiles);
+  const long maxsp = M / 256 > 0 ? M / 256 : 1;
+  if (sp > maxsp) sp = maxsp;
+  if (sp < 1) sp = 1;
+  long per = cdiv(M, sp);
+  per = cdiv(per, WBK) * WBK;
+  *mps = (int)per;
+  *splits = (int)cdiv(M, per);
+}
+
+constexpr int kCout1Chunk = 2048;
+
+extern "C" size_t xas_conv_wgrad_workspace_floats(const xas_conv_shape* s) {
+  if (!s) return 0;
+  if (s->Cout == 1) return (size_t)cdiv((long)s->N * s->Ho * s->Wo, kCout1Chunk) * s->R * s->S * s->Cin;
+  int bm, bn, sp, mps;
+  wgrad_plan(s, &bm, &bn, &sp, &mps);
+  return (size_t)sp * s->Cout * s->R * s->S * s->Cin;
+}
+
+template <int BM, int BN, bool VEC>
+static int launch_wgrad(const WgradParams& p, int splits, hipStream_t st) {
+  const size_t lds = (size_t)2 * WBK * ((BM + 4) + (BN + 4)) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<BM, BN, VEC>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)cdiv(p.Cout, BM), (unsigned)cdiv(p.KK, BN), (unsigned)splits);
+  hipLaunchKernelGGL((wgrad_kernel<BM, BN, VEC>), grid, dim3(256), lds, st, p);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int xas_conv_wgrad(const float* x, const float* dy, float* dw_packed, float* workspace,
+                              const xas_conv_shape* s, void* stream) {
+  if (check_shape(s, "conv_wgrad")) return 1;
+  XAS_REQUIRE(x && dy && dw_packed && workspace, "conv_wgrad: null buffer");
+  XAS_REQUIRE(s->Cout % 4 == 0 || s->Cout == 1, "conv_wgrad: Cout=%d must be a multiple of 4 (or 1)", s->Cout);
+  hipStream_t st = as_stream(stream);
+  if (s->Cout == 1) {
+    const int KK = s->R * s->S * s->Cin;
+    const int chunks = (int)cdiv((long)s->N * s->Ho * s->Wo, kCout1Chunk);
+    hipLaunchKernelGGL(wgrad_cout1_kernel, dim3((unsigned)cdiv(KK, 64), (unsigned)chunks), dim3(64), 0, st, x, dy,
+                       workspace, *s, kCout1Chunk);
+    XAS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(KK, 256)), dim3(256), 0, st, workspace, chunks, (long)KK,
+                       dw_packed);
+    XAS_LAUNCH_CHECK();
+    return 0;
+  }
+  int bm, bn, splits, mps;
+  wgrad_plan(s, &bm, &bn, &splits, &mps);
+  WgradParams p{};
+  p.x = x; p.dy = dy; p.out = (splits == 1) ? dw_packed : workspace;
+  p.N = s->N; p.Hi = s->Hi; p.Wi = s->Wi; p.Cin = s->Cin; p.Cout = s->Cout; p.R = s->R; p.S = s->S;
+  p.stride = s->stride; p.pad = s->pad; p.Ho = s->Ho; p.Wo = s->Wo;
+  p.KK = s->R * s->S * s->Cin; p.M = s->N * s->Ho * s->Wo; p.m_per_split = mps;
+  p.div_hw.init((unsigned)(s->Ho * s->Wo)); p.div_w.init((unsigned)s->Wo);
+  p.div_cin.init((unsigned)s->Cin); p.div_s.init((unsigned)s->S);
+  XAS_REQUIRE(s->Cout % 4 == 0, "conv_wgrad: Cout=%d not supported by the MFMA path", s->Cout);
+  const bool vec = (s->Cin % 4 == 0) && (((uintptr_t)x & 15) == 0);
+  int rc;
+  if (bm == 128) rc = vec ? launch_wgrad<128, 128, true>(p, splits, st) : launch_wgrad<128, 128, false>(p, splits, st);
+  else rc = vec ? launch_wgrad<64, 128, true>(p, splits, st) : launch_wgrad<64, 128, false>(p, splits, st);
+  if (rc) return rc;
+  if (splits > 1) {
+    const long n = (long)s->Cout * p.KK;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, workspace, splits, n, dw_packed);
+    XAS_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int xas_pack_weight(const float* oihw, float* packed, int Cout, int Cin, int R, int S, int transposed,
+                               void* stream) {
+  XAS_REQUIRE(oihw && packed && Cout > 0 && Cin > 0 && R > 0 && S > 0, "pack_weight: bad arguments");
+  const long total = (long)Cout * Cin * R * S;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, as_stream(stream), oihw, packed,
+                     Cout, Cin, R, S, transposed, 0);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int xas_unpack_weight(const float* packed, float* oihw, int Cout, int Cin, int R, int S, int transposed,
+                                 void* stream) {
+  XAS_REQUIRE(oihw && packed && Cout > 0 && Cin > 0 && R > 0 && S > 0, "unpack_weight: bad arguments");
+  const long total = (long)Cout * Cin * R * S;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, as_stream(stream), packed, oihw,
+                     Cout, Cin, R, S, transposed, 1);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}

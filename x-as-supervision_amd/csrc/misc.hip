@@ -1,0 +1,426 @@
+// Small fused kernels: mask losses, GCN-discriminator building blocks, SMPL skinning,
+// multi-tensor Adam.  gfx950.
+#include "common.h"
+
+namespace xas {
+
+// ------------------------------------------------------------------ mask losses
+// modules/base_losses/loss_func.py:4-16.  mode bit0 = clip (m > 0.1), bit1 = weighted.
+constexpr int kLossThreads = 256;
+constexpr int kLossPerThread = 16;
+
+__global__ void mask_loss_partial_kernel(const float* __restrict__ m, const float* __restrict__ gt,
+                                         const float* __restrict__ w, long n, int mode, float* __restrict__ partial) {
+  __shared__ float sm[20];
+  float a = 0.f, b = 0.f;
+  const long base = (long)blockIdx.x * kLossThreads * kLossPerThread;
+  for (int k = 0; k < kLossPerThread; ++k) {
+    const long i = base + (long)k * kLossThreads + threadIdx.x;
+    if (i < n) {
+      const float mv = m[i], d = mv - gt[i];
+      const float clip = ((mode & 1) && !(mv > 0.1f)) ? 0.f : 1.f;
+      if (mode & 2) a += d * d * clip * w[i];
+      else { a += d * d; b += clip; }
+    }
+  }
+  a = block_sum(a, sm);
+  b = block_sum(b, sm);
+  if (threadIdx.x == 0) { partial[blockIdx.x * 2] = a; partial[blockIdx.x * 2 + 1] = b; }
+}
+
+__global__ void mask_loss_finalize_kernel(const float* __restrict__ partial, int nblk, long n, int mode,
+                                          float* __restrict__ out) {
+  __shared__ float sm[20];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) { a += partial[i * 2]; b += partial[i * 2 + 1]; }
+  a = block_sum(a, sm);
+  b = block_sum(b, sm);
+  if (threadIdx.x == 0) {
+    out[0] = a / (float)n;
+    out[1] = (mode & 2) ? 1.f : b / (float)n;
+    out[2] = out[0] * out[1];
+  }
+}
+
+__global__ void mask_loss_bwd_kernel(const float* __restrict__ m, const float* __restrict__ gt,
+                                     const float* __restrict__ w, long n, int mode, const float* __restrict__ out,
+                                     const float* __restrict__ gscalar, float* __restrict__ dm) {
+  const float g = gscalar[0] * 2.f / (float)n;
+  const float clipmean = out[1];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float mv = m[i], d = mv - gt[i];
+    if (mode & 2) {
+      const float clip = ((mode & 1) && !(mv > 0.1f)) ? 0.f : 1.f;
+      dm[i] = g * d * clip * w[i];
+    } else {
+      dm[i] = g * d * clipmean;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ graph aggregate
+__global__ void graph_aggregate_kernel(const float* __restrict__ x, const float* __restrict__ adj, int B, int N, int C,
+                                       float* __restrict__ y) {
+  const long total = (long)B * N * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % C; const long t = i / C; const int node = t % N; const long b = t / N;
+    const float* xb = x + b * N * C + c;
+    const float* ar = adj + node * N;
+    float acc = 0.f;
+    for (int j = 0; j < N; ++j) { const float a = ar[j]; if (a != 0.f) acc = fmaf(a, xb[(size_t)j * C], acc); }
+    y[i] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ graph LayerNorm (+relu, +residual)
+// PyG norm.LayerNorm(mode='graph', batch=None): (x - mean_all) / (std_all + eps) * gamma + beta
+constexpr int kGlnThreads = 256;
+
+__global__ void gln_partial_kernel(const float* __restrict__ x, long n, float* __restrict__ partial) {
+  __shared__ float sm[20];
+  const float pivot = x[0];
+  float a = 0.f, b = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float d = x[i] - pivot;
+    a += d; b = fmaf(d, d, b);
+  }
+  a = block_sum(a, sm);
+  b = block_sum(b, sm);
+  if (threadIdx.x == 0) { partial[blockIdx.x * 2] = a; partial[blockIdx.x * 2 + 1] = b; }
+}
+
+__global__ void gln_stats_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ x, long n,
+                                 float* __restrict__ stats) {
+  if (threadIdx.x != 0) return;
+  double a = 0.0, b = 0.0;
+  for (int i = 0; i < nblk; ++i) { a += partial[i * 2]; b += partial[i * 2 + 1]; }
+  const double m = a / (double)n;
+  double v = b / (double)n - m * m;
+  if (v < 0.0) v = 0.0;
+  stats[0] = (float)((double)x[0] + m);
+  stats[1] = (float)sqrt(v);
+}
+
+__global__ void gln_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, const float* __restrict__ res,
+                                 const float* __restrict__ stats, long n, int C, float eps, float* __restrict__ y) {
+  const float mean = stats[0], inv = 1.f / (stats[1] + eps);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    float v = (x[i] - mean) * inv * gamma[c] + beta[c];
+    v = fmaxf(v, 0.f);
+    if (res) v += res[i];
+    y[i] = v;
+  }
+}
+
+// per-channel sums of g and g*xhat where g = dy * relu'(ln(x)); one block per channel group of 64
+__global__ void gln_bwd_cols_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ stats, long rows, int C, float eps,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float s1[4][64], s2[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  const float mean = stats[0], inv = 1.f / (stats[1] + eps);
+  float a = 0.f, b = 0.f;
+  if (c < C) {
+    const float gmm = gamma[c], bt = beta[c];
+    for (long r = ry; r < rows; r += 4) {
+      const float xh = (x[r * C + c] - mean) * inv;
+      const float g = (xh * gmm + bt > 0.f) ? dy[r * C + c] : 0.f;
+      a += g; b = fmaf(g, xh, b);
+    }
+  }
+  s1[ry][cx] = a; s2[ry][cx] = b;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    dbeta[c] = (s1[0][cx] + s1[1][cx]) + (s1[2][cx] + s1[3][cx]);
+    dgamma[c] = (s2[0][cx] + s2[1][cx]) + (s2[2][cx] + s2[3][cx]);
+  }
+}
+
+__global__ void gln_bwd_scalar_kernel(const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                      const float* __restrict__ dbeta, int C, float* __restrict__ ab) {
+  __shared__ float sm[20];
+  float a = 0.f, b = 0.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) { a = fmaf(gamma[c], dbeta[c], a); b = fmaf(gamma[c], dgamma[c], b); }
+  a = block_sum(a, sm);
+  b = block_sum(b, sm);
+  if (threadIdx.x == 0) { ab[0] = a; ab[1] = b; }
+}
+
+__global__ void gln_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ stats, const float* __restrict__ ab, long n, int C,
+                                     float eps, float* __restrict__ dx) {
+  const float mean = stats[0], sigma = stats[1], s = sigma + eps, inv = 1.f / s;
+  const float A = ab[0] / (float)n;
+  const float Bc = sigma > 0.f ? ab[1] / ((float)n * sigma) : 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    const float xh = (x[i] - mean) * inv;
+    const float g = (xh * gamma[c] + beta[c] > 0.f) ? dy[i] * gamma[c] : 0.f;
+    dx[i] = (g - A) * inv - xh * Bc;
+  }
+}
+
+// ------------------------------------------------------------------ SMPL LBS forward
+__global__ void smpl_joints_kernel(const float* __restrict__ betas, const float* __restrict__ vt,
+                                   const float* __restrict__ sd, const float* __restrict__ jr, int V,
+                                   float* __restrict__ ws, int per /* floats per sample record */) {
+  __shared__ float sm[20];
+  const int b = blockIdx.x, j = blockIdx.y;
+  float bt[10];
+  for (int k = 0; k < 10; ++k) bt[k] = betas[b * 10 + k];
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) {
+    const float w = jr[(size_t)j * V + v];
+    if (w == 0.f) continue;
+    float p[3];
+    for (int c = 0; c < 3; ++c) {
+      float s = vt[v * 3 + c];
+      const float* d = sd + ((size_t)v * 3 + c) * 10;
+      for (int k = 0; k < 10; ++k) s = fmaf(d[k], bt[k], s);
+      p[c] = s;
+    }
+    ax = fmaf(w, p[0], ax); ay = fmaf(w, p[1], ay); az = fmaf(w, p[2], az);
+  }
+  ax = block_sum(ax, sm); ay = block_sum(ay, sm); az = block_sum(az, sm);
+  if (threadIdx.x == 0) { float* o = ws + (size_t)b * per + j * 3; o[0] = ax; o[1] = ay; o[2] = az; }
+}
+
+// one block (64 threads) per sample: Rodrigues, kinematic chain, pose map.
+// ws layout per sample: j0[72] | G2[24*16] | pose_map[207]
+__global__ void smpl_chain_kernel(const float* __restrict__ pose, const int* __restrict__ parents, int center_idx,
+                                  float* __restrict__ ws, float* __restrict__ joints_out) {
+  __shared__ float R[24][9];
+  __shared__ float G[24][16];
+  const int b = blockIdx.x, t = threadIdx.x;
+  float* wsb = ws + (size_t)b * (72 + 24 * 16 + 207);
+  const float* j0 = wsb;
+  if (t < 24) {
+    const float ax = pose[b * 72 + t * 3], ay = pose[b * 72 + t * 3 + 1], az = pose[b * 72 + t * 3 + 2];
+    const float ex = ax + 1e-8f, ey = ay + 1e-8f, ez = az + 1e-8f;
+    const float angle = sqrtf(ex * ex + ey * ey + ez * ez);
+    const float nx = ax / angle, ny = ay / angle, nz = az / angle;
+    const float half = angle * 0.5f, sn = sinf(half);
+    float w = cosf(half), x = sn * nx, y = sn * ny, z = sn * nz;
+    const float qn = sqrtf(w * w + x * x + y * y + z * z);
+    w /= qn; x /= qn; y /= qn; z /= qn;
+    float* r = R[t];
+    r[0] = w * w + x * x - y * y - z * z; r[1] = 2 * x * y - 2 * w * z; r[2] = 2 * w * y + 2 * x * z;
+    r[3] = 2 * w * z + 2 * x * y; r[4] = w * w - x * x + y * y - z * z; r[5] = 2 * y * z - 2 * w * x;
+    r[6] = 2 * x * z - 2 * w * y; r[7] = 2 * w * x + 2 * y * z; r[8] = w * w - x * x - y * y + z * z;
+    if (t >= 1) {
+      float* pm = wsb + 72 + 24 * 16 + (t - 1) * 9;
+      for (int e = 0; e < 9; ++e) pm[e] = r[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    for (int i = 0; i < 24; ++i) {
+      float L[16];
+      const int par = i == 0 ? -1 : parents[i];
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) L[r * 4 + c] = R[i][r * 3 + c];
+        L[r * 4 + 3] = j0[i * 3 + r] - (par >= 0 ? j0[par * 3 + r] : 0.f);
+      }
+      L[12] = L[13] = L[14] = 0.f; L[15] = 1.f;
+      if (par < 0) { for (int e = 0; e < 16; ++e) G[i][e] = L[e]; }
+      else {
+        for (int r = 0; r < 4; ++r)
+          for (int c = 0; c < 4; ++c) {
+            float s = 0.f;
+            for (int k = 0; k < 4; ++k) s = fmaf(G[par][r * 4 + k], L[k * 4 + c], s);
+            G[i][r * 4 + c] = s;
+          }
+      }
+    }
+  }
+  __syncthreads();
+  if (t < 24) {
+    float* g2 = wsb + 72 + t * 16;
+    for (int r = 0; r < 4; ++r) {
+      const float corr = G[t][r * 4] * j0[t * 3] + G[t][r * 4 + 1] * j0[t * 3 + 1] + G[t][r * 4 + 2] * j0[t * 3 + 2];
+      for (int c = 0; c < 3; ++c) g2[r * 4 + c] = G[t][r * 4 + c];
+      g2[r * 4 + 3] = G[t][r * 4 + 3] - corr;
+    }
+    float* o = joints_out + ((size_t)b * 24 + t) * 3;
+    for (int r = 0; r < 3; ++r) o[r] = G[t][r * 4 + 3] - (center_idx >= 0 ? G[center_idx][r * 4 + 3] : 0.f);
+  }
+}
+
+__global__ void smpl_verts_kernel(const float* __restrict__ betas, const float* __restrict__ vt,
+                                  const float* __restrict__ sd, const float* __restrict__ pd,
+                                  const float* __restrict__ wts, const float* __restrict__ ws, int V, int center_idx,
+                                  float* __restrict__ verts) {
+  __shared__ float g2[24 * 16];
+  __shared__ float pm[207];
+  __shared__ float bt[10];
+  __shared__ float cen[3];
+  const int b = blockIdx.y;
+  const float* wsb = ws + (size_t)b * (72 + 24 * 16 + 207);
+  for (int i = threadIdx.x; i < 24 * 16; i += blockDim.x) g2[i] = wsb[72 + i];
+  for (int i = threadIdx.x; i < 207; i += blockDim.x) pm[i] = wsb[72 + 24 * 16 + i];
+  if (threadIdx.x < 10) bt[threadIdx.x] = betas[b * 10 + threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    // joint translation of the centre joint: G[c][r][3] = G2[c][r][3] + (G[c][r][:3] . j0[c])
+    float v = 0.f;
+    if (center_idx >= 0) {
+      const int r = threadIdx.x;
+      const float* g = g2 + center_idx * 16 + r * 4;
+      const float* j = wsb + center_idx * 3;
+      v = g[3] + g[0] * j[0] + g[1] * j[1] + g[2] * j[2];
+    }
+    cen[threadIdx.x] = v;
+  }
+  __syncthreads();
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  float p[3];
+  for (int c = 0; c < 3; ++c) {
+    float s = vt[v * 3 + c];
+    const float* d = sd + ((size_t)v * 3 + c) * 10;
+    for (int k = 0; k < 10; ++k) s = fmaf(d[k], bt[k], s);
+    const float* q = pd + ((size_t)v * 3 + c) * 207;
+    for (int k = 0; k < 207; ++k) s = fmaf(q[k], pm[k], s);
+    p[c] = s;
+  }
+  float T[12];
+  for (int e = 0; e < 12; ++e) T[e] = 0.f;
+  for (int j = 0; j < 24; ++j) {
+    const float w = wts[(size_t)v * 24 + j];
+    if (w == 0.f) continue;
+    for (int e = 0; e < 12; ++e) T[e] = fmaf(w, g2[j * 16 + e], T[e]);
+  }
+  float* o = verts + ((size_t)b * V + v) * 3;
+  for (int r = 0; r < 3; ++r) o[r] = T[r * 4] * p[0] + T[r * 4 + 1] * p[1] + T[r * 4 + 2] * p[2] + T[r * 4 + 3] - cen[r];
+}
+
+// ------------------------------------------------------------------ Adam
+__global__ void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+                            float4* __restrict__ v, long n4, float b1, float b2, float eps, float step_size,
+                            float inv_sqrt_bc2) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 gv = g[i];
+    float4 mv = m[i], vv = v[i], pv = p[i];
+#define XAS_ADAM1(f)                                                   \
+    mv.f = b1 * mv.f + (1.f - b1) * gv.f;                              \
+    vv.f = b2 * vv.f + (1.f - b2) * gv.f * gv.f;                       \
+    pv.f -= step_size * mv.f / (sqrtf(vv.f) * inv_sqrt_bc2 + eps);
+    XAS_ADAM1(x) XAS_ADAM1(y) XAS_ADAM1(z) XAS_ADAM1(w)
+#undef XAS_ADAM1
+    m[i] = mv; v[i] = vv; p[i] = pv;
+  }
+}
+
+static inline unsigned ew_grid(long n, int per_block = 256) {
+  long b = cdiv(n, per_block);
+  return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace xas
+
+using namespace xas;
+
+extern "C" int xas_loss_nblk(long n) { return (int)cdiv(n, (long)kLossThreads * kLossPerThread); }
+
+extern "C" int xas_mask_loss_fwd(const float* m, const float* gt, const float* weight, long n, int mode,
+                                 float* partial, float* out, void* stream) {
+  XAS_REQUIRE(m && gt && partial && out && n > 0, "mask_loss: bad arguments");
+  XAS_REQUIRE(!(mode & 2) || weight, "mask_loss: weighted mode needs a weight map");
+  const int nblk = xas_loss_nblk(n);
+  hipLaunchKernelGGL(mask_loss_partial_kernel, dim3(nblk), dim3(kLossThreads), 0, as_stream(stream), m, gt, weight, n,
+                     mode, partial);
+  XAS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mask_loss_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial, nblk, n, mode, out);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int xas_mask_loss_bwd(const float* m, const float* gt, const float* weight, long n, int mode,
+                                 const float* out, const float* grad_scalar, float* dm, void* stream) {
+  XAS_REQUIRE(m && gt && out && grad_scalar && dm && n > 0, "mask_loss bwd: bad arguments");
+  XAS_REQUIRE(!(mode & 2) || weight, "mask_loss bwd: weighted mode needs a weight map");
+  hipLaunchKernelGGL(mask_loss_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), m, gt, weight, n, mode,
+                     out, grad_scalar, dm);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int xas_graph_aggregate(const float* x, const float* adj, int B, int N, int C, float* y, void* stream) {
+  XAS_REQUIRE(x && adj && y && B > 0 && N > 0 && C > 0, "graph_aggregate: bad arguments");
+  hipLaunchKernelGGL(graph_aggregate_kernel, dim3(ew_grid((long)B * N * C)), dim3(256), 0, as_stream(stream), x, adj, B,
+                     N, C, y);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+static int gln_nblk(long n) { long b = cdiv(n, (long)kGlnThreads * 8); return (int)(b > 256 ? 256 : (b < 1 ? 1 : b)); }
+
+extern "C" size_t xas_gln_workspace_floats(long n) { return (size_t)gln_nblk(n) * 2 + 8; }
+
+extern "C" int xas_gln_fwd(const float* x, const float* gamma, const float* beta, const float* residual, long rows,
+                           int C, float eps, float* y, float* stats, float* workspace, void* stream) {
+  XAS_REQUIRE(x && gamma && beta && y && stats && workspace && rows > 0 && C > 0, "gln_fwd: bad arguments");
+  const long n = rows * C;
+  const int nblk = gln_nblk(n);
+  hipLaunchKernelGGL(gln_partial_kernel, dim3(nblk), dim3(kGlnThreads), 0, as_stream(stream), x, n, workspace);
+  XAS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gln_stats_kernel, dim3(1), dim3(64), 0, as_stream(stream), workspace, nblk, x, n, stats);
+  XAS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gln_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), x, gamma, beta, residual,
+                     stats, n, C, eps, y);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int xas_gln_bwd(const float* x, const float* beta, const float* dy, const float* gamma,
+                           const float* stats, long rows, int C, float eps, float* dx, float* dgamma, float* dbeta,
+                           float* workspace, void* stream) {
+  XAS_REQUIRE(x && beta && dy && gamma && stats && dx && dgamma && dbeta && workspace && rows > 0 && C > 0,
+              "gln_bwd: bad arguments");
+  const long n = rows * C;
+  hipLaunchKernelGGL(gln_bwd_cols_kernel, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, as_stream(stream), x, dy, gamma,
+                     beta, stats, rows, C, eps, dgamma, dbeta);
+  XAS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gln_bwd_scalar_kernel, dim3(1), dim3(256), 0, as_stream(stream), gamma, dgamma, dbeta, C, workspace);
+  XAS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gln_bwd_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), x, dy, gamma, beta, stats,
+                     workspace, n, C, eps, dx);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int xas_smpl_lbs_fwd(const float* pose, const float* betas, const float* v_template,
+                                const float* shapedirs, const float* posedirs, const float* j_regressor,
+                                const float* weights, const int* parents, int B, int V, int center_idx, float* verts,
+                                float* joints, float* workspace, void* stream) {
+  XAS_REQUIRE(pose && betas && v_template && shapedirs && posedirs && j_regressor && weights && parents && verts &&
+                  joints && workspace, "smpl_lbs: null buffer");
+  XAS_REQUIRE(B > 0 && V > 0 && center_idx < 24, "smpl_lbs: bad shape");
+  hipStream_t st = as_stream(stream);
+  const int per = 72 + 24 * 16 + 207;      // per-sample record: j0 | G' | pose map
+  hipLaunchKernelGGL(smpl_joints_kernel, dim3(B, 24), dim3(256), 0, st, betas, v_template, shapedirs, j_regressor, V,
+                     workspace, per);
+  XAS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(smpl_chain_kernel, dim3(B), dim3(64), 0, st, pose, parents, center_idx, workspace, joints);
+  XAS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(smpl_verts_kernel, dim3((unsigned)cdiv(V, 128), B), dim3(128), 0, st, betas, v_template, shapedirs,
+                     posedirs, weights, workspace, V, center_idx, verts);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int xas_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                             float eps, int step, void* stream) {
+  XAS_REQUIRE(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1, "adam: bad arguments (n must be a multiple of 4)");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, as_stream(stream), reinterpret_cast<float4*>(p),
+                     reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v),
+                     n / 4, beta1, beta2, eps, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)));
+  XAS_LAUNCH_CHECK();
+  return 0;
+}

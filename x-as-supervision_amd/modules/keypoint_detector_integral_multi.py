@@ -1,0 +1,31 @@
+"""Multi-hypothesis 3-D key-point detector (reference: modules/keypoint_detector_integral_multi.py:7-88).
+
+`net` (ResNet-50 + deconv head) produces logits [B, K*D, 64, 64] with NHWC storage; the softmax over
+D*H*W, the three marginals, the depth-peak top-k and the windowed expectations run as ONE fused HIP
+reduction that reads the logits once (xas_head_softargmax_fwd) instead of ~15 ATen kernels and five
+passes over a 604 MB tensor.  Ties between equal peak scores resolve to the lower depth bin.
+"""
+import torch.nn as nn
+
+from modules.integral_base_modules.network import get_default_network_config, get_pose_net
+from xas_amd import ops_head
+
+
+class KPDetector3DMulti(nn.Module):
+    def __init__(self, name, num_kp, depth_dim, num_hypo, neighbor_size, num_layers=50):
+        super().__init__()
+        cfg = get_default_network_config()
+        cfg.depth_dim = depth_dim
+        cfg.num_layers = num_layers
+        self.num_hypo = num_hypo
+        self.neighbor_size = neighbor_size
+        self.num_kp = num_kp
+        self.net = get_pose_net(cfg, num_joints=num_kp)
+        self.name = name
+        self.last_peak_indices = None      # int64 [B, K, num_hypo] of the latest forward (diagnostics / tests)
+
+    def forward(self, x):
+        heatmap = self.net(x)
+        kps, depth_prob_map, idx = ops_head.softargmax_multi(heatmap, self.num_kp, self.num_hypo, self.neighbor_size)
+        self.last_peak_indices = idx
+        return kps, depth_prob_map

@@ -37,6 +37,7 @@ SIGNATURES = {
     'xas_unpack_weight': ('ppiiiiip', 'i'),
     'xas_bn_workspace_floats': ('li', 'z'),
     'xas_bn_stats': ('plipppp', 'i'),
+    'xas_col_sum': ('plippp', 'i'),
     'xas_bn_apply': ('ppppppfilipp', 'i'),
     'xas_bn_update_running': ('ppppflip', 'i'),
     'xas_bn_bwd_reduce': ('pppppfilipppp', 'i'),

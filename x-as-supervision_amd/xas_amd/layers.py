@@ -1,0 +1,98 @@
+"""nn.Module wrappers with torch-compatible parameter names (weight, bias, running_mean, ...), so
+reference checkpoints load unchanged, running on the HIP ops."""
+import math
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import ops_nn as F
+
+
+def _kaiming_fan_out_(w):
+    """nn.init.kaiming_normal_(mode='fan_out', nonlinearity='relu') (resnet.py:28, deconv_head.py:45,53)."""
+    fan_out = w.shape[0] * w[0][0].numel()
+    with torch.no_grad():
+        w.normal_(0.0, math.sqrt(2.0 / fan_out))
+
+
+class Conv2d(nn.Module):
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True, init='default'):
+        super().__init__()
+        self.stride, self.padding = stride, padding
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        if init == 'kaiming_fan_out':
+            _kaiming_fan_out_(self.weight)
+        else:                                   # torch.nn.Conv2d default
+            nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+            if bias:
+                bound = 1 / math.sqrt(cin * k * k)
+                nn.init.uniform_(self.bias, -bound, bound)
+        self._cache = F._PackCache()
+
+    def forward(self, x):
+        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self._cache)
+
+
+class ConvTranspose2d(nn.Module):
+    """weight layout [Cin, Cout, k, k] as torch.nn.ConvTranspose2d; no bias (deconv_head.py:27-29)."""
+
+    def __init__(self, cin, cout, k, stride, padding):
+        super().__init__()
+        self.stride, self.padding = stride, padding
+        self.weight = nn.Parameter(torch.empty(cin, cout, k, k))
+        _kaiming_fan_out_(self.weight)
+        self._cache = F._PackCache()
+
+    def forward(self, x):
+        return F.conv_transpose2d(x, self.weight, self.stride, self.padding, self._cache)
+
+
+class Linear(nn.Module):
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1 / math.sqrt(cin)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        return F.linear(x, self.weight, self.bias)
+
+
+class BatchNorm2d(nn.Module):
+    """Training-mode batch norm fused with the following activation (and residual add).
+    sync=True reproduces nn.SyncBatchNorm: statistics are exchanged across the default process
+    group when one is initialised with world_size > 1 (resnet.py:18,40; deconv_head.py:30;
+    physique_network.py:18,25,33); otherwise it is rank-local like torchvision's BatchNorm2d."""
+
+    def __init__(self, c, act=F.ACT_NONE, sync=False, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.act, self.sync, self.eps, self.momentum = act, sync, eps, momentum
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer('running_mean', torch.zeros(c))
+        self.register_buffer('running_var', torch.ones(c))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x, residual=None):
+        group = None
+        if self.sync and self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            group = dist.group.WORLD
+        if self.training:
+            self.num_batches_tracked += 1
+        return F.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, residual, self.training,
+                            self.momentum, self.eps, self.act, group)
+
+
+class MaxPool3x3s2(nn.Module):
+    def forward(self, x):
+        return F.maxpool3x3s2(x)
+
+
+class Upsample2x(nn.Module):
+    def forward(self, x):
+        return F.upsample2x(x)

@@ -1,0 +1,343 @@
+"""Layer ops (conv / conv-transpose / linear / batch-norm / pool / upsample / sigmoid) as
+autograd Functions over the C ABI.  Activations are torch channels_last tensors: logically
+[N,C,H,W] like the reference, physically NHWC like the kernels want."""
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import ConvShape, call, ptr, query
+
+CL = torch.channels_last
+_weights_epoch = [0]          # bumped by the fused optimizer (raw-pointer updates bypass tensor._version)
+
+
+def bump_weights_epoch():
+    _weights_epoch[0] += 1
+
+
+def to_cl(x):
+    """Return x with NHWC storage (no copy when it already has it)."""
+    if x.dim() != 4:
+        raise RuntimeError('expected a 4-D activation tensor')
+    return x if x.is_contiguous(memory_format=CL) else x.contiguous(memory_format=CL)
+
+
+def empty_cl(n, c, h, w, like):
+    return torch.empty((n, c, h, w), device=like.device, dtype=torch.float32, memory_format=CL)
+
+
+def from_nchw(x):
+    """[N,C,H,W] contiguous NCHW image batch -> channels_last tensor (xas_nchw_to_nhwc)."""
+    if x.is_contiguous(memory_format=CL):
+        return x
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    y = empty_cl(n, c, h, w, x)
+    call('xas_nchw_to_nhwc', ptr(x), n, c, h, w, ptr(y))
+    return y
+
+
+def _shape(n, hi, wi, cin, cout, r, s, stride, pad, ho, wo):
+    return ConvShape(n, hi, wi, cin, cout, r, s, stride, pad, ho, wo)
+
+
+class _PackCache:
+    """Packed copies of a weight, rebuilt when the parameter changes."""
+
+    def __init__(self):
+        self.key = None
+        self.packed = {}
+
+    def get(self, w, transposed):
+        key = (w.data_ptr(), w._version, _weights_epoch[0])
+        if key != self.key:
+            self.key, self.packed = key, {}
+        if transposed not in self.packed:
+            co, ci, r, s = w.shape
+            p = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+            call('xas_pack_weight', ptr(w.detach().contiguous()), ptr(p), co, ci, r, s, int(transposed))
+            self.packed[transposed] = p
+        return self.packed[transposed]
+
+
+def _col_sum(t2d_ptr_tensor, M, C):
+    out = torch.empty(C, device=t2d_ptr_tensor.device, dtype=torch.float32)
+    ws = torch.empty(query('xas_bn_workspace_floats', M, C), device=out.device, dtype=torch.float32)
+    call('xas_col_sum', ptr(t2d_ptr_tensor), M, C, ptr(out), ptr(ws))
+    return out
+
+
+def _bias_grad(dy, M, C):
+    if C % 4 == 0:
+        return _col_sum(dy, M, C)
+    # C == 1 (mask output conv, logit layer): a plain sum of a contiguous vector
+    return dy.reshape(M, C).sum(0)
+
+
+def _wgrad(x, dy, shp, w_shape, transposed=False):
+    """-> gradient in OIHW layout for a conv described by shp (x: gathered side, dy: row side)."""
+    co, ci, r, s = shp.Cout, shp.Cin, shp.R, shp.S
+    dwp = torch.empty(co * ci * r * s, device=x.device, dtype=torch.float32)
+    ws = torch.empty(max(1, query('xas_conv_wgrad_workspace_floats', shp)), device=x.device, dtype=torch.float32)
+    call('xas_conv_wgrad', ptr(x), ptr(dy), ptr(dwp), ptr(ws), shp)
+    dw = torch.empty(w_shape, device=x.device, dtype=torch.float32)
+    call('xas_unpack_weight', ptr(dwp), ptr(dw), co, ci, r, s, 0)
+    return dw
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, cache):
+        x = to_cl(x)
+        n, ci, hi, wi = x.shape
+        co, ci2, r, s = weight.shape
+        if ci != ci2:
+            raise RuntimeError('conv2d: input has %d channels, weight expects %d' % (ci, ci2))
+        ho, wo = (hi + 2 * pad - r) // stride + 1, (wi + 2 * pad - s) // stride + 1
+        shp = _shape(n, hi, wi, ci, co, r, s, stride, pad, ho, wo)
+        y = empty_cl(n, co, ho, wo, x)
+        call('xas_conv_fwd', ptr(x), ptr(cache.get(weight, 0)), ptr(bias), ptr(y), shp)
+        ctx.save_for_backward(x, weight)
+        ctx.shp, ctx.cache, ctx.has_bias = shp, cache, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        shp = ctx.shp
+        dy = to_cl(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            call('xas_conv_dgrad', ptr(dy), ptr(ctx.cache.get(weight, 1)), ptr(dx), shp)
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad(x, dy, shp, weight.shape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _bias_grad(dy, shp.N * shp.Ho * shp.Wo, shp.Cout)
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, weight, bias, stride, pad, cache):
+    return _Conv2d.apply(x, weight, bias, stride, pad, cache)
+
+
+class _ConvTranspose2d(torch.autograd.Function):
+    """y = conv_transpose2d(x, weight[Cin_t, Cout_t, R, S], stride, pad) == data-gradient of the conv
+    whose OIHW weight has the same memory layout (deconv_head.py:27-29)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad, cache):
+        x = to_cl(x)
+        n, cit, h, w = x.shape
+        cit2, cot, r, s = weight.shape
+        if cit != cit2:
+            raise RuntimeError('conv_transpose2d: channel mismatch')
+        hb, wb = (h - 1) * stride - 2 * pad + r, (w - 1) * stride - 2 * pad + s
+        # equivalent conv: big side (hb,wb,cot) -> small side (h,w,cit)
+        shp = _shape(n, hb, wb, cot, cit, r, s, stride, pad, h, w)
+        y = empty_cl(n, cot, hb, wb, x)
+        call('xas_conv_dgrad', ptr(x), ptr(cache.get(weight, 1)), ptr(y), shp)
+        ctx.save_for_backward(x, weight)
+        ctx.shp, ctx.cache = shp, cache
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        shp = ctx.shp
+        dy = to_cl(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            call('xas_conv_fwd', ptr(dy), ptr(ctx.cache.get(weight, 0)), None, ptr(dx), shp)
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad(dy, x, shp, weight.shape)
+        return dx, dw, None, None, None
+
+
+def conv_transpose2d(x, weight, stride, pad, cache):
+    return _ConvTranspose2d.apply(x, weight, stride, pad, cache)
+
+
+class _Linear(torch.autograd.Function):
+    """y = x @ W^T + b as a 1x1 'convolution' over rows (discriminator.py:8-21, 186-191)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        rows, ci = x.shape
+        co = weight.shape[0]
+        shp = _shape(rows, 1, 1, ci, co, 1, 1, 1, 0, 1, 1)
+        y = torch.empty(rows, co, device=x.device, dtype=torch.float32)
+        call('xas_conv_fwd', ptr(x), ptr(weight.detach().contiguous()), ptr(bias), ptr(y), shp)
+        ctx.save_for_backward(x, weight)
+        ctx.shp, ctx.has_bias = shp, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        shp = ctx.shp
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().t().contiguous()            # [Cin][Cout]
+            dx = torch.empty_like(x)
+            call('xas_conv_dgrad', ptr(dy), ptr(wt), ptr(dx), shp)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            ws = torch.empty(max(1, query('xas_conv_wgrad_workspace_floats', shp)), device=x.device, dtype=torch.float32)
+            call('xas_conv_wgrad', ptr(x), ptr(dy), ptr(dw), ptr(ws), shp)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _bias_grad(dy, shp.N, shp.Cout)
+        return dx, dw, db
+
+
+def linear(x, weight, bias):
+    return _Linear.apply(x, weight, bias)
+
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+def _sync_stats(mean, var, count, group):
+    """SyncBatchNorm statistic exchange: ONE all_gather of [mean | var | count] per layer
+    (torch issues all_gather of mean/invstd/count: _functions.SyncBatchNorm.forward)."""
+    world = dist.get_world_size(group)
+    C = mean.numel()
+    packed = torch.cat([mean, var, mean.new_tensor([float(count)])])
+    gathered = torch.empty(world * (2 * C + 1), device=mean.device, dtype=torch.float32)
+    dist.all_gather_into_tensor(gathered, packed, group=group)
+    g = gathered.view(world, 2 * C + 1)
+    cnt = g[:, 2 * C:]                                    # [world,1]
+    total = cnt.sum()
+    gm = (g[:, :C] * cnt).sum(0) / total
+    gv = ((g[:, C:2 * C] + g[:, :C] ** 2) * cnt).sum(0) / total - gm * gm
+    return gm.contiguous(), gv.clamp_min_(0).contiguous()
+
+
+class _BatchNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, group):
+        x = to_cl(x)
+        n, c, h, w = x.shape
+        M = n * h * w
+        dev = x.device
+        count = float(M)
+        if training:
+            mean = torch.empty(c, device=dev, dtype=torch.float32)
+            var = torch.empty(c, device=dev, dtype=torch.float32)
+            ws = torch.empty(query('xas_bn_workspace_floats', M, c), device=dev, dtype=torch.float32)
+            call('xas_bn_stats', ptr(x), M, c, ptr(mean), ptr(var), ptr(ws))
+            if group is not None:
+                mean, var = _sync_stats(mean, var, M, group)
+                count = float(M) * dist.get_world_size(group)     # equal per-rank batches (train.py:274)
+            if running_mean is not None:
+                call('xas_bn_update_running', ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
+                     float(momentum), int(count), c)
+        else:
+            mean, var = running_mean, running_var
+        res = to_cl(residual) if residual is not None else None
+        y = torch.empty_like(x)
+        call('xas_bn_apply', ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(res), float(eps), act, M, c, ptr(y))
+        ctx.save_for_backward(x, y, mean, var, gamma)
+        ctx.cfg = (M, c, float(eps), act, count, group, training, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, var, gamma = ctx.saved_tensors
+        M, c, eps, act, count, group, training, has_res = ctx.cfg
+        if not training:
+            raise RuntimeError('batch-norm backward in eval mode is not part of the training path')
+        dy = to_cl(dy)
+        dev = x.device
+        sdz = torch.empty(2 * c, device=dev, dtype=torch.float32)
+        ws = torch.empty(query('xas_bn_workspace_floats', M, c), device=dev, dtype=torch.float32)
+        call('xas_bn_bwd_reduce', ptr(x), ptr(y), ptr(dy), ptr(mean), ptr(var), eps, act, M, c, ptr(sdz),
+             ptr(sdz[c:]), ptr(ws))
+        dgamma, dbeta = sdz[c:].clone(), sdz[:c].clone()      # local sums: DDP averages parameter grads later
+        if group is not None:
+            dist.all_reduce(sdz, group=group)                 # one coalesced 2C message per layer
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        call('xas_bn_bwd_apply', ptr(x), ptr(y), ptr(dy), ptr(mean), ptr(var), ptr(gamma), ptr(sdz), ptr(sdz[c:]), eps,
+             act, M, c, float(count), ptr(dx), ptr(dres))
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, residual=None, training=True, momentum=0.1, eps=1e-5,
+               act=ACT_NONE, group=None):
+    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, group)
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = to_cl(x)
+        n, c, h, w = x.shape
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = empty_cl(n, c, ho, wo, x)
+        idx = torch.empty(n * ho * wo * c, device=x.device, dtype=torch.int8)
+        call('xas_maxpool3x3s2_fwd', ptr(x), n, h, w, c, ptr(y), ptr(idx))
+        ctx.save_for_backward(idx)
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        n, c, h, w = ctx.shape
+        dy = to_cl(dy)
+        dx = empty_cl(n, c, h, w, dy)
+        call('xas_maxpool3x3s2_bwd', ptr(dy), ptr(idx), n, h, w, c, ptr(dx))
+        return dx
+
+
+def maxpool3x3s2(x):
+    return _MaxPool.apply(x)
+
+
+class _Upsample2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = to_cl(x)
+        n, c, h, w = x.shape
+        y = empty_cl(n, c, 2 * h, 2 * w, x)
+        call('xas_upsample2x_fwd', ptr(x), n, h, w, c, ptr(y))
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w = ctx.shape
+        dy = to_cl(dy)
+        dx = empty_cl(n, c, h, w, dy)
+        call('xas_upsample2x_bwd', ptr(dy), n, h, w, c, ptr(dx))
+        return dx
+
+
+def upsample2x(x):
+    return _Upsample2x.apply(x)
+
+
+class _Sigmoid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous() if x.dim() != 4 else to_cl(x)
+        y = torch.empty_like(x)
+        call('xas_sigmoid_fwd', ptr(x), x.numel(), ptr(y))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous() if dy.dim() != 4 else to_cl(dy)
+        dx = torch.empty_like(y)
+        call('xas_sigmoid_bwd', ptr(y), ptr(dy), y.numel(), ptr(dx))
+        return dx
+
+
+def sigmoid(x):
+    return _Sigmoid.apply(x)
