@@ -1,0 +1,228 @@
+"""GPU parity of the physique net, GCN discriminator, SMPL layer, fused Adam, the model wiring and the
+full optimisation step (HIP path through the C ABI) against goldens / the CPU oracle."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import inputs as gi
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def maxabs(a, b):
+    return float((a.detach().cpu() - b.detach().cpu()).abs().max())
+
+
+def test_physique_net_vs_golden():
+    from modules.physique_network import PhysiqueMaskGenerator
+    from oracle.nets import PhysiqueNet
+    g = golden('physique')
+    ora = gi.seeded_fill_(PhysiqueNet([32, 64, 128]), seed=51)
+    net = PhysiqueMaskGenerator([32, 64, 128])
+    assert list(net.state_dict().keys()) == g['keys'].tolist()
+    net.load_state_dict(ora.state_dict(), strict=True)
+    net.cuda().train()
+    x = T(g['x']).cuda().requires_grad_(True)
+    y = net(x)
+    assert maxabs(y, T(g['y'])) < 5e-6
+    (y * T(g['grad_out']).cuda()).sum().backward()
+    assert rel(x.grad, T(g['grad_x'])) < 2e-4
+    assert rel(net.encoder[0][0].weight.grad, T(g['grad_enc0_w'])) < 2e-4
+    assert rel(net.decoder[4].bias.grad, T(g['grad_dec4_b'])) < 2e-4
+    assert abs(float(net.decoder[1][1].weight.grad.norm()) / float(g['grad_dec1_w_norm']) - 1) < 2e-4
+    sd = net.state_dict()
+    assert maxabs(sd['encoder.0.1.running_mean'], T(g['run_mean_enc0'])) < 1e-6
+    assert maxabs(sd['encoder.0.1.running_var'], T(g['run_var_enc0'])) < 1e-6
+
+
+def _discs(seed=7):
+    from modules.discriminator import GCNDiscriminatorDecouple
+    from modules.model import cal_links
+    from oracle.nets import GCNDecouple
+    cfg = gi.model_params('S2')['smpl_disc_params']
+    ora = gi.seeded_fill_(GCNDecouple(cfg), seed=seed, gain=1.0)
+    hip = GCNDiscriminatorDecouple(cfg)
+    assert sorted(hip.state_dict().keys()) == sorted(ora.state_dict().keys())
+    hip.load_state_dict(ora.state_dict(), strict=True)
+    p, c = cal_links(gi.HM36_PARENTS, gi.LINE_SELECT, use_root=False, extension=False)
+    ora.parent_ids, ora.child_ids = p, c
+    hip.parent_ids, hip.child_ids = p, c
+    return hip.cuda(), ora
+
+
+@pytest.mark.parametrize('B', [2, 32])
+def test_gcn_discriminator_vs_oracle(B):
+    hip, ora = _discs()
+    g = torch.Generator().manual_seed(B)
+    kp = torch.randn(B, 18, 3, generator=g) * 0.5
+    keep = (torch.rand(B, 512, generator=g) >= 0.2).float()
+    kc = kp.clone().requires_grad_(True)
+    yo = ora(kc, drop_mask=keep)
+    gy = torch.randn(B, 1, generator=g)
+    (yo * gy).sum().backward()
+    hip.train()
+    hip.header.drop_mask = keep.cuda()
+    kg = kp.cuda().requires_grad_(True)
+    yg = hip(kg)
+    assert yg.shape == (B, 1)
+    (yg * gy.cuda()).sum().backward()
+    assert maxabs(yg, yo) < 2e-5 * max(1.0, float(yo.abs().max()))
+    assert rel(kg.grad, kc.grad) < 1e-4
+    po = dict(ora.named_parameters())
+    for n, p in hip.named_parameters():
+        assert rel(p.grad, po[n].grad) < 2e-4, n
+    hip.eval()
+    assert maxabs(hip(kp.cuda()), ora(kp)) < 2e-5 * max(1.0, float(yo.abs().max()))
+
+
+def test_smpl_layer_vs_golden():
+    from modules.smplpytorch.pytorch.smpl_layer import SMPL_Layer
+    from modules.util import smpl_to_h36m
+    g = golden('smpl')
+    buf = gi.smpl_buffers(seed=71)
+    lay = SMPL_Layer.from_arrays(buf, center_idx=0).cuda()
+    verts, jtr = lay(T(g['pose']).cuda(), T(g['betas']).cuda())
+    assert verts.shape == (3, 6890, 3) and jtr.shape == (3, 24, 3)
+    assert maxabs(verts[:, ::10], T(g['verts_sub'])) < 3e-5
+    assert maxabs(jtr, T(g['joints'])) < 3e-5
+    assert maxabs(smpl_to_h36m(verts, T(buf['h36m_regressor']).cuda()), T(g['h36m'])) < 3e-5
+    assert 'th_posedirs' in lay.state_dict() and 'th_weights' in lay.state_dict()
+
+
+def test_fused_adam_vs_torch():
+    from xas_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(0)
+    shapes = [(64, 3, 7, 7), (64,), (17, 5), (1,), (128, 64, 3, 3)]
+    ps = [torch.randn(s, generator=g) for s in shapes]
+    a = [nn.Parameter(p.clone().cuda()) for p in ps]
+    b = [nn.Parameter(p.clone()) for p in ps]
+    oa = FusedAdam(a, lr=2e-4, betas=(0.5, 0.999))
+    ob = torch.optim.Adam(b, lr=2e-4, betas=(0.5, 0.999))
+    for it in range(3):
+        for pa, pb in zip(a, b):
+            gr = torch.randn(pb.shape, generator=g) * (0.1 + it)
+            pb.grad = gr.clone()
+            if pa.grad is None:
+                oa.zero_grad()
+            pa.grad.copy_(gr.cuda())
+        oa.step()
+        ob.step()
+        oa.zero_grad()
+        ob.zero_grad()
+    for pa, pb in zip(a, b):
+        assert maxabs(pa, pb) < 2e-7
+        assert float(pa.grad.abs().max()) == 0.0
+    sd = oa.state_dict()
+    assert set(sd['state'][0].keys()) == {'step', 'exp_avg', 'exp_avg_sq'}
+    assert maxabs(sd['state'][4]['exp_avg'], ob.state_dict()['state'][4]['exp_avg']) < 1e-6
+
+
+class LinearDisc(nn.Module):
+    name = 'LinearStandIn'
+
+    def __init__(self):
+        super().__init__()
+        self.fc = nn.Linear(54, 1)
+
+    def forward(self, kp):
+        return self.fc(kp.reshape(kp.shape[0], -1))
+
+
+def _hip_models(stage, cam_ids):
+    from modules.keypoint_detector_integral_multi import KPDetector3DMulti
+    from modules.physique_network import PhysiqueMaskGenerator
+    from oracle import step as ostep
+    from oracle.nets import PhysiqueNet
+    ora_reg = gi.seeded_fill_(ostep.Regressor('resnet_multi', 18, 64, 3, 15), seed=61)
+    with torch.no_grad():
+        ora_reg.net.head.features[9].bias.copy_(T(gi.planted_depth_bias(18, 64, seed=62)))
+    ora_phys = gi.seeded_fill_(PhysiqueNet([32, 64, 128]), seed=81)
+    reg = KPDetector3DMulti('resnet_multi', 18, 64, 3, 15)
+    reg.load_state_dict(ora_reg.state_dict())
+    phys = PhysiqueMaskGenerator([32, 64, 128])
+    phys.load_state_dict(ora_phys.state_dict())
+    return reg.cuda().train(), phys.cuda().train(), ora_reg.train(), ora_phys.train()
+
+
+@pytest.mark.parametrize('stage', ['S1', 'S2'])
+def test_model_wiring_vs_golden(stage):
+    from modules.model import Counter3DDisc, Counter3DModel
+    g = golden('model_HM36_Multi_Sur' + stage)
+    cfg = gi.model_params(stage, cam_ids=(0, 1))
+    reg, phys, _, _ = _hip_models(stage, (0, 1))
+    disc = gi.seeded_fill_(LinearDisc(), seed=82).cuda()
+    gen = Counter3DModel(cfg, reg, None, None, phys)
+    dis = Counter3DDisc(cfg, disc, None, None)
+    x = {k: T(v).cuda() for k, v in gi.synthetic_batch(2, [0, 1], seed=83).items()}
+    ld, info = dis(x, gen.regressor)
+    assert abs(float(ld) - float(g['loss_disc'])) < 1e-5 + 2e-4 * abs(float(g['loss_disc']))
+    ld.mean().backward()
+    assert rel(disc.fc.weight.grad, T(g['grad_disc_w'])) < 2e-3 or float(T(g['grad_disc_w']).norm()) == 0
+    disc.zero_grad()
+    losses, out = gen(x, dis.smpl_discriminator)
+    for k, v in losses.items():
+        ref = float(g['loss_' + k])
+        assert abs(float(v.mean()) - ref) < 1e-5 + 3e-4 * abs(ref), (k, float(v.mean()), ref)
+    tot = sum(v.mean() for v in losses.values())
+    assert abs(float(tot) - float(g['total'])) < 1e-5 + 3e-4 * abs(float(g['total']))
+    tot.backward()
+    w = out['pose_3d_depth_cam_0']
+    assert maxabs(w, T(g['pose_3d_cam_0'])) < 0.2                # mm, |coords| ~ 1e3..1e4
+    assert maxabs(out['kp_gt_world'], T(g['kp_gt_world'])) < 0.05
+    assert maxabs(out['mask_heatmap_line_cam_1'][:, :, ::4, ::4], T(g['mask_line_sub'])) < 2e-4
+    p = dict(reg.named_parameters())
+    assert rel(p['net.head.features.9.bias'].grad, T(g['g_fin_b'])) < 3e-2
+    assert rel(p['net.backbone.conv1.weight'].grad, T(g['g_conv1'])) < 5e-2
+    if float(T(g['g_phys_dec4_w']).norm()) > 0:
+        assert rel(phys.decoder[4].weight.grad, T(g['g_phys_dec4_w'])) < 3e-2
+    for key in ('pose_2d_pred_cam_0_ori', 'depth_map_cam_0', 'pose_3d_gt_cam_0_pseudo', 'mask_physique_cam_0',
+                'pose_2d_pred_cam_1_pseudo'):
+        assert key in out
+    for key in ('pose_smpl_2d_cam_0', 'pose_smpl_3d_cam_1', 'smpl_logits_cam_0', 'pred_logits_cam_1'):
+        assert key in info
+
+
+def test_full_train_step_vs_oracle():
+    """disc + gen step with the real GCN discriminator and Adam: losses of two consecutive steps."""
+    from modules.discriminator import GCNDiscriminatorDecouple
+    from modules.model import Counter3DDisc, Counter3DModel
+    from oracle import step as ostep
+    from oracle.nets import GCNDecouple
+    from xas_amd.engine import TrainStep
+    from xas_amd.optim import FusedAdam
+    cfg = gi.model_params('S2', cam_ids=(0, 1))
+    full = {'model_params': cfg, 'train_params': {'lr_kp_detector': 1e-4, 'lr_discriminator': 1e-4}}
+    reg, phys, oreg, ophys = _hip_models('S2', (0, 1))
+    odisc = gi.seeded_fill_(GCNDecouple(cfg['smpl_disc_params']), seed=9)
+    disc = GCNDiscriminatorDecouple(cfg['smpl_disc_params'])
+    disc.load_state_dict(odisc.state_dict())
+    disc.cuda().train()
+    disc.header.p = 0.0                                         # no dropout on either side
+    gen, dis = Counter3DModel(cfg, reg, None, None, phys), Counter3DDisc(cfg, disc, None, None)
+    odisc.parent_ids, odisc.child_ids = dis.parent_ids, dis.child_ids
+    opt_det = FusedAdam(list(reg.parameters()) + list(phys.parameters()), lr=1e-4, betas=(0.5, 0.999))
+    opt_disc = FusedAdam(disc.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    o_det = torch.optim.Adam(list(oreg.parameters()) + list(ophys.parameters()), lr=1e-4, betas=(0.5, 0.999))
+    o_disc = torch.optim.Adam(odisc.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    step = TrainStep(full, gen, dis, opt_det, opt_disc)
+    xn = gi.synthetic_batch(2, [0, 1], seed=91)
+    xg = {k: T(v).cuda() for k, v in xn.items()}
+    xc = {k: T(v) for k, v in xn.items()}
+    for it in range(2):
+        ld, lk, tot, _ = step(xg)
+        old, olk = ostep.train_step(cfg, oreg, ophys, odisc, o_det, o_disc, xc)
+        tol = 3e-4 if it == 0 else 2e-2     # step 2 sees weights after one Adam step (sign-like update: chaotic where g ~ 0)
+        assert abs(float(ld) - float(old)) < 1e-5 + tol * abs(float(old)), (it, float(ld), float(old))
+        for k in olk:
+            assert abs(float(lk[k].mean()) - float(olk[k])) < 1e-5 + tol * abs(float(olk[k])), (it, k, float(lk[k].mean()), float(olk[k]))
+    assert torch.isfinite(opt_det.param_arena).all()

@@ -1,0 +1,60 @@
+"""Losses of the training step (reference: modules/base_losses/loss_func.py:4-76).
+
+The two mask losses (2 M pixels each, 8 per step) are fused HIP reductions; the joint-level losses act on
+[B,18,3] tensors and are composed from a handful of device ops.
+"""
+import torch
+
+from xas_amd import ops_misc
+
+_LIMB_FAR = [16, 15, 13, 12, 3, 2, 6, 5]
+_LIMB_NEAR = [15, 14, 12, 11, 2, 1, 5, 4]
+
+
+def compute_mask_reconstruction_loss(mask, gt, weight=None, use_clip=False):
+    """MSE(mask, gt) with optional clip (mask > 0.1) and geodesic weight map (loss_func.py:4-16).
+    Returns the SCALAR the trainer reduces to: with weight=None and use_clip=True the reference returns
+    the tensor mse * clip and takes .mean() at train.py:182; the value is identical."""
+    return ops_misc.mask_loss(mask, gt, weight, use_clip)
+
+
+def compute_bone_sym_loss(keypoints):
+    limb = (keypoints[:, _LIMB_FAR] - keypoints[:, _LIMB_NEAR]).norm(dim=2) * 1e-3
+    return ((limb[:, 0::2] - limb[:, 1::2]) ** 2).mean()
+
+
+def compute_kp_sym_loss(keypoints, is_3D=True):
+    mid = (keypoints[:, [11, 1]] + keypoints[:, [14, 4]]) / 2
+    anchor = keypoints[:, [-1, 0]]
+    if is_3D:
+        return ((mid * 1e-3 - anchor * 1e-3) ** 2).mean()
+    return ((mid - anchor) ** 2).mean()
+
+
+def compute_supervision(keypoint, keypoint_gt, feature_shape=None, mode='mean'):
+    if feature_shape is not None:
+        scale = keypoint.new_tensor([feature_shape[0] - 1, feature_shape[1] - 1] +
+                                    ([feature_shape[2] - 1] if keypoint.shape[-1] == 3 else []))
+        xy = (keypoint[..., :2] + 1) / 2.0
+        keypoint = torch.cat([xy, keypoint[..., 2:]], dim=-1) * scale
+    err = (keypoint - keypoint_gt) ** 2
+    if mode == 'mean':
+        return err.mean()
+    if mode == 'sum':
+        return err.sum() / keypoint.shape[0]
+    return err
+
+
+def _lsgan(logits, target):
+    err = (logits - target) ** 2
+    if logits.dim() == 2:
+        return err.mean()
+    if logits.dim() == 3:
+        return err.min(dim=1)[0].mean()           # best hypothesis per sample
+    raise ValueError('Invalid dimension of logits')
+
+
+def compute_disc_loss(pred_logits, gt_logits):
+    if gt_logits is None:
+        return _lsgan(pred_logits, 1.0)
+    return 0.5 * _lsgan(gt_logits, 1.0) + 0.5 * _lsgan(pred_logits, 0.0)

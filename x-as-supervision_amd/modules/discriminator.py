@@ -1,0 +1,129 @@
+"""GCN pose discriminators (reference: modules/discriminator.py:8-238).
+
+Only `GCNDiscriminatorDecouple` (config name 'res_sage_gcn_decouple', every shipped YAML) and
+`GCNSAGEDiscriminator` are built on the HIP kernels; `GCNDiscriminator` (GCNConv with bone-length edge
+weights, unused by the shipped configs) raises NotImplementedError when constructed.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from modules.gcn import GCN_SAGE_residual
+from xas_amd import layers as L
+
+
+class FFNHeader(nn.Module):
+    def __init__(self, in_channels, hidden_channels, p_dropout=0.2):
+        super().__init__()
+        self.layer1 = L.Linear(in_channels, hidden_channels)
+        self.layer2 = L.Linear(hidden_channels, 1)
+        self.p = p_dropout
+        self.drop_mask = None          # tests inject a keep-mask to make train-mode outputs reproducible
+
+    def forward(self, x):
+        h = torch.relu(self.layer1(x))
+        if self.training and self.p > 0:
+            keep = self.drop_mask if self.drop_mask is not None else (torch.rand_like(h) >= self.p).to(h.dtype)
+            h = h * keep / (1.0 - self.p)
+        return self.layer2(h)
+
+
+class GCNDiscriminator_base(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.input_dim = cfg['input_dim']
+        self.hidden_dim = cfg['hidden_dim']
+        self.output_dim = cfg['output_dim']
+        self.disc_sup_dim = cfg['disc_sup_dim']
+        self.num_nodes = cfg['num_node']
+        self.use_self_loop = cfg['use_self_loop']
+        self.input_layer = nn.Identity()
+        self.gcn = nn.Identity()
+        self.header = L.Linear(self.output_dim * self.num_nodes, 1)
+        self.parent_ids, self.child_ids = None, None
+        self._graph_key, self._graph = None, None
+        self._pe = {}
+
+    def cal_positional_encoding(self, keypoints):
+        """PE[i,j] = sin(i / 10000^(2j/C)) for even j, cos for odd j; i = node index (discriminator.py:42-51)."""
+        B, J, C = keypoints.shape
+        key = (J, C, keypoints.device)
+        if key not in self._pe:
+            pe = torch.tensor([[math.sin(i / 10000 ** (2 * j / C)) if j % 2 == 0 else math.cos(i / 10000 ** (2 * j / C))
+                                for j in range(C)] for i in range(J)], dtype=torch.float32)
+            self._pe[key] = pe.to(keypoints.device)
+        return self._pe[key].unsqueeze(0).expand(B, J, C)
+
+    def graph(self, batch_size, device):
+        """Constant dense mean-aggregation matrix for the skeleton set by Counter3DDisc (model.py:208-210);
+        equivalent to the edge list of compute_graph_matrix (discriminator.py:53-68)."""
+        key = (tuple(self.parent_ids), tuple(self.child_ids), str(device))
+        if key != self._graph_key:
+            n = self.num_nodes
+            a = torch.eye(n) if self.use_self_loop else torch.zeros(n, n)
+            a[self.parent_ids, self.child_ids] = 1.0
+            a[self.child_ids, self.parent_ids] = 1.0
+            a = a / a.sum(dim=1, keepdim=True).clamp_min(1.0)
+            self._graph_key = key
+            self._graph = (a.to(device).contiguous(), a.t().contiguous().to(device))
+        return (self._graph[0], self._graph[1], batch_size, self.num_nodes)
+
+    def header_forward(self, graph_features, batch_size):
+        return self.header(graph_features.reshape(batch_size, -1))
+
+
+class GCNDiscriminator(GCNDiscriminator_base):
+    def __init__(self, cfg):
+        raise NotImplementedError('GCNConv discriminators (simple_gcn / res_gcn) are not used by any shipped '
+                                  'config and are not built on the MI355X path')
+
+
+def _stream(hidden, out, num_layers):
+    return nn.Sequential(*[GCN_SAGE_residual(hidden, hidden, hidden) for _ in range(num_layers)],
+                         GCN_SAGE_residual(hidden, -1, out, single_layer=True))
+
+
+class GCNSAGEDiscriminator(GCNDiscriminator_base):
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.name = 'ResSAGEGCN'
+        self.num_layers = cfg['num_layers']
+        self.gcn = _stream(self.hidden_dim, self.output_dim, self.num_layers)
+        self.use_pe = cfg['use_pe'] if 'use_pe' in cfg else False
+        self.input_layer = L.Linear(self.disc_sup_dim * (2 if self.use_pe else 1), self.input_dim)
+
+    def forward(self, keypoints):
+        B = keypoints.shape[0]
+        g = self.graph(B, keypoints.device)
+        if self.use_pe:
+            keypoints = torch.cat([keypoints, self.cal_positional_encoding(keypoints)], dim=-1)
+        x = self.input_layer(keypoints.reshape(B * self.num_nodes, -1))
+        return self.header_forward(self.gcn((x, g))[0], B)
+
+
+class GCNDiscriminatorDecouple(GCNDiscriminator_base):
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.use_pe = cfg['use_pe'] if 'use_pe' in cfg else False
+        cin = self.disc_sup_dim * (2 if self.use_pe else 1)
+        self.joint_input_layer = L.Linear(cin, self.input_dim)
+        self.bone_input_layer = L.Linear(cin, self.input_dim)
+        self.name = 'ResGCNDecouple'
+        self.num_layers = cfg['num_layers']
+        self.joint_gcn = _stream(self.hidden_dim, self.output_dim, self.num_layers)
+        self.bone_gcn = _stream(self.hidden_dim, self.output_dim, self.num_layers)
+        self.header = FFNHeader(self.output_dim * self.num_nodes * 2, 512)
+
+    def forward(self, keypoints):
+        B, _, dim = keypoints.shape
+        bone = keypoints[:, self.parent_ids, :] - keypoints[:, self.child_ids, :]
+        bone = torch.cat([keypoints.new_zeros(B, 1, dim), bone], dim=1)       # zero row for the root node
+        g = self.graph(B, keypoints.device)
+        if self.use_pe:
+            pe = self.cal_positional_encoding(keypoints)
+            keypoints = torch.cat([keypoints, pe], dim=-1)
+            bone = torch.cat([bone, pe], dim=-1)
+        j = self.joint_gcn((self.joint_input_layer(keypoints.reshape(B * self.num_nodes, -1)), g))[0]
+        b = self.bone_gcn((self.bone_input_layer(bone.reshape(B * self.num_nodes, -1)), g))[0]
+        return self.header_forward(torch.cat([j, b], dim=-1), B)

@@ -1,0 +1,179 @@
+"""Generator-side and discriminator-side training graphs (reference: modules/model.py:8-264).
+
+Same constructor signatures, attributes (`regressor`, `smpl_discriminator`) and output-dict keys as the
+reference; inside, each camera does: fused detector -> ONE patch->world launch for all hypotheses ->
+ONE fused line-mask launch -> fused mask losses.  Quirks of the reference are reproduced on purpose:
+the `smpl_gen` input subtracts HYPOTHESIS 0 (model.py:124 indexes axis 1) and is detached, so the
+regressor receives no adversarial gradient; symmetry / pseudo losses take the min over hypotheses of
+batch means; zero-weight losses are still computed and back-propagated.
+"""
+import torch
+
+from modules.base_losses.loss_func import (compute_bone_sym_loss, compute_disc_loss, compute_kp_sym_loss,
+                                           compute_mask_reconstruction_loss, compute_supervision)
+from modules.util import convert_patch_to_world, draw_lines_max, random_rotation_3D
+
+
+def cal_links(parent_ids, line_select_ids=None, use_root=False, extension=True):
+    """(parent, child) joint lists of the drawn lines: the selected skeleton bones plus, optionally, eight
+    torso links that fill the trunk (model.py:8-22)."""
+    pairs = list(zip(parent_ids, range(len(parent_ids))))
+    if not use_root:
+        pairs = pairs[1:]
+    pairs = [pairs[i] for i in line_select_ids]
+    if extension:
+        pairs += list(zip([7, 7, 7, 7, 0, 0, 1, 4], [1, 4, 11, 14, 2, 5, 14, 11]))
+    return [p for p, _ in pairs], [c for _, c in pairs]
+
+
+def _cams(x, cam_id_list):
+    return ['mono'] if 'cam_mono_img' in x else cam_id_list
+
+
+def _to_world(kps, x, key, mono):
+    if mono:
+        return convert_patch_to_world(kps, x, key, is_norm=True, RECT_WIDTH=256, mono=True, patch=False)
+    return convert_patch_to_world(kps, x, key, is_norm=True)
+
+
+class Counter3DModel(torch.nn.Module):
+    def __init__(self, cfg, regressor, smpl_layer, h36m_regressor, physique_network=None):
+        super().__init__()
+        self.regressor = regressor
+        self.cam_id_list = cfg['cam_id_list']
+        self.body_width = float(cfg.get('body_width', 3.0)) * 1e-3
+        self.parent_ids, self.child_ids = cal_links(cfg['parent_ids'], line_select_ids=cfg.get('line_select_ids'),
+                                                    use_root=False, extension=True)
+        self.loss_config = cfg['loss_config']
+        self.use_learned_width = cfg.get('use_learned_width', False)
+        self.smpl_layer = smpl_layer
+        self.h36m_regressor = h36m_regressor
+        self.physique_network = physique_network
+        self.DISC_SUP_DIMENSION = cfg['smpl_disc_params'].get('disc_sup_dim', 3)
+        self.use_aug = cfg['smpl_disc_params'].get('use_aug', False)
+
+    def forward(self, x, smpl_discriminator):
+        cams = _cams(x, self.cam_id_list)
+        lc = self.loss_config
+        losses, out = {}, {}
+        kps, world, recon = {}, {}, {}
+        for cam in cams:
+            key = 'cam_{}'.format(cam)
+            img = x[key + '_img']
+            kps[key], depth_map = self.regressor(img)
+            assert kps[key].dim() == 4, "use aligned multi-hypothesis settings"
+            out['pose_2d_pred_{}_ori'.format(key)] = kps[key][[0], 0].detach().clone()
+            out['depth_map_{}'.format(key)] = depth_map
+            world[key] = _to_world(kps[key], x, key, cam == 'mono')           # [B, Hy, K, 3], one launch
+            out['pose_3d_depth_{}'.format(key)] = world[key][:, 0].detach().clone()
+            # multi-hypothesis only changes z, so one mask per camera (hypothesis 0's x, y)
+            recon[key] = draw_lines_max(kps[key][:, 0, :, :2], img.shape[-1], self.parent_ids, self.child_ids,
+                                        self.body_width)
+            out['mask_heatmap_line_{}'.format(key)] = recon[key].detach()
+        if 'mono' not in cams:
+            out['kp_gt_world'] = convert_patch_to_world(x['cam_0_joints'], x, 'cam_0', is_norm=False)[[0]]
+
+        if 'symmetry_loss' in lc:
+            w = lc['symmetry_loss']['weight']
+            total = 0
+            for cam in cams:
+                if cam == 'mono':
+                    continue
+                key = 'cam_{}'.format(cam)
+                per_hypo = []
+                for h in range(world[key].shape[1]):
+                    v = compute_bone_sym_loss(world[key][:, h]) * w['bone'] + compute_kp_sym_loss(world[key][:, h]) * w['kp']
+                    if 'kp_2d' in w:
+                        v = v + compute_kp_sym_loss(kps[key][:, h, :, :2], is_3D=False) * 1e2 * w['kp_2d']
+                    per_hypo.append(v)
+                total = total + torch.stack(per_hypo).min()
+            losses['symmetry'] = total
+
+        if 'smpl_gen_loss' in lc:
+            total = 0
+            for cam in cams:
+                key = 'cam_{}'.format(cam)
+                rel = ((world[key] - world[key][:, [0]]) / 1000)[..., :self.DISC_SUP_DIMENSION]
+                logits = torch.stack([smpl_discriminator(rel[:, h].detach()) for h in range(rel.shape[1])], dim=1)
+                if not self.use_aug:
+                    total = total + compute_disc_loss(logits, None)
+                else:
+                    rot = torch.stack([smpl_discriminator(random_rotation_3D((world[key] - world[key][:, [0]])[:, h] / 1000)
+                                                          [..., :self.DISC_SUP_DIMENSION]) for h in range(rel.shape[1])], dim=1)
+                    total = total + compute_disc_loss(logits, None) * 0.7 + compute_disc_loss(rot, None) * 0.3
+            losses['smpl_gen'] = total * lc['smpl_gen_loss']['weight']
+
+        if 'smpl_pseudo_img_loss' in lc:
+            total = 0
+            for cam in cams:
+                key = 'cam_{}'.format(cam)
+                pred, _ = self.regressor(x[key + '_pseudo_img'])
+                gt = x[key + '_pseudo_joints']
+                out['pose_2d_pred_{}_pseudo'.format(key)] = pred[[0], 0].detach().clone()
+                out['pose_3d_pred_{}_pseudo'.format(key)] = _to_world(pred[:, 0].detach(), x, key, True)[[0]]
+                out['pose_3d_gt_{}_pseudo'.format(key)] = _to_world(gt, x, key, True)[[0]]
+                total = total + torch.stack([compute_supervision(pred[:, h], gt) for h in range(pred.shape[1])]).min()
+            losses['smpl_pseudo_img'] = total * lc['smpl_pseudo_img_loss']['weight']
+
+        if 'physique_recons_loss' in lc and self.physique_network is not None:
+            use_map = lc['physique_recons_loss']['use_dis_map']
+            total = 0
+            for cam in cams:
+                key = 'cam_{}'.format(cam)
+                phys = self.physique_network(recon[key])
+                out['mask_physique_{}'.format(key)] = phys[[0]].detach()
+                total = total + compute_mask_reconstruction_loss(
+                    phys, x[key + '_mask'], weight=x[key + '_geodesic_dis'] if use_map else None)
+            losses['physique_recons'] = total * lc['physique_recons_loss']['weight']
+
+        if 'recons_loss' in lc:
+            use_map = lc['recons_loss']['use_dis_map']
+            total = 0
+            for cam in cams:
+                key = 'cam_{}'.format(cam)
+                total = total + compute_mask_reconstruction_loss(
+                    recon[key], x[key + '_mask'], weight=x[key + '_geodesic_dis'] if use_map else None, use_clip=True)
+            losses['reconstruction'] = total * lc['recons_loss']['weight']
+        return losses, out
+
+
+class Counter3DDisc(torch.nn.Module):
+    def __init__(self, cfg, smpl_discriminator, smpl_layer, h36m_regressor):
+        super().__init__()
+        self.smpl_discriminator = smpl_discriminator
+        self.cam_id_list = cfg['cam_id_list']
+        self.parent_ids, self.child_ids = cal_links(cfg['parent_ids'], line_select_ids=cfg.get('line_select_ids'),
+                                                    use_root=False, extension=False)
+        self.loss_config = cfg['loss_config']
+        if 'GCN' in self.smpl_discriminator.name:
+            self.smpl_discriminator.parent_ids = self.parent_ids
+            self.smpl_discriminator.child_ids = self.child_ids
+        self.smpl_layer = smpl_layer
+        self.h36m_regressor = h36m_regressor
+        self.DISC_SUP_DIMENSION = cfg['smpl_disc_params'].get('disc_sup_dim', 3)
+        self.use_aug = cfg['smpl_disc_params'].get('use_aug', False)
+
+    def forward(self, x, regressor):
+        total = 0
+        out = {}
+        d = self.DISC_SUP_DIMENSION
+        for cam in _cams(x, self.cam_id_list):
+            key = 'cam_{}'.format(cam)
+            pred, _ = regressor(x[key + '_img'])                       # train-mode BN: running stats move here too
+            real = x[key + '_pseudo_joints']
+            real_world = _to_world(real, x, key, True)
+            out['pose_smpl_2d_{}'.format(key)] = real[[0]]
+            out['pose_smpl_3d_{}'.format(key)] = real_world[[0]].clone()
+            fake_logits = torch.stack([self.smpl_discriminator(pred[:, h, :, :d].detach()) for h in range(pred.shape[1])],
+                                      dim=1)
+            real_logits = self.smpl_discriminator(real[..., :d])
+            out['smpl_logits_{}'.format(key)] = real_logits[[0]]
+            out['pred_logits_{}'.format(key)] = fake_logits[[0], 0]
+            if self.use_aug:
+                rot = random_rotation_3D(real_world)
+                out['pose_smpl_3d_{}_rot'.format(key)] = rot[[0]]
+                total = total + compute_disc_loss(fake_logits, real_logits) * 0.6 \
+                    + compute_disc_loss(self.smpl_discriminator(rot[..., :d]), None) * 0.4
+            else:
+                total = total + compute_disc_loss(fake_logits, real_logits)
+        return total * self.loss_config['smpl_disc_loss']['weight'], out

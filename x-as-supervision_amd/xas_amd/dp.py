@@ -1,0 +1,118 @@
+"""Data-parallel gradient averaging over RCCL/xGMI (reference: two DistributedDataParallel wrappers,
+train.py:87-88, whose reducer all-reduces 25 MB buckets on the NCCL stream).
+
+MI355X-first design: gradients already live in ONE contiguous arena per optimizer (optim.FusedAdam), laid
+out in parameter-registration order.  Backward produces gradients roughly in reverse order, so the arena is
+cut into a few large buckets from the tail; a post-accumulate-grad hook on the LAST parameter to become
+ready in each bucket (counted) launches that bucket's all-reduce on a side HIP stream behind an event, so the
+collective overlaps the rest of backward.  xGMI is point-to-point (7 links x ~153 GB/s): a handful of large
+messages beats many small ones, so the default is 4 buckets of ~35 MB for the 139 MB generator arena.
+`finish()` makes the compute stream wait for the side stream and divides by world size (mean) inside the
+wait, before the optimizer step.
+
+Works with any torch.distributed backend: `nccl` (= RCCL on ROCm) on GPUs, `gloo` in the CPU tests.
+Buffers are NOT broadcast every forward (the reference's broadcast_buffers=True re-sends 19 MB of constant
+SMPL arrays per call): BN running statistics are synchronised once per step instead (`sync_buffers`).
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, arena, params, offsets, num_buckets=4, group=None, use_side_stream=True):
+        self.arena = arena
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.enabled = self.world > 1
+        self.pending = []
+        self.stream = None
+        if not self.enabled:
+            return
+        n = arena.numel()
+        # bucket boundaries on parameter boundaries, roughly equal sizes, tail first
+        target = max(1, n // max(1, num_buckets))
+        bounds, start = [], None
+        ends = [o + (p.numel() + 3) // 4 * 4 for p, o in zip(params, offsets)]
+        cur_end = n
+        for i in range(len(params) - 1, -1, -1):
+            if cur_end - offsets[i] >= target or i == 0:
+                bounds.append((offsets[i], cur_end, i))
+                cur_end = offsets[i]
+        self.buckets = []
+        for lo, hi, first_idx in bounds:
+            members = [j for j, o in enumerate(offsets) if lo <= o < hi and params[j].requires_grad]
+            if members and hi > lo:
+                self.buckets.append(dict(lo=lo, hi=hi, members=members, ready=0))
+        self._member_bucket = {}
+        for bi, b in enumerate(self.buckets):
+            for j in b['members']:
+                self._member_bucket[j] = bi
+        if arena.is_cuda and use_side_stream:
+            self.stream = torch.cuda.Stream()
+        self._hooks = []
+        for j, p in enumerate(params):
+            if j in self._member_bucket:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(j)))
+        self._armed = False
+
+    def _make_hook(self, j):
+        def hook(_p):
+            if not self._armed:
+                return
+            b = self.buckets[self._member_bucket[j]]
+            b['ready'] += 1
+            if b['ready'] == len(b['members']):
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        view = self.arena[b['lo']:b['hi']]
+        if self.stream is not None:
+            ev = torch.cuda.Event()
+            ev.record()                                   # gradients of this bucket are complete on the compute stream
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                work = dist.all_reduce(view, group=self.group, async_op=True)
+        else:
+            work = dist.all_reduce(view, group=self.group, async_op=True)
+        b['launched'] = True
+        self.pending.append(work)
+
+    def arm(self):
+        """Call before the backward whose gradients should be reduced."""
+        if not self.enabled:
+            return
+        for b in self.buckets:
+            b['ready'] = 0
+            b['launched'] = False
+        self._armed = True
+
+    def finish(self):
+        """Wait for all buckets (launching any whose hooks never fired: unused parameters), then average."""
+        if not self.enabled:
+            return
+        self._armed = False
+        for b in self.buckets:
+            if not b.get('launched'):
+                self._launch(b)
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.arena.mul_(1.0 / self.world)
+
+
+def sync_buffers(module, group=None):
+    """Broadcast floating-point buffers (BN running statistics) from rank 0, coalesced into one message."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    bufs = [b for b in module.buffers() if b.dtype.is_floating_point and b.numel() < (1 << 16)]
+    if not bufs:
+        return
+    flat = torch.cat([b.reshape(-1) for b in bufs])
+    dist.broadcast(flat, src=0, group=group)
+    o = 0
+    for b in bufs:
+        b.copy_(flat[o:o + b.numel()].view_as(b))
+        o += b.numel()

@@ -1,0 +1,116 @@
+"""Model construction and the optimisation step (reference: train.py:147-269).
+
+`prepare_model(config)` mirrors train.py:212-269 (same classes, same optimizer hyper-parameters) with
+FusedAdam; `TrainStep` runs exactly the body of the reference's hot loop (train.py:160-190): discriminator
+forward/backward/update, then generator forward/backward/update, with data-parallel gradient averaging on a
+side stream when a process group is active.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from modules.discriminator import GCNDiscriminator, GCNDiscriminatorDecouple, GCNSAGEDiscriminator
+from modules.keypoint_detector_integral import KPDetector3D
+from modules.keypoint_detector_integral_multi import KPDetector3DMulti
+from modules.model import Counter3DDisc, Counter3DModel
+from modules.physique_network import PhysiqueMaskGenerator
+
+from .dp import GradReducer, sync_buffers
+from .optim import FusedAdam
+
+
+def prepare_model(config, smpl_arrays=None):
+    """-> unsup_model, unsup_disc, optimizer_detector, optimizer_discriminator  (train.py:212-269)."""
+    mp, tp = config['model_params'], config['train_params']
+    det = mp['detector_params']
+    regressor = KPDetector3DMulti(**det) if det['name'] == 'resnet_multi' else KPDetector3D(**det)
+    disc = smpl_layer = h36m = None
+    if 'smpl_disc_params' in mp:
+        name = mp['smpl_disc_params']['name']
+        if 'gcn' not in name:
+            raise NotImplementedError
+        if 'decouple' in name:
+            disc = GCNDiscriminatorDecouple(mp['smpl_disc_params'])
+        elif 'sage' in name:
+            disc = GCNSAGEDiscriminator(mp['smpl_disc_params'])
+        else:
+            disc = GCNDiscriminator(mp['smpl_disc_params'])
+        smpl_layer, h36m = _load_smpl(mp, smpl_arrays)
+    phys = None
+    if 'physique_mask_generator_params' in mp:
+        phys = PhysiqueMaskGenerator(mp['physique_mask_generator_params']['layers'])
+    net_params = list(regressor.parameters()) + (list(phys.parameters()) if phys is not None else [])
+    opt_det = FusedAdam(net_params, lr=tp['lr_kp_detector'], betas=(0.5, 0.999))
+    opt_disc = FusedAdam(disc.parameters(), lr=tp['lr_discriminator'], betas=(0.5, 0.999)) if disc is not None else None
+    unsup_model = Counter3DModel(mp, regressor, smpl_layer, h36m, phys)
+    unsup_disc = Counter3DDisc(mp, disc, smpl_layer, h36m)
+    return unsup_model, unsup_disc, opt_det, opt_disc
+
+
+def _load_smpl(mp, smpl_arrays):
+    """SMPL layer + H36M joint regressor (train.py:230-238).  The layer is constructed for API parity; it is
+    not called on the training path.  Without the licensed files (benchmarks, tests) it is skipped."""
+    from modules.smplpytorch.pytorch.smpl_layer import SMPL_Layer
+    if smpl_arrays is not None:
+        return SMPL_Layer.from_arrays(smpl_arrays, center_idx=0), torch.as_tensor(smpl_arrays['h36m_regressor'])
+    root = mp.get('smpl_layer_params', {}).get('model_path', '')
+    reg = os.path.join(root, 'J_regressor_h36m.npy')
+    if os.path.exists(reg):
+        return (SMPL_Layer(center_idx=0, gender='neutral', model_root=root),
+                torch.tensor(np.load(reg), dtype=torch.float32))
+    return None, None
+
+
+class TrainStep:
+    """One optimisation step = train.py:160-190.  Holds the two reducers (DDP equivalents)."""
+
+    def __init__(self, config, unsup_model, unsup_disc, opt_det, opt_disc, num_buckets=4):
+        self.model, self.disc = unsup_model, unsup_disc
+        self.opt_det, self.opt_disc = opt_det, opt_disc
+        interval = config['model_params']['loss_config']['smpl_disc_loss']['update_interval']
+        self.disc_every = interval if interval >= 1 else 1
+        self.gen_every = 1 if interval >= 1 else int(1.0 / interval)
+        self.cur_step = 0
+        self.red_det = self.red_disc = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            f = opt_det
+            f.grad_arena
+            self.red_det = GradReducer(f._flat['g'], f._flat['params'], f._flat['offs'], num_buckets)
+            if opt_disc is not None:
+                opt_disc.grad_arena
+                g = opt_disc
+                self.red_disc = GradReducer(g._flat['g'], g._flat['params'], g._flat['offs'], 1)
+            sync_buffers(self.model)
+            dist.broadcast(opt_det.param_arena, src=0)
+            if opt_disc is not None:
+                dist.broadcast(opt_disc.param_arena, src=0)
+
+    def __call__(self, x):
+        out = {}
+        loss_disc, loss_kp, total = None, {}, None
+        if self.opt_disc is not None and self.cur_step % self.disc_every == 0:
+            loss_disc, info = self.disc(x, self.model.regressor)
+            out.update(info)
+            loss_disc = loss_disc.mean()
+            if self.red_disc:
+                self.red_disc.arm()
+            loss_disc.backward()
+            if self.red_disc:
+                self.red_disc.finish()
+            self.opt_disc.step()
+            self.opt_disc.zero_grad()
+        if self.cur_step % self.gen_every == 0:
+            loss_kp, info = self.model(x, self.disc.smpl_discriminator)
+            out.update(info)
+            total = sum(v.mean() for v in loss_kp.values())
+            if self.red_det:
+                self.red_det.arm()
+            total.backward()
+            if self.red_det:
+                self.red_det.finish()
+            self.opt_det.step()
+            self.opt_det.zero_grad()
+        self.cur_step += 1
+        return loss_disc, loss_kp, total, out
