@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X-native X-as-Supervision training step (BASELINE.json north_star).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+One "step" = the reference's hot-loop body (train.py:160-190): discriminator forward/backward/Adam, then
+generator forward/backward/Adam, on one synthetic batch of the workload HM36_Multi_SurS1 (4 cameras,
+256x256, multi-hypothesis detector), B = 32 samples per GPU, fp32, inputs resident in HBM.  One sample
+= 4 real + 4 pseudo images = 8 input images; the step runs 12 detector forwards and 8 detector backwards
+per sample.  Rank 0 prints ONE JSON line (metric = images/s over the whole job).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'x-as-supervision_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, 'Peak FP32 (matrix)'
+IMAGES_PER_SAMPLE = {'HM36': 8, 'MPI': 10}
+
+
+def host_threads():
+    """Cores this process may use: the GPU box gives one GPU's share (16), not the host's core count."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(workload, threads):
+    """Oracle (CPU restatement of the reference step, stock PyTorch fp32) on a bounded sample: ONE full
+    disc+gen step at B=2 on the host cores."""
+    from oracle import step as ostep
+    from oracle.nets import GCNDecouple, PhysiqueNet
+    from xas_amd.synthetic import model_config, synthetic_batch
+    torch.set_num_threads(threads)
+    cfg = model_config(workload)['model_params']
+    torch.manual_seed(0)
+    reg = ostep.Regressor(**cfg['detector_params']).train()
+    phys = PhysiqueNet(cfg['physique_mask_generator_params']['layers']).train()
+    disc = GCNDecouple(cfg['smpl_disc_params'])
+    from oracle.geometry import skeleton_links
+    disc.parent_ids, disc.child_ids = skeleton_links(cfg['parent_ids'], cfg['line_select_ids'], False, False)
+    o_det = torch.optim.Adam(list(reg.parameters()) + list(phys.parameters()), lr=2e-4, betas=(0.5, 0.999))
+    o_disc = torch.optim.Adam(disc.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    B = 2
+    x = synthetic_batch(B, cfg['cam_id_list'], torch.device('cpu'), seed=1)
+    t0 = time.perf_counter()
+    ostep.train_step(cfg, reg, phys, disc, o_det, o_disc, x)
+    dt = time.perf_counter() - t0
+    per_sample = IMAGES_PER_SAMPLE['MPI' if workload.startswith('MPI') else 'HM36']
+    return {'value': B * per_sample / dt, 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+            'sample': '1 full disc+gen step incl. Adam, %s, B=%d, fp32, oracle on torch CPU (%.1f s)' % (workload, B, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=32, help='samples per GPU')
+    ap.add_argument('--workload', default='HM36_Multi_SurS1')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=dev)
+
+    from xas_amd import engine
+    from xas_amd.prof import KernelTimer
+    from xas_amd.synthetic import model_config, synthetic_batch
+    cfg = model_config(args.workload)
+    torch.manual_seed(1234)
+    model, disc, opt_det, opt_disc = engine.prepare_model(cfg)
+    model.to(dev).train()
+    disc.to(dev).train()
+    step = engine.TrainStep(cfg, model, disc, opt_det, opt_disc)
+    cams = cfg['model_params']['cam_id_list']
+    x = synthetic_batch(args.batch, cams, dev, seed=100 + rank)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def log(msg):
+        if rank == 0:
+            print('[bench] ' + msg, file=sys.stderr, flush=True)
+
+    log('model built, batch resident; warmup %d step(s)' % args.warmup)
+    for i in range(args.warmup):
+        tw = time.perf_counter()
+        step(x)
+        torch.cuda.synchronize()
+        log('warmup step %d: %.1f ms' % (i, (time.perf_counter() - tw) * 1e3))
+    sync()
+    timer = KernelTimer()
+    t0 = time.perf_counter()
+    with timer:
+        for _ in range(args.steps):
+            step(x)
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    log('timed %d steps: %.1f ms/step' % (args.steps, dt / args.steps * 1e3))
+
+    per_sample = IMAGES_PER_SAMPLE['MPI' if args.workload.startswith('MPI') else 'HM36']
+    samples = world * args.batch * args.steps
+    if rank == 0:
+        summ = timer.summary()
+        mfma = {k: v for k, v in summ.items() if not k.endswith(':direct')}
+        fl = sum(v['flops'] for v in mfma.values())
+        ms = sum(v['ms'] for v in mfma.values())
+        n_launch = sum(v['launches'] for v in mfma.values())
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        line = {
+            'metric': 'images/sec HM36_Multi_SurS1 256px bs32 (full disc+gen training step)',
+            'value': samples * per_sample / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': args.workload, 'batch_per_gpu': args.batch, 'cameras': len(cams),
+                       'image': '256x256', 'images_per_sample': per_sample, 'parallelism': 'dp%d' % world,
+                       'samples_per_s': samples / dt, 'detector_forwards_per_s': samples * 3 * len(cams) / dt},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                         'kernel': 'igemm_kernel / wgrad_kernel (fp32 MFMA implicit-GEMM conv family)',
+                         'launches_per_step': n_launch / args.steps, 'avg_launch_us': ms * 1e3 / max(1, n_launch),
+                         'conv_ms_per_step': ms / args.steps,
+                         'families': {k: {'launches': v['launches'] // args.steps, 'ms_per_step': v['ms'] / args.steps,
+                                          'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 else 0.0}
+                                      for k, v in summ.items()}},
+        }
+        if not args.no_cpu_baseline:
+            threads = host_threads()
+            log('timing the CPU oracle step (B=2) on %d host threads' % threads)
+            line['cpu_baseline'] = cpu_baseline(args.workload, threads)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -60,6 +60,23 @@ def test_conv2d_fwd_bwd(n, cin, h, w, cout, k, stride, pad):
     assert rel(m.bias.grad, bc.grad) < 3e-6
 
 
+@pytest.mark.parametrize('h,w', [(64, 64), (50, 70), (256, 256)])
+def test_stem_conv_mfma(h, w):
+    """7x7 s2 p3, 3 -> 64, no bias: the dedicated MFMA stem kernel (resnet.py:16)."""
+    from xas_amd import layers as L
+    g = torch.Generator().manual_seed(h)
+    x = torch.randn(2, 3, h, w, generator=g)
+    m = L.Conv2d(3, 64, 7, 2, 3, bias=False, init='kaiming_fan_out').cuda()
+    wc = m.weight.detach().cpu().requires_grad_(True)
+    yc = TF.conv2d(x, wc, None, 2, 3)
+    gy = torch.randn(yc.shape, generator=g)
+    (yc * gy).sum().backward()
+    yg = m(x.cuda())
+    (yg * gy.cuda()).sum().backward()
+    assert yg.shape == yc.shape and rel(yg, yc) < 2e-6 and maxabs(yg, yc) < 2e-5
+    assert rel(m.weight.grad, wc.grad) < 3e-6
+
+
 @pytest.mark.parametrize('n,cin,h,cout', [(2, 2048, 4, 256), (2, 256, 8, 256), (1, 64, 5, 32)])
 def test_conv_transpose2d(n, cin, h, cout):
     from xas_amd import layers as L

@@ -363,6 +363,73 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int splits, 
   out[i] = s;
 }
 
+
+// ------------------------------------------------------------------------------------
+// Stem: 7x7 stride-2 pad-3 convolution of the 3-channel image (resnet.py:16), K = 147.
+// A workgroup owns an 8 x 16 output patch of one image for all 64 output channels: the
+// 21 x 37 x 3 input patch and the whole [148][64] weight matrix live in LDS, and each MFMA
+// operand is one ds_read_b32 at (lane base + compile-time tap offset).
+// ------------------------------------------------------------------------------------
+constexpr int ST_TH = 8, ST_TW = 16;                 // output tile
+constexpr int ST_PH = (ST_TH - 1) * 2 + 7;           // 21
+constexpr int ST_PW = (ST_TW - 1) * 2 + 7;           // 37
+constexpr int ST_K = 147, ST_KP = 148, ST_CO = 64, ST_LDW = ST_CO + 1;
+
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       float* __restrict__ y, int N, int H, int W, int Ho, int Wo) {
+  __shared__ float patch[ST_PH * ST_PW * 3 + 8];
+  __shared__ float ws[ST_KP * ST_LDW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_w = (Wo + ST_TW - 1) / ST_TW;
+  const int ty = blockIdx.x / tiles_w, tx = blockIdx.x % tiles_w, n = blockIdx.y;
+  const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+  const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+  // input patch [21][37][3], zero padded
+  for (int e = tid; e < ST_PH * ST_PW * 3; e += 256) {
+    const int c = e % 3, px = (e / 3) % ST_PW, py = e / (3 * ST_PW);
+    const int iy = iy0 + py, ix = ix0 + px;
+    patch[e] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                   ? x[(((size_t)n * H + iy) * W + ix) * 3 + c] : 0.f;
+  }
+  // weights packed [co][r][s][c] = [co][k] -> ws[k][co]; row 147 is the zero pad
+  for (int e = tid; e < ST_CO * ST_K; e += 256) {
+    const int co = e / ST_K, k = e % ST_K;
+    ws[k * ST_LDW + co] = w[e];
+  }
+  if (tid < ST_CO) ws[ST_K * ST_LDW + tid] = 0.f;
+  __syncthreads();
+
+  const int i = lane & 31, h = lane >> 5;
+  const int ly = wave * 2 + (i >> 4), lx = i & 15;            // pixel of this lane inside the tile
+  const int base = ((ly * 2) * ST_PW + lx * 2) * 3;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll
+  for (int kk = 0; kk < ST_KP / 2; ++kk) {
+    // tap offsets of k = 2kk and 2kk+1 in the patch (k = (r*7 + s)*3 + c); k = 147 reads tap 0 (weight is 0)
+    const int k0 = 2 * kk, k1 = (2 * kk + 1 < ST_K) ? 2 * kk + 1 : 0;
+    const int o0 = ((k0 / 21) * ST_PW + (k0 / 3) % 7) * 3 + k0 % 3;
+    const int o1 = ((k1 / 21) * ST_PW + (k1 / 3) % 7) * 3 + k1 % 3;
+    const float a = patch[base + (h ? o1 : o0)];
+    const float b0 = ws[(2 * kk + h) * ST_LDW + i];
+    const float b1 = ws[(2 * kk + h) * ST_LDW + 32 + i];
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+  }
+  const int col = lane & 31, rsub = 4 * (lane >> 5);
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int pi = (reg & 3) + 8 * (reg >> 2) + rsub;          // pixel index within the wave's 2 x 16 strip
+    const int oy = oy0 + wave * 2 + (pi >> 4), ox = ox0 + (pi & 15);
+    if (oy < Ho && ox < Wo) {
+      float* o = y + (((size_t)n * Ho + oy) * Wo + ox) * ST_CO;
+      o[col] = acc0[reg];
+      o[32 + col] = acc1[reg];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // direct (VALU) fallbacks for shapes the MFMA tiles do not cover (Cin = 1 / 3, Cout = 1)
 // ------------------------------------------------------------------------------------
@@ -501,6 +568,13 @@ extern "C" int xas_conv_fwd(const float* x, const float* w_packed, const float* 
   if (check_shape(s, "conv_fwd") || check_fwd_dims(s, "conv_fwd")) return 1;
   XAS_REQUIRE(x && w_packed && y, "conv_fwd: null buffer");
   hipStream_t st = as_stream(stream);
+  if (s->Cin == 3 && s->R == 7 && s->S == 7 && s->stride == 2 && s->pad == 3 && s->Cout == ST_CO && bias == nullptr) {
+    const int tiles = (int)(cdiv(s->Ho, ST_TH) * cdiv(s->Wo, ST_TW));
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3(tiles, s->N), dim3(256), 0, st, x, w_packed, y, s->N, s->Hi, s->Wi, s->Ho,
+                       s->Wo);
+    XAS_LAUNCH_CHECK();
+    return 0;
+  }
   if (s->Cin % BK != 0 || s->Cout < 16) {
     const long total = (long)s->N * s->Ho * s->Wo * s->Cout;
     hipLaunchKernelGGL(direct_fwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, x, w_packed, bias, y, *s);

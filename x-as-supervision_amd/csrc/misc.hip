@@ -114,19 +114,21 @@ __global__ void gln_apply_kernel(const float* __restrict__ x, const float* __res
   }
 }
 
-// per-channel sums of g and g*xhat where g = dy * relu'(ln(x)); one block per channel group of 64
-__global__ void gln_bwd_cols_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const float* __restrict__ stats, long rows, int C, float eps,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ float s1[4][64], s2[4][64];
+// per-channel sums of g and g*xhat where g = dy * relu'(ln(x)); block = 64 channels x 16 row lanes
+__global__ __launch_bounds__(1024) void gln_bwd_cols_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ stats, long rows, int C,
+                                                            float eps, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
+  __shared__ float s1[16][64], s2[16][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
   const float mean = stats[0], inv = 1.f / (stats[1] + eps);
   float a = 0.f, b = 0.f;
   if (c < C) {
     const float gmm = gamma[c], bt = beta[c];
-    for (long r = ry; r < rows; r += 4) {
+    for (long r = ry; r < rows; r += 16) {
       const float xh = (x[r * C + c] - mean) * inv;
       const float g = (xh * gmm + bt > 0.f) ? dy[r * C + c] : 0.f;
       a += g; b = fmaf(g, xh, b);
@@ -135,8 +137,10 @@ __global__ void gln_bwd_cols_kernel(const float* __restrict__ x, const float* __
   s1[ry][cx] = a; s2[ry][cx] = b;
   __syncthreads();
   if (ry == 0 && c < C) {
-    dbeta[c] = (s1[0][cx] + s1[1][cx]) + (s1[2][cx] + s1[3][cx]);
-    dgamma[c] = (s2[0][cx] + s2[1][cx]) + (s2[2][cx] + s2[3][cx]);
+    float u = 0.f, v = 0.f;
+    for (int k = 0; k < 16; ++k) { u += s1[k][cx]; v += s2[k][cx]; }
+    dbeta[c] = u;
+    dgamma[c] = v;
   }
 }
 
@@ -383,7 +387,7 @@ extern "C" int xas_gln_bwd(const float* x, const float* beta, const float* dy, c
   XAS_REQUIRE(x && beta && dy && gamma && stats && dx && dgamma && dbeta && workspace && rows > 0 && C > 0,
               "gln_bwd: bad arguments");
   const long n = rows * C;
-  hipLaunchKernelGGL(gln_bwd_cols_kernel, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, as_stream(stream), x, dy, gamma,
+  hipLaunchKernelGGL(gln_bwd_cols_kernel, dim3((unsigned)cdiv(C, 64)), dim3(1024), 0, as_stream(stream), x, dy, gamma,
                      beta, stats, rows, C, eps, dgamma, dbeta);
   XAS_LAUNCH_CHECK();
   hipLaunchKernelGGL(gln_bwd_scalar_kernel, dim3(1), dim3(256), 0, as_stream(stream), gamma, dgamma, dbeta, C, workspace);

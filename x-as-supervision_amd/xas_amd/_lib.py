@@ -105,8 +105,13 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+profiler = None      # set by xas_amd.prof.KernelTimer: brackets selected entry points with HIP events
+
+
 def call(name, *args):
     """Launch wrapper: appends the current HIP stream and turns a non-zero status into RuntimeError."""
+    if profiler is not None and name in profiler.names:
+        return profiler.timed_call(name, args)
     rc = fn(name)(*args, stream())
     if rc != 0:
         raise RuntimeError('%s failed (%d): %s' % (name, rc, load().xas_last_error().decode()))

@@ -1,0 +1,54 @@
+"""Per-entry-point device timing with HIP events recorded on the stream the kernels are launched on
+(torch's current stream), plus the algorithmic FLOP count of every convolution launch."""
+import torch
+
+from . import _lib
+
+CONV_ENTRIES = ('xas_conv_fwd', 'xas_conv_dgrad', 'xas_conv_wgrad')
+
+
+def conv_flops(shape):
+    """2 * MACs of the convolution described by an xas_conv_shape (same count for fwd / dgrad / wgrad)."""
+    return 2.0 * shape.N * shape.Ho * shape.Wo * shape.Cout * shape.R * shape.S * shape.Cin
+
+
+class KernelTimer:
+    def __init__(self, names=CONV_ENTRIES):
+        self.names = set(names)
+        self.records = []          # (name, start_event, end_event, flops, mfma_path)
+
+    def __enter__(self):
+        _lib.profiler = self
+        return self
+
+    def __exit__(self, *exc):
+        _lib.profiler = None
+
+    def timed_call(self, name, args):
+        shape = next((a for a in args if isinstance(a, _lib.ConvShape)), None)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = _lib.fn(name)(*args, _lib.stream())
+        b.record()
+        if rc != 0:
+            raise RuntimeError('%s failed (%d): %s' % (name, rc, _lib.load().xas_last_error().decode()))
+        mfma = False
+        if shape is not None:
+            if name == 'xas_conv_fwd':
+                mfma = (shape.Cin % 32 == 0 and shape.Cout >= 16) or (shape.Cin == 3 and shape.R == 7 and shape.Cout == 64)
+            elif name == 'xas_conv_dgrad':
+                mfma = shape.Cout % 32 == 0 and shape.Cin >= 16
+            else:
+                mfma = shape.Cout != 1
+        self.records.append((name, a, b, conv_flops(shape) if shape is not None else 0.0, mfma))
+
+    def summary(self):
+        """-> dict per entry point: launches, total ms, total flops (call after torch.cuda.synchronize())."""
+        out = {}
+        for name, a, b, fl, mfma in self.records:
+            key = name + ('' if mfma else ':direct')
+            d = out.setdefault(key, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
+            d['launches'] += 1
+            d['ms'] += a.elapsed_time(b)
+            d['flops'] += fl
+        return out
