@@ -39,7 +39,7 @@ def host_threads():
 
 def cpu_baseline(workload, threads):
     """Oracle (CPU restatement of the reference step, stock PyTorch fp32) on a bounded sample: ONE full
-    disc+gen step at B=2 on the host cores."""
+    disc+gen step at B=8 on the host cores."""
     from oracle import step as ostep
     from oracle.nets import GCNDecouple, PhysiqueNet
     from xas_amd.synthetic import model_config, synthetic_batch
@@ -53,7 +53,7 @@ def cpu_baseline(workload, threads):
     disc.parent_ids, disc.child_ids = skeleton_links(cfg['parent_ids'], cfg['line_select_ids'], False, False)
     o_det = torch.optim.Adam(list(reg.parameters()) + list(phys.parameters()), lr=2e-4, betas=(0.5, 0.999))
     o_disc = torch.optim.Adam(disc.parameters(), lr=2e-4, betas=(0.5, 0.999))
-    B = 2
+    B = 8                      # ~10 s of host work on a 16-core share; the GPU leg runs B = 32
     x = synthetic_batch(B, cfg['cam_id_list'], torch.device('cpu'), seed=1)
     t0 = time.perf_counter()
     ostep.train_step(cfg, reg, phys, disc, o_det, o_disc, x)
@@ -71,6 +71,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='samples per GPU')
     ap.add_argument('--workload', default='HM36_Multi_SurS1')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--shape-report', default=None, help='write a per-conv-shape timing table to this file')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -151,9 +152,14 @@ def main():
                                           'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 else 0.0}
                                       for k, v in summ.items()}},
         }
+        if args.shape_report:
+            with open(args.shape_report, 'w') as f:
+                f.write('entry (N,Hi,Wi,Cin,Cout,R,stride) launches ms_total TFLOP/s\n')
+                for name, sig, n, ms_, tf in timer.by_shape():
+                    f.write('%-16s %-36s %5d %9.3f %7.2f\n' % (name, sig, n, ms_, tf))
         if not args.no_cpu_baseline:
             threads = host_threads()
-            log('timing the CPU oracle step (B=2) on %d host threads' % threads)
+            log('timing the CPU oracle step (B=8) on %d host threads' % threads)
             line['cpu_baseline'] = cpu_baseline(args.workload, threads)
         print(json.dumps(line), flush=True)
     if world > 1:

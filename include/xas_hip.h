@@ -120,6 +120,9 @@ int xas_conv_dgrad(const float* dy, const float* w_packed_t, float* dx,
 size_t xas_conv_wgrad_workspace_floats(const xas_conv_shape* s);
 int xas_conv_wgrad(const float* x, const float* dy, float* dw_packed, float* workspace,
                    const xas_conv_shape* s, void* stream);
+/* same, but the split slabs are summed straight into the parameter's OIHW layout [Cout][Cin][R][S] */
+int xas_conv_wgrad_oihw(const float* x, const float* dy, float* dw_oihw, float* workspace,
+                        const xas_conv_shape* s, void* stream);
 /* OIHW [Cout][Cin][R][S] <-> packed.  transposed=0: [Cout][R][S][Cin];
  * transposed=1: [Cin][R][S][Cout].  unpack adds nothing: it overwrites dst. */
 int xas_pack_weight(const float* oihw, float* packed, int Cout, int Cin, int R, int S,
@@ -199,15 +202,18 @@ int xas_mask_loss_bwd(const float* m, const float* gt, const float* weight, long
  * ---------------------------------------------------------------------------------- */
 /* y[b,i,:] = sum_j adj[i][j] * x[b,j,:]  (adj: N x N row-normalised, device) */
 int xas_graph_aggregate(const float* x, const float* adj, int B, int N, int C, float* y, void* stream);
-/* graph LayerNorm over the WHOLE tensor + per-channel affine + relu (+ residual):
- * stats[0]=mean, stats[1]=std  ; workspace xas_gln_workspace_floats(n) */
-size_t xas_gln_workspace_floats(long n);
+/* graph LayerNorm (normalise over the WHOLE [rows, C] tensor of one discriminator call) + per-channel
+ * affine + relu (+ residual).  `groups` independent calls are batched: x is [groups*rows, C] and the
+ * statistics are per group.  stats: [groups][2] = (mean, std).
+ * workspace: xas_gln_workspace_floats(rows*C, groups, C) floats. */
+size_t xas_gln_workspace_floats(long n, int groups, int C);
 int xas_gln_fwd(const float* x, const float* gamma, const float* beta, const float* residual,
-                long rows, int C, float eps, float* y, float* stats, float* workspace, void* stream);
+                long rows, int C, int groups, float eps, float* y, float* stats, float* workspace,
+                void* stream);
 /* backward of y = relu(ln(x)) (+ residual: pass-through handled by the caller); the relu mask is
- * recomputed from x, gamma, beta. */
+ * recomputed from x, gamma, beta; dgamma / dbeta are summed over the groups. */
 int xas_gln_bwd(const float* x, const float* beta, const float* dy, const float* gamma,
-                const float* stats, long rows, int C, float eps, float* dx, float* dgamma,
+                const float* stats, long rows, int C, int groups, float eps, float* dx, float* dgamma,
                 float* dbeta, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------

@@ -85,6 +85,30 @@ def test_gcn_discriminator_vs_oracle(B):
     assert maxabs(hip(kp.cuda()), ora(kp)) < 2e-5 * max(1.0, float(yo.abs().max()))
 
 
+def test_discriminator_groups_equal_separate_calls():
+    """forward_groups == one call per input (graph-LayerNorm statistics stay per input), values and grads."""
+    hip, _ = _discs(seed=11)
+    hip.train()
+    hip.header.p = 0.0
+    g = torch.Generator().manual_seed(5)
+    xs = [(torch.randn(32, 18, 3, generator=g) * (0.2 + i)).cuda().requires_grad_(True) for i in range(5)]
+    sep = [hip(x) for x in xs]
+    torch.stack(sep).pow(2).sum().backward()
+    gsep = [x.grad.clone() for x in xs]
+    psep = {n: p.grad.clone() for n, p in hip.named_parameters()}
+    hip.zero_grad()
+    for x in xs:
+        x.grad = None
+    grp = hip.forward_groups(xs)
+    torch.stack(grp).pow(2).sum().backward()
+    for a, b in zip(sep, grp):
+        assert maxabs(a, b) < 1e-5 * max(1.0, float(a.abs().max()))
+    for x, gs in zip(xs, gsep):
+        assert rel(x.grad, gs) < 1e-4
+    for n, p in hip.named_parameters():
+        assert rel(p.grad, psep[n]) < 1e-4, n
+
+
 def test_smpl_layer_vs_golden():
     from modules.smplpytorch.pytorch.smpl_layer import SMPL_Layer
     from modules.util import smpl_to_h36m

@@ -355,6 +355,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
 }
 
+// sum the split slabs and write OIHW [Cout][Cin][R][S] directly (packed index -> OIHW index)
+__global__ void slab_reduce_unpack_kernel(const float* __restrict__ slabs, int splits, int Cout, int Cin, int R, int S,
+                                          float* __restrict__ oihw) {
+  const long n = (long)Cout * Cin * R * S;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // packed index [co][r][s][ci]
+  if (i >= n) return;
+  float acc = 0.f;
+  for (int k = 0; k < splits; ++k) acc += slabs[(size_t)k * n + i];
+  long t = i;
+  const int ci = t % Cin; t /= Cin;
+  const int q = t % S; t /= S;
+  const int r = t % R; const int co = t / R;
+  oihw[(((long)co * Cin + ci) * R + r) * S + q] = acc;
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int splits, long n, float* __restrict__ out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -429,6 +444,122 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     }
   }
 }
+
+// ------------------------------------------------------------------------------------
+// "Thin" 3x3 convolutions with ONE channel on one side (physique_network.py:41 first conv 1 -> 32,
+// :50 last conv 32 -> 1): HBM-bound, no GEMM shape; vector side C <= 64, C % 4 == 0.
+//   T1 vec->scalar : out[m]    = b + sum_tap sum_c V[src(m,tap)][c] * W[tap][c]   (fwd Cout=1, dgrad Cin=1)
+//   T2 scalar->vec : out[m][c] = b[c] + sum_tap S[src(m,tap)] * W[c][tap]         (fwd Cin=1, dgrad Cout=1)
+//   T3 reduction   : dW[c][tap] = sum_m S * V[c]                                  (wgrad Cout=1 / Cin=1)
+// `flip` walks the taps transposed (data gradient, stride 1): src = m + pad - tap.
+// ------------------------------------------------------------------------------------
+struct ThinParams {
+  int N, H, W, C;       // pixel grid (same for both sides: stride 1, 'same' padding) and vector width
+  int pad, flip;
+};
+
+__device__ __forceinline__ bool thin_src(const ThinParams& p, int h, int w, int r, int q, int* hs, int* ws) {
+  *hs = p.flip ? h + p.pad - r : h - p.pad + r;
+  *ws = p.flip ? w + p.pad - q : w - p.pad + q;
+  return (unsigned)*hs < (unsigned)p.H && (unsigned)*ws < (unsigned)p.W;
+}
+
+__global__ __launch_bounds__(256) void thin_vec2scalar_kernel(const float* __restrict__ V, const float* __restrict__ Wt,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              ThinParams p) {
+  __shared__ float4 wl[9 * 16];
+  const int C4 = p.C / 4;
+  for (int e = threadIdx.x; e < 9 * C4; e += blockDim.x) wl[e] = reinterpret_cast<const float4*>(Wt)[e];
+  __syncthreads();
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long M = (long)p.N * p.H * p.W;
+  if (m >= M) return;
+  const int w = m % p.W; const long t = m / p.W; const int h = t % p.H; const int n = t / p.H;
+  float acc = bias ? bias[0] : 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    int hs, ws;
+    if (!thin_src(p, h, w, tap / 3, tap % 3, &hs, &ws)) continue;
+    const float4* v = reinterpret_cast<const float4*>(V + (((size_t)n * p.H + hs) * p.W + ws) * p.C);
+    for (int c = 0; c < C4; ++c) {
+      const float4 a = v[c], b = wl[tap * C4 + c];
+      acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+    }
+  }
+  out[m] = acc;
+}
+
+// Wct: [C][9] (packed [C][R][S][1])
+__global__ __launch_bounds__(256) void thin_scalar2vec_kernel(const float* __restrict__ S, const float* __restrict__ Wct,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              ThinParams p) {
+  const int C4 = p.C / 4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long M = (long)p.N * p.H * p.W;
+  if (i >= M * C4) return;
+  const int c = (int)(i % C4) * 4;
+  const long m = i / C4;
+  const int w = m % p.W; const long t = m / p.W; const int h = t % p.H; const int n = t / p.H;
+  float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0, 0, 0, 0);
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    int hs, ws;
+    if (!thin_src(p, h, w, tap / 3, tap % 3, &hs, &ws)) continue;
+    const float sv = S[((size_t)n * p.H + hs) * p.W + ws];
+    acc.x = fmaf(sv, Wct[(c + 0) * 9 + tap], acc.x); acc.y = fmaf(sv, Wct[(c + 1) * 9 + tap], acc.y);
+    acc.z = fmaf(sv, Wct[(c + 2) * 9 + tap], acc.z); acc.w = fmaf(sv, Wct[(c + 3) * 9 + tap], acc.w);
+  }
+  *reinterpret_cast<float4*>(out + m * p.C + c) = acc;
+}
+
+// slabs[chunk][c][tap];  scalar_at_src = 0: S = dy[m], V = x[src(m,tap)]   (wgrad Cout = 1)
+//                        scalar_at_src = 1: S = x[src(m,tap)], V = dy[m]   (wgrad Cin = 1)
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict__ S, const float* __restrict__ V,
+                                                         float* __restrict__ slabs, ThinParams p, int scalar_at_src,
+                                                         int m_per_chunk) {
+  __shared__ float4 red[256];
+  const int C4 = p.C / 4, lanes = 256 / C4;
+  const int cq = threadIdx.x % C4, pl = threadIdx.x / C4;
+  const long M = (long)p.N * p.H * p.W;
+  const long mbeg = (long)blockIdx.x * m_per_chunk, mend = min(M, mbeg + m_per_chunk);
+  float4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = make_float4(0, 0, 0, 0);
+  for (long m = mbeg + pl; m < mend; m += lanes) {
+    const int w = m % p.W; const long t = m / p.W; const int h = t % p.H; const int n = t / p.H;
+    float s0 = 0.f; float4 v0 = make_float4(0, 0, 0, 0);
+    if (!scalar_at_src) s0 = S[m]; else v0 = *reinterpret_cast<const float4*>(V + m * p.C + cq * 4);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      int hs, ws;
+      if (!thin_src(p, h, w, tap / 3, tap % 3, &hs, &ws)) continue;
+      const size_t sp = ((size_t)n * p.H + hs) * p.W + ws;
+      const float sv = scalar_at_src ? S[sp] : s0;
+      const float4 vv = scalar_at_src ? v0 : *reinterpret_cast<const float4*>(V + sp * p.C + cq * 4);
+      acc[tap].x = fmaf(sv, vv.x, acc[tap].x); acc[tap].y = fmaf(sv, vv.y, acc[tap].y);
+      acc[tap].z = fmaf(sv, vv.z, acc[tap].z); acc[tap].w = fmaf(sv, vv.w, acc[tap].w);
+    }
+  }
+  float* o = slabs + (size_t)blockIdx.x * p.C * 9;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    __syncthreads();
+    red[threadIdx.x] = acc[tap];
+    __syncthreads();
+    if (pl == 0) {
+      float4 s4 = red[cq];
+      for (int k = 1; k < lanes; ++k) { const float4 r = red[k * C4 + cq]; s4.x += r.x; s4.y += r.y; s4.z += r.z; s4.w += r.w; }
+      o[(cq * 4 + 0) * 9 + tap] = s4.x; o[(cq * 4 + 1) * 9 + tap] = s4.y;
+      o[(cq * 4 + 2) * 9 + tap] = s4.z; o[(cq * 4 + 3) * 9 + tap] = s4.w;
+    }
+  }
+}
+
+static bool thin_ok(const xas_conv_shape* s, int C) {
+  return s->R == 3 && s->S == 3 && s->stride == 1 && s->pad == 1 && C % 4 == 0 && C >= 4 && C <= 64 &&
+         (256 % (C / 4)) == 0 && s->Ho == s->Hi && s->Wo == s->Wi;
+}
+constexpr int kThinChunk = 2048;
 
 // ------------------------------------------------------------------------------------
 // direct (VALU) fallbacks for shapes the MFMA tiles do not cover (Cin = 1 / 3, Cout = 1)
@@ -554,7 +685,12 @@ static int launch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStre
 
 template <int MODE>
 static int dispatch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
-  if (p.Cd >= 96) return launch_igemm<128, 128, MODE>(p, Mrows_max, phases, st);
+  if (p.Cd >= 96) {
+    // small problems (layer3/4 at B=32: M = 8192 / 2048 rows): 128x128 tiles leave most of the 256 CUs idle
+    const long blocks128 = cdiv(Mrows_max, 128) * cdiv(p.Cd, 128) * phases;
+    if (blocks128 <= 512) return launch_igemm<64, 64, MODE>(p, Mrows_max, phases, st);
+    return launch_igemm<128, 128, MODE>(p, Mrows_max, phases, st);
+  }
   if (p.Cd >= 48) return launch_igemm<128, 64, MODE>(p, Mrows_max, phases, st);
   return launch_igemm<128, 32, MODE>(p, Mrows_max, phases, st);
 }
@@ -572,6 +708,21 @@ extern "C" int xas_conv_fwd(const float* x, const float* w_packed, const float* 
     const int tiles = (int)(cdiv(s->Ho, ST_TH) * cdiv(s->Wo, ST_TW));
     hipLaunchKernelGGL(stem_fwd_kernel, dim3(tiles, s->N), dim3(256), 0, st, x, w_packed, y, s->N, s->Hi, s->Wi, s->Ho,
                        s->Wo);
+    XAS_LAUNCH_CHECK();
+    return 0;
+  }
+  if (s->Cout == 1 && thin_ok(s, s->Cin)) {
+    ThinParams tp{s->N, s->Hi, s->Wi, s->Cin, s->pad, 0};
+    const long M = (long)s->N * s->Hi * s->Wi;
+    hipLaunchKernelGGL(thin_vec2scalar_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, x, w_packed, bias, y, tp);
+    XAS_LAUNCH_CHECK();
+    return 0;
+  }
+  if (s->Cin == 1 && thin_ok(s, s->Cout)) {
+    ThinParams tp{s->N, s->Hi, s->Wi, s->Cout, s->pad, 0};
+    const long M = (long)s->N * s->Hi * s->Wi;
+    hipLaunchKernelGGL(thin_scalar2vec_kernel, dim3((unsigned)cdiv(M * (s->Cout / 4), 256)), dim3(256), 0, st, x, w_packed,
+                       bias, y, tp);
     XAS_LAUNCH_CHECK();
     return 0;
   }
@@ -598,6 +749,21 @@ extern "C" int xas_conv_dgrad(const float* dy, const float* w_packed_t, float* d
   XAS_REQUIRE((s->Ho - 1) * s->stride - 2 * s->pad + s->R <= s->Hi && (s->Wo - 1) * s->stride - 2 * s->pad + s->S <= s->Wi,
               "conv_dgrad: Hi/Wi (%d,%d) too small for Ho/Wo (%d,%d)", s->Hi, s->Wi, s->Ho, s->Wo);
   hipStream_t st = as_stream(stream);
+  if (s->Cin == 1 && thin_ok(s, s->Cout)) {          // dx[m] = sum dy[src] . wt[0][tap][:]
+    ThinParams tp{s->N, s->Hi, s->Wi, s->Cout, s->pad, 1};
+    const long M = (long)s->N * s->Hi * s->Wi;
+    hipLaunchKernelGGL(thin_vec2scalar_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, dy, w_packed_t, nullptr, dx, tp);
+    XAS_LAUNCH_CHECK();
+    return 0;
+  }
+  if (s->Cout == 1 && thin_ok(s, s->Cin)) {          // dx[m][ci] = sum dy[src] * wt[ci][tap]
+    ThinParams tp{s->N, s->Hi, s->Wi, s->Cin, s->pad, 1};
+    const long M = (long)s->N * s->Hi * s->Wi;
+    hipLaunchKernelGGL(thin_scalar2vec_kernel, dim3((unsigned)cdiv(M * (s->Cin / 4), 256)), dim3(256), 0, st, dy,
+                       w_packed_t, nullptr, dx, tp);
+    XAS_LAUNCH_CHECK();
+    return 0;
+  }
   if (s->Cout % BK != 0 || s->Cin < 16) {
     const long total = (long)s->N * s->Hi * s->Wi * s->Cin;
     hipLaunchKernelGGL(direct_dgrad_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, dy, w_packed_t, dx, *s);
@@ -616,10 +782,10 @@ extern "C" int xas_conv_dgrad(const float* dy, const float* w_packed_t, float* d
 static void wgrad_plan(const xas_conv_shape* s, int* bm, int* bn, int* splits, int* mps) {
   const long KK = (long)s->R * s->S * s->Cin, M = (long)s->N * s->Ho * s->Wo;
   *bm = s->Cout >= 96 ? 128 : 64;
-  *bn = 128;
+  *bn = KK <= 64 ? 64 : 128;
   const long tiles = cdiv(s->Cout, *bm) * cdiv(KK, *bn);
-  long sp = cdiv(1024, tiles);
-  const long maxsp = M / 256 > 0 ? M / 256 : 1;
+  long sp = cdiv(768, tiles);                      // ~3 blocks per CU in total
+  const long maxsp = M / 1024 > 0 ? M / 1024 : 1;  // >= 32 K-steps per block amortise prologue + slab write
   if (sp > maxsp) sp = maxsp;
   if (sp < 1) sp = 1;
   long per = cdiv(M, sp);
@@ -632,6 +798,10 @@ constexpr int kCout1Chunk = 2048;
 
 extern "C" size_t xas_conv_wgrad_workspace_floats(const xas_conv_shape* s) {
   if (!s) return 0;
+  if ((s->Cout == 1 && thin_ok(s, s->Cin)) || (s->Cin == 1 && thin_ok(s, s->Cout))) {
+    const long C = s->Cout == 1 ? s->Cin : s->Cout;
+    return (size_t)(cdiv((long)s->N * s->Hi * s->Wi, kThinChunk) + 1) * C * 9;
+  }
   if (s->Cout == 1) return (size_t)cdiv((long)s->N * s->Ho * s->Wo, kCout1Chunk) * s->R * s->S * s->Cin;
   int bm, bn, sp, mps;
   wgrad_plan(s, &bm, &bn, &sp, &mps);
@@ -653,27 +823,66 @@ static int launch_wgrad(const WgradParams& p, int splits, hipStream_t st) {
   return 0;
 }
 
+static int conv_wgrad_impl(const float* x, const float* dy, float* dw_out, float* workspace, const xas_conv_shape* s,
+                           void* stream, bool oihw);
+
 extern "C" int xas_conv_wgrad(const float* x, const float* dy, float* dw_packed, float* workspace,
                               const xas_conv_shape* s, void* stream) {
+  return conv_wgrad_impl(x, dy, dw_packed, workspace, s, stream, false);
+}
+
+extern "C" int xas_conv_wgrad_oihw(const float* x, const float* dy, float* dw_oihw, float* workspace,
+                                   const xas_conv_shape* s, void* stream) {
+  return conv_wgrad_impl(x, dy, dw_oihw, workspace, s, stream, true);
+}
+
+static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, float* workspace, const xas_conv_shape* s,
+                           void* stream, bool oihw) {
   if (check_shape(s, "conv_wgrad")) return 1;
   XAS_REQUIRE(x && dy && dw_packed && workspace, "conv_wgrad: null buffer");
   XAS_REQUIRE(s->Cout % 4 == 0 || s->Cout == 1, "conv_wgrad: Cout=%d must be a multiple of 4 (or 1)", s->Cout);
   hipStream_t st = as_stream(stream);
+  if ((s->Cout == 1 && thin_ok(s, s->Cin)) || (s->Cin == 1 && thin_ok(s, s->Cout))) {
+    // slabs [chunk][c][tap] == OIHW order for both cases ([1][Cin][3][3] resp. [Cout][1][3][3]); the packed
+    // layouts are [1][tap][c] resp. [c][tap]
+    const bool cout1 = s->Cout == 1;
+    const int C = cout1 ? s->Cin : s->Cout;
+    ThinParams tp{s->N, s->Hi, s->Wi, C, s->pad, 0};
+    const long M = (long)s->N * s->Hi * s->Wi;
+    const int chunks = (int)cdiv(M, kThinChunk);
+    hipLaunchKernelGGL(thin_wgrad_kernel, dim3(chunks), dim3(256), 0, st, cout1 ? dy : x, cout1 ? x : dy, workspace, tp,
+                       cout1 ? 0 : 1, kThinChunk);
+    XAS_LAUNCH_CHECK();
+    const long n = (long)C * 9;
+    if (oihw || !cout1) {
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, workspace, chunks, n, dw_packed);
+    } else {          // packed [1][tap][c] wanted: treat the [c][tap] sums as an "OIHW" with Cout=1 and repack
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, workspace, chunks, n,
+                         workspace + (size_t)chunks * n);
+      XAS_LAUNCH_CHECK();
+      hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, workspace + (size_t)chunks * n,
+                         dw_packed, 1, C, 3, 3, 0, 0);
+    }
+    XAS_LAUNCH_CHECK();
+    return 0;
+  }
   if (s->Cout == 1) {
     const int KK = s->R * s->S * s->Cin;
     const int chunks = (int)cdiv((long)s->N * s->Ho * s->Wo, kCout1Chunk);
     hipLaunchKernelGGL(wgrad_cout1_kernel, dim3((unsigned)cdiv(KK, 64), (unsigned)chunks), dim3(64), 0, st, x, dy,
                        workspace, *s, kCout1Chunk);
     XAS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(KK, 256)), dim3(256), 0, st, workspace, chunks, (long)KK,
-                       dw_packed);
+    if (oihw) hipLaunchKernelGGL(slab_reduce_unpack_kernel, dim3((unsigned)cdiv(KK, 256)), dim3(256), 0, st, workspace,
+                                 chunks, 1, s->Cin, s->R, s->S, dw_packed);
+    else hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(KK, 256)), dim3(256), 0, st, workspace, chunks,
+                            (long)KK, dw_packed);
     XAS_LAUNCH_CHECK();
     return 0;
   }
   int bm, bn, splits, mps;
   wgrad_plan(s, &bm, &bn, &splits, &mps);
   WgradParams p{};
-  p.x = x; p.dy = dy; p.out = (splits == 1) ? dw_packed : workspace;
+  p.x = x; p.dy = dy; p.out = (splits == 1 && !oihw) ? dw_packed : workspace;
   p.N = s->N; p.Hi = s->Hi; p.Wi = s->Wi; p.Cin = s->Cin; p.Cout = s->Cout; p.R = s->R; p.S = s->S;
   p.stride = s->stride; p.pad = s->pad; p.Ho = s->Ho; p.Wo = s->Wo;
   p.KK = s->R * s->S * s->Cin; p.M = s->N * s->Ho * s->Wo; p.m_per_split = mps;
@@ -682,11 +891,16 @@ extern "C" int xas_conv_wgrad(const float* x, const float* dy, float* dw_packed,
   XAS_REQUIRE(s->Cout % 4 == 0, "conv_wgrad: Cout=%d not supported by the MFMA path", s->Cout);
   const bool vec = (s->Cin % 4 == 0) && (((uintptr_t)x & 15) == 0);
   int rc;
-  if (bm == 128) rc = vec ? launch_wgrad<128, 128, true>(p, splits, st) : launch_wgrad<128, 128, false>(p, splits, st);
+  if (bn == 64 && vec) rc = bm == 128 ? launch_wgrad<128, 64, true>(p, splits, st) : launch_wgrad<64, 64, true>(p, splits, st);
+  else if (bm == 128) rc = vec ? launch_wgrad<128, 128, true>(p, splits, st) : launch_wgrad<128, 128, false>(p, splits, st);
   else rc = vec ? launch_wgrad<64, 128, true>(p, splits, st) : launch_wgrad<64, 128, false>(p, splits, st);
   if (rc) return rc;
-  if (splits > 1) {
-    const long n = (long)s->Cout * p.KK;
+  const long n = (long)s->Cout * p.KK;
+  if (oihw) {
+    hipLaunchKernelGGL(slab_reduce_unpack_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, workspace, splits,
+                       s->Cout, s->Cin, s->R, s->S, dw_packed);
+    XAS_LAUNCH_CHECK();
+  } else if (splits > 1) {
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, workspace, splits, n, dw_packed);
     XAS_LAUNCH_CHECK();
   }

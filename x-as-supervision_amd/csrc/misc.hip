@@ -73,39 +73,48 @@ __global__ void graph_aggregate_kernel(const float* __restrict__ x, const float*
 }
 
 // ------------------------------------------------------------------ graph LayerNorm (+relu, +residual)
-// PyG norm.LayerNorm(mode='graph', batch=None): (x - mean_all) / (std_all + eps) * gamma + beta
+// PyG norm.LayerNorm(mode='graph', batch=None): (x - mean_all) / (std_all + eps) * gamma + beta, where
+// "all" = the whole [rows, C] tensor of ONE discriminator call.  G independent calls are batched as G
+// groups of `rows` rows each (x is [G*rows, C]); statistics stay per group.
 constexpr int kGlnThreads = 256;
 
 __global__ void gln_partial_kernel(const float* __restrict__ x, long n, float* __restrict__ partial) {
   __shared__ float sm[20];
-  const float pivot = x[0];
+  const float* xg = x + (size_t)blockIdx.y * n;
+  const float pivot = xg[0];
   float a = 0.f, b = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float d = x[i] - pivot;
+    const float d = xg[i] - pivot;
     a += d; b = fmaf(d, d, b);
   }
   a = block_sum(a, sm);
   b = block_sum(b, sm);
-  if (threadIdx.x == 0) { partial[blockIdx.x * 2] = a; partial[blockIdx.x * 2 + 1] = b; }
+  if (threadIdx.x == 0) {
+    float* o = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+    o[0] = a; o[1] = b;
+  }
 }
 
 __global__ void gln_stats_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ x, long n,
-                                 float* __restrict__ stats) {
-  if (threadIdx.x != 0) return;
+                                 int G, float* __restrict__ stats) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
   double a = 0.0, b = 0.0;
-  for (int i = 0; i < nblk; ++i) { a += partial[i * 2]; b += partial[i * 2 + 1]; }
+  for (int i = 0; i < nblk; ++i) { a += partial[((size_t)g * nblk + i) * 2]; b += partial[((size_t)g * nblk + i) * 2 + 1]; }
   const double m = a / (double)n;
   double v = b / (double)n - m * m;
   if (v < 0.0) v = 0.0;
-  stats[0] = (float)((double)x[0] + m);
-  stats[1] = (float)sqrt(v);
+  stats[g * 2] = (float)((double)x[(size_t)g * n] + m);
+  stats[g * 2 + 1] = (float)sqrt(v);
 }
 
 __global__ void gln_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, const float* __restrict__ res,
-                                 const float* __restrict__ stats, long n, int C, float eps, float* __restrict__ y) {
-  const float mean = stats[0], inv = 1.f / (stats[1] + eps);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+                                 const float* __restrict__ stats, long n, int G, int C, float eps, float* __restrict__ y) {
+  const long total = n * G;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i / n);
+    const float mean = stats[g * 2], inv = 1.f / (stats[g * 2 + 1] + eps);
     const int c = i % C;
     float v = (x[i] - mean) * inv * gamma[c] + beta[c];
     v = fmaxf(v, 0.f);
@@ -114,24 +123,24 @@ __global__ void gln_apply_kernel(const float* __restrict__ x, const float* __res
   }
 }
 
-// per-channel sums of g and g*xhat where g = dy * relu'(ln(x)); block = 64 channels x 16 row lanes
+// per group, per channel: sums of g and g*xhat where g = dy * relu'(ln(x)); block = 64 channels x 16 row lanes
 __global__ __launch_bounds__(1024) void gln_bwd_cols_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
                                                             const float* __restrict__ stats, long rows, int C,
-                                                            float eps, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta) {
+                                                            float eps, float* __restrict__ gsum /* [G][2][C] */) {
   __shared__ float s1[16][64], s2[16][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cx;
-  const float mean = stats[0], inv = 1.f / (stats[1] + eps);
+  const int c = blockIdx.x * 64 + cx, g = blockIdx.y;
+  const float mean = stats[g * 2], inv = 1.f / (stats[g * 2 + 1] + eps);
+  const size_t base = (size_t)g * rows * C;
   float a = 0.f, b = 0.f;
   if (c < C) {
     const float gmm = gamma[c], bt = beta[c];
     for (long r = ry; r < rows; r += 16) {
-      const float xh = (x[r * C + c] - mean) * inv;
-      const float g = (xh * gmm + bt > 0.f) ? dy[r * C + c] : 0.f;
-      a += g; b = fmaf(g, xh, b);
+      const float xh = (x[base + r * C + c] - mean) * inv;
+      const float gg = (xh * gmm + bt > 0.f) ? dy[base + r * C + c] : 0.f;
+      a += gg; b = fmaf(gg, xh, b);
     }
   }
   s1[ry][cx] = a; s2[ry][cx] = b;
@@ -139,33 +148,48 @@ __global__ __launch_bounds__(1024) void gln_bwd_cols_kernel(const float* __restr
   if (ry == 0 && c < C) {
     float u = 0.f, v = 0.f;
     for (int k = 0; k < 16; ++k) { u += s1[k][cx]; v += s2[k][cx]; }
-    dbeta[c] = u;
-    dgamma[c] = v;
+    gsum[((size_t)g * 2) * C + c] = u;          // d beta contribution
+    gsum[((size_t)g * 2 + 1) * C + c] = v;      // d gamma contribution
   }
 }
 
-__global__ void gln_bwd_scalar_kernel(const float* __restrict__ gamma, const float* __restrict__ dgamma,
-                                      const float* __restrict__ dbeta, int C, float* __restrict__ ab) {
+// per group: A = sum_c gamma*dbeta_g, B = sum_c gamma*dgamma_g ; block 0 also reduces dgamma/dbeta over groups
+__global__ void gln_bwd_scalar_kernel(const float* __restrict__ gamma, const float* __restrict__ gsum, int G, int C,
+                                      float* __restrict__ ab, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   __shared__ float sm[20];
-  float a = 0.f, b = 0.f;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) { a = fmaf(gamma[c], dbeta[c], a); b = fmaf(gamma[c], dgamma[c], b); }
-  a = block_sum(a, sm);
-  b = block_sum(b, sm);
-  if (threadIdx.x == 0) { ab[0] = a; ab[1] = b; }
+  const int g = blockIdx.x;
+  if (g < G) {
+    float a = 0.f, b = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      a = fmaf(gamma[c], gsum[((size_t)g * 2) * C + c], a);
+      b = fmaf(gamma[c], gsum[((size_t)g * 2 + 1) * C + c], b);
+    }
+    a = block_sum(a, sm);
+    b = block_sum(b, sm);
+    if (threadIdx.x == 0) { ab[g * 2] = a; ab[g * 2 + 1] = b; }
+  } else {                       // extra block: parameter gradients = sum over groups
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float u = 0.f, v = 0.f;
+      for (int k = 0; k < G; ++k) { u += gsum[((size_t)k * 2) * C + c]; v += gsum[((size_t)k * 2 + 1) * C + c]; }
+      dbeta[c] = u; dgamma[c] = v;
+    }
+  }
 }
 
 __global__ void gln_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                     const float* __restrict__ stats, const float* __restrict__ ab, long n, int C,
+                                     const float* __restrict__ stats, const float* __restrict__ ab, long n, int G, int C,
                                      float eps, float* __restrict__ dx) {
-  const float mean = stats[0], sigma = stats[1], s = sigma + eps, inv = 1.f / s;
-  const float A = ab[0] / (float)n;
-  const float Bc = sigma > 0.f ? ab[1] / ((float)n * sigma) : 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+  const long total = n * G;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i / n);
+    const float mean = stats[g * 2], sigma = stats[g * 2 + 1], inv = 1.f / (sigma + eps);
+    const float A = ab[g * 2] / (float)n;
+    const float Bc = sigma > 0.f ? ab[g * 2 + 1] / ((float)n * sigma) : 0.f;
     const int c = i % C;
     const float xh = (x[i] - mean) * inv;
-    const float g = (xh * gamma[c] + beta[c] > 0.f) ? dy[i] * gamma[c] : 0.f;
-    dx[i] = (g - A) * inv - xh * Bc;
+    const float gg = (xh * gamma[c] + beta[c] > 0.f) ? dy[i] * gamma[c] : 0.f;
+    dx[i] = (gg - A) * inv - xh * Bc;
   }
 }
 
@@ -362,38 +386,44 @@ extern "C" int xas_graph_aggregate(const float* x, const float* adj, int B, int 
   return 0;
 }
 
-static int gln_nblk(long n) { long b = cdiv(n, (long)kGlnThreads * 8); return (int)(b > 256 ? 256 : (b < 1 ? 1 : b)); }
+static int gln_nblk(long n) { long b = cdiv(n, (long)kGlnThreads * 8); return (int)(b > 64 ? 64 : (b < 1 ? 1 : b)); }
 
-extern "C" size_t xas_gln_workspace_floats(long n) { return (size_t)gln_nblk(n) * 2 + 8; }
+extern "C" size_t xas_gln_workspace_floats(long n, int groups, int C) {
+  return (size_t)groups * (gln_nblk(n) * 2 + 2 + 2 * (size_t)C) + 8;
+}
 
 extern "C" int xas_gln_fwd(const float* x, const float* gamma, const float* beta, const float* residual, long rows,
-                           int C, float eps, float* y, float* stats, float* workspace, void* stream) {
-  XAS_REQUIRE(x && gamma && beta && y && stats && workspace && rows > 0 && C > 0, "gln_fwd: bad arguments");
+                           int C, int groups, float eps, float* y, float* stats, float* workspace, void* stream) {
+  XAS_REQUIRE(x && gamma && beta && y && stats && workspace && rows > 0 && C > 0 && groups > 0, "gln_fwd: bad arguments");
   const long n = rows * C;
   const int nblk = gln_nblk(n);
-  hipLaunchKernelGGL(gln_partial_kernel, dim3(nblk), dim3(kGlnThreads), 0, as_stream(stream), x, n, workspace);
+  hipLaunchKernelGGL(gln_partial_kernel, dim3(nblk, groups), dim3(kGlnThreads), 0, as_stream(stream), x, n, workspace);
   XAS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gln_stats_kernel, dim3(1), dim3(64), 0, as_stream(stream), workspace, nblk, x, n, stats);
+  hipLaunchKernelGGL(gln_stats_kernel, dim3((unsigned)cdiv(groups, 64)), dim3(64), 0, as_stream(stream), workspace, nblk,
+                     x, n, groups, stats);
   XAS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gln_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), x, gamma, beta, residual,
-                     stats, n, C, eps, y);
+  hipLaunchKernelGGL(gln_apply_kernel, dim3(ew_grid(n * groups)), dim3(256), 0, as_stream(stream), x, gamma, beta,
+                     residual, stats, n, groups, C, eps, y);
   XAS_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int xas_gln_bwd(const float* x, const float* beta, const float* dy, const float* gamma,
-                           const float* stats, long rows, int C, float eps, float* dx, float* dgamma, float* dbeta,
-                           float* workspace, void* stream) {
-  XAS_REQUIRE(x && beta && dy && gamma && stats && dx && dgamma && dbeta && workspace && rows > 0 && C > 0,
+                           const float* stats, long rows, int C, int groups, float eps, float* dx, float* dgamma,
+                           float* dbeta, float* workspace, void* stream) {
+  XAS_REQUIRE(x && beta && dy && gamma && stats && dx && dgamma && dbeta && workspace && rows > 0 && C > 0 && groups > 0,
               "gln_bwd: bad arguments");
   const long n = rows * C;
-  hipLaunchKernelGGL(gln_bwd_cols_kernel, dim3((unsigned)cdiv(C, 64)), dim3(1024), 0, as_stream(stream), x, dy, gamma,
-                     beta, stats, rows, C, eps, dgamma, dbeta);
+  float* gsum = workspace;                              // [G][2][C]
+  float* ab = workspace + (size_t)groups * 2 * C;       // [G][2]
+  hipLaunchKernelGGL(gln_bwd_cols_kernel, dim3((unsigned)cdiv(C, 64), groups), dim3(1024), 0, as_stream(stream), x, dy,
+                     gamma, beta, stats, rows, C, eps, gsum);
   XAS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gln_bwd_scalar_kernel, dim3(1), dim3(256), 0, as_stream(stream), gamma, dgamma, dbeta, C, workspace);
+  hipLaunchKernelGGL(gln_bwd_scalar_kernel, dim3(groups + 1), dim3(256), 0, as_stream(stream), gamma, gsum, groups, C, ab,
+                     dgamma, dbeta);
   XAS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gln_bwd_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), x, dy, gamma, beta, stats,
-                     workspace, n, C, eps, dx);
+  hipLaunchKernelGGL(gln_bwd_apply_kernel, dim3(ew_grid(n * groups)), dim3(256), 0, as_stream(stream), x, dy, gamma, beta,
+                     stats, ab, n, groups, C, eps, dx);
   XAS_LAUNCH_CHECK();
   return 0;
 }

@@ -69,6 +69,19 @@ class GCNDiscriminator_base(nn.Module):
             self._graph = (a.to(device).contiguous(), a.t().contiguous().to(device))
         return (self._graph[0], self._graph[1], batch_size, self.num_nodes)
 
+    def forward_groups(self, inputs):
+        """Evaluate the discriminator on several independent inputs [B,N,C] in ONE batched pass and return
+        the list of logits.  Equivalent to `[self(x) for x in inputs]` (graph-LayerNorm statistics stay per
+        input), but every kernel is launched once for all of them: the reference issues 28 separate
+        discriminator calls per step (model.py:126-129, 241-245), ~300 tiny kernels each."""
+        G = len(inputs)
+        B = inputs[0].shape[0]
+        out = self._forward(torch.cat(list(inputs), dim=0), groups=G)
+        return list(out.split(B, dim=0))
+
+    def forward(self, keypoints):
+        return self._forward(keypoints, groups=1)
+
     def header_forward(self, graph_features, batch_size):
         return self.header(graph_features.reshape(batch_size, -1))
 
@@ -93,9 +106,9 @@ class GCNSAGEDiscriminator(GCNDiscriminator_base):
         self.use_pe = cfg['use_pe'] if 'use_pe' in cfg else False
         self.input_layer = L.Linear(self.disc_sup_dim * (2 if self.use_pe else 1), self.input_dim)
 
-    def forward(self, keypoints):
+    def _forward(self, keypoints, groups=1):
         B = keypoints.shape[0]
-        g = self.graph(B, keypoints.device)
+        g = self.graph(B, keypoints.device) + (groups,)
         if self.use_pe:
             keypoints = torch.cat([keypoints, self.cal_positional_encoding(keypoints)], dim=-1)
         x = self.input_layer(keypoints.reshape(B * self.num_nodes, -1))
@@ -115,11 +128,11 @@ class GCNDiscriminatorDecouple(GCNDiscriminator_base):
         self.bone_gcn = _stream(self.hidden_dim, self.output_dim, self.num_layers)
         self.header = FFNHeader(self.output_dim * self.num_nodes * 2, 512)
 
-    def forward(self, keypoints):
+    def _forward(self, keypoints, groups=1):
         B, _, dim = keypoints.shape
         bone = keypoints[:, self.parent_ids, :] - keypoints[:, self.child_ids, :]
         bone = torch.cat([keypoints.new_zeros(B, 1, dim), bone], dim=1)       # zero row for the root node
-        g = self.graph(B, keypoints.device)
+        g = self.graph(B, keypoints.device) + (groups,)
         if self.use_pe:
             pe = self.cal_positional_encoding(keypoints)
             keypoints = torch.cat([keypoints, pe], dim=-1)

@@ -40,7 +40,7 @@ class SAGEConv(nn.Module):
         self.lin_r = L.Linear(cin, cout, bias=False)
 
     def forward(self, x, graph):
-        adj, adj_t, B, N = graph
+        adj, adj_t, B, N = graph[:4]
         return self.lin_l(ops_misc.graph_aggregate(x, adj, adj_t, B, N)) + self.lin_r(x)
 
 
@@ -68,8 +68,9 @@ class GCN_SAGE_residual(nn.Module):
 
     def forward(self, input):
         x, graph = input
-        y = ops_misc.graph_layernorm_relu(self.gc1(x, graph), self.ln1.weight, self.ln1.bias, None, self.ln1.eps)
+        groups = graph[4] if len(graph) > 4 else 1          # independent calls batched along the rows
+        y = ops_misc.graph_layernorm_relu(self.gc1(x, graph), self.ln1.weight, self.ln1.bias, None, self.ln1.eps, groups)
         if self.single_layer:
             return (y, graph)
-        y = ops_misc.graph_layernorm_relu(self.gc2(y, graph), self.ln2.weight, self.ln2.bias, x, self.ln2.eps)
+        y = ops_misc.graph_layernorm_relu(self.gc2(y, graph), self.ln2.weight, self.ln2.bias, x, self.ln2.eps, groups)
         return (y, graph)

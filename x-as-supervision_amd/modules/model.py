@@ -30,6 +30,13 @@ def _cams(x, cam_id_list):
     return ['mono'] if 'cam_mono_img' in x else cam_id_list
 
 
+def _disc_many(disc, inputs):
+    """Logits of the discriminator on a list of inputs: one batched pass when the module offers it."""
+    if hasattr(disc, 'forward_groups'):
+        return disc.forward_groups(inputs)
+    return [disc(t) for t in inputs]
+
+
 def _to_world(kps, x, key, mono):
     if mono:
         return convert_patch_to_world(kps, x, key, is_norm=True, RECT_WIDTH=256, mono=True, patch=False)
@@ -91,10 +98,16 @@ class Counter3DModel(torch.nn.Module):
 
         if 'smpl_gen_loss' in lc:
             total = 0
+            rels = {}
             for cam in cams:
                 key = 'cam_{}'.format(cam)
-                rel = ((world[key] - world[key][:, [0]]) / 1000)[..., :self.DISC_SUP_DIMENSION]
-                logits = torch.stack([smpl_discriminator(rel[:, h].detach()) for h in range(rel.shape[1])], dim=1)
+                rels[key] = ((world[key] - world[key][:, [0]]) / 1000)[..., :self.DISC_SUP_DIMENSION].detach()
+            hy = world['cam_{}'.format(cams[0])].shape[1]
+            flat = _disc_many(smpl_discriminator, [rels['cam_{}'.format(c)][:, h] for c in cams for h in range(hy)])
+            for ci, cam in enumerate(cams):
+                key = 'cam_{}'.format(cam)
+                rel = rels[key]
+                logits = torch.stack(flat[ci * hy:(ci + 1) * hy], dim=1)
                 if not self.use_aug:
                     total = total + compute_disc_loss(logits, None)
                 else:
@@ -157,16 +170,26 @@ class Counter3DDisc(torch.nn.Module):
         total = 0
         out = {}
         d = self.DISC_SUP_DIMENSION
-        for cam in _cams(x, self.cam_id_list):
+        cams = _cams(x, self.cam_id_list)
+        preds, reals, inputs = {}, {}, []
+        for cam in cams:
             key = 'cam_{}'.format(cam)
-            pred, _ = regressor(x[key + '_img'])                       # train-mode BN: running stats move here too
-            real = x[key + '_pseudo_joints']
+            # The reference builds (and discards) an autograd graph here (model.py:231, output detached at :243);
+            # only the values and the train-mode BN running-statistic updates matter, so no graph is recorded.
+            with torch.no_grad():
+                pred, _ = regressor(x[key + '_img'])
+            preds[key], reals[key] = pred, x[key + '_pseudo_joints']
+            inputs += [preds[key][:, h, :, :d] for h in range(pred.shape[1])] + [reals[key][..., :d]]
+        logits = _disc_many(self.smpl_discriminator, inputs)           # every hypothesis / camera in one pass
+        per_cam = len(inputs) // len(cams)
+        for ci, cam in enumerate(cams):
+            key = 'cam_{}'.format(cam)
+            real = reals[key]
             real_world = _to_world(real, x, key, True)
             out['pose_smpl_2d_{}'.format(key)] = real[[0]]
             out['pose_smpl_3d_{}'.format(key)] = real_world[[0]].clone()
-            fake_logits = torch.stack([self.smpl_discriminator(pred[:, h, :, :d].detach()) for h in range(pred.shape[1])],
-                                      dim=1)
-            real_logits = self.smpl_discriminator(real[..., :d])
+            mine = logits[ci * per_cam:(ci + 1) * per_cam]
+            fake_logits, real_logits = torch.stack(mine[:-1], dim=1), mine[-1]
             out['smpl_logits_{}'.format(key)] = real_logits[[0]]
             out['pred_logits_{}'.format(key)] = fake_logits[[0], 0]
             if self.use_aug:

@@ -33,6 +33,7 @@ SIGNATURES = {
     'xas_conv_dgrad': ('pppsp', 'i'),
     'xas_conv_wgrad_workspace_floats': ('s', 'z'),
     'xas_conv_wgrad': ('ppppsp', 'i'),
+    'xas_conv_wgrad_oihw': ('ppppsp', 'i'),
     'xas_pack_weight': ('ppiiiiip', 'i'),
     'xas_unpack_weight': ('ppiiiiip', 'i'),
     'xas_bn_workspace_floats': ('li', 'z'),
@@ -54,9 +55,9 @@ SIGNATURES = {
     'xas_mask_loss_fwd': ('pppliPpp'.replace('P', 'p'), 'i'),
     'xas_mask_loss_bwd': ('pppliPppp'.replace('P', 'p'), 'i'),
     'xas_graph_aggregate': ('ppiiipp', 'i'),
-    'xas_gln_workspace_floats': ('l', 'z'),
-    'xas_gln_fwd': ('pppplifpppp', 'i'),
-    'xas_gln_bwd': ('ppppplifppppp', 'i'),
+    'xas_gln_workspace_floats': ('lii', 'z'),
+    'xas_gln_fwd': ('ppppliifpppp', 'i'),
+    'xas_gln_bwd': ('pppppliifppppp', 'i'),
     'xas_smpl_lbs_fwd': ('ppppppppiiipppp', 'i'),
     'xas_adam_step': ('pppplffffip', 'i'),
 }

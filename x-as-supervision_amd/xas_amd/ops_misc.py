@@ -60,35 +60,38 @@ def graph_aggregate(x, adj, adj_t, B, N):
 
 class _GraphLayerNormRelu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, eps):
+    def forward(ctx, x, gamma, beta, residual, eps, groups):
         x = x.contiguous()
-        rows, C = x.shape
+        rows_all, C = x.shape
+        rows = rows_all // groups
         y = torch.empty_like(x)
-        stats = torch.empty(2, device=x.device, dtype=torch.float32)
-        ws = torch.empty(query('xas_gln_workspace_floats', rows * C), device=x.device, dtype=torch.float32)
+        stats = torch.empty(groups * 2, device=x.device, dtype=torch.float32)
+        ws = torch.empty(query('xas_gln_workspace_floats', rows * C, groups, C), device=x.device, dtype=torch.float32)
         res = residual.contiguous() if residual is not None else None
-        call('xas_gln_fwd', ptr(x), ptr(gamma), ptr(beta), ptr(res), rows, C, float(eps), ptr(y), ptr(stats), ptr(ws))
+        call('xas_gln_fwd', ptr(x), ptr(gamma), ptr(beta), ptr(res), rows, C, groups, float(eps), ptr(y), ptr(stats), ptr(ws))
         ctx.save_for_backward(x, gamma, beta, stats)
-        ctx.eps, ctx.has_res = float(eps), residual is not None
+        ctx.cfg = (float(eps), residual is not None, groups, rows)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, stats = ctx.saved_tensors
-        rows, C = x.shape
+        eps, has_res, groups, rows = ctx.cfg
+        C = x.shape[1]
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dg = torch.empty_like(gamma)
         db = torch.empty_like(beta)
-        ws = torch.empty(8, device=x.device, dtype=torch.float32)
-        call('xas_gln_bwd', ptr(x), ptr(beta), ptr(dy), ptr(gamma), ptr(stats), rows, C, ctx.eps, ptr(dx), ptr(dg),
+        ws = torch.empty(query('xas_gln_workspace_floats', rows * C, groups, C), device=x.device, dtype=torch.float32)
+        call('xas_gln_bwd', ptr(x), ptr(beta), ptr(dy), ptr(gamma), ptr(stats), rows, C, groups, eps, ptr(dx), ptr(dg),
              ptr(db), ptr(ws))
-        return dx, dg, db, (dy if ctx.has_res else None), None
+        return dx, dg, db, (dy if has_res else None), None, None
 
 
-def graph_layernorm_relu(x, gamma, beta, residual=None, eps=1e-5):
-    """relu(PyG graph-mode LayerNorm(x)) (+ residual)   (modules/gcn.py:93-110)."""
-    return _GraphLayerNormRelu.apply(x, gamma, beta, residual, eps)
+def graph_layernorm_relu(x, gamma, beta, residual=None, eps=1e-5, groups=1):
+    """relu(PyG graph-mode LayerNorm(x)) (+ residual)   (modules/gcn.py:93-110).  x: [groups*rows, C]; the
+    normalisation statistics are taken per group (= per original discriminator call)."""
+    return _GraphLayerNormRelu.apply(x, gamma, beta, residual, eps, groups)
 
 
 def smpl_lbs(pose, betas, v_template, shapedirs, posedirs, j_regressor, weights, parents, center_idx=0):

@@ -77,11 +77,9 @@ def _bias_grad(dy, M, C):
 def _wgrad(x, dy, shp, w_shape, transposed=False):
     """-> gradient in OIHW layout for a conv described by shp (x: gathered side, dy: row side)."""
     co, ci, r, s = shp.Cout, shp.Cin, shp.R, shp.S
-    dwp = torch.empty(co * ci * r * s, device=x.device, dtype=torch.float32)
     ws = torch.empty(max(1, query('xas_conv_wgrad_workspace_floats', shp)), device=x.device, dtype=torch.float32)
-    call('xas_conv_wgrad', ptr(x), ptr(dy), ptr(dwp), ptr(ws), shp)
     dw = torch.empty(w_shape, device=x.device, dtype=torch.float32)
-    call('xas_unpack_weight', ptr(dwp), ptr(dw), co, ci, r, s, 0)
+    call('xas_conv_wgrad_oihw', ptr(x), ptr(dy), ptr(dw), ptr(ws), shp)
     return dw
 
 

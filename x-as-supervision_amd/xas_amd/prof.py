@@ -4,7 +4,7 @@ import torch
 
 from . import _lib
 
-CONV_ENTRIES = ('xas_conv_fwd', 'xas_conv_dgrad', 'xas_conv_wgrad')
+CONV_ENTRIES = ('xas_conv_fwd', 'xas_conv_dgrad', 'xas_conv_wgrad', 'xas_conv_wgrad_oihw')
 
 
 def conv_flops(shape):
@@ -40,15 +40,29 @@ class KernelTimer:
                 mfma = shape.Cout % 32 == 0 and shape.Cin >= 16
             else:
                 mfma = shape.Cout != 1
-        self.records.append((name, a, b, conv_flops(shape) if shape is not None else 0.0, mfma))
+        sig = None
+        if shape is not None:
+            sig = (shape.N, shape.Hi, shape.Wi, shape.Cin, shape.Cout, shape.R, shape.stride)
+        self.records.append((name, a, b, conv_flops(shape) if shape is not None else 0.0, mfma, sig))
 
     def summary(self):
         """-> dict per entry point: launches, total ms, total flops (call after torch.cuda.synchronize())."""
         out = {}
-        for name, a, b, fl, mfma in self.records:
+        for name, a, b, fl, mfma, _sig in self.records:
             key = name + ('' if mfma else ':direct')
             d = out.setdefault(key, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
             d['launches'] += 1
             d['ms'] += a.elapsed_time(b)
             d['flops'] += fl
         return out
+
+    def by_shape(self):
+        """-> list of (name, shape signature, launches, ms, tflops) sorted by time."""
+        agg = {}
+        for name, a, b, fl, mfma, sig in self.records:
+            d = agg.setdefault((name, sig), [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += a.elapsed_time(b)
+            d[2] += fl
+        rows = [(k[0], k[1], v[0], v[1], (v[2] / (v[1] * 1e-3) / 1e12) if v[1] > 0 else 0.0) for k, v in agg.items()]
+        return sorted(rows, key=lambda r: -r[3])
