@@ -21,7 +21,7 @@ static int col_geom(long M, int C, ColGeom* g) {
   while (cb < 256 && C % (cb * 2) == 0) cb *= 2;
   g->CB = cb;
   g->TX = g->CB / 4; g->TY = 256 / g->TX; g->ncb = C / g->CB;
-  long want = 1024 / g->ncb;                 // ~4 blocks per CU in total
+  long want = 512 / g->ncb;                  // ~2 blocks per CU in total; keeps the finalize pass short
   long maxslab = cdiv(M, (long)g->TY * 8);   // at least 8 rows per thread
   if (want > maxslab) want = maxslab;
   if (want < 1) want = 1;
@@ -93,24 +93,24 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
 }
 
 // partial: [nslab][2][C] -> out1[c], out2[c]; MODE 0 converts pivot sums to mean / biased var.
-// Block = 32 channels x 8 slab lanes; slabs are summed in double, in a fixed order.
+// Block = 32 channels x 32 slab lanes; slabs are summed in double, in a fixed order.
 template <int MODE>
-__global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restrict__ partial,
+__global__ __launch_bounds__(1024) void col_finalize_kernel(const float* __restrict__ partial,
                                                            const float* __restrict__ x, int nslab, int C, long M,
                                                            float* __restrict__ out1, float* __restrict__ out2) {
-  __shared__ double r1[8][32], r2[8][32];
+  __shared__ double r1[32][32], r2[32][32];
   const int cx = threadIdx.x & 31, sy = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cx;
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
-    for (int s = sy; s < nslab; s += 8) {
+    for (int s = sy; s < nslab; s += 32) {
       s1 += (double)partial[((size_t)s * 2) * C + c];
       s2 += (double)partial[((size_t)s * 2 + 1) * C + c];
     }
   r1[sy][cx] = s1; r2[sy][cx] = s2;
   __syncthreads();
   if (sy != 0 || c >= C) return;
-  for (int k = 1; k < 8; ++k) { s1 += r1[k][cx]; s2 += r2[k][cx]; }
+  for (int k = 1; k < 32; ++k) { s1 += r1[k][cx]; s2 += r2[k][cx]; }
   if (MODE == 0) {
     const double m = s1 / (double)M;
     double v = s2 / (double)M - m * m;
@@ -352,7 +352,7 @@ extern "C" int xas_bn_stats(const float* x, long M, int C, float* mean, float* v
   hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(g.nslab, g.ncb), dim3(256), 0, as_stream(stream), x, nullptr, nullptr,
                      nullptr, nullptr, 0.f, 0, M, C, g, workspace);
   XAS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_finalize_kernel<0>, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, as_stream(stream), workspace, x,
+  hipLaunchKernelGGL(col_finalize_kernel<0>, dim3((unsigned)cdiv(C, 32)), dim3(1024), 0, as_stream(stream), workspace, x,
                      g.nslab, C, M, mean, var_biased);
   XAS_LAUNCH_CHECK();
   return 0;
@@ -366,7 +366,7 @@ extern "C" int xas_col_sum(const float* x, long M, int C, float* out, float* wor
                      nullptr, nullptr, 0.f, 0, M, C, g, workspace);
   XAS_LAUNCH_CHECK();
   // second output (unused sums of the second accumulator) lands in workspace tail
-  hipLaunchKernelGGL(col_finalize_kernel<1>, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, as_stream(stream), workspace, x,
+  hipLaunchKernelGGL(col_finalize_kernel<1>, dim3((unsigned)cdiv(C, 32)), dim3(1024), 0, as_stream(stream), workspace, x,
                      g.nslab, C, M, out, workspace + (size_t)g.nslab * 2 * C);
   XAS_LAUNCH_CHECK();
   return 0;
@@ -405,7 +405,7 @@ extern "C" int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy
   hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(g.nslab, g.ncb), dim3(256), 0, as_stream(stream), x, y, dy, mean,
                      var_biased, eps, act, M, C, g, workspace);
   XAS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_finalize_kernel<1>, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, as_stream(stream), workspace, x,
+  hipLaunchKernelGGL(col_finalize_kernel<1>, dim3((unsigned)cdiv(C, 32)), dim3(1024), 0, as_stream(stream), workspace, x,
                      g.nslab, C, M, sum_dz, sum_dz_xhat);
   XAS_LAUNCH_CHECK();
   return 0;

@@ -57,8 +57,8 @@ struct IgemmParams {
 // ------------------------------------------------------------------------------------
 template <int BM, int BN>
 struct TileCfg {
-  static constexpr int WAVES_N = (BN >= 64) ? 2 : 1;
-  static constexpr int WAVES_M = 4 / WAVES_N;
+  static constexpr int WAVES_M = (BM >= 64 && BN >= 64) ? 2 : (BM < 64 ? 1 : 4);
+  static constexpr int WAVES_N = 4 / WAVES_M;
   static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   static constexpr int MI = WM / 32, NI = WN / 32;
   static_assert(MI >= 1 && NI >= 1, "tile too small");
@@ -355,29 +355,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
 }
 
-// sum the split slabs and write OIHW [Cout][Cin][R][S] directly (packed index -> OIHW index)
-__global__ void slab_reduce_unpack_kernel(const float* __restrict__ slabs, int splits, int Cout, int Cin, int R, int S,
-                                          float* __restrict__ oihw) {
-  const long n = (long)Cout * Cin * R * S;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // packed index [co][r][s][ci]
-  if (i >= n) return;
+// Sum the split slabs (fixed order -> deterministic).  Block = 64 elements x 16 slab lanes, so a reduction
+// over hundreds of slabs is 16-way parallel instead of one long dependent chain per element.
+// unpack != 0: element i is a packed index [co][r][s][ci] and is written to OIHW [co][ci][r][s].
+__global__ __launch_bounds__(1024) void slab_reduce_kernel2(const float* __restrict__ slabs, int splits, long n,
+                                                            int unpack, int Cin, int R, int S,
+                                                            float* __restrict__ out) {
+  __shared__ float red[16][64];
+  const int ex = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + ex;
   float acc = 0.f;
-  for (int k = 0; k < splits; ++k) acc += slabs[(size_t)k * n + i];
-  long t = i;
-  const int ci = t % Cin; t /= Cin;
-  const int q = t % S; t /= S;
-  const int r = t % R; const int co = t / R;
-  oihw[(((long)co * Cin + ci) * R + r) * S + q] = acc;
+  if (i < n)
+    for (int k = ly; k < splits; k += 16) acc += slabs[(size_t)k * n + i];
+  red[ly][ex] = acc;
+  __syncthreads();
+  if (ly != 0 || i >= n) return;
+  for (int k = 1; k < 16; ++k) acc += red[k][ex];
+  long o = i;
+  if (unpack) {
+    long t = i;
+    const int ci = t % Cin; t /= Cin;
+    const int q = t % S; t /= S;
+    const int r = t % R; const long co = t / R;
+    o = ((co * Cin + ci) * R + r) * S + q;
+  }
+  out[o] = acc;
 }
-
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int splits, long n, float* __restrict__ out) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * n + i];
-  out[i] = s;
-}
-
 
 // ------------------------------------------------------------------------------------
 // Stem: 7x7 stride-2 pad-3 convolution of the 3-channel image (resnet.py:16), K = 147.
@@ -781,11 +784,12 @@ extern "C" int xas_conv_dgrad(const float* dy, const float* w_packed_t, float* d
 
 static void wgrad_plan(const xas_conv_shape* s, int* bm, int* bn, int* splits, int* mps) {
   const long KK = (long)s->R * s->S * s->Cin, M = (long)s->N * s->Ho * s->Wo;
-  *bm = s->Cout >= 96 ? 128 : 64;
+  *bm = s->Cout >= 96 ? 128 : (s->Cout > 32 ? 64 : 32);
   *bn = KK <= 64 ? 64 : 128;
+  if (*bm == 32) *bn = 128;
   const long tiles = cdiv(s->Cout, *bm) * cdiv(KK, *bn);
-  long sp = cdiv(768, tiles);                      // ~3 blocks per CU in total
-  const long maxsp = M / 1024 > 0 ? M / 1024 : 1;  // >= 32 K-steps per block amortise prologue + slab write
+  long sp = cdiv(1024, tiles);                     // ~4 blocks per CU in total
+  const long maxsp = M / 256 > 0 ? M / 256 : 1;    // >= 8 K-steps per block
   if (sp > maxsp) sp = maxsp;
   if (sp < 1) sp = 1;
   long per = cdiv(M, sp);
@@ -855,9 +859,10 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
     XAS_LAUNCH_CHECK();
     const long n = (long)C * 9;
     if (oihw || !cout1) {
-      hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, workspace, chunks, n, dw_packed);
+      hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, workspace, chunks, n, 0, 1, 1, 1,
+                         dw_packed);
     } else {          // packed [1][tap][c] wanted: treat the [c][tap] sums as an "OIHW" with Cout=1 and repack
-      hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, workspace, chunks, n,
+      hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, workspace, chunks, n, 0, 1, 1, 1,
                          workspace + (size_t)chunks * n);
       XAS_LAUNCH_CHECK();
       hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, workspace + (size_t)chunks * n,
@@ -872,10 +877,8 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
     hipLaunchKernelGGL(wgrad_cout1_kernel, dim3((unsigned)cdiv(KK, 64), (unsigned)chunks), dim3(64), 0, st, x, dy,
                        workspace, *s, kCout1Chunk);
     XAS_LAUNCH_CHECK();
-    if (oihw) hipLaunchKernelGGL(slab_reduce_unpack_kernel, dim3((unsigned)cdiv(KK, 256)), dim3(256), 0, st, workspace,
-                                 chunks, 1, s->Cin, s->R, s->S, dw_packed);
-    else hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(KK, 256)), dim3(256), 0, st, workspace, chunks,
-                            (long)KK, dw_packed);
+    hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(KK, 64)), dim3(1024), 0, st, workspace, chunks, (long)KK,
+                       oihw ? 1 : 0, s->Cin, s->R, s->S, dw_packed);
     XAS_LAUNCH_CHECK();
     return 0;
   }
@@ -891,17 +894,15 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
   XAS_REQUIRE(s->Cout % 4 == 0, "conv_wgrad: Cout=%d not supported by the MFMA path", s->Cout);
   const bool vec = (s->Cin % 4 == 0) && (((uintptr_t)x & 15) == 0);
   int rc;
-  if (bn == 64 && vec) rc = bm == 128 ? launch_wgrad<128, 64, true>(p, splits, st) : launch_wgrad<64, 64, true>(p, splits, st);
+  if (bm == 32) rc = vec ? launch_wgrad<32, 128, true>(p, splits, st) : launch_wgrad<32, 128, false>(p, splits, st);
+  else if (bn == 64 && vec) rc = bm == 128 ? launch_wgrad<128, 64, true>(p, splits, st) : launch_wgrad<64, 64, true>(p, splits, st);
   else if (bm == 128) rc = vec ? launch_wgrad<128, 128, true>(p, splits, st) : launch_wgrad<128, 128, false>(p, splits, st);
   else rc = vec ? launch_wgrad<64, 128, true>(p, splits, st) : launch_wgrad<64, 128, false>(p, splits, st);
   if (rc) return rc;
   const long n = (long)s->Cout * p.KK;
-  if (oihw) {
-    hipLaunchKernelGGL(slab_reduce_unpack_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, workspace, splits,
-                       s->Cout, s->Cin, s->R, s->S, dw_packed);
-    XAS_LAUNCH_CHECK();
-  } else if (splits > 1) {
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, workspace, splits, n, dw_packed);
+  if (oihw || splits > 1) {
+    hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, workspace, splits, n,
+                       oihw ? 1 : 0, s->Cin, s->R, s->S, dw_packed);
     XAS_LAUNCH_CHECK();
   }
   return 0;

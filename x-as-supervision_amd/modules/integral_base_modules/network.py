@@ -21,8 +21,14 @@ class ResPoseNet(nn.Module):
         super().__init__()
         self.backbone = backbone
         self.head = head
+        self._counters = None
 
     def forward(self, x):
+        if self.training:
+            if self._counters is None:
+                from xas_amd.layers import SharedBatchCounters
+                self._counters = SharedBatchCounters(self)
+            self._counters.bump()
         return self.head(self.backbone(x))
 
 

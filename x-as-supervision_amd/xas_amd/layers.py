@@ -77,12 +77,13 @@ class BatchNorm2d(nn.Module):
         self.register_buffer('running_mean', torch.zeros(c))
         self.register_buffer('running_var', torch.ones(c))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+        self._nbt_shared = False       # True once a parent owns the counter (share_batch_counters)
 
     def forward(self, x, residual=None):
         group = None
         if self.sync and self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             group = dist.group.WORLD
-        if self.training:
+        if self.training and not self._nbt_shared:
             self.num_batches_tracked += 1
         return F.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, residual, self.training,
                             self.momentum, self.eps, self.act, group)
@@ -96,3 +97,29 @@ class MaxPool3x3s2(nn.Module):
 class Upsample2x(nn.Module):
     def forward(self, x):
         return F.upsample2x(x)
+
+
+class SharedBatchCounters:
+    """All `num_batches_tracked` buffers of a network that runs every norm exactly once per forward are
+    re-homed into one int64 arena, so a forward bumps them with ONE launch instead of one per layer (56 in the
+    detector).  The buffers stay ordinary state-dict entries (views of the arena)."""
+
+    def __init__(self, net):
+        self.net = net
+        self.arena = None
+
+    def _bind(self):
+        mods = [m for m in self.net.modules() if isinstance(m, BatchNorm2d)]
+        dev = mods[0].num_batches_tracked.device
+        arena = torch.stack([m.num_batches_tracked.reshape(()) for m in mods]).to(dev)
+        for i, m in enumerate(mods):
+            m._buffers['num_batches_tracked'] = arena[i]
+            m._nbt_shared = True
+        self.arena, self.mods = arena, mods
+
+    def bump(self):
+        ok = self.arena is not None and all(
+            m._buffers['num_batches_tracked'].data_ptr() == self.arena.data_ptr() + 8 * i for i, m in enumerate(self.mods))
+        if not ok:                      # first use, or the buffers were replaced (.to(), load_state_dict)
+            self._bind()
+        self.arena += 1

@@ -254,8 +254,9 @@ class _BatchNorm(torch.autograd.Function):
         ws = torch.empty(query('xas_bn_workspace_floats', M, c), device=dev, dtype=torch.float32)
         call('xas_bn_bwd_reduce', ptr(x), ptr(y), ptr(dy), ptr(mean), ptr(var), eps, act, M, c, ptr(sdz),
              ptr(sdz[c:]), ptr(ws))
-        dgamma, dbeta = sdz[c:].clone(), sdz[:c].clone()      # local sums: DDP averages parameter grads later
+        dgamma, dbeta = sdz[c:], sdz[:c]                      # local sums: DDP averages parameter grads later
         if group is not None:
+            dgamma, dbeta = dgamma.clone(), dbeta.clone()
             dist.all_reduce(sdz, group=group)                 # one coalesced 2C message per layer
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
