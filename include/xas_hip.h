@@ -27,6 +27,8 @@ extern "C" {
 #endif
 
 const char* xas_last_error(void);
+/* kernel-tuning experiment flags (benchmarks only; 0 = shipped configuration) */
+int xas_set_tuning(int flags);
 int xas_abi_version(void);
 
 /* ------------------------------------------------------------------------------------

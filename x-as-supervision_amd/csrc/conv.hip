@@ -24,6 +24,9 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int BK = 32;        // K-step (channels of one tap)
 constexpr int LDK = BK + 4;   // padded LDS row, dwords
 
+// 64 bytes of zeros: out-of-range taps / rows load from here instead of branching around the load
+__device__ __constant__ float4 g_zero16[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+
 struct FastDiv {              // n / d and n % d for 0 <= n < 2^31, d >= 1
   unsigned d, mul, shift;
   __host__ void init(unsigned dd) {
@@ -50,7 +53,11 @@ struct IgemmParams {
   int R, S, stride, pad;
   FastDiv div_hw, div_w;   // row -> (n, a, b) decode over the row grid
   int Hrow, Wrow;          // row grid (fwd: Ho x Wo; dgrad: per-phase grid, set in kernel)
+  int tune;                // experiment flags (xas_set_tuning): bit1 setprio around MFMAs, bit2 plain tile order
+  int nMt, nNt, mt_per_xcd;   // tile counts and M-tiles per XCD for the XCD-aware block order
 };
+
+static int g_tune = 0;
 
 // ------------------------------------------------------------------------------------
 // shared MFMA core: As[BM][LDK], Bs[BN][LDK] -> acc
@@ -64,11 +71,15 @@ struct TileCfg {
   static_assert(MI >= 1 && NI >= 1, "tile too small");
 };
 
+// Consecutive MFMAs go to DIFFERENT accumulators (k outer, tile inner): a chain of dependent
+// v_mfma_f32_32x32x2_f32 on one accumulator does not issue back to back, and a wave with a single 32x32
+// tile (64x64 block tile) keeps two partial accumulators (even / odd k) that are summed in the epilogue.
 template <int BM, int BN>
 __device__ __forceinline__ void mfma_tile(const float* __restrict__ As, const float* __restrict__ Bs,
-                                          f32x16 (&acc)[TileCfg<BM, BN>::MI][TileCfg<BM, BN>::NI], int wm, int wn,
-                                          int lane) {
+                                          f32x16 (&acc)[TileCfg<BM, BN>::MI][TileCfg<BM, BN>::NI],
+                                          f32x16& acc2, int wm, int wn, int lane) {
   using C = TileCfg<BM, BN>;
+  constexpr bool SPLIT = (C::MI == 1 && C::NI == 1);
   const int i = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int kk = 0; kk < BK / 8; ++kk) {
@@ -79,15 +90,29 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ As, const fl
 #pragma unroll
     for (int ni = 0; ni < C::NI; ++ni)
       b[ni] = *reinterpret_cast<const float4*>(Bs + (wn * C::WN + ni * 32 + i) * LDK + kk * 8 + h * 4);
+    if (SPLIT) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].x, b[0].x, acc[0][0], 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].y, b[0].y, acc2, 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].z, b[0].z, acc[0][0], 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].w, b[0].w, acc2, 0, 0, 0);
+    } else {
 #pragma unroll
-    for (int mi = 0; mi < C::MI; ++mi)
+      for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < C::NI; ++ni) {
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
-      }
+        for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
+    }
   }
 }
 
@@ -121,7 +146,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     rstep = st; sa = 1;
   }
   const int Mrows = p.N * Hrow * Wrow;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2 each):
+  // linear id L runs on XCD L % 8.  Give every XCD a contiguous range of M-tiles and walk the N-tiles of one
+  // M-tile back to back, so the gathered activation rows are fetched into that XCD's L2 once and re-used by
+  // all N-tiles, while the (small) weight matrix stays L2-resident.  Placement only affects speed.
+  int mt, nt;
+  if (p.tune & 4) { mt = blockIdx.x % p.nMt; nt = blockIdx.x / p.nMt; }       // plain order (experiment)
+  else {
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    mt = xcd * p.mt_per_xcd + q / p.nNt;
+    nt = q - (q / p.nNt) * p.nNt;
+    if (mt >= p.nMt) return;
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
   if (m0 >= Mrows) return;                           // uniform per block (uneven phases)
   const int HW = Hrow * Wrow;
 
@@ -149,45 +186,75 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
+  f32x16 acc2;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+
+  // Loads are issued UNCONDITIONALLY from a clamped (always valid) address; rows that are out of range are
+  // zeroed later, when the registers are written to LDS.  A `cond ? load : 0` makes hipcc branch around each
+  // load and wait vmcnt(0) in the middle of the prefetch, exposing the full memory latency every K-step.
   float4 ra4[APASS], rb4[BPASS];
+  unsigned okmask = 0;
   auto load_step = [&](int ks) {
     const int tap = ks / cchunks, c0 = (ks - tap * cchunks) * BK + kq * 4;
     const int jr = tap / ns, js = tap - jr * ns;
     // fwd: source = base + tap ; dgrad: source = base - tap index (transposed walk)
     const int dh = (MODE == 0) ? jr : -jr, dw = (MODE == 0) ? js : -js;
     const int wtap = (base_r + rstep * jr) * p.S + (base_s + rstep * js);
+    unsigned m = 0;
 #pragma unroll
     for (int j = 0; j < APASS; ++j) {
       const int hs = ra[j] + dh, ws = rb[j] + dw;
       const bool ok = rn[j] >= 0 && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
-      ra4[j] = ok ? *reinterpret_cast<const float4*>(p.src + (((size_t)rn[j] * p.Hs + hs) * p.Ws + ws) * p.Cs + c0)
-                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      const size_t off = ok ? (((size_t)rn[j] * p.Hs + hs) * p.Ws + ws) * p.Cs : (size_t)0;
+      ra4[j] = *reinterpret_cast<const float4*>(p.src + off + c0);
+      m |= (ok ? 1u : 0u) << j;
     }
 #pragma unroll
     for (int j = 0; j < BPASS; ++j) {
       const int n = n0 + lrow + 32 * j;
-      rb4[j] = n < p.Cd ? *reinterpret_cast<const float4*>(p.wgt + (size_t)n * wrow_stride + (size_t)wtap * p.Cs + c0)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = n < p.Cd;
+      rb4[j] = *reinterpret_cast<const float4*>(p.wgt + (ok ? (size_t)n * wrow_stride : (size_t)0) + (size_t)wtap * p.Cs + c0);
+      m |= (ok ? 1u : 0u) << (16 + j);
     }
+    okmask = m;
   };
   auto store_step = [&](int buf) {
     float* a = As + buf * BM * LDK;
     float* b = Bs + buf * BN * LDK;
 #pragma unroll
-    for (int j = 0; j < APASS; ++j) *reinterpret_cast<float4*>(a + (lrow + 32 * j) * LDK + kq * 4) = ra4[j];
+    for (int j = 0; j < APASS; ++j) {
+      const bool ok = (okmask >> j) & 1u;
+      float4 v = ra4[j];
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      *reinterpret_cast<float4*>(a + (lrow + 32 * j) * LDK + kq * 4) = v;
+    }
 #pragma unroll
-    for (int j = 0; j < BPASS; ++j) *reinterpret_cast<float4*>(b + (lrow + 32 * j) * LDK + kq * 4) = rb4[j];
+    for (int j = 0; j < BPASS; ++j) {
+      const bool ok = (okmask >> (16 + j)) & 1u;
+      float4 v = rb4[j];
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      *reinterpret_cast<float4*>(b + (lrow + 32 * j) * LDK + kq * 4) = v;
+    }
   };
 
   if (nk > 0) load_step(0);
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = ks & 1;
-    store_step(buf);
-    __syncthreads();
-    if (ks + 1 < nk) load_step(ks + 1);
-    mfma_tile<BM, BN>(As + buf * BM * LDK, Bs + buf * BN * LDK, acc, wm, wn, lane);
+    if (!(p.tune & 16) || ks < 2) {          // ablation bit4: no LDS restaging / barrier after the first 2 steps
+      store_step(buf);
+      __syncthreads();
+    }
+    if (ks + 1 < nk && (!(p.tune & 8) || ks < 1)) load_step(ks + 1);   // ablation bit3: no global loads
+    if (p.tune & 2) __builtin_amdgcn_s_setprio(1);
+    mfma_tile<BM, BN>(As + buf * BM * LDK, Bs + buf * BN * LDK, acc, acc2, wm, wn, lane);
+    if (p.tune & 2) __builtin_amdgcn_s_setprio(0);
   }
 
+  if (C::MI == 1 && C::NI == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
+  }
   // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ---
   const int col_l = lane & 31, rsub = 4 * (lane >> 5);
 #pragma unroll
@@ -268,30 +335,35 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
   float4 ra4[APASS], rb4[BPASS];
+  unsigned okmask = 0;
   auto load_step = [&](int mk) {
+    unsigned msk = 0;
 #pragma unroll
     for (int j = 0; j < APASS; ++j) {
       const int m = mk + arow + AROWS * j, co = co0 + aq * 4;
-      ra4[j] = (m < mend && co < p.Cout) ? *reinterpret_cast<const float4*>(p.dy + (size_t)m * p.Cout + co)
-                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = m < mend && co < p.Cout;
+      ra4[j] = *reinterpret_cast<const float4*>(p.dy + (ok ? (size_t)m * p.Cout + co : (size_t)0));
+      msk |= (ok ? 1u : 0u) << j;
     }
 #pragma unroll
     for (int j = 0; j < BPASS; ++j) {
       const int m = mk + brow + BROWS * j;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < mend && bcol_ok) {
-        const int n = p.div_hw.div(m); const int rem = m - n * HWo;
+      if (VEC) {
+        const int mm = m < mend ? m : mbeg;
+        const int n = p.div_hw.div(mm); const int rem = mm - n * HWo;
         const int ho = p.div_w.div(rem), wo = rem - ho * p.Wo;
-        if (VEC) {
-          const int hi = ho * p.stride - p.pad + tap_r, wi = wo * p.stride - p.pad + tap_s;
-          if ((unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi)
-            v = *reinterpret_cast<const float4*>(p.x + (((size_t)n * p.Hi + hi) * p.Wi + wi) * p.Cin + tap_c);
-        } else {
-          float t[4];
+        const int hi = ho * p.stride - p.pad + tap_r, wi = wo * p.stride - p.pad + tap_s;
+        const bool ok = m < mend && bcol_ok && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
+        rb4[j] = *reinterpret_cast<const float4*>(p.x + (ok ? (((size_t)n * p.Hi + hi) * p.Wi + wi) * p.Cin + tap_c : (size_t)0));
+        msk |= (ok ? 1u : 0u) << (16 + j);
+      } else {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m < mend && bcol_ok) {
+          const int n = p.div_hw.div(m); const int rem = m - n * HWo;
+          const int ho = p.div_w.div(rem), wo = rem - ho * p.Wo;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int nn = nnb + e;
-            t[e] = 0.f;
             if (nn < p.KK) {
               const int tap = p.div_cin.div(nn); const int c = nn - tap * p.Cin;
               const int r = p.div_s.div(tap), s = tap - r * p.S;
@@ -300,19 +372,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
                 t[e] = p.x[(((size_t)n * p.Hi + hi) * p.Wi + wi) * p.Cin + c];
             }
           }
-          v = make_float4(t[0], t[1], t[2], t[3]);
         }
+        rb4[j] = make_float4(t[0], t[1], t[2], t[3]);
+        msk |= 1u << (16 + j);
       }
-      rb4[j] = v;
     }
+    okmask = msk;
   };
   auto store_step = [&](int buf) {
     float* a = As + buf * WBK * LDA;
     float* b = Bs + buf * WBK * LDB;
 #pragma unroll
-    for (int j = 0; j < APASS; ++j) *reinterpret_cast<float4*>(a + (arow + AROWS * j) * LDA + aq * 4) = ra4[j];
+    for (int j = 0; j < APASS; ++j) {
+      const bool ok = (okmask >> j) & 1u;
+      float4 v = ra4[j];
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      *reinterpret_cast<float4*>(a + (arow + AROWS * j) * LDA + aq * 4) = v;
+    }
 #pragma unroll
-    for (int j = 0; j < BPASS; ++j) *reinterpret_cast<float4*>(b + (brow + BROWS * j) * LDB + bq * 4) = rb4[j];
+    for (int j = 0; j < BPASS; ++j) {
+      const bool ok = (okmask >> (16 + j)) & 1u;
+      float4 v = rb4[j];
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      *reinterpret_cast<float4*>(b + (brow + BROWS * j) * LDB + bq * 4) = v;
+    }
   };
 
   const int i = lane & 31, h = lane >> 5;
@@ -680,8 +763,11 @@ static int launch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStre
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid((unsigned)cdiv(Mrows_max, BM), (unsigned)cdiv(p.Cd, BN), (unsigned)phases);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE>), grid, dim3(256), lds, st, p);
+  IgemmParams q = p;
+  q.nMt = (int)cdiv(Mrows_max, BM); q.nNt = (int)cdiv(p.Cd, BN); q.mt_per_xcd = (int)cdiv(q.nMt, 8);
+  const unsigned nblk = (q.tune & 4) ? (unsigned)(q.nMt * q.nNt) : (unsigned)(8 * q.mt_per_xcd * q.nNt);
+  dim3 grid(nblk, 1, (unsigned)phases);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE>), grid, dim3(256), lds, st, q);
   XAS_LAUNCH_CHECK();
   return 0;
 }
@@ -701,6 +787,8 @@ static int dispatch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipSt
 }  // namespace xas
 
 using namespace xas;
+
+extern "C" int xas_set_tuning(int flags) { g_tune = flags; return 0; }
 
 extern "C" int xas_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
                             const xas_conv_shape* s, void* stream) {
@@ -739,7 +827,7 @@ extern "C" int xas_conv_fwd(const float* x, const float* w_packed, const float* 
   IgemmParams p{};
   p.src = x; p.wgt = w_packed; p.bias = bias; p.out = y; p.N = s->N;
   p.Hs = s->Hi; p.Ws = s->Wi; p.Cs = s->Cin; p.Hd = s->Ho; p.Wd = s->Wo; p.Cd = s->Cout;
-  p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.Hrow = s->Ho; p.Wrow = s->Wo;
+  p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.Hrow = s->Ho; p.Wrow = s->Wo; p.tune = g_tune;
   p.div_hw.init((unsigned)(s->Ho * s->Wo)); p.div_w.init((unsigned)s->Wo);
   return dispatch_igemm<0>(p, s->N * s->Ho * s->Wo, 1, st);
 }
@@ -777,7 +865,7 @@ extern "C" int xas_conv_dgrad(const float* dy, const float* w_packed_t, float* d
   IgemmParams p{};
   p.src = dy; p.wgt = w_packed_t; p.bias = nullptr; p.out = dx; p.N = s->N;
   p.Hs = s->Ho; p.Ws = s->Wo; p.Cs = s->Cout; p.Hd = s->Hi; p.Wd = s->Wi; p.Cd = s->Cin;
-  p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad;
+  p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.tune = g_tune;
   const int Hp = (s->Hi + s->stride - 1) / s->stride, Wp = (s->Wi + s->stride - 1) / s->stride;
   return dispatch_igemm<1>(p, s->N * Hp * Wp, s->stride * s->stride, st);
 }
