@@ -1,0 +1,132 @@
+"""Data-parallel path on CPU with the gloo backend, world_size 2: the bucketed gradient reducer averages
+exactly like a single process on the concatenated batch, SyncBatchNorm statistic exchange reproduces the
+global-batch statistics, buffers are broadcast from rank 0.  (No GPU, no HIP kernels: the reducer and the
+statistic exchange are backend-agnostic torch.distributed code.)"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (ROOT, os.path.join(ROOT, 'x-as-supervision_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn, world=2):
+    ctx = mp.get_context('spawn')
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fn, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, 'worker failed'
+    return dict(ret)
+
+
+def _reducer_case(rank, world):
+    from xas_amd.dp import GradReducer
+    torch.manual_seed(0)                                   # identical parameters on every rank
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
+                              torch.nn.Linear(16, 4))
+    params = list(net.parameters())
+    offs, n = [], 0
+    for p in params:
+        offs.append(n)
+        n += (p.numel() + 3) // 4 * 4
+    arena = torch.zeros(n)
+    for p, o in zip(params, offs):
+        p.grad = arena[o:o + p.numel()].view(p.shape)      # gradients accumulate into the flat arena
+    red = GradReducer(arena, params, offs, num_buckets=3, use_side_stream=False)
+    assert red.enabled and len(red.buckets) >= 2
+    g = torch.Generator().manual_seed(123)
+    x_all = torch.randn(world * 6, 8, generator=g)
+    x = x_all[rank * 6:(rank + 1) * 6]
+    out = []
+    for it in range(2):                                    # two steps: hooks re-arm correctly
+        arena.zero_()
+        red.arm()
+        net(x).pow(2).mean().backward()
+        red.finish()
+        out.append(arena.clone())
+    # reference: single process, mean over ranks of the per-rank mean losses
+    ref = torch.zeros(n)
+    for r in range(world):
+        net2 = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
+                                   torch.nn.Linear(16, 4))
+        net2.load_state_dict(net.state_dict())
+        net2(x_all[r * 6:(r + 1) * 6]).pow(2).mean().backward()
+        for p, o in zip(net2.parameters(), offs):
+            ref[o:o + p.numel()] += p.grad.reshape(-1) / world
+    return [float((o - ref).abs().max()) for o in out]
+
+
+def test_bucketed_reducer_world2():
+    res = _run(_reducer_case)
+    for r in (0, 1):
+        assert max(res[r]) < 1e-6
+
+
+def _syncbn_stats_case(rank, world):
+    from xas_amd.ops_nn import _sync_stats
+    g = torch.Generator().manual_seed(7)
+    x_all = torch.randn(world * 10, 5, generator=g) * 3 + 1
+    x = x_all[rank * 10:(rank + 1) * 10]
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    gm, gv = _sync_stats(mean, var, x.shape[0], dist.group.WORLD)
+    return float((gm - x_all.mean(0)).abs().max()), float((gv - x_all.var(0, unbiased=False)).abs().max())
+
+
+def test_syncbn_statistic_exchange_world2():
+    res = _run(_syncbn_stats_case)
+    for r in (0, 1):
+        assert res[r][0] < 1e-6 and res[r][1] < 1e-5
+
+
+def _buffers_case(rank, world):
+    from xas_amd.dp import sync_buffers
+    bn = torch.nn.BatchNorm1d(6)
+    with torch.no_grad():
+        bn.running_mean.fill_(float(rank + 1))
+        bn.running_var.fill_(float(10 * (rank + 1)))
+    sync_buffers(bn)
+    return float(bn.running_mean[0]), float(bn.running_var[0]), int(bn.num_batches_tracked)
+
+
+def test_buffer_broadcast_world2():
+    res = _run(_buffers_case)
+    assert res[0][:2] == (1.0, 10.0) and res[1][:2] == (1.0, 10.0)
+
+
+def test_reducer_disabled_without_process_group():
+    sys.path.insert(0, os.path.join(ROOT, 'x-as-supervision_amd'))
+    from xas_amd.dp import GradReducer
+    p = torch.nn.Parameter(torch.zeros(4))
+    red = GradReducer(torch.zeros(4), [p], [0])
+    assert not red.enabled
+    red.arm()
+    red.finish()
