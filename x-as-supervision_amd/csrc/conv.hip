@@ -71,6 +71,8 @@ struct TileCfg {
   static_assert(MI >= 1 && NI >= 1, "tile too small");
 };
 
+// Operand roles are swapped (MFMA "A" = weight rows, "B" = pixel rows), so an accumulator holds
+// D[n][m]: lane = pixel m, registers 4g..4g+3 = four CONSECUTIVE output channels -> float4 stores.
 // Consecutive MFMAs go to DIFFERENT accumulators (k outer, tile inner): a chain of dependent
 // v_mfma_f32_32x32x2_f32 on one accumulator does not issue back to back, and a wave with a single 32x32
 // tile (64x64 block tile) keeps two partial accumulators (even / odd k) that are summed in the epilogue.
@@ -91,27 +93,27 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ As, const fl
     for (int ni = 0; ni < C::NI; ++ni)
       b[ni] = *reinterpret_cast<const float4*>(Bs + (wn * C::WN + ni * 32 + i) * LDK + kk * 8 + h * 4);
     if (SPLIT) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].x, b[0].x, acc[0][0], 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].y, b[0].y, acc2, 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].z, b[0].z, acc[0][0], 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].w, b[0].w, acc2, 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0].x, a[0].x, acc[0][0], 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0].y, a[0].y, acc2, 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0].z, a[0].z, acc[0][0], 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0].w, a[0].w, acc2, 0, 0, 0);
     } else {
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni].x, a[mi].x, acc[mi][ni], 0, 0, 0);
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni].y, a[mi].y, acc[mi][ni], 0, 0, 0);
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni].z, a[mi].z, acc[mi][ni], 0, 0, 0);
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni].w, a[mi].w, acc[mi][ni], 0, 0, 0);
     }
   }
 }
@@ -164,6 +166,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 
   // rows this thread stages: lrow + 32*j
   int rn[APASS], ra[APASS], rb[APASS];               // image, source base coords (already * sa + off)
+  long rbase[APASS];                                 // element offset of (rn, ra, rb, channel 0) in the source
 #pragma unroll
   for (int j = 0; j < APASS; ++j) {
     const int m = m0 + lrow + 32 * j;
@@ -172,7 +175,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       if (MODE == 0) { n = p.div_hw.div(m); const int rem = m - n * HW; a = p.div_w.div(rem); b = rem - a * Wrow; }
       else { n = m / HW; const int rem = m - n * HW; a = rem / Wrow; b = rem - a * Wrow; }
       rn[j] = n; ra[j] = a * sa + off_h; rb[j] = b * sa + off_w;
-    } else { rn[j] = -1; ra[j] = 0; rb[j] = 0; }
+      rbase[j] = (((long)n * p.Hs + ra[j]) * p.Ws + rb[j]) * p.Cs;
+    } else { rn[j] = -1; ra[j] = 0; rb[j] = 0; rbase[j] = 0; }
   }
   const int cchunks = p.Cs / BK;
   const int nk = nr * ns * cchunks;
@@ -201,12 +205,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     // fwd: source = base + tap ; dgrad: source = base - tap index (transposed walk)
     const int dh = (MODE == 0) ? jr : -jr, dw = (MODE == 0) ? js : -js;
     const int wtap = (base_r + rstep * jr) * p.S + (base_s + rstep * js);
+    const long delta = ((long)dh * p.Ws + dw) * p.Cs;          // uniform over the block
     unsigned m = 0;
 #pragma unroll
     for (int j = 0; j < APASS; ++j) {
       const int hs = ra[j] + dh, ws = rb[j] + dw;
       const bool ok = rn[j] >= 0 && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
-      const size_t off = ok ? (((size_t)rn[j] * p.Hs + hs) * p.Ws + ws) * p.Cs : (size_t)0;
+      const long off = ok ? rbase[j] + delta : 0l;
       ra4[j] = *reinterpret_cast<const float4*>(p.src + off + c0);
       m |= (ok ? 1u : 0u) << j;
     }
@@ -255,27 +260,38 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
   }
-  // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ---
-  const int col_l = lane & 31, rsub = 4 * (lane >> 5);
+  // ---- epilogue.  Accumulator layout (operands swapped): column = lane & 31 = pixel row m of the tile,
+  // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) = output channel -> registers 4g..4g+3 are four
+  // consecutive channels of one pixel: one 16-byte store each, row address computed once per lane.
+  const int pix_l = lane & 31, csub = 4 * (lane >> 5);
+  const bool vec_ok = (p.Cd & 3) == 0;
 #pragma unroll
   for (int mi = 0; mi < C::MI; ++mi) {
+    const int m = m0 + wm * C::WM + mi * 32 + pix_l;
+    if (m >= Mrows) continue;
+    size_t orow;
+    if (MODE == 0) orow = (size_t)m;
+    else {
+      const int n = m / HW; const int rem = m - n * HW; const int a = rem / Wrow, b = rem - a * Wrow;
+      orow = ((size_t)n * p.Hd + (ph + p.stride * a)) * p.Wd + (pw + p.stride * b);
+    }
+    float* orow_p = p.out + orow * p.Cd;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int m = m0 + wm * C::WM + mi * 32 + (reg & 3) + 8 * (reg >> 2) + rsub;
-      if (m >= Mrows) continue;
-      size_t orow;
-      if (MODE == 0) orow = (size_t)m;
-      else {
-        const int n = m / HW; const int rem = m - n * HW; const int a = rem / Wrow, b = rem - a * Wrow;
-        orow = ((size_t)n * p.Hd + (ph + p.stride * a)) * p.Wd + (pw + p.stride * b);
-      }
+    for (int ni = 0; ni < C::NI; ++ni) {
 #pragma unroll
-      for (int ni = 0; ni < C::NI; ++ni) {
-        const int n = n0 + wn * C::WN + ni * 32 + col_l;
-        if (n < p.Cd) {
-          float v = acc[mi][ni][reg];
-          if (MODE == 0 && p.bias) v += p.bias[n];
-          p.out[orow * p.Cd + n] = v;
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * C::WN + ni * 32 + 8 * g + csub;
+        float4 v = make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
+        if (vec_ok && n + 3 < p.Cd) {
+          if (MODE == 0 && p.bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+          }
+          *reinterpret_cast<float4*>(orow_p + n) = v;
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.Cd) orow_p[n + e] = vv[e] + ((MODE == 0 && p.bias) ? p.bias[n + e] : 0.f);
         }
       }
     }
