@@ -125,6 +125,9 @@ int xas_conv_wgrad(const float* x, const float* dy, float* dw_packed, float* wor
 /* same, but the split slabs are summed straight into the parameter's OIHW layout [Cout][Cin][R][S] */
 int xas_conv_wgrad_oihw(const float* x, const float* dy, float* dw_oihw, float* workspace,
                         const xas_conv_shape* s, void* stream);
+/* same, ACCUMULATING: dw_oihw += gradient (used to add straight into the parameter's .grad arena) */
+int xas_conv_wgrad_acc(const float* x, const float* dy, float* dw_oihw, float* workspace,
+                       const xas_conv_shape* s, void* stream);
 /* OIHW [Cout][Cin][R][S] <-> packed.  transposed=0: [Cout][R][S][Cin];
  * transposed=1: [Cin][R][S][Cout].  unpack adds nothing: it overwrites dst. */
 int xas_pack_weight(const float* oihw, float* packed, int Cout, int Cin, int R, int S,

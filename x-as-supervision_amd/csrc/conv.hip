@@ -471,14 +471,14 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel2(const float* __restr
   if (ly != 0 || i >= n) return;
   for (int k = 1; k < 16; ++k) acc += red[k][ex];
   long o = i;
-  if (unpack) {
+  if (unpack & 1) {
     long t = i;
     const int ci = t % Cin; t /= Cin;
     const int q = t % S; t /= S;
     const int r = t % R; const long co = t / R;
     o = ((co * Cin + ci) * R + r) * S + q;
   }
-  out[o] = acc;
+  if (unpack & 2) out[o] += acc; else out[o] = acc;
 }
 
 // ------------------------------------------------------------------------------------
@@ -891,8 +891,12 @@ static void wgrad_plan(const xas_conv_shape* s, int* bm, int* bn, int* splits, i
   *bm = s->Cout >= 96 ? 128 : (s->Cout > 32 ? 64 : 32);
   *bn = KK <= 64 ? 64 : 128;
   if (*bm == 32) *bn = 128;
+  const int wt = (g_tune >> 8) & 3;               // experiment: 1 -> target 512 blocks, 2 -> 256, 3 -> 2048
+  const int wf = (g_tune >> 10) & 1;              // experiment: force 64x64 tiles
+  if (wf && s->Cout >= 64 && KK >= 64 && s->Cin % 4 == 0) { *bm = 64; *bn = 64; }
   const long tiles = cdiv(s->Cout, *bm) * cdiv(KK, *bn);
-  long sp = cdiv(1024, tiles);                     // ~4 blocks per CU in total
+  const long target = wt == 1 ? 512 : (wt == 2 ? 256 : (wt == 3 ? 1024 : 2048));   // measured: 2048 > 1024 > 512
+  long sp = cdiv(target, tiles);                   // ~4 blocks per CU in total
   const long maxsp = M / 256 > 0 ? M / 256 : 1;    // >= 8 K-steps per block
   if (sp > maxsp) sp = maxsp;
   if (sp < 1) sp = 1;
@@ -932,7 +936,7 @@ static int launch_wgrad(const WgradParams& p, int splits, hipStream_t st) {
 }
 
 static int conv_wgrad_impl(const float* x, const float* dy, float* dw_out, float* workspace, const xas_conv_shape* s,
-                           void* stream, bool oihw);
+                           void* stream, bool oihw, bool accumulate = false);
 
 extern "C" int xas_conv_wgrad(const float* x, const float* dy, float* dw_packed, float* workspace,
                               const xas_conv_shape* s, void* stream) {
@@ -944,8 +948,14 @@ extern "C" int xas_conv_wgrad_oihw(const float* x, const float* dy, float* dw_oi
   return conv_wgrad_impl(x, dy, dw_oihw, workspace, s, stream, true);
 }
 
+extern "C" int xas_conv_wgrad_acc(const float* x, const float* dy, float* dw_oihw, float* workspace,
+                                  const xas_conv_shape* s, void* stream) {
+  return conv_wgrad_impl(x, dy, dw_oihw, workspace, s, stream, true, true);
+}
+
 static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, float* workspace, const xas_conv_shape* s,
-                           void* stream, bool oihw) {
+                           void* stream, bool oihw, bool accumulate) {
+  const int rflag = (oihw ? 1 : 0) | (accumulate ? 2 : 0);
   if (check_shape(s, "conv_wgrad")) return 1;
   XAS_REQUIRE(x && dy && dw_packed && workspace, "conv_wgrad: null buffer");
   XAS_REQUIRE(s->Cout % 4 == 0 || s->Cout == 1, "conv_wgrad: Cout=%d must be a multiple of 4 (or 1)", s->Cout);
@@ -963,8 +973,8 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
     XAS_LAUNCH_CHECK();
     const long n = (long)C * 9;
     if (oihw || !cout1) {
-      hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, workspace, chunks, n, 0, 1, 1, 1,
-                         dw_packed);
+      hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, workspace, chunks, n,
+                         accumulate ? 2 : 0, 1, 1, 1, dw_packed);
     } else {          // packed [1][tap][c] wanted: treat the [c][tap] sums as an "OIHW" with Cout=1 and repack
       hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, workspace, chunks, n, 0, 1, 1, 1,
                          workspace + (size_t)chunks * n);
@@ -982,7 +992,7 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
                        workspace, *s, kCout1Chunk);
     XAS_LAUNCH_CHECK();
     hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(KK, 64)), dim3(1024), 0, st, workspace, chunks, (long)KK,
-                       oihw ? 1 : 0, s->Cin, s->R, s->S, dw_packed);
+                       rflag, s->Cin, s->R, s->S, dw_packed);
     XAS_LAUNCH_CHECK();
     return 0;
   }
@@ -1006,7 +1016,7 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
   const long n = (long)s->Cout * p.KK;
   if (oihw || splits > 1) {
     hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, workspace, splits, n,
-                       oihw ? 1 : 0, s->Cin, s->R, s->S, dw_packed);
+                       rflag, s->Cin, s->R, s->S, dw_packed);
     XAS_LAUNCH_CHECK();
   }
   return 0;

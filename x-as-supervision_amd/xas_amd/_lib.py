@@ -35,6 +35,7 @@ SIGNATURES = {
     'xas_conv_wgrad_workspace_floats': ('s', 'z'),
     'xas_conv_wgrad': ('ppppsp', 'i'),
     'xas_conv_wgrad_oihw': ('ppppsp', 'i'),
+    'xas_conv_wgrad_acc': ('ppppsp', 'i'),
     'xas_pack_weight': ('ppiiiiip', 'i'),
     'xas_unpack_weight': ('ppiiiiip', 'i'),
     'xas_bn_workspace_floats': ('li', 'z'),

@@ -17,6 +17,7 @@ from modules.keypoint_detector_integral_multi import KPDetector3DMulti
 from modules.model import Counter3DDisc, Counter3DModel
 from modules.physique_network import PhysiqueMaskGenerator
 
+from . import ops_nn
 from .dp import GradReducer, sync_buffers
 from .optim import FusedAdam
 
@@ -74,6 +75,9 @@ class TrainStep:
         self.gen_every = 1 if interval >= 1 else int(1.0 / interval)
         self.cur_step = 0
         self.red_det = self.red_disc = None
+        opt_det.grad_arena                       # materialise the gradient arenas: conv weight gradients are
+        if opt_disc is not None:                 # accumulated straight into them on a side stream
+            opt_disc.grad_arena
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             f = opt_det
             f.grad_arena
@@ -97,6 +101,7 @@ class TrainStep:
             if self.red_disc:
                 self.red_disc.arm()
             loss_disc.backward()
+            ops_nn.join_side_stream()
             if self.red_disc:
                 self.red_disc.finish()
             self.opt_disc.step()
@@ -108,6 +113,7 @@ class TrainStep:
             if self.red_det:
                 self.red_det.arm()
             total.backward()
+            ops_nn.join_side_stream()
             if self.red_det:
                 self.red_det.finish()
             self.opt_det.step()

@@ -15,6 +15,44 @@ def bump_weights_epoch():
     _weights_epoch[0] += 1
 
 
+# ---- weight gradients on a side stream -------------------------------------------------------------------
+# The weight gradient of a conv depends only on (x, dy) and nothing downstream in backward needs it, so it is
+# launched on a second HIP stream and ADDED straight into the parameter's .grad (a view of the optimizer's
+# gradient arena): the many short wgrad kernels overlap the data-gradient / batch-norm chain of the main
+# stream, and autograd's per-contribution `grad += dw` kernels disappear.  join_side_stream() is called before
+# anything consumes the gradients (all-reduce, Adam, zero_grad).
+_side = {'stream': None, 'enabled': True, 'dirty': False}
+
+
+def side_stream():
+    if _side['stream'] is None:
+        _side['stream'] = torch.cuda.Stream()
+    return _side['stream']
+
+
+def join_side_stream():
+    """Make the current stream wait for every weight gradient launched on the side stream."""
+    if _side['dirty'] and _side['stream'] is not None:
+        torch.cuda.current_stream().wait_stream(_side['stream'])
+        _side['dirty'] = False
+
+
+def _wgrad_into_grad(x, dy, shp, weight):
+    """Accumulate the OIHW weight gradient into weight.grad on the side stream; False if not applicable."""
+    g = weight.grad
+    if not _side['enabled'] or g is None or not g.is_contiguous() or g.dtype != torch.float32:
+        return False
+    main, side = torch.cuda.current_stream(), side_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        ws = torch.empty(max(1, query('xas_conv_wgrad_workspace_floats', shp)), device=x.device, dtype=torch.float32)
+        call('xas_conv_wgrad_acc', ptr(x), ptr(dy), ptr(g), ptr(ws), shp)
+    x.record_stream(side)
+    dy.record_stream(side)
+    _side['dirty'] = True
+    return True
+
+
 def to_cl(x):
     """Return x with NHWC storage (no copy when it already has it)."""
     if x.dim() != 4:
@@ -108,7 +146,7 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             call('xas_conv_dgrad', ptr(dy), ptr(ctx.cache.get(weight, 1)), ptr(dx), shp)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not _wgrad_into_grad(x, dy, shp, weight):
             dw = _wgrad(x, dy, shp, weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _bias_grad(dy, shp.N * shp.Ho * shp.Wo, shp.Cout)
@@ -148,7 +186,7 @@ class _ConvTranspose2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             call('xas_conv_fwd', ptr(dy), ptr(ctx.cache.get(weight, 0)), None, ptr(dx), shp)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not _wgrad_into_grad(dy, x, shp, weight):
             dw = _wgrad(dy, x, shp, weight.shape)
         return dx, dw, None, None, None
 

@@ -78,6 +78,7 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         if self._flat is None:
             self._build()
+        ops_nn.join_side_stream()                    # weight gradients accumulated on the side stream
         self._check_views()
         f = self._flat
         g0 = self.param_groups[0]
@@ -90,6 +91,7 @@ class FusedAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         if self._flat is None:
             self._build()
+        ops_nn.join_side_stream()
         self._check_views()
         self._flat['g'].zero_()
 

@@ -4,7 +4,7 @@ import torch
 
 from . import _lib
 
-CONV_ENTRIES = ('xas_conv_fwd', 'xas_conv_dgrad', 'xas_conv_wgrad', 'xas_conv_wgrad_oihw')
+CONV_ENTRIES = ('xas_conv_fwd', 'xas_conv_dgrad', 'xas_conv_wgrad', 'xas_conv_wgrad_oihw', 'xas_conv_wgrad_acc')
 
 
 def conv_flops(shape):
