@@ -71,6 +71,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='samples per GPU')
     ap.add_argument('--workload', default='HM36_Multi_SurS1')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--tune', type=int, default=0, help='kernel tuning experiment flags (xas_set_tuning)')
     ap.add_argument('--shape-report', default=None, help='write a per-conv-shape timing table to this file')
     args = ap.parse_args()
 
@@ -88,6 +89,8 @@ def main():
     from xas_amd import engine
     from xas_amd.prof import KernelTimer
     from xas_amd.synthetic import model_config, synthetic_batch
+    from xas_amd import _lib as _xl
+    _xl.query('xas_set_tuning', args.tune)
     cfg = model_config(args.workload)
     torch.manual_seed(1234)
     model, disc, opt_det, opt_disc = engine.prepare_model(cfg)
@@ -146,6 +149,9 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
                          'kernel': 'igemm_kernel / wgrad_kernel (fp32 MFMA implicit-GEMM conv family)',
+                         'note': 'weight-gradient kernels run on a side stream concurrently with the main chain, so '
+                                 'per-launch durations include sharing; step_conv_tflops_over_wall is the whole-step view',
+                         'step_conv_tflops_over_wall': sum(v['flops'] for v in summ.values()) / dt / 1e12,
                          'launches_per_step': n_launch / args.steps, 'avg_launch_us': ms * 1e3 / max(1, n_launch),
                          'conv_ms_per_step': ms / args.steps,
                          'families': {k: {'launches': v['launches'] // args.steps, 'ms_per_step': v['ms'] / args.steps,

@@ -121,13 +121,13 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ As, const fl
 // ------------------------------------------------------------------------------------
 // fwd (MODE 0) and dgrad (MODE 1)
 // ------------------------------------------------------------------------------------
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int NBUF = 2>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   using C = TileCfg<BM, BN>;
   constexpr int APASS = BM / 32, BPASS = BN / 32;
   extern __shared__ __align__(16) float lds[];
-  float* As = lds;                       // [2][BM][LDK]
-  float* Bs = lds + 2 * BM * LDK;        // [2][BN][LDK]
+  float* As = lds;                       // [NBUF][BM][LDK]
+  float* Bs = lds + NBUF * BM * LDK;     // [NBUF][BN][LDK]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
@@ -245,7 +245,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 
   if (nk > 0) load_step(0);
   for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
+    const int buf = NBUF == 2 ? (ks & 1) : 0;
+    if (NBUF == 1 && ks > 0) __syncthreads();          // single buffer: everyone is done reading the previous tile
     if (!(p.tune & 16) || ks < 2) {          // ablation bit4: no LDS restaging / barrier after the first 2 steps
       store_step(buf);
       __syncthreads();
@@ -770,12 +771,12 @@ static int check_fwd_dims(const xas_conv_shape* s, const char* who) {
   return 0;
 }
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int NBUF = 2>
 static int launch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
-  const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+  const size_t lds = (size_t)NBUF * (BM + BN) * LDK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, NBUF>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -783,13 +784,14 @@ static int launch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStre
   q.nMt = (int)cdiv(Mrows_max, BM); q.nNt = (int)cdiv(p.Cd, BN); q.mt_per_xcd = (int)cdiv(q.nMt, 8);
   const unsigned nblk = (q.tune & 4) ? (unsigned)(q.nMt * q.nNt) : (unsigned)(8 * q.mt_per_xcd * q.nNt);
   dim3 grid(nblk, 1, (unsigned)phases);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE>), grid, dim3(256), lds, st, q);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, NBUF>), grid, dim3(256), lds, st, q);
   XAS_LAUNCH_CHECK();
   return 0;
 }
 
 template <int MODE>
 static int dispatch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
+  if ((g_tune & 2048) && p.Cd >= 96) return launch_igemm<128, 128, MODE, 1>(p, Mrows_max, phases, st);   // experiment
   if (p.Cd >= 96) {
     // small problems (layer3/4 at B=32: M = 8192 / 2048 rows): 128x128 tiles leave most of the 256 CUs idle
     const long blocks128 = cdiv(Mrows_max, 128) * cdiv(p.Cd, 128) * phases;
@@ -895,7 +897,7 @@ static void wgrad_plan(const xas_conv_shape* s, int* bm, int* bn, int* splits, i
   const int wf = (g_tune >> 10) & 1;              // experiment: force 64x64 tiles
   if (wf && s->Cout >= 64 && KK >= 64 && s->Cin % 4 == 0) { *bm = 64; *bn = 64; }
   const long tiles = cdiv(s->Cout, *bm) * cdiv(KK, *bn);
-  const long target = wt == 1 ? 512 : (wt == 2 ? 256 : (wt == 3 ? 1024 : 2048));   // measured: 2048 > 1024 > 512
+  const long target = wt == 1 ? 512 : (wt == 2 ? 256 : (wt == 3 ? 2048 : 1024));
   long sp = cdiv(target, tiles);                   // ~4 blocks per CU in total
   const long maxsp = M / 256 > 0 ? M / 256 : 1;    // >= 8 K-steps per block
   if (sp > maxsp) sp = maxsp;
