@@ -129,6 +129,16 @@ def main():
     dt = float(t.item())
     log('timed %d steps: %.1f ms/step' % (args.steps, dt / args.steps * 1e3))
 
+    # one extra, UNTIMED step with the side stream disabled: the same kernels measured without concurrent
+    # neighbours (kernel quality), beside the overlapped figures of the timed region (step throughput)
+    from xas_amd import ops_nn as _ops
+    serial = KernelTimer()
+    _ops._side['enabled'] = False
+    with serial:
+        step(x)
+    sync()
+    _ops._side['enabled'] = True
+
     per_sample = IMAGES_PER_SAMPLE['MPI' if args.workload.startswith('MPI') else 'HM36']
     samples = world * args.batch * args.steps
     if rank == 0:
@@ -151,6 +161,9 @@ def main():
                          'kernel': 'igemm_kernel / wgrad_kernel (fp32 MFMA implicit-GEMM conv family)',
                          'note': 'weight-gradient kernels run on a side stream concurrently with the main chain, so '
                                  'per-launch durations include sharing; step_conv_tflops_over_wall is the whole-step view',
+                         'serial': (lambda sm: {'achieved': sum(v['flops'] for k, v in sm.items() if not k.endswith(':direct')) /
+                                                (sum(v['ms'] for k, v in sm.items() if not k.endswith(':direct')) * 1e-3) / 1e12,
+                                                'unit': 'TFLOP/s', 'what': 'same launches, one extra untimed step without stream overlap'})(serial.summary()),
                          'step_conv_tflops_over_wall': sum(v['flops'] for v in summ.values()) / dt / 1e12,
                          'launches_per_step': n_launch / args.steps, 'avg_launch_us': ms * 1e3 / max(1, n_launch),
                          'conv_ms_per_step': ms / args.steps,

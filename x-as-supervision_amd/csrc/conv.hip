@@ -79,19 +79,21 @@ struct TileCfg {
 template <int BM, int BN>
 __device__ __forceinline__ void mfma_tile(const float* __restrict__ As, const float* __restrict__ Bs,
                                           f32x16 (&acc)[TileCfg<BM, BN>::MI][TileCfg<BM, BN>::NI],
-                                          f32x16& acc2, int wm, int wn, int lane) {
+                                          f32x16& acc2, int wm, int wn, int lane, int tune = 0) {
   using C = TileCfg<BM, BN>;
   constexpr bool SPLIT = (C::MI == 1 && C::NI == 1);
   const int i = lane & 31, h = lane >> 5;
+  float4 a[C::MI], b[C::NI];
 #pragma unroll
   for (int kk = 0; kk < BK / 8; ++kk) {
-    float4 a[C::MI], b[C::NI];
+    if (!(tune & 4096) || kk == 0) {        // ablation bit12: LDS fragments read once per K-step only
 #pragma unroll
-    for (int mi = 0; mi < C::MI; ++mi)
-      a[mi] = *reinterpret_cast<const float4*>(As + (wm * C::WM + mi * 32 + i) * LDK + kk * 8 + h * 4);
+      for (int mi = 0; mi < C::MI; ++mi)
+        a[mi] = *reinterpret_cast<const float4*>(As + (wm * C::WM + mi * 32 + i) * LDK + kk * 8 + h * 4);
 #pragma unroll
-    for (int ni = 0; ni < C::NI; ++ni)
-      b[ni] = *reinterpret_cast<const float4*>(Bs + (wn * C::WN + ni * 32 + i) * LDK + kk * 8 + h * 4);
+      for (int ni = 0; ni < C::NI; ++ni)
+        b[ni] = *reinterpret_cast<const float4*>(Bs + (wn * C::WN + ni * 32 + i) * LDK + kk * 8 + h * 4);
+    }
     if (SPLIT) {
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0].x, a[0].x, acc[0][0], 0, 0, 0);
       acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0].y, a[0].y, acc2, 0, 0, 0);
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     }
     if (ks + 1 < nk && (!(p.tune & 8) || ks < 1)) load_step(ks + 1);   // ablation bit3: no global loads
     if (p.tune & 2) __builtin_amdgcn_s_setprio(1);
-    mfma_tile<BM, BN>(As + buf * BM * LDK, Bs + buf * BN * LDK, acc, acc2, wm, wn, lane);
+    mfma_tile<BM, BN>(As + buf * BM * LDK, Bs + buf * BN * LDK, acc, acc2, wm, wn, lane, p.tune);
     if (p.tune & 2) __builtin_amdgcn_s_setprio(0);
   }
 

@@ -12,6 +12,7 @@ import torch
 from modules.base_losses.loss_func import (compute_bone_sym_loss, compute_disc_loss, compute_kp_sym_loss,
                                            compute_mask_reconstruction_loss, compute_supervision)
 from modules.util import convert_patch_to_world, draw_lines_max, random_rotation_3D
+from xas_amd import ops_nn, streams
 
 
 def cal_links(parent_ids, line_select_ids=None, use_root=False, extension=True):
@@ -59,24 +60,67 @@ class Counter3DModel(torch.nn.Module):
         self.DISC_SUP_DIMENSION = cfg['smpl_disc_params'].get('disc_sup_dim', 3)
         self.use_aug = cfg['smpl_disc_params'].get('use_aug', False)
 
+    def _camera_pass(self, x, cam, lc, out):
+        """Everything of one camera that does not need the other cameras: detector, geometry, mask renderer,
+        physique net, mask losses, pseudo-image branch.  Runs on that camera's HIP stream."""
+        key = 'cam_{}'.format(cam)
+        img = x[key + '_img']
+        r = {}
+        kps, depth_map = self.regressor(img)
+        assert kps.dim() == 4, "use aligned multi-hypothesis settings"
+        out['pose_2d_pred_{}_ori'.format(key)] = kps[[0], 0].detach().clone()
+        out['depth_map_{}'.format(key)] = depth_map
+        world = _to_world(kps, x, key, cam == 'mono')                  # [B, Hy, K, 3], one launch
+        out['pose_3d_depth_{}'.format(key)] = world[:, 0].detach().clone()
+        # multi-hypothesis only changes z, so one mask per camera (hypothesis 0's x, y)
+        recon = draw_lines_max(kps[:, 0, :, :2], img.shape[-1], self.parent_ids, self.child_ids, self.body_width)
+        out['mask_heatmap_line_{}'.format(key)] = recon.detach()
+        r.update(kps=kps, world=world, recon=recon)
+        if 'physique_recons_loss' in lc and self.physique_network is not None:
+            phys = self.physique_network(recon)
+            out['mask_physique_{}'.format(key)] = phys[[0]].detach()
+            r['phys'] = compute_mask_reconstruction_loss(
+                phys, x[key + '_mask'], weight=x[key + '_geodesic_dis'] if lc['physique_recons_loss']['use_dis_map'] else None)
+        if 'recons_loss' in lc:
+            r['recons'] = compute_mask_reconstruction_loss(
+                recon, x[key + '_mask'], weight=x[key + '_geodesic_dis'] if lc['recons_loss']['use_dis_map'] else None,
+                use_clip=True)
+        streams.to_main(*[v for v in r.values() if isinstance(v, torch.Tensor)])
+        return r
+
+    def _pseudo_pass(self, x, cam, out):
+        """Pseudo-image branch of one camera (model.py:145-164): detector on the synthetic image, supervised by
+        its joints, min over hypotheses of the batch-mean error."""
+        key = 'cam_{}'.format(cam)
+        pred, _ = self.regressor(x[key + '_pseudo_img'])
+        gt = x[key + '_pseudo_joints']
+        out['pose_2d_pred_{}_pseudo'.format(key)] = pred[[0], 0].detach().clone()
+        out['pose_3d_pred_{}_pseudo'.format(key)] = _to_world(pred[:, 0].detach(), x, key, True)[[0]]
+        out['pose_3d_gt_{}_pseudo'.format(key)] = _to_world(gt, x, key, True)[[0]]
+        v = torch.stack([compute_supervision(pred[:, h], gt) for h in range(pred.shape[1])]).min()
+        streams.to_main(v)
+        return v
+
     def forward(self, x, smpl_discriminator):
         cams = _cams(x, self.cam_id_list)
         lc = self.loss_config
         losses, out = {}, {}
-        kps, world, recon = {}, {}, {}
-        for cam in cams:
-            key = 'cam_{}'.format(cam)
-            img = x[key + '_img']
-            kps[key], depth_map = self.regressor(img)
-            assert kps[key].dim() == 4, "use aligned multi-hypothesis settings"
-            out['pose_2d_pred_{}_ori'.format(key)] = kps[key][[0], 0].detach().clone()
-            out['depth_map_{}'.format(key)] = depth_map
-            world[key] = _to_world(kps[key], x, key, cam == 'mono')           # [B, Hy, K, 3], one launch
-            out['pose_3d_depth_{}'.format(key)] = world[key][:, 0].detach().clone()
-            # multi-hypothesis only changes z, so one mask per camera (hypothesis 0's x, y)
-            recon[key] = draw_lines_max(kps[key][:, 0, :, :2], img.shape[-1], self.parent_ids, self.child_ids,
-                                        self.body_width)
-            out['mask_heatmap_line_{}'.format(key)] = recon[key].detach()
+        ops_nn.prepack(self.regressor)                    # packed weights ready before the camera streams fork
+        if self.physique_network is not None:
+            ops_nn.prepack(self.physique_network)
+        per_cam = {}
+        with streams.fork() as fk:
+            # host enqueue order (real images of every camera, then the pseudo images) is the reference's
+            # order of detector calls: it fixes the order of the batch-norm running-statistic updates
+            for i, cam in enumerate(cams):
+                with fk.run(i):
+                    per_cam['cam_{}'.format(cam)] = self._camera_pass(x, cam, lc, out)
+            if 'smpl_pseudo_img_loss' in lc:
+                for i, cam in enumerate(cams):
+                    with fk.run(i):
+                        per_cam['cam_{}'.format(cam)]['pseudo'] = self._pseudo_pass(x, cam, out)
+        kps = {k: v['kps'] for k, v in per_cam.items()}
+        world = {k: v['world'] for k, v in per_cam.items()}
         if 'mono' not in cams:
             out['kp_gt_world'] = convert_patch_to_world(x['cam_0_joints'], x, 'cam_0', is_norm=False)[[0]]
 
@@ -117,36 +161,13 @@ class Counter3DModel(torch.nn.Module):
             losses['smpl_gen'] = total * lc['smpl_gen_loss']['weight']
 
         if 'smpl_pseudo_img_loss' in lc:
-            total = 0
-            for cam in cams:
-                key = 'cam_{}'.format(cam)
-                pred, _ = self.regressor(x[key + '_pseudo_img'])
-                gt = x[key + '_pseudo_joints']
-                out['pose_2d_pred_{}_pseudo'.format(key)] = pred[[0], 0].detach().clone()
-                out['pose_3d_pred_{}_pseudo'.format(key)] = _to_world(pred[:, 0].detach(), x, key, True)[[0]]
-                out['pose_3d_gt_{}_pseudo'.format(key)] = _to_world(gt, x, key, True)[[0]]
-                total = total + torch.stack([compute_supervision(pred[:, h], gt) for h in range(pred.shape[1])]).min()
-            losses['smpl_pseudo_img'] = total * lc['smpl_pseudo_img_loss']['weight']
-
+            losses['smpl_pseudo_img'] = sum(per_cam['cam_{}'.format(c)]['pseudo'] for c in cams) \
+                * lc['smpl_pseudo_img_loss']['weight']
         if 'physique_recons_loss' in lc and self.physique_network is not None:
-            use_map = lc['physique_recons_loss']['use_dis_map']
-            total = 0
-            for cam in cams:
-                key = 'cam_{}'.format(cam)
-                phys = self.physique_network(recon[key])
-                out['mask_physique_{}'.format(key)] = phys[[0]].detach()
-                total = total + compute_mask_reconstruction_loss(
-                    phys, x[key + '_mask'], weight=x[key + '_geodesic_dis'] if use_map else None)
-            losses['physique_recons'] = total * lc['physique_recons_loss']['weight']
-
+            losses['physique_recons'] = sum(per_cam['cam_{}'.format(c)]['phys'] for c in cams) \
+                * lc['physique_recons_loss']['weight']
         if 'recons_loss' in lc:
-            use_map = lc['recons_loss']['use_dis_map']
-            total = 0
-            for cam in cams:
-                key = 'cam_{}'.format(cam)
-                total = total + compute_mask_reconstruction_loss(
-                    recon[key], x[key + '_mask'], weight=x[key + '_geodesic_dis'] if use_map else None, use_clip=True)
-            losses['reconstruction'] = total * lc['recons_loss']['weight']
+            losses['reconstruction'] = sum(per_cam['cam_{}'.format(c)]['recons'] for c in cams) * lc['recons_loss']['weight']
         return losses, out
 
 
@@ -172,14 +193,20 @@ class Counter3DDisc(torch.nn.Module):
         d = self.DISC_SUP_DIMENSION
         cams = _cams(x, self.cam_id_list)
         preds, reals, inputs = {}, {}, []
+        ops_nn.prepack(regressor)
+        with streams.fork() as fk:
+            for i, cam in enumerate(cams):
+                key = 'cam_{}'.format(cam)
+                # The reference builds (and discards) an autograd graph here (model.py:231, output detached at
+                # :243); only the values and the train-mode BN running-statistic updates matter, so no graph is
+                # recorded.  Each camera's detector runs on its own stream.
+                with fk.run(i), torch.no_grad():
+                    pred, _ = regressor(x[key + '_img'])
+                    streams.to_main(pred)
+                preds[key], reals[key] = pred, x[key + '_pseudo_joints']
         for cam in cams:
             key = 'cam_{}'.format(cam)
-            # The reference builds (and discards) an autograd graph here (model.py:231, output detached at :243);
-            # only the values and the train-mode BN running-statistic updates matter, so no graph is recorded.
-            with torch.no_grad():
-                pred, _ = regressor(x[key + '_img'])
-            preds[key], reals[key] = pred, x[key + '_pseudo_joints']
-            inputs += [preds[key][:, h, :, :d] for h in range(pred.shape[1])] + [reals[key][..., :d]]
+            inputs += [preds[key][:, h, :, :d] for h in range(preds[key].shape[1])] + [reals[key][..., :d]]
         logits = _disc_many(self.smpl_discriminator, inputs)           # every hypothesis / camera in one pass
         per_cam = len(inputs) // len(cams)
         for ci, cam in enumerate(cams):

@@ -84,7 +84,12 @@ class BatchNorm2d(nn.Module):
         if self.sync and self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             group = dist.group.WORLD
         if self.training and not self._nbt_shared:
-            self.num_batches_tracked += 1
+            from . import streams
+            if streams.forked():
+                with torch.cuda.stream(streams.book_stream()):
+                    self.num_batches_tracked += 1
+            else:
+                self.num_batches_tracked += 1
         return F.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, residual, self.training,
                             self.momentum, self.eps, self.act, group)
 
@@ -122,4 +127,9 @@ class SharedBatchCounters:
             m._buffers['num_batches_tracked'].data_ptr() == self.arena.data_ptr() + 8 * i for i, m in enumerate(self.mods))
         if not ok:                      # first use, or the buffers were replaced (.to(), load_state_dict)
             self._bind()
-        self.arena += 1
+        from . import streams
+        if streams.forked():            # concurrent camera streams: serialise the read-modify-write
+            with torch.cuda.stream(streams.book_stream()):
+                self.arena += 1
+        else:
+            self.arena += 1

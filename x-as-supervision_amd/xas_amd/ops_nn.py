@@ -5,6 +5,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
+from . import streams
 from ._lib import ConvShape, call, ptr, query
 
 CL = torch.channels_last
@@ -269,8 +270,18 @@ class _BatchNorm(torch.autograd.Function):
                 mean, var = _sync_stats(mean, var, M, group)
                 count = float(M) * dist.get_world_size(group)     # equal per-rank batches (train.py:274)
             if running_mean is not None:
-                call('xas_bn_update_running', ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
-                     float(momentum), int(count), c)
+                if streams.forked():
+                    # order-dependent update: serialised on the bookkeeping stream in host program order
+                    book, cur = streams.book_stream(), torch.cuda.current_stream()
+                    book.wait_stream(cur)
+                    with torch.cuda.stream(book):
+                        call('xas_bn_update_running', ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
+                             float(momentum), int(count), c)
+                    mean.record_stream(book)
+                    var.record_stream(book)
+                else:
+                    call('xas_bn_update_running', ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
+                         float(momentum), int(count), c)
         else:
             mean, var = running_mean, running_var
         res = to_cl(residual) if residual is not None else None
@@ -378,3 +389,14 @@ class _Sigmoid(torch.autograd.Function):
 
 def sigmoid(x):
     return _Sigmoid.apply(x)
+
+
+def prepack(module):
+    """Build the packed weight copies of every conv under `module` on the CURRENT stream (called on the main
+    stream before camera streams fork, so no two streams race to fill a cache)."""
+    for m in module.modules():
+        cache = getattr(m, '_cache', None)
+        w = getattr(m, 'weight', None)
+        if isinstance(cache, _PackCache) and w is not None and w.dim() == 4 and w.is_cuda:
+            cache.get(w, 0)
+            cache.get(w, 1)
