@@ -29,6 +29,8 @@ extern "C" {
 const char* xas_last_error(void);
 /* kernel-tuning experiment flags (benchmarks only; 0 = shipped configuration) */
 int xas_set_tuning(int flags);
+/* diagnostic builds: device buffer of 8 uint64 that the igemm kernels add per-phase cycle sums to (NULL = off) */
+int xas_set_debug_buffer(void* device_ptr);
 int xas_abi_version(void);
 
 /* ------------------------------------------------------------------------------------

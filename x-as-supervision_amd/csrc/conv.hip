@@ -55,7 +55,10 @@ struct IgemmParams {
   int Hrow, Wrow;          // row grid (fwd: Ho x Wo; dgrad: per-phase grid, set in kernel)
   int tune;                // experiment flags (xas_set_tuning): bit1 setprio around MFMAs, bit2 plain tile order
   int nMt, nNt, mt_per_xcd;   // tile counts and M-tiles per XCD for the XCD-aware block order
+  unsigned long long* dbg;    // diagnostic builds only: per-phase cycle sums (xas_set_debug_buffer)
 };
+
+static unsigned long long* g_dbg = nullptr;
 
 static int g_tune = 0;
 
@@ -199,9 +202,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   // Loads are issued UNCONDITIONALLY from a clamped (always valid) address; rows that are out of range are
   // zeroed later, when the registers are written to LDS.  A `cond ? load : 0` makes hipcc branch around each
   // load and wait vmcnt(0) in the middle of the prefetch, exposing the full memory latency every K-step.
-  float4 ra4[APASS], rb4[BPASS];
-  unsigned okmask = 0;
-  auto load_step = [&](int ks) {
+  // Two register sets: the global loads of K-step ks+2 are issued while step ks is computed, so a load has
+  // TWO MFMA phases to arrive (in-kernel stamps showed 3-4k cycles of load latency under load against a
+  // 2-4k cycle MFMA phase: with one step of look-ahead the waves sat in s_waitcnt vmcnt before every LDS
+  // store).  The sets are separate named arrays and the loop is unrolled by two: a runtime-indexed register
+  // array would be demoted to scratch memory.
+  float4 ra4_0[APASS], rb4_0[BPASS], ra4_1[APASS], rb4_1[BPASS];
+  unsigned okmask_0 = 0, okmask_1 = 0;
+  auto load_step = [&](int ks, float4 (&ra4)[APASS], float4 (&rb4)[BPASS], unsigned& okmask) {
     const int tap = ks / cchunks, c0 = (ks - tap * cchunks) * BK + kq * 4;
     const int jr = tap / ns, js = tap - jr * ns;
     // fwd: source = base + tap ; dgrad: source = base - tap index (transposed walk)
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     }
     okmask = m;
   };
-  auto store_step = [&](int buf) {
+  auto store_step = [&](int buf, const float4 (&ra4)[APASS], const float4 (&rb4)[BPASS], unsigned okmask) {
     float* a = As + buf * BM * LDK;
     float* b = Bs + buf * BN * LDK;
 #pragma unroll
@@ -245,18 +253,38 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     }
   };
 
-  if (nk > 0) load_step(0);
-  for (int ks = 0; ks < nk; ++ks) {
-    const int buf = NBUF == 2 ? (ks & 1) : 0;
-    if (NBUF == 1 && ks > 0) __syncthreads();          // single buffer: everyone is done reading the previous tile
-    if (!(p.tune & 16) || ks < 2) {          // ablation bit4: no LDS restaging / barrier after the first 2 steps
-      store_step(buf);
-      __syncthreads();
-    }
-    if (ks + 1 < nk && (!(p.tune & 8) || ks < 1)) load_step(ks + 1);   // ablation bit3: no global loads
-    if (p.tune & 2) __builtin_amdgcn_s_setprio(1);
-    mfma_tile<BM, BN>(As + buf * BM * LDK, Bs + buf * BN * LDK, acc, acc2, wm, wn, lane, p.tune);
-    if (p.tune & 2) __builtin_amdgcn_s_setprio(0);
+  unsigned long long t_store = 0, t_bar = 0, t_load = 0, t_mfma = 0, t0 = 0, t1 = 0;
+  const bool stamp = p.dbg != nullptr;
+#define XAS_STAMP(acc_var)                                                     \
+  if (stamp) {                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    acc_var += t1 - t0; t0 = t1;                                               \
+  }
+#define XAS_KSTEP(KS, BUF, RA, RB, MASK)                                                          \
+  {                                                                                               \
+    store_step(BUF, RA, RB, MASK);                                                                \
+    XAS_STAMP(t_store)                                                                            \
+    __syncthreads();                                                                              \
+    XAS_STAMP(t_bar)                                                                              \
+    if ((KS) + 2 < nk) load_step((KS) + 2, RA, RB, MASK);                                         \
+    XAS_STAMP(t_load)                                                                             \
+    mfma_tile<BM, BN>(As + (BUF) * BM * LDK, Bs + (BUF) * BN * LDK, acc, acc2, wm, wn, lane, p.tune); \
+    XAS_STAMP(t_mfma)                                                                             \
+  }
+  if (nk > 0) load_step(0, ra4_0, rb4_0, okmask_0);
+  if (nk > 1) load_step(1, ra4_1, rb4_1, okmask_1);
+  if (stamp) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory"); }
+  for (int ks = 0; ks < nk; ks += 2) {
+    XAS_KSTEP(ks, 0, ra4_0, rb4_0, okmask_0)
+    if (ks + 1 < nk) XAS_KSTEP(ks + 1, 1, ra4_1, rb4_1, okmask_1)
+  }
+#undef XAS_KSTEP
+#undef XAS_STAMP
+  if (stamp && lane == 0) {
+    atomicAdd(p.dbg + 0, t_store); atomicAdd(p.dbg + 1, t_bar); atomicAdd(p.dbg + 2, t_load);
+    atomicAdd(p.dbg + 3, t_mfma); atomicAdd(p.dbg + 4, (unsigned long long)nk);
   }
 
   if (C::MI == 1 && C::NI == 1) {
@@ -793,7 +821,6 @@ static int launch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStre
 
 template <int MODE>
 static int dispatch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
-  if ((g_tune & 2048) && p.Cd >= 96) return launch_igemm<128, 128, MODE, 1>(p, Mrows_max, phases, st);   // experiment
   if (p.Cd >= 96) {
     // small problems (layer3/4 at B=32: M = 8192 / 2048 rows): 128x128 tiles leave most of the 256 CUs idle
     const long blocks128 = cdiv(Mrows_max, 128) * cdiv(p.Cd, 128) * phases;
@@ -809,6 +836,7 @@ static int dispatch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipSt
 using namespace xas;
 
 extern "C" int xas_set_tuning(int flags) { g_tune = flags; return 0; }
+extern "C" int xas_set_debug_buffer(void* p) { g_dbg = reinterpret_cast<unsigned long long*>(p); return 0; }
 
 extern "C" int xas_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
                             const xas_conv_shape* s, void* stream) {
@@ -847,7 +875,7 @@ extern "C" int xas_conv_fwd(const float* x, const float* w_packed, const float* 
   IgemmParams p{};
   p.src = x; p.wgt = w_packed; p.bias = bias; p.out = y; p.N = s->N;
   p.Hs = s->Hi; p.Ws = s->Wi; p.Cs = s->Cin; p.Hd = s->Ho; p.Wd = s->Wo; p.Cd = s->Cout;
-  p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.Hrow = s->Ho; p.Wrow = s->Wo; p.tune = g_tune;
+  p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.Hrow = s->Ho; p.Wrow = s->Wo; p.tune = g_tune; p.dbg = g_dbg;
   p.div_hw.init((unsigned)(s->Ho * s->Wo)); p.div_w.init((unsigned)s->Wo);
   return dispatch_igemm<0>(p, s->N * s->Ho * s->Wo, 1, st);
 }
@@ -885,7 +913,7 @@ extern "C" int xas_conv_dgrad(const float* dy, const float* w_packed_t, float* d
   IgemmParams p{};
   p.src = dy; p.wgt = w_packed_t; p.bias = nullptr; p.out = dx; p.N = s->N;
   p.Hs = s->Ho; p.Ws = s->Wo; p.Cs = s->Cout; p.Hd = s->Hi; p.Wd = s->Wi; p.Cd = s->Cin;
-  p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.tune = g_tune;
+  p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.tune = g_tune; p.dbg = g_dbg;
   const int Hp = (s->Hi + s->stride - 1) / s->stride, Wp = (s->Wi + s->stride - 1) / s->stride;
   return dispatch_igemm<1>(p, s->N * Hp * Wp, s->stride * s->stride, st);
 }
