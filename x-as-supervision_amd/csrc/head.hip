@@ -17,12 +17,15 @@ namespace xas {
 
 struct HeadGeom {
   int B, K, D, HW, W, C4, G, R, P, nchunk, rec;  // rec = 3 + D floats per (b,chunk,k)
+  int wshift;                                     // log2(W): W is a power of two, so pix -> (h, w) is shift/mask
 };
 
 static int make_geom(int B, int K, int D, HeadGeom* g) {
   XAS_REQUIRE(B > 0 && K > 0 && D >= 4 && D <= 64 && (D & (D - 1)) == 0,
               "head: need power-of-two depth_dim in [4,64], got B=%d K=%d D=%d", B, K, D);
   g->B = B; g->K = K; g->D = D; g->W = D; g->HW = D * D;
+  g->wshift = 0;
+  while ((1 << g->wshift) < D) ++g->wshift;
   g->C4 = K * D / 4;
   g->G = D / 4;
   int gcd = 1;
@@ -32,7 +35,7 @@ static int make_geom(int B, int K, int D, HeadGeom* g) {
   while ((long)g->C4 * R * 2 <= 640 && R * 2 <= g->HW) R *= 2;
   XAS_REQUIRE((long)g->C4 * R <= 1024, "head: K*D=%d too wide for one workgroup", K * D);
   g->R = R;
-  g->P = R > 64 ? R : 64;
+  g->P = R > 128 ? R : 128;       // pixels per workgroup: 128 amortises the block-level merge (64: 3.8 TB/s)
   if (g->P > g->HW) g->P = g->HW;
   g->P = (g->P / R) * R;
   XAS_REQUIRE(g->P >= R, "head: heat-map too small");
@@ -52,13 +55,36 @@ __global__ void head_partial_kernel(const float4* __restrict__ logits, float* __
   const float4* base = logits + ((size_t)b * g.HW + pix0) * g.C4 + c4;
 
   float m = -INFINITY, sx = 0.f, sy = 0.f, z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
-#pragma unroll 4
-  for (int p = slot; p < pend; p += g.R) {
+  // four pixels per trip: one running-max update (one rescale exp) per 16 values keeps the loop-carried
+  // dependency short; the 4 loads are issued back to back
+  int p = slot;
+  for (; p + 3 * g.R < pend; p += 4 * g.R) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = base[(size_t)(p + u * g.R) * g.C4];
+    float mn = m;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mn = fmaxf(mn, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
+    const float sc = __expf(m - mn);          // exp(-inf) = 0 on the first trip
+    m = mn;
+    z0 *= sc; z1 *= sc; z2 *= sc; z3 *= sc; sx *= sc; sy *= sc;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pix = pix0 + p + u * g.R;
+      const float fw = (float)(pix & (g.W - 1)), fh = (float)(pix >> g.wshift);
+      const float e0 = __expf(v[u].x - mn), e1 = __expf(v[u].y - mn), e2 = __expf(v[u].z - mn), e3 = __expf(v[u].w - mn);
+      const float es = (e0 + e1) + (e2 + e3);
+      z0 += e0; z1 += e1; z2 += e2; z3 += e3;
+      sx = fmaf(es, fw, sx);
+      sy = fmaf(es, fh, sy);
+    }
+  }
+  for (; p < pend; p += g.R) {
     const float4 v = base[(size_t)p * g.C4];
     const int pix = pix0 + p;
-    const float fw = (float)(pix % g.W), fh = (float)(pix / g.W);
+    const float fw = (float)(pix & (g.W - 1)), fh = (float)(pix >> g.wshift);
     const float mn = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
-    const float sc = __expf(m - mn);          // exp(-inf) = 0 on the first pixel
+    const float sc = __expf(m - mn);
     m = mn;
     const float e0 = __expf(v.x - mn), e1 = __expf(v.y - mn), e2 = __expf(v.z - mn), e3 = __expf(v.w - mn);
     const float es = (e0 + e1) + (e2 + e3);
@@ -199,7 +225,7 @@ __global__ void head_bwd_kernel(const float4* __restrict__ logits, const float* 
   for (int p = slot; p < pend; p += g.R) {
     const float4 v = logits[off + (size_t)p * g.C4];
     const int pix = pix0 + p;
-    const float lin = cx * (float)(pix % g.W) + cy * (float)(pix / g.W) + c0;
+    const float lin = cx * (float)(pix & (g.W - 1)) + cy * (float)(pix >> g.wshift) + c0;
     float4 o;
     o.x = __expf(v.x - lse) * (lin + gz.x);
     o.y = __expf(v.y - lse) * (lin + gz.y);
