@@ -149,7 +149,7 @@ def main():
         n_launch = sum(v['launches'] for v in mfma.values())
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         line = {
-            'metric': 'images/sec HM36_Multi_SurS1 256px bs32 (full disc+gen training step)',
+            'metric': 'images/sec %s 256px bs%d (full disc+gen training step)' % (args.workload, args.batch),
             'value': samples * per_sample / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
