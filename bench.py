@@ -71,6 +71,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='samples per GPU')
     ap.add_argument('--workload', default='HM36_Multi_SurS1')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo to rehearse ranks on one GPU)')
     ap.add_argument('--tune', type=int, default=0, help='kernel tuning experiment flags (xas_set_tuning)')
     ap.add_argument('--shape-report', default=None, help='write a per-conv-shape timing table to this file')
     args = ap.parse_args()
@@ -80,11 +81,15 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    local = local % max(1, torch.cuda.device_count())     # rehearsal: several ranks on one card
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     from xas_amd import engine
     from xas_amd.prof import KernelTimer
