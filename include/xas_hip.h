@@ -148,8 +148,12 @@ int xas_unpack_weight(const float* packed, float* oihw, int Cout, int Cin, int R
  * act: 0 none, 1 relu, 2 leaky-relu(0.01).
  * ---------------------------------------------------------------------------------- */
 size_t xas_bn_workspace_floats(long M, int C);
+/* running_mean/var != NULL (rank-local norms): the running-statistic update (momentum, unbiased variance
+ * from `count`) is fused into the finalize launch; pass NULL for SyncBatchNorm and call
+ * xas_bn_update_running after the statistic exchange. */
 int xas_bn_stats(const float* x, long M, int C, float* mean, float* var_biased,
-                 float* workspace, void* stream);
+                 float* workspace, float* running_mean, float* running_var, float momentum,
+                 long count, void* stream);
 /* out[c] = sum_m x[m][c]  (bias gradients: deconv_head.py:34, physique_network.py:17, discriminator.py:11);
  * workspace: xas_bn_workspace_floats(M, C) */
 int xas_col_sum(const float* x, long M, int C, float* out, float* workspace, void* stream);

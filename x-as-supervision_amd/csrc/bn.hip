@@ -21,7 +21,7 @@ static int col_geom(long M, int C, ColGeom* g) {
   while (cb < 256 && C % (cb * 2) == 0) cb *= 2;
   g->CB = cb;
   g->TX = g->CB / 4; g->TY = 256 / g->TX; g->ncb = C / g->CB;
-  long want = 512 / g->ncb;                  // ~2 blocks per CU in total; keeps the finalize pass short
+  long want = 256 / g->ncb;                  // ~1 block per CU in total; keeps the finalize pass short
   long maxslab = cdiv(M, (long)g->TY * 8);   // at least 8 rows per thread
   if (want > maxslab) want = maxslab;
   if (want < 1) want = 1;
@@ -92,31 +92,41 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
   }
 }
 
-// partial: [nslab][2][C] -> out1[c], out2[c]; MODE 0 converts pivot sums to mean / biased var.
-// Block = 32 channels x 32 slab lanes; slabs are summed in double, in a fixed order.
+// partial: [nslab][2][C] -> out1[c], out2[c]; MODE 0 converts pivot sums to mean / biased var and, when
+// running buffers are given, applies the running-statistic update in the same launch.
+// Block = 64 channels x 16 slab lanes; slabs are summed in double, in a fixed order (deterministic).
 template <int MODE>
 __global__ __launch_bounds__(1024) void col_finalize_kernel(const float* __restrict__ partial,
                                                            const float* __restrict__ x, int nslab, int C, long M,
-                                                           float* __restrict__ out1, float* __restrict__ out2) {
-  __shared__ double r1[32][32], r2[32][32];
-  const int cx = threadIdx.x & 31, sy = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
+                                                           float* __restrict__ out1, float* __restrict__ out2,
+                                                           float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, float momentum,
+                                                           float unbias) {
+  __shared__ double r1[16][64], r2[16][64];
+  const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
-    for (int s = sy; s < nslab; s += 32) {
+    for (int s = sy; s < nslab; s += 16) {
       s1 += (double)partial[((size_t)s * 2) * C + c];
       s2 += (double)partial[((size_t)s * 2 + 1) * C + c];
     }
   r1[sy][cx] = s1; r2[sy][cx] = s2;
   __syncthreads();
   if (sy != 0 || c >= C) return;
-  for (int k = 1; k < 32; ++k) { s1 += r1[k][cx]; s2 += r2[k][cx]; }
+#pragma unroll
+  for (int k = 1; k < 16; ++k) { s1 += r1[k][cx]; s2 += r2[k][cx]; }
   if (MODE == 0) {
     const double m = s1 / (double)M;
     double v = s2 / (double)M - m * m;
     if (v < 0.0) v = 0.0;
-    out1[c] = (float)((double)x[c] + m);
-    out2[c] = (float)v;
+    const float mean_f = (float)((double)x[c] + m), var_f = (float)v;
+    out1[c] = mean_f;
+    out2[c] = var_f;
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean_f;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (var_f * unbias);
+    }
   } else {
     out1[c] = (float)s1;
     out2[c] = (float)s2;
@@ -345,15 +355,17 @@ extern "C" size_t xas_bn_workspace_floats(long M, int C) {
 }
 
 extern "C" int xas_bn_stats(const float* x, long M, int C, float* mean, float* var_biased, float* workspace,
-                            void* stream) {
+                            float* running_mean, float* running_var, float momentum, long count, void* stream) {
   ColGeom g;
   if (col_geom(M, C, &g)) return 1;
   XAS_REQUIRE(x && mean && var_biased && workspace, "bn_stats: null buffer");
+  XAS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats: running buffers come in pairs");
+  const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
   hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(g.nslab, g.ncb), dim3(256), 0, as_stream(stream), x, nullptr, nullptr,
                      nullptr, nullptr, 0.f, 0, M, C, g, workspace);
   XAS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_finalize_kernel<0>, dim3((unsigned)cdiv(C, 32)), dim3(1024), 0, as_stream(stream), workspace, x,
-                     g.nslab, C, M, mean, var_biased);
+  hipLaunchKernelGGL(col_finalize_kernel<0>, dim3((unsigned)cdiv(C, 64)), dim3(1024), 0, as_stream(stream), workspace, x,
+                     g.nslab, C, M, mean, var_biased, running_mean, running_var, momentum, unbias);
   XAS_LAUNCH_CHECK();
   return 0;
 }
@@ -366,8 +378,8 @@ extern "C" int xas_col_sum(const float* x, long M, int C, float* out, float* wor
                      nullptr, nullptr, 0.f, 0, M, C, g, workspace);
   XAS_LAUNCH_CHECK();
   // second output (unused sums of the second accumulator) lands in workspace tail
-  hipLaunchKernelGGL(col_finalize_kernel<1>, dim3((unsigned)cdiv(C, 32)), dim3(1024), 0, as_stream(stream), workspace, x,
-                     g.nslab, C, M, out, workspace + (size_t)g.nslab * 2 * C);
+  hipLaunchKernelGGL(col_finalize_kernel<1>, dim3((unsigned)cdiv(C, 64)), dim3(1024), 0, as_stream(stream), workspace, x,
+                     g.nslab, C, M, out, workspace + (size_t)g.nslab * 2 * C, nullptr, nullptr, 0.f, 1.f);
   XAS_LAUNCH_CHECK();
   return 0;
 }
@@ -405,8 +417,8 @@ extern "C" int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy
   hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(g.nslab, g.ncb), dim3(256), 0, as_stream(stream), x, y, dy, mean,
                      var_biased, eps, act, M, C, g, workspace);
   XAS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_finalize_kernel<1>, dim3((unsigned)cdiv(C, 32)), dim3(1024), 0, as_stream(stream), workspace, x,
-                     g.nslab, C, M, sum_dz, sum_dz_xhat);
+  hipLaunchKernelGGL(col_finalize_kernel<1>, dim3((unsigned)cdiv(C, 64)), dim3(1024), 0, as_stream(stream), workspace, x,
+                     g.nslab, C, M, sum_dz, sum_dz_xhat, nullptr, nullptr, 0.f, 1.f);
   XAS_LAUNCH_CHECK();
   return 0;
 }

@@ -40,7 +40,7 @@ SIGNATURES = {
     'xas_pack_weight': ('ppiiiiip', 'i'),
     'xas_unpack_weight': ('ppiiiiip', 'i'),
     'xas_bn_workspace_floats': ('li', 'z'),
-    'xas_bn_stats': ('plipppp', 'i'),
+    'xas_bn_stats': ('plipppppflp', 'i'),
     'xas_col_sum': ('plippp', 'i'),
     'xas_bn_apply': ('ppppppfilipp', 'i'),
     'xas_bn_update_running': ('ppppflip', 'i'),

@@ -265,11 +265,14 @@ class _BatchNorm(torch.autograd.Function):
             mean = torch.empty(c, device=dev, dtype=torch.float32)
             var = torch.empty(c, device=dev, dtype=torch.float32)
             ws = torch.empty(query('xas_bn_workspace_floats', M, c), device=dev, dtype=torch.float32)
-            call('xas_bn_stats', ptr(x), M, c, ptr(mean), ptr(var), ptr(ws))
+            fuse_running = group is None and running_mean is not None and not streams.forked()
+            call('xas_bn_stats', ptr(x), M, c, ptr(mean), ptr(var), ptr(ws),
+                 ptr(running_mean) if fuse_running else None, ptr(running_var) if fuse_running else None,
+                 float(momentum), int(M))
             if group is not None:
                 mean, var = _sync_stats(mean, var, M, group)
                 count = float(M) * dist.get_world_size(group)     # equal per-rank batches (train.py:274)
-            if running_mean is not None:
+            if running_mean is not None and not fuse_running:
                 if streams.forked():
                     # order-dependent update: serialised on the bookkeeping stream in host program order
                     book, cur = streams.book_stream(), torch.cuda.current_stream()
