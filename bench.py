@@ -153,6 +153,11 @@ def main():
         ms = sum(v['ms'] for v in mfma.values())
         n_launch = sum(v['launches'] for v in mfma.values())
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'r01_conv_traffic.json')
+        if os.path.exists(tpath) and args.workload == 'HM36_Multi_SurS1' and args.batch == 32:
+            with open(tpath) as tf:
+                traffic = json.load(tf).get('bytes_per_launch')   # PMC passes of this same command (see file)
         line = {
             'metric': 'images/sec %s 256px bs%d (full disc+gen training step)' % (args.workload, args.batch),
             'value': samples * per_sample / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
@@ -162,7 +167,8 @@ def main():
                        'image': '256x256', 'images_per_sample': per_sample, 'parallelism': 'dp%d' % world,
                        'samples_per_s': samples / dt, 'detector_forwards_per_s': samples * 3 * len(cams) / dt},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+                         'algorithmic_bytes_per_launch': timer.bytes_total / max(1, n_launch),
                          'kernel': 'igemm_kernel / wgrad_kernel (fp32 MFMA implicit-GEMM conv family)',
                          'note': 'weight-gradient kernels run on a side stream concurrently with the main chain, so '
                                  'per-launch durations include sharing; step_conv_tflops_over_wall is the whole-step view',

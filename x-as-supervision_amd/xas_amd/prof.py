@@ -12,10 +12,17 @@ def conv_flops(shape):
     return 2.0 * shape.N * shape.Ho * shape.Wo * shape.Cout * shape.R * shape.S * shape.Cin
 
 
+def conv_bytes(shape):
+    """Algorithmic HBM bytes of one conv launch: both activation tensors and the weights, once each."""
+    return 4.0 * (shape.N * shape.Hi * shape.Wi * shape.Cin + shape.Cout * shape.R * shape.S * shape.Cin
+                  + shape.N * shape.Ho * shape.Wo * shape.Cout)
+
+
 class KernelTimer:
     def __init__(self, names=CONV_ENTRIES):
         self.names = set(names)
         self.records = []          # (name, start_event, end_event, flops, mfma_path)
+        self.bytes_total = 0.0     # algorithmic bytes of the MFMA-path launches
 
     def __enter__(self):
         _lib.profiler = self
@@ -44,6 +51,7 @@ class KernelTimer:
         if shape is not None:
             sig = (shape.N, shape.Hi, shape.Wi, shape.Cin, shape.Cout, shape.R, shape.stride)
         self.records.append((name, a, b, conv_flops(shape) if shape is not None else 0.0, mfma, sig))
+        self.bytes_total += conv_bytes(shape) if (shape is not None and mfma) else 0.0
 
     def summary(self):
         """-> dict per entry point: launches, total ms, total flops (call after torch.cuda.synchronize())."""
