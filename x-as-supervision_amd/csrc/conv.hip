@@ -340,6 +340,8 @@ struct WgradParams {
   int KK;                                            // R*S*Cin
   int M;                                             // N*Ho*Wo
   int m_per_split;
+  int nct, ntiles, nsplits;                           // Cout tiles, tiles per split, pixel splits
+  int tune;
   FastDiv div_hw, div_w, div_cin, div_s;
 };
 
@@ -357,8 +359,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   float* Bs = lds + 2 * WBK * LDA;                   // [2][WBK][LDB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
-  const int co0 = blockIdx.x * BM, nn0 = blockIdx.y * BN;
-  const int split = blockIdx.z;
+  // Block order.  Measured both ways (tools/ab_step.py, PMC): grouping all tiles of one pixel split on ONE XCD
+  // cuts the kernel's HBM fetch 2-7x, yet the step is 3 % SLOWER (the tiles of a split then hammer the same L2
+  // lines at the same time); the plain order below is the shipped one.
+  int split, tile;
+  if (!(p.tune & 8192)) {                    // default: tiles fastest, dealt round-robin over the XCDs
+    tile = blockIdx.x % p.ntiles; split = blockIdx.x / p.ntiles;
+  } else {                                   // experiment (bit13): one split per XCD - 2-7x less HBM traffic (PMC) but slower
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    split = xcd + 8 * (q / p.ntiles);
+    tile = q - (q / p.ntiles) * p.ntiles;
+  }
+  if (split >= p.nsplits) return;
+  const int co0 = (tile % p.nct) * BM, nn0 = (tile / p.nct) * BN;
   const int mbeg = split * p.m_per_split, mend = min(p.M, mbeg + p.m_per_split);
   const int HWo = p.Ho * p.Wo;
 
@@ -961,8 +974,13 @@ static int launch_wgrad(const WgradParams& p, int splits, hipStream_t st) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid((unsigned)cdiv(p.Cout, BM), (unsigned)cdiv(p.KK, BN), (unsigned)splits);
-  hipLaunchKernelGGL((wgrad_kernel<BM, BN, VEC>), grid, dim3(256), lds, st, p);
+  WgradParams q = p;
+  q.nct = (int)cdiv(p.Cout, BM);
+  q.ntiles = q.nct * (int)cdiv(p.KK, BN);
+  q.nsplits = splits;
+  q.tune = g_tune;
+  dim3 grid((unsigned)(8 * cdiv(splits, 8) * q.ntiles));
+  hipLaunchKernelGGL((wgrad_kernel<BM, BN, VEC>), grid, dim3(256), lds, st, q);
   XAS_LAUNCH_CHECK();
   return 0;
 }
