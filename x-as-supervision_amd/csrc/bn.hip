@@ -30,7 +30,8 @@ static int col_geom(long M, int C, ColGeom* g) {
   return 0;
 }
 
-template <int MODE>   // 0: stats of x around pivot ; 1: bn backward sums ; 2: plain column sums of x
+template <int MODE>   // 0: stats of x around pivot ; 1: bn backward sums ; 2: plain column sums of x ;
+                      // 3: bn backward sums WITHOUT x: xhat = (z - beta)/gamma with z recovered from y (act != 0)
 __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ dy, const float* __restrict__ mean,
                                                          const float* __restrict__ var, float eps, int act, long M,
@@ -47,6 +48,11 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
     p1 = p0;
   } else if (MODE == 2) {
     p0 = make_float4(0, 0, 0, 0); p1 = p0;
+  } else if (MODE == 3) {                                  // `mean` carries beta, `var` carries gamma
+    p0 = *reinterpret_cast<const float4*>(mean + c);
+    const float4 gm = *reinterpret_cast<const float4*>(var + c);
+    p1 = make_float4(gm.x != 0.f ? 1.f / gm.x : 0.f, gm.y != 0.f ? 1.f / gm.y : 0.f, gm.z != 0.f ? 1.f / gm.z : 0.f,
+                     gm.w != 0.f ? 1.f / gm.w : 0.f);
   } else {
     p0 = *reinterpret_cast<const float4*>(mean + c);
     const float4 v = *reinterpret_cast<const float4*>(var + c);
@@ -54,6 +60,20 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
   }
 #pragma unroll 4
   for (long r = r0 + ty; r < r1; r += g.TY) {
+    if (MODE == 3) {
+      float4 g4 = *reinterpret_cast<const float4*>(dy + r * C + c);
+      const float4 yv = *reinterpret_cast<const float4*>(y + r * C + c);
+      const float neg = act == 1 ? 0.f : 0.01f, up = act == 1 ? 0.f : 100.f;
+      float4 z;                                            // pre-activation value
+      z.x = yv.x > 0.f ? yv.x : yv.x * up; z.y = yv.y > 0.f ? yv.y : yv.y * up;
+      z.z = yv.z > 0.f ? yv.z : yv.z * up; z.w = yv.w > 0.f ? yv.w : yv.w * up;
+      g4.x *= yv.x > 0.f ? 1.f : neg; g4.y *= yv.y > 0.f ? 1.f : neg;
+      g4.z *= yv.z > 0.f ? 1.f : neg; g4.w *= yv.w > 0.f ? 1.f : neg;
+      s1.x += g4.x; s1.y += g4.y; s1.z += g4.z; s1.w += g4.w;
+      s2.x = fmaf(g4.x, (z.x - p0.x) * p1.x, s2.x); s2.y = fmaf(g4.y, (z.y - p0.y) * p1.y, s2.y);
+      s2.z = fmaf(g4.z, (z.z - p0.z) * p1.z, s2.z); s2.w = fmaf(g4.w, (z.w - p0.w) * p1.w, s2.w);
+      continue;
+    }
     const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c);
     if (MODE == 2) {
       s1.x += xv.x; s1.y += xv.y; s1.z += xv.z; s1.w += xv.w;
@@ -160,29 +180,41 @@ __global__ void bn_apply_kernel(const float4* __restrict__ x, const float* __res
 __global__ void bn_bwd_apply_kernel(const float4* __restrict__ x, const float4* __restrict__ y,
                                     const float4* __restrict__ dy, const float* __restrict__ mean,
                                     const float* __restrict__ var, const float* __restrict__ gamma,
-                                    const float* __restrict__ sdz, const float* __restrict__ sdzx, float eps, int act,
-                                    long n4, int C4, float inv_count, float4* __restrict__ dx,
-                                    float4* __restrict__ dres) {
+                                    const float* __restrict__ beta, const float* __restrict__ sdz,
+                                    const float* __restrict__ sdzx, float eps, int act, long n4, int C4,
+                                    float inv_count, float4* __restrict__ dx, float4* __restrict__ dres) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4) * 4;
     const float4 m = *reinterpret_cast<const float4*>(mean + c), v = *reinterpret_cast<const float4*>(var + c);
     const float4 g = *reinterpret_cast<const float4*>(gamma + c);
     const float4 a = *reinterpret_cast<const float4*>(sdz + c), b = *reinterpret_cast<const float4*>(sdzx + c);
-    const float4 xv = x[i];
     float4 dz = dy[i];
+    float4 yv = make_float4(0, 0, 0, 0);
     if (act) {
-      const float4 yv = y[i];
+      yv = y[i];
       const float neg = act == 1 ? 0.f : 0.01f;
       dz.x *= yv.x > 0.f ? 1.f : neg; dz.y *= yv.y > 0.f ? 1.f : neg;
       dz.z *= yv.z > 0.f ? 1.f : neg; dz.w *= yv.w > 0.f ? 1.f : neg;
     }
     if (dres) dres[i] = dz;
+    float4 xh;                                             // normalised input
+    float4 is = make_float4(rsqrtf(v.x + eps), rsqrtf(v.y + eps), rsqrtf(v.z + eps), rsqrtf(v.w + eps));
+    if (x) {
+      const float4 xv = x[i];
+      xh = make_float4((xv.x - m.x) * is.x, (xv.y - m.y) * is.y, (xv.z - m.z) * is.z, (xv.w - m.w) * is.w);
+    } else {                                               // recovered from y: z = act^-1(y), xhat = (z - beta) / gamma
+      const float4 bt = *reinterpret_cast<const float4*>(beta + c);
+      const float up = act == 1 ? 0.f : 100.f;
+      xh.x = g.x != 0.f ? ((yv.x > 0.f ? yv.x : yv.x * up) - bt.x) / g.x : 0.f;
+      xh.y = g.y != 0.f ? ((yv.y > 0.f ? yv.y : yv.y * up) - bt.y) / g.y : 0.f;
+      xh.z = g.z != 0.f ? ((yv.z > 0.f ? yv.z : yv.z * up) - bt.z) / g.z : 0.f;
+      xh.w = g.w != 0.f ? ((yv.w > 0.f ? yv.w : yv.w * up) - bt.w) / g.w : 0.f;
+    }
     float4 o;
-    float is;
-    is = rsqrtf(v.x + eps); o.x = g.x * is * (dz.x - a.x * inv_count - (xv.x - m.x) * is * b.x * inv_count);
-    is = rsqrtf(v.y + eps); o.y = g.y * is * (dz.y - a.y * inv_count - (xv.y - m.y) * is * b.y * inv_count);
-    is = rsqrtf(v.z + eps); o.z = g.z * is * (dz.z - a.z * inv_count - (xv.z - m.z) * is * b.z * inv_count);
-    is = rsqrtf(v.w + eps); o.w = g.w * is * (dz.w - a.w * inv_count - (xv.w - m.w) * is * b.w * inv_count);
+    o.x = g.x * is.x * (dz.x - a.x * inv_count - xh.x * b.x * inv_count);
+    o.y = g.y * is.y * (dz.y - a.y * inv_count - xh.y * b.y * inv_count);
+    o.z = g.z * is.z * (dz.z - a.z * inv_count - xh.z * b.z * inv_count);
+    o.w = g.w * is.w * (dz.w - a.w * inv_count - xh.w * b.w * inv_count);
     dx[i] = o;
   }
 }
@@ -408,14 +440,20 @@ extern "C" int xas_bn_update_running(const float* mean, const float* var_biased,
 }
 
 extern "C" int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy, const float* mean,
-                                 const float* var_biased, float eps, int act, long M, int C, float* sum_dz,
-                                 float* sum_dz_xhat, float* workspace, void* stream) {
+                                 const float* var_biased, const float* gamma, const float* beta, float eps, int act,
+                                 long M, int C, float* sum_dz, float* sum_dz_xhat, float* workspace, void* stream) {
   ColGeom g;
   if (col_geom(M, C, &g)) return 1;
-  XAS_REQUIRE(x && dy && mean && var_biased && sum_dz && sum_dz_xhat && workspace && (act == 0 || y),
+  XAS_REQUIRE(dy && mean && var_biased && sum_dz && sum_dz_xhat && workspace && (act == 0 || y),
               "bn_bwd_reduce: null buffer");
-  hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(g.nslab, g.ncb), dim3(256), 0, as_stream(stream), x, y, dy, mean,
-                     var_biased, eps, act, M, C, g, workspace);
+  XAS_REQUIRE(x || (act != 0 && y && gamma && beta), "bn_bwd_reduce: without x the layer needs an activation, y, gamma, beta");
+  if (x) {
+    hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(g.nslab, g.ncb), dim3(256), 0, as_stream(stream), x, y, dy, mean,
+                       var_biased, eps, act, M, C, g, workspace);
+  } else {            // x-free form: xhat recovered from the saved output (one activation tensor less to read)
+    hipLaunchKernelGGL(col_reduce_kernel<3>, dim3(g.nslab, g.ncb), dim3(256), 0, as_stream(stream), y, y, dy, beta,
+                       gamma, eps, act, M, C, g, workspace);
+  }
   XAS_LAUNCH_CHECK();
   hipLaunchKernelGGL(col_finalize_kernel<1>, dim3((unsigned)cdiv(C, 64)), dim3(1024), 0, as_stream(stream), workspace, x,
                      g.nslab, C, M, sum_dz, sum_dz_xhat, nullptr, nullptr, 0.f, 1.f);
@@ -424,16 +462,19 @@ extern "C" int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy
 }
 
 extern "C" int xas_bn_bwd_apply(const float* x, const float* y, const float* dy, const float* mean,
-                                const float* var_biased, const float* gamma, const float* sum_dz,
+                                const float* var_biased, const float* gamma, const float* beta, const float* sum_dz,
                                 const float* sum_dz_xhat, float eps, int act, long M, int C, double count, float* dx,
                                 float* dresidual, void* stream) {
-  XAS_REQUIRE(x && dy && mean && var_biased && gamma && sum_dz && sum_dz_xhat && dx && (act == 0 || y),
+  XAS_REQUIRE(dy && mean && var_biased && gamma && sum_dz && sum_dz_xhat && dx && (act == 0 || y),
               "bn_bwd_apply: null buffer");
+  XAS_REQUIRE(x || (act == 2 && y && beta),
+              "bn_bwd_apply: without x the layer needs an INVERTIBLE activation (leaky ReLU), y and beta: dx needs xhat "
+              "of every element, also where ReLU clipped the output");
   XAS_REQUIRE(M > 0 && C >= 4 && C % 4 == 0 && count > 0, "bn_bwd_apply: bad shape");
   const long n4 = M * (C / 4);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(y),
-                     reinterpret_cast<const float4*>(dy), mean, var_biased, gamma, sum_dz, sum_dz_xhat, eps, act, n4,
+                     reinterpret_cast<const float4*>(dy), mean, var_biased, gamma, beta, sum_dz, sum_dz_xhat, eps, act, n4,
                      C / 4, (float)(1.0 / count), reinterpret_cast<float4*>(dx), reinterpret_cast<float4*>(dresidual));
   XAS_LAUNCH_CHECK();
   return 0;

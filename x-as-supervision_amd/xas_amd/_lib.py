@@ -44,8 +44,8 @@ SIGNATURES = {
     'xas_col_sum': ('plippp', 'i'),
     'xas_bn_apply': ('ppppppfilipp', 'i'),
     'xas_bn_update_running': ('ppppflip', 'i'),
-    'xas_bn_bwd_reduce': ('pppppfilipppp', 'i'),
-    'xas_bn_bwd_apply': ('ppppppppfilidppp', 'i'),
+    'xas_bn_bwd_reduce': ('pppppppfilipppp', 'i'),
+    'xas_bn_bwd_apply': ('pppppppppfilidppp', 'i'),
     'xas_maxpool3x3s2_fwd': ('piiiippp', 'i'),
     'xas_maxpool3x3s2_bwd': ('ppiiiipp', 'i'),
     'xas_upsample2x_fwd': ('piiiipp', 'i'),

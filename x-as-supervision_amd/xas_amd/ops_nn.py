@@ -290,30 +290,36 @@ class _BatchNorm(torch.autograd.Function):
         res = to_cl(residual) if residual is not None else None
         y = torch.empty_like(x)
         call('xas_bn_apply', ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(res), float(eps), act, M, c, ptr(y))
-        ctx.save_for_backward(x, y, mean, var, gamma)
-        ctx.cfg = (M, c, float(eps), act, count, group, training, residual is not None)
+        # Backward without re-reading x where xhat can be recovered from the saved output y:
+        #   reduce pass (sums of dz and dz*xhat): only elements with dz != 0 matter -> any activation, no residual;
+        #   apply pass (dx needs xhat of EVERY element): only an invertible activation (leaky ReLU); then x is
+        #   not kept alive at all.
+        xfree_reduce = training and act != ACT_NONE and residual is None
+        xfree_apply = xfree_reduce and act == ACT_LEAKY
+        ctx.save_for_backward(y if xfree_apply else x, y, mean, var, gamma, beta)
+        ctx.cfg = (M, c, float(eps), act, count, group, training, residual is not None, xfree_reduce, xfree_apply)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, var, gamma = ctx.saved_tensors
-        M, c, eps, act, count, group, training, has_res = ctx.cfg
+        x, y, mean, var, gamma, beta = ctx.saved_tensors
+        M, c, eps, act, count, group, training, has_res, xfree_reduce, xfree_apply = ctx.cfg
         if not training:
             raise RuntimeError('batch-norm backward in eval mode is not part of the training path')
         dy = to_cl(dy)
         dev = x.device
         sdz = torch.empty(2 * c, device=dev, dtype=torch.float32)
         ws = torch.empty(query('xas_bn_workspace_floats', M, c), device=dev, dtype=torch.float32)
-        call('xas_bn_bwd_reduce', ptr(x), ptr(y), ptr(dy), ptr(mean), ptr(var), eps, act, M, c, ptr(sdz),
-             ptr(sdz[c:]), ptr(ws))
+        call('xas_bn_bwd_reduce', None if xfree_reduce else ptr(x), ptr(y), ptr(dy), ptr(mean), ptr(var), ptr(gamma),
+             ptr(beta), eps, act, M, c, ptr(sdz), ptr(sdz[c:]), ptr(ws))
         dgamma, dbeta = sdz[c:], sdz[:c]                      # local sums: DDP averages parameter grads later
         if group is not None:
             dgamma, dbeta = dgamma.clone(), dbeta.clone()
             dist.all_reduce(sdz, group=group)                 # one coalesced 2C message per layer
-        dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if has_res else None
-        call('xas_bn_bwd_apply', ptr(x), ptr(y), ptr(dy), ptr(mean), ptr(var), ptr(gamma), ptr(sdz), ptr(sdz[c:]), eps,
-             act, M, c, float(count), ptr(dx), ptr(dres))
+        dx = torch.empty_like(y)
+        dres = torch.empty_like(y) if has_res else None
+        call('xas_bn_bwd_apply', None if xfree_apply else ptr(x), ptr(y), ptr(dy), ptr(mean), ptr(var), ptr(gamma),
+             ptr(beta), ptr(sdz), ptr(sdz[c:]), eps, act, M, c, float(count), ptr(dx), ptr(dres))
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
 
 
