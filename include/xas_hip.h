@@ -212,6 +212,24 @@ int xas_mask_loss_bwd(const float* m, const float* gt, const float* weight, long
                       const float* out, const float* grad_scalar, float* dm, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Joint-level losses as the model combines them (loss_func.py:18-76, model.py:98-164): a batch mean per
+ * hypothesis, then the MIN over hypotheses; gradient flows to the winning hypothesis only.
+ * pred [B][Hy][K][3].  kind 0: supervision vs gt [B][K][3] ; kind 1: w0*bone_sym + w1*kp_sym (3-D, mm*1e-3)
+ * [+ w2 * kp_sym on the (x,y) of the patch joints passed as `gt` = kps [B][Hy][K][3], or NULL] ;
+ * kind 2: w0 * kp_sym on (x,y).  out: 2+Hy floats = {min, argmin, v_0..v_{Hy-1}}.  grad_aux (kind 1 with the
+ * 2-D term, else NULL): gradient w.r.t. the patch joints.
+ * xas_lsgan_*: logits [B][Hy] -> out[0] = mean_b min_h (x - target)^2, idx[b] = argmin.
+ * ---------------------------------------------------------------------------------- */
+int xas_pose_loss_fwd(const float* pred, const float* gt, int B, int Hy, int K, int kind, float w0, float w1,
+                      float w2, float* out, void* stream);
+int xas_pose_loss_bwd(const float* pred, const float* gt, int B, int Hy, int K, int kind, float w0, float w1,
+                      float w2, const float* out, const float* grad_scalar, float* grad_pred, float* grad_aux,
+                      void* stream);
+int xas_lsgan_fwd(const float* logits, int B, int Hy, float target, float* out, int* idx, void* stream);
+int xas_lsgan_bwd(const float* logits, int B, int Hy, float target, const int* idx, const float* grad_scalar,
+                  float* grad_logits, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * GCN discriminator building blocks (discriminator.py:180-238, gcn.py:79-110 with
  * torch_geometric SAGEConv(mean) / graph LayerNorm semantics).  Node features [B*N][C].
  * ---------------------------------------------------------------------------------- */

@@ -109,6 +109,59 @@ def test_discriminator_groups_equal_separate_calls():
         assert rel(p.grad, psep[n]) < 1e-4, n
 
 
+def test_fused_pose_losses_vs_oracle_and_golden():
+    """Fused min-over-hypotheses losses and LSGAN terms vs the oracle's loss functions (values and gradients),
+    and vs the reference goldens for the single-hypothesis forms."""
+    from modules.base_losses import loss_func as LF
+    from oracle import losses as L
+    g = golden('losses')
+    gen = torch.Generator().manual_seed(3)
+    # goldens: Hy = 1 forms
+    kp3, kp2 = T(g['kp3']), T(g['kp2'])
+    v = LF.compute_symmetry_min(kp3.unsqueeze(1).cuda(), 1.0, 0.0)
+    assert abs(float(v) - float(g['bone_sym'])) < 1e-6 + 1e-5 * abs(float(g['bone_sym']))
+    v = LF.compute_symmetry_min(kp3.unsqueeze(1).cuda(), 0.0, 1.0)
+    assert abs(float(v) - float(g['kp_sym3'])) < 1e-6 + 1e-5 * abs(float(g['kp_sym3']))
+    v = LF.compute_supervision_min(kp3.unsqueeze(1).cuda(), kp3.flip(0).cuda())
+    assert abs(float(v) - float(g['sup'])) < 1e-1 + 1e-5 * abs(float(g['sup']))
+    assert abs(float(LF.compute_disc_loss(T(g['lg3']).cuda(), None)) - float(g['disc_gen3'])) < 1e-6
+    assert abs(float(LF.compute_disc_loss(T(g['lg2']).cuda(), None)) - float(g['disc_gen2'])) < 1e-6
+    assert abs(float(LF.compute_disc_loss(T(g['lg3']).cuda(), T(g['gt2']).cuda())) - float(g['disc_d'])) < 1e-6
+    # multi-hypothesis min + gradients vs the oracle composition
+    B, Hy, K = 32, 3, 18
+    world = torch.randn(B, Hy, K, 3, generator=gen) * 400
+    kps = torch.randn(B, Hy, K, 3, generator=gen) * 0.5
+    gt = torch.randn(B, K, 3, generator=gen) * 0.5
+    for wb, wk, w2 in ((0.1, 0.1, 0.0), (0.3, 0.05, 0.5)):
+        wc, kc = world.clone().requires_grad_(True), kps.clone().requires_grad_(True)
+        ref = torch.stack([L.bone_sym(wc[:, h]) * wb + L.kp_sym(wc[:, h]) * wk + L.kp_sym(kc[:, h, :, :2], False) * 1e2 * w2
+                           for h in range(Hy)]).min()
+        ref.backward()
+        wg, kg = world.cuda().requires_grad_(True), kps.cuda().requires_grad_(True)
+        out = LF.compute_symmetry_min(wg, wb, wk, kg, w2)
+        out.backward()
+        assert abs(float(out) - float(ref)) < 1e-6 + 1e-5 * abs(float(ref))
+        assert rel(wg.grad, wc.grad) < 1e-4
+        if w2:
+            assert rel(kg.grad, kc.grad) < 1e-4
+    pc = kps.clone().requires_grad_(True)
+    ref = torch.stack([L.supervision(pc[:, h], gt) for h in range(Hy)]).min()
+    ref.backward()
+    pg = kps.cuda().requires_grad_(True)
+    out = LF.compute_supervision_min(pg, gt.cuda())
+    out.backward()
+    assert abs(float(out) - float(ref)) < 1e-6 and rel(pg.grad, pc.grad) < 1e-5
+    lg = torch.randn(B, Hy, 1, generator=gen)
+    rl = torch.randn(B, 1, generator=gen)
+    lc, rc = lg.clone().requires_grad_(True), rl.clone().requires_grad_(True)
+    ref = L.disc_loss(lc, rc)
+    ref.backward()
+    lgp, rgp = lg.cuda().requires_grad_(True), rl.cuda().requires_grad_(True)
+    out = LF.compute_disc_loss(lgp, rgp)
+    out.backward()
+    assert abs(float(out) - float(ref)) < 1e-6 and rel(lgp.grad, lc.grad) < 1e-5 and rel(rgp.grad, rc.grad) < 1e-5
+
+
 def test_smpl_layer_vs_golden():
     from modules.smplpytorch.pytorch.smpl_layer import SMPL_Layer
     from modules.util import smpl_to_h36m

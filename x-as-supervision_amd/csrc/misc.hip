@@ -58,6 +58,191 @@ __global__ void mask_loss_bwd_kernel(const float* __restrict__ m, const float* _
   }
 }
 
+
+// ------------------------------------------------------------------ joint-level losses
+// modules/base_losses/loss_func.py:18-76 as the model combines them (modules/model.py:98-164): every loss is a
+// batch mean per hypothesis followed by a MIN over the hypothesis axis (symmetry, pseudo supervision) or a
+// per-sample min (LSGAN).  One workgroup per launch: B*K*3 values.
+//
+// pose_loss: kind 0 = supervision  : v_h = mean_{b,k,c} (pred[b,h,k,c] - gt[b,k,c])^2
+//            kind 1 = symmetry 3-D : v_h = w0 * bone_sym(p_h) + w1 * kp_sym(p_h)      (p in mm, scaled 1e-3)
+//            kind 2 = kp_sym 2-D   : v_h = w0 * mean((mid - anchor)^2) over (x, y) only (no 1e-3 scale)
+// out[0] = min_h v_h, out[1] = argmin (as float), out[2..2+Hy) = v_h.   First minimum wins (torch.min).
+constexpr int kPoseThreads = 256;
+__constant__ int kLimbFar[8] = {16, 15, 13, 12, 3, 2, 6, 5};
+__constant__ int kLimbNear[8] = {15, 14, 12, 11, 2, 1, 5, 4};
+
+__device__ __forceinline__ float limb_len(const float* p, int l) {
+  const float dx = p[kLimbFar[l] * 3] - p[kLimbNear[l] * 3], dy = p[kLimbFar[l] * 3 + 1] - p[kLimbNear[l] * 3 + 1],
+              dz = p[kLimbFar[l] * 3 + 2] - p[kLimbNear[l] * 3 + 2];
+  return sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+__global__ void pose_loss_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int B, int Hy, int K,
+                                     int kind, float w0, float w1, float w2, float* __restrict__ out) {
+  __shared__ float sm[20];
+  __shared__ float vh[8];
+  for (int h = 0; h < Hy; ++h) {
+    float acc = 0.f;
+    if (kind == 0) {
+      const int n = B * K * 3;
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int b = i / (K * 3), r = i % (K * 3);
+        const float d = pred[((size_t)b * Hy + h) * K * 3 + r] - gt[(size_t)b * K * 3 + r];
+        acc = fmaf(d, d, acc);
+      }
+      acc = block_sum(acc, sm) / (float)n;
+    } else if (kind == 1) {
+      float a_bone = 0.f, a_kp = 0.f;
+      for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float* p = pred + ((size_t)b * Hy + h) * K * 3;
+        for (int l = 0; l < 8; l += 2) {
+          const float d = limb_len(p, l) * 1e-3f - limb_len(p, l + 1) * 1e-3f;
+          a_bone = fmaf(d, d, a_bone);
+        }
+        // mid-points of (11,14) vs joint K-1 and of (1,4) vs joint 0
+        for (int c = 0; c < 3; ++c) {
+          const float m0 = (p[11 * 3 + c] + p[14 * 3 + c]) / 2 * 1e-3f - p[(K - 1) * 3 + c] * 1e-3f;
+          const float m1 = (p[1 * 3 + c] + p[4 * 3 + c]) / 2 * 1e-3f - p[0 * 3 + c] * 1e-3f;
+          a_kp = fmaf(m0, m0, a_kp); a_kp = fmaf(m1, m1, a_kp);
+        }
+      }
+      a_bone = block_sum(a_bone, sm) / (float)(B * 4);
+      a_kp = block_sum(a_kp, sm) / (float)(B * 6);
+      acc = w0 * a_bone + w1 * a_kp;
+      if (gt) {                      // optional 2-D term on the patch joints `gt` = kps [B][Hy][K][3] (model.py:110-111)
+        float a2 = 0.f;
+        for (int b = threadIdx.x; b < B; b += blockDim.x) {
+          const float* p = gt + ((size_t)b * Hy + h) * K * 3;
+          for (int c = 0; c < 2; ++c) {
+            const float m0 = (p[11 * 3 + c] + p[14 * 3 + c]) / 2 - p[(K - 1) * 3 + c];
+            const float m1 = (p[1 * 3 + c] + p[4 * 3 + c]) / 2 - p[0 * 3 + c];
+            a2 = fmaf(m0, m0, a2); a2 = fmaf(m1, m1, a2);
+          }
+        }
+        acc += w2 * block_sum(a2, sm) / (float)(B * 4);
+      }
+    } else {
+      for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float* p = pred + ((size_t)b * Hy + h) * K * 3;
+        for (int c = 0; c < 2; ++c) {
+          const float m0 = (p[11 * 3 + c] + p[14 * 3 + c]) / 2 - p[(K - 1) * 3 + c];
+          const float m1 = (p[1 * 3 + c] + p[4 * 3 + c]) / 2 - p[0 * 3 + c];
+          acc = fmaf(m0, m0, acc); acc = fmaf(m1, m1, acc);
+        }
+      }
+      acc = w0 * block_sum(acc, sm) / (float)(B * 4);
+    }
+    if (threadIdx.x == 0) vh[h] = acc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int best = 0;
+    for (int h = 1; h < Hy; ++h) if (vh[h] < vh[best]) best = h;
+    out[0] = vh[best]; out[1] = (float)best;
+    for (int h = 0; h < Hy; ++h) out[2 + h] = vh[h];
+  }
+}
+
+// gradient of out[0] w.r.t. pred (only hypothesis argmin receives gradient); g = upstream scalar gradient
+__global__ void pose_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int B, int Hy, int K,
+                                     int kind, float w0, float w1, float w2, const float* __restrict__ out,
+                                     const float* __restrict__ gscalar, float* __restrict__ gpred,
+                                     float* __restrict__ gaux) {
+  const int best = (int)out[1];
+  const float g = gscalar[0];
+  const int n = B * Hy * K * 3;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { gpred[i] = 0.f; if (gaux) gaux[i] = 0.f; }
+  __syncthreads();
+  if (kind == 0) {
+    const float s = g * 2.f / (float)(B * K * 3);
+    for (int i = threadIdx.x; i < B * K * 3; i += blockDim.x) {
+      const int b = i / (K * 3), r = i % (K * 3);
+      const size_t o = ((size_t)b * Hy + best) * K * 3 + r;
+      gpred[o] = s * (pred[o] - gt[(size_t)b * K * 3 + r]);
+    }
+    return;
+  }
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const float* p = pred + ((size_t)b * Hy + best) * K * 3;
+    float* q = gpred + ((size_t)b * Hy + best) * K * 3;
+    if (kind == 1) {
+      const float sb = g * w0 * 2.f / (float)(B * 4), sk = g * w1 * 2.f / (float)(B * 6);
+      for (int l = 0; l < 8; l += 2) {
+        const float la = limb_len(p, l), lb = limb_len(p, l + 1);
+        const float d = (la - lb) * 1e-3f;
+        // d/dp of |p_far - p_near| = unit vector; scaled by 1e-3
+        for (int side = 0; side < 2; ++side) {
+          const int ll = l + side;
+          const float len = side == 0 ? la : lb, sgn = side == 0 ? 1.f : -1.f;
+          if (len > 0.f)
+            for (int c = 0; c < 3; ++c) {
+              const float u = (p[kLimbFar[ll] * 3 + c] - p[kLimbNear[ll] * 3 + c]) / len;
+              const float gg = sb * d * sgn * 1e-3f * u;
+              q[kLimbFar[ll] * 3 + c] += gg;
+              q[kLimbNear[ll] * 3 + c] -= gg;
+            }
+        }
+      }
+      for (int c = 0; c < 3; ++c) {
+        const float m0 = ((p[11 * 3 + c] + p[14 * 3 + c]) / 2 - p[(K - 1) * 3 + c]) * 1e-3f;
+        const float m1 = ((p[1 * 3 + c] + p[4 * 3 + c]) / 2 - p[0 * 3 + c]) * 1e-3f;
+        const float g0 = sk * m0 * 1e-3f, g1 = sk * m1 * 1e-3f;
+        q[11 * 3 + c] += 0.5f * g0; q[14 * 3 + c] += 0.5f * g0; q[(K - 1) * 3 + c] -= g0;
+        q[1 * 3 + c] += 0.5f * g1; q[4 * 3 + c] += 0.5f * g1; q[0 * 3 + c] -= g1;
+      }
+      if (gt && gaux) {
+        const float* p2 = gt + ((size_t)b * Hy + best) * K * 3;
+        float* q2 = gaux + ((size_t)b * Hy + best) * K * 3;
+        const float s2 = g * w2 * 2.f / (float)(B * 4);
+        for (int c = 0; c < 2; ++c) {
+          const float m0 = (p2[11 * 3 + c] + p2[14 * 3 + c]) / 2 - p2[(K - 1) * 3 + c];
+          const float m1 = (p2[1 * 3 + c] + p2[4 * 3 + c]) / 2 - p2[0 * 3 + c];
+          q2[11 * 3 + c] += 0.5f * s2 * m0; q2[14 * 3 + c] += 0.5f * s2 * m0; q2[(K - 1) * 3 + c] -= s2 * m0;
+          q2[1 * 3 + c] += 0.5f * s2 * m1; q2[4 * 3 + c] += 0.5f * s2 * m1; q2[0 * 3 + c] -= s2 * m1;
+        }
+      }
+    } else {
+      const float sk = g * w0 * 2.f / (float)(B * 4);
+      for (int c = 0; c < 2; ++c) {
+        const float m0 = (p[11 * 3 + c] + p[14 * 3 + c]) / 2 - p[(K - 1) * 3 + c];
+        const float m1 = (p[1 * 3 + c] + p[4 * 3 + c]) / 2 - p[0 * 3 + c];
+        q[11 * 3 + c] += 0.5f * sk * m0; q[14 * 3 + c] += 0.5f * sk * m0; q[(K - 1) * 3 + c] -= sk * m0;
+        q[1 * 3 + c] += 0.5f * sk * m1; q[4 * 3 + c] += 0.5f * sk * m1; q[0 * 3 + c] -= sk * m1;
+      }
+    }
+  }
+}
+
+// LSGAN term (loss_func.py:54-76): logits [B][Hy] (Hy = 1 for the 2-D case); out[0] = mean_b min_h (x - t)^2 ;
+// argmin per sample is written to idx[b] for the backward.
+__global__ void lsgan_fwd_kernel(const float* __restrict__ logits, int B, int Hy, float target, float* __restrict__ out,
+                                 int* __restrict__ idx) {
+  __shared__ float sm[20];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float best = INFINITY; int bi = 0;
+    for (int h = 0; h < Hy; ++h) {
+      const float d = logits[b * Hy + h] - target, e = d * d;
+      if (e < best) { best = e; bi = h; }
+    }
+    idx[b] = bi;
+    acc += best;
+  }
+  acc = block_sum(acc, sm);
+  if (threadIdx.x == 0) out[0] = acc / (float)B;
+}
+
+__global__ void lsgan_bwd_kernel(const float* __restrict__ logits, int B, int Hy, float target,
+                                 const int* __restrict__ idx, const float* __restrict__ gscalar,
+                                 float* __restrict__ glogits) {
+  const float s = gscalar[0] * 2.f / (float)B;
+  for (int i = threadIdx.x; i < B * Hy; i += blockDim.x) {
+    const int b = i / Hy, h = i % Hy;
+    glogits[i] = (h == idx[b]) ? s * (logits[i] - target) : 0.f;
+  }
+}
+
 // ------------------------------------------------------------------ graph aggregate
 __global__ void graph_aggregate_kernel(const float* __restrict__ x, const float* __restrict__ adj, int B, int N, int C,
                                        float* __restrict__ y) {
@@ -455,6 +640,42 @@ extern "C" int xas_adam_step(float* p, const float* g, float* m, float* v, long 
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, as_stream(stream), reinterpret_cast<float4*>(p),
                      reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v),
                      n / 4, beta1, beta2, eps, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)));
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int xas_pose_loss_fwd(const float* pred, const float* gt, int B, int Hy, int K, int kind, float w0, float w1,
+                                 float w2, float* out, void* stream) {
+  XAS_REQUIRE(pred && out && B > 0 && Hy >= 1 && Hy <= 6 && K >= 1, "pose_loss: bad arguments");
+  XAS_REQUIRE(kind >= 0 && kind <= 2 && (kind != 0 || gt) && (kind == 0 || K >= 17), "pose_loss: bad kind / skeleton");
+  hipLaunchKernelGGL(pose_loss_fwd_kernel, dim3(1), dim3(kPoseThreads), 0, as_stream(stream), pred, gt, B, Hy, K, kind, w0,
+                     w1, w2, out);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int xas_pose_loss_bwd(const float* pred, const float* gt, int B, int Hy, int K, int kind, float w0, float w1,
+                                 float w2, const float* out, const float* grad_scalar, float* grad_pred, float* grad_aux,
+                                 void* stream) {
+  XAS_REQUIRE(pred && out && grad_scalar && grad_pred && B > 0 && Hy >= 1 && Hy <= 6, "pose_loss bwd: bad arguments");
+  hipLaunchKernelGGL(pose_loss_bwd_kernel, dim3(1), dim3(kPoseThreads), 0, as_stream(stream), pred, gt, B, Hy, K, kind, w0,
+                     w1, w2, out, grad_scalar, grad_pred, grad_aux);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int xas_lsgan_fwd(const float* logits, int B, int Hy, float target, float* out, int* idx, void* stream) {
+  XAS_REQUIRE(logits && out && idx && B > 0 && Hy >= 1, "lsgan: bad arguments");
+  hipLaunchKernelGGL(lsgan_fwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), logits, B, Hy, target, out, idx);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int xas_lsgan_bwd(const float* logits, int B, int Hy, float target, const int* idx, const float* grad_scalar,
+                             float* grad_logits, void* stream) {
+  XAS_REQUIRE(logits && idx && grad_scalar && grad_logits && B > 0 && Hy >= 1, "lsgan bwd: bad arguments");
+  hipLaunchKernelGGL(lsgan_bwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), logits, B, Hy, target, idx, grad_scalar,
+                     grad_logits);
   XAS_LAUNCH_CHECK();
   return 0;
 }

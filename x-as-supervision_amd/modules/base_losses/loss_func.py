@@ -1,7 +1,8 @@
 """Losses of the training step (reference: modules/base_losses/loss_func.py:4-76).
 
-The two mask losses (2 M pixels each, 8 per step) are fused HIP reductions; the joint-level losses act on
-[B,18,3] tensors and are composed from a handful of device ops.
+The two mask losses (2 M pixels each, 8 per step) are fused HIP reductions; the LSGAN terms and the
+min-over-hypotheses symmetry / supervision losses used by the model are single fused kernels too
+(`compute_symmetry_min`, `compute_supervision_min`); the per-function forms below keep the reference API.
 """
 import torch
 
@@ -46,15 +47,23 @@ def compute_supervision(keypoint, keypoint_gt, feature_shape=None, mode='mean'):
 
 
 def _lsgan(logits, target):
-    err = (logits - target) ** 2
-    if logits.dim() == 2:
-        return err.mean()
-    if logits.dim() == 3:
-        return err.min(dim=1)[0].mean()           # best hypothesis per sample
-    raise ValueError('Invalid dimension of logits')
+    if logits.dim() not in (2, 3):
+        raise ValueError('Invalid dimension of logits')
+    return ops_misc.lsgan_term(logits, target)    # fused: per-sample min over the hypothesis axis, batch mean
 
 
 def compute_disc_loss(pred_logits, gt_logits):
     if gt_logits is None:
         return _lsgan(pred_logits, 1.0)
     return 0.5 * _lsgan(gt_logits, 1.0) + 0.5 * _lsgan(pred_logits, 0.0)
+
+
+def compute_supervision_min(pred, gt):
+    """min over hypotheses h of compute_supervision(pred[:, h], gt): one fused kernel (model.py:158-162)."""
+    return ops_misc.supervision_min(pred, gt)
+
+
+def compute_symmetry_min(world, w_bone, w_kp, kps=None, w_kp2d=None):
+    """min over hypotheses of w_bone*bone_sym + w_kp*kp_sym [+ 100*w_kp2d*kp_sym_2d]: one fused kernel
+    (model.py:104-114)."""
+    return ops_misc.symmetry_min(world, w_bone, w_kp, kps if w_kp2d is not None else None, w_kp2d or 0.0)

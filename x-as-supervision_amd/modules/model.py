@@ -9,8 +9,8 @@ batch means; zero-weight losses are still computed and back-propagated.
 """
 import torch
 
-from modules.base_losses.loss_func import (compute_bone_sym_loss, compute_disc_loss, compute_kp_sym_loss,
-                                           compute_mask_reconstruction_loss, compute_supervision)
+from modules.base_losses.loss_func import (compute_disc_loss, compute_mask_reconstruction_loss,
+                                           compute_supervision_min, compute_symmetry_min)
 from modules.util import convert_patch_to_world, draw_lines_max, random_rotation_3D
 from xas_amd import ops_nn, streams
 
@@ -97,7 +97,7 @@ class Counter3DModel(torch.nn.Module):
         out['pose_2d_pred_{}_pseudo'.format(key)] = pred[[0], 0].detach().clone()
         out['pose_3d_pred_{}_pseudo'.format(key)] = _to_world(pred[:, 0].detach(), x, key, True)[[0]]
         out['pose_3d_gt_{}_pseudo'.format(key)] = _to_world(gt, x, key, True)[[0]]
-        v = torch.stack([compute_supervision(pred[:, h], gt) for h in range(pred.shape[1])]).min()
+        v = compute_supervision_min(pred, gt)
         streams.to_main(v)
         return v
 
@@ -131,13 +131,7 @@ class Counter3DModel(torch.nn.Module):
                 if cam == 'mono':
                     continue
                 key = 'cam_{}'.format(cam)
-                per_hypo = []
-                for h in range(world[key].shape[1]):
-                    v = compute_bone_sym_loss(world[key][:, h]) * w['bone'] + compute_kp_sym_loss(world[key][:, h]) * w['kp']
-                    if 'kp_2d' in w:
-                        v = v + compute_kp_sym_loss(kps[key][:, h, :, :2], is_3D=False) * 1e2 * w['kp_2d']
-                    per_hypo.append(v)
-                total = total + torch.stack(per_hypo).min()
+                total = total + compute_symmetry_min(world[key], w['bone'], w['kp'], kps[key], w.get('kp_2d'))
             losses['symmetry'] = total
 
         if 'smpl_gen_loss' in lc:

@@ -57,6 +57,10 @@ SIGNATURES = {
     'xas_loss_nblk': ('l', 'i'),
     'xas_mask_loss_fwd': ('pppliPpp'.replace('P', 'p'), 'i'),
     'xas_mask_loss_bwd': ('pppliPppp'.replace('P', 'p'), 'i'),
+    'xas_pose_loss_fwd': ('ppiiiifffpp', 'i'),
+    'xas_pose_loss_bwd': ('ppiiiifffppppp', 'i'),
+    'xas_lsgan_fwd': ('piifppp', 'i'),
+    'xas_lsgan_bwd': ('piifpppp', 'i'),
     'xas_graph_aggregate': ('ppiiipp', 'i'),
     'xas_gln_workspace_floats': ('lii', 'z'),
     'xas_gln_fwd': ('ppppliifpppp', 'i'),

@@ -106,3 +106,64 @@ def smpl_lbs(pose, betas, v_template, shapedirs, posedirs, j_regressor, weights,
          ptr(weights.contiguous()), ptr(parents), B, V, -1 if center_idx is None else int(center_idx), ptr(verts),
          ptr(joints), ptr(ws))
     return verts, joints
+
+
+class _PoseLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, aux, kind, w0, w1, w2):
+        pred = pred.contiguous()
+        B, Hy, K, _ = pred.shape
+        a = aux.contiguous() if aux is not None else None
+        out = torch.empty(2 + Hy, device=pred.device, dtype=torch.float32)
+        call('xas_pose_loss_fwd', ptr(pred), ptr(a), B, Hy, K, kind, float(w0), float(w1), float(w2), ptr(out))
+        ctx.save_for_backward(pred, a if a is not None else pred.new_empty(0), out)
+        ctx.cfg = (kind, float(w0), float(w1), float(w2), aux is not None, aux is not None and aux.requires_grad and kind == 1)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, a, out = ctx.saved_tensors
+        kind, w0, w1, w2, has_aux, aux_grad = ctx.cfg
+        B, Hy, K, _ = pred.shape
+        gp = torch.empty_like(pred)
+        ga = torch.empty_like(pred) if aux_grad else None
+        call('xas_pose_loss_bwd', ptr(pred), ptr(a) if has_aux else None, B, Hy, K, kind, w0, w1, w2, ptr(out),
+             ptr(g.contiguous().reshape(1)), ptr(gp), ptr(ga))
+        return gp, ga, None, None, None, None
+
+
+def supervision_min(pred, gt):
+    """min over hypotheses of mean((pred[:, h] - gt)^2)   (model.py:158-162 with loss_func.py:38-52)."""
+    return _PoseLoss.apply(pred, gt, 0, 1.0, 0.0, 0.0)
+
+
+def symmetry_min(world, w_bone, w_kp, kps=None, w_kp2d=0.0):
+    """min over hypotheses of w_bone*bone_sym + w_kp*kp_sym (+ 100*w_kp2d*kp_sym(kps[..., :2]))  (model.py:104-114)."""
+    return _PoseLoss.apply(world, kps, 1, w_bone, w_kp, 100.0 * w_kp2d)
+
+
+class _Lsgan(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        x = logits.contiguous()
+        B = x.shape[0]
+        Hy = x.numel() // B
+        out = torch.empty(1, device=x.device, dtype=torch.float32)
+        idx = torch.empty(B, device=x.device, dtype=torch.int32)
+        call('xas_lsgan_fwd', ptr(x), B, Hy, float(target), ptr(out), ptr(idx))
+        ctx.save_for_backward(x, idx)
+        ctx.cfg = (B, Hy, float(target))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, idx = ctx.saved_tensors
+        B, Hy, target = ctx.cfg
+        gx = torch.empty_like(x)
+        call('xas_lsgan_bwd', ptr(x), B, Hy, target, ptr(idx), ptr(g.contiguous().reshape(1)), ptr(gx))
+        return gx, None
+
+
+def lsgan_term(logits, target):
+    """mean_b min_h (logits[b, h] - target)^2; logits [B, Hy, 1] or [B, 1]   (loss_func.py:54-76)."""
+    return _Lsgan.apply(logits, target)
