@@ -163,35 +163,44 @@ def create_logger(opt):
     return log_dir, tb
 
 
-if __name__ == '__main__':
+CLI = (  # same flags as the reference entry (train.py:305-315) + --synthetic
+    ('--config', dict(required=True, help='path to config')),
+    ('--log_dir', dict(default='log', help='path to log into')),
+    ('--checkpoint', dict(default=None, help='path to checkpoint to restore')),
+    ('--batch_size', dict(default=None, type=int)),
+    ('--epoch', dict(default=None, type=int)),
+    ('--worker', dict(default=10, type=int)),
+    ('--extra_tag', dict(default='')),
+    ('--finetune', dict(default=False, action='store_true', help='finetune the model')),
+    ('--seed', dict(default=-1, type=int)),
+    ('--synthetic', dict(default=0, type=int, help='train on N synthetic batches per epoch')),
+)
+
+
+def main():
     parser = ArgumentParser()
-    parser.add_argument('--config', required=True, help='path to config')
-    parser.add_argument('--log_dir', default='log', help='path to log into')
-    parser.add_argument('--checkpoint', default=None, help='path to checkpoint to restore')
-    parser.add_argument('--batch_size', default=None, type=int)
-    parser.add_argument('--epoch', default=None, type=int)
-    parser.add_argument('--worker', default=10, type=int)
-    parser.add_argument('--extra_tag', default='')
-    parser.add_argument('--finetune', default=False, action='store_true', help='finetune the model')
-    parser.add_argument('--seed', default=-1, type=int)
-    parser.add_argument('--synthetic', default=0, type=int, help='train on N synthetic batches per epoch')
+    for flag, kw in CLI:
+        parser.add_argument(flag, **kw)
     opt = parser.parse_args()
     with open(opt.config) as f:
         config = yaml.load(f, Loader=yaml.FullLoader)
     config['model_params']['cam_id_list'] = config['dataset_params']['cam_id_list']
-    if opt.batch_size:
-        config['train_params']['batch_size'] = opt.batch_size
-    if opt.epoch:
-        config['train_params']['num_epochs'] = opt.epoch
+    for key, val in (('batch_size', opt.batch_size), ('num_epochs', opt.epoch)):
+        if val:
+            config['train_params'][key] = val
     ddp_setup()
     setup_seed(opt.seed)
+    rank_local, world = int(os.environ['LOCAL_RANK']), int(os.environ['WORLD_SIZE'])
     save_dir, tb_logger = create_logger(opt)
-    unsup_model, unsup_disc, opt_det, opt_disc = engine.prepare_model(config)
-    device = torch.device('cuda', int(os.environ['LOCAL_RANK']))
-    loader = prepare_data(config, int(os.environ['WORLD_SIZE']), opt.worker, opt.synthetic, device, opt.seed)
-    trainer = Trainer(config, unsup_model, unsup_disc, loader, opt_det, save_dir, checkpoint_path=opt.checkpoint,
-                      optimizer_discriminator=opt_disc, mode='finetune' if opt.finetune else 'train')
+    nets = engine.prepare_model(config)
+    loader = prepare_data(config, world, opt.worker, opt.synthetic, torch.device('cuda', rank_local), opt.seed)
+    trainer = Trainer(config, nets[0], nets[1], loader, nets[2], save_dir, checkpoint_path=opt.checkpoint,
+                      optimizer_discriminator=nets[3], mode='finetune' if opt.finetune else 'train')
     trainer.train(tb_logger)
     if tb_logger is not None:
         tb_logger.close()
     destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
