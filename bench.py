@@ -73,6 +73,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo to rehearse ranks on one GPU)')
     ap.add_argument('--tune', type=int, default=0, help='kernel tuning experiment flags (xas_set_tuning)')
+    ap.add_argument('--dedupe', action='store_true',
+                    help='NOT the headline: share the real-image detector forward between the discriminator and the '
+                         'generator update (engine.TrainStep(dedupe=True)); the JSON line is marked config.dedupe')
     ap.add_argument('--shape-report', default=None, help='write a per-conv-shape timing table to this file')
     args = ap.parse_args()
 
@@ -101,7 +104,7 @@ def main():
     model, disc, opt_det, opt_disc = engine.prepare_model(cfg)
     model.to(dev).train()
     disc.to(dev).train()
-    step = engine.TrainStep(cfg, model, disc, opt_det, opt_disc)
+    step = engine.TrainStep(cfg, model, disc, opt_det, opt_disc, dedupe=args.dedupe)
     cams = cfg['model_params']['cam_id_list']
     x = synthetic_batch(args.batch, cams, dev, seed=100 + rank)
 
@@ -165,7 +168,9 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': args.workload, 'batch_per_gpu': args.batch, 'cameras': len(cams),
                        'image': '256x256', 'images_per_sample': per_sample, 'parallelism': 'dp%d' % world,
-                       'samples_per_s': samples / dt, 'detector_forwards_per_s': samples * 3 * len(cams) / dt},
+                       'samples_per_s': samples / dt,
+                       'detector_forwards_per_s': samples * (2 if args.dedupe else 3) * len(cams) / dt,
+                       'dedupe': bool(args.dedupe)},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': timer.bytes_total / max(1, n_launch),

@@ -303,3 +303,40 @@ def test_full_train_step_vs_oracle():
         for k in olk:
             assert abs(float(lk[k].mean()) - float(olk[k])) < 1e-5 + tol * abs(float(olk[k])), (it, k, float(lk[k].mean()), float(olk[k]))
     assert torch.isfinite(opt_det.param_arena).all()
+
+
+def test_dedupe_step_is_bit_identical():
+    """TrainStep(dedupe=True) computes the real-image detector forward once instead of twice; parameters, Adam
+    moments, running statistics and batch counters after two steps must equal the default path's bit for bit.
+    The default path itself must be reproducible run to run (no floating-point atomics anywhere in the step)."""
+    from modules.discriminator import GCNDiscriminatorDecouple
+    from modules.model import Counter3DDisc, Counter3DModel
+    from xas_amd.engine import TrainStep
+    from xas_amd.optim import FusedAdam
+    cfg = gi.model_params('S2', cam_ids=(0, 1))
+    full = {'model_params': cfg, 'train_params': {'lr_kp_detector': 1e-4, 'lr_discriminator': 1e-4}}
+    xg = {k: T(v).cuda() for k, v in gi.synthetic_batch(2, [0, 1], seed=93).items()}
+    states = []
+    for dedupe in (False, False, True):
+        reg, phys, _, _ = _hip_models('S2', (0, 1))
+        disc = gi.seeded_fill_(GCNDiscriminatorDecouple(cfg['smpl_disc_params']), seed=9).cuda().train()
+        disc.header.p = 0.0
+        gen, dis = Counter3DModel(cfg, reg, None, None, phys), Counter3DDisc(cfg, disc, None, None)
+        opt_det = FusedAdam(list(reg.parameters()) + list(phys.parameters()), lr=1e-4, betas=(0.5, 0.999))
+        opt_disc = FusedAdam(disc.parameters(), lr=1e-4, betas=(0.5, 0.999))
+        step = TrainStep(full, gen, dis, opt_det, opt_disc, dedupe=dedupe)
+        losses = []
+        for _ in range(2):
+            ld, lk, tot, _ = step(xg)
+            losses.append((float(ld), float(tot)))
+        torch.cuda.synchronize()
+        bufs = {k: v.clone() for k, v in reg.state_dict().items() if 'running' in k or 'num_batches' in k}
+        states.append((opt_det.param_arena.clone(), opt_disc.param_arena.clone(), bufs, losses))
+    a = states[0]
+    for b in states[1:]:
+        assert a[3] == b[3]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert a[2].keys() == b[2].keys() and len(a[2]) > 50
+        for k in a[2]:
+            assert torch.equal(a[2][k], b[2][k]), k
+    assert int(a[2]['net.backbone.bn1.num_batches_tracked']) == 2 * (2 + 2 + 2)   # disc + real + pseudo passes, 2 cams

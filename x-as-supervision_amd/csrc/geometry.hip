@@ -183,54 +183,82 @@ __global__ void draw_lines_max_fwd_kernel(const float* __restrict__ kps, long sb
   }
 }
 
+// Backward of the max-over-lines mask.  Every pixel sends a gradient to the two end points of its winning line.
+// The per-block sums are formed in a FIXED order (per-line scan of the block's pixel records by one wave, butterfly
+// wave sum, then lines -> joints in line order), never with floating-point atomics, so the detector gradient is
+// reproducible run to run.
 __global__ void draw_lines_max_bwd_kernel(const float* __restrict__ kps, long sb, long sj, const int* parents,
                                           const int* children, int L, unsigned fine, float body_width, int S, int K,
                                           const float* __restrict__ gmask, float* __restrict__ partial) {
+  constexpr int kRec = kLineThreads * kPixPerThread;
   __shared__ LineSeg segs[kMaxLines];
-  __shared__ float acc[64 * 2];
+  __shared__ int rec_line[kRec];
+  __shared__ float rec_g[4][kRec];
+  __shared__ float line_sum[kMaxLines][4];
   const int b = blockIdx.y;
   load_lines(segs, kps, sb, sj, b, parents, children, L, fine, body_width);
-  for (int i = threadIdx.x; i < K * 2; i += blockDim.x) acc[i] = 0.f;
-  __syncthreads();
   const int pix0 = (blockIdx.x * kLineThreads + threadIdx.x) * kPixPerThread;
   const float fs = (float)(S - 1);
+#pragma unroll
   for (int q = 0; q < kPixPerThread; ++q) {
     const int pix = pix0 + q;
-    if (pix >= S * S) break;
-    const float go = gmask[(size_t)b * S * S + pix];
-    const float gx = 2.f * ((float)(pix % S) / fs) - 1.f, gy = 2.f * ((float)(pix / S) / fs) - 1.f;
-    float best = -INFINITY, bt = 0.f, t;
-    int bl = 0;
-    for (int l = 0; l < L; ++l) {
-      const float e = seg_exponent(segs[l], gx, gy, body_width, &t);
-      if (e > best) { best = e; bl = l; bt = t; }        // first maximum wins, as torch.max
-    }
-    const float ge = go * __expf(best);
-    if (ge == 0.f) continue;
-    const LineSeg s = segs[bl];
-    const float gd2 = -ge * s.scale / body_width;
+    const int e = q * kLineThreads + threadIdx.x;
+    int bl = -1;
     float gax = 0.f, gay = 0.f, gbx = 0.f, gby = 0.f;
-    if (bt <= 0.f) {
-      gax = -2.f * (gx - s.ax) * gd2; gay = -2.f * (gy - s.ay) * gd2;
-    } else if (bt >= 1.f) {
-      gbx = -2.f * (gx - s.bx) * gd2; gby = -2.f * (gy - s.by) * gd2;
-    } else {
-      const float rx = gx - (s.ax + bt * s.vx), ry = gy - (s.ay + bt * s.vy);
-      const float grx = 2.f * rx * gd2, gry = 2.f * ry * gd2;
-      const float gt = -(grx * s.vx + gry * s.vy);
-      const float gnum = gt / s.den, gden = -gt * bt / s.den;
-      float gvx = -bt * grx + (gx - s.ax) * gnum + 2.f * s.vx * gden;
-      float gvy = -bt * gry + (gy - s.ay) * gnum + 2.f * s.vy * gden;
-      gax = -grx - s.vx * gnum - gvx; gay = -gry - s.vy * gnum - gvy;
-      gbx = gvx; gby = gvy;
+    if (pix < S * S) {
+      const float go = gmask[(size_t)b * S * S + pix];
+      const float gx = 2.f * ((float)(pix % S) / fs) - 1.f, gy = 2.f * ((float)(pix / S) / fs) - 1.f;
+      float best = -INFINITY, bt = 0.f, t;
+      int win = 0;
+      for (int l = 0; l < L; ++l) {
+        const float ex = seg_exponent(segs[l], gx, gy, body_width, &t);
+        if (ex > best) { best = ex; win = l; bt = t; }     // first maximum wins, as torch.max
+      }
+      const float ge = go * __expf(best);
+      if (ge != 0.f) {
+        bl = win;
+        const LineSeg s = segs[win];
+        const float gd2 = -ge * s.scale / body_width;
+        if (bt <= 0.f) {
+          gax = -2.f * (gx - s.ax) * gd2; gay = -2.f * (gy - s.ay) * gd2;
+        } else if (bt >= 1.f) {
+          gbx = -2.f * (gx - s.bx) * gd2; gby = -2.f * (gy - s.by) * gd2;
+        } else {
+          const float rx = gx - (s.ax + bt * s.vx), ry = gy - (s.ay + bt * s.vy);
+          const float grx = 2.f * rx * gd2, gry = 2.f * ry * gd2;
+          const float gt = -(grx * s.vx + gry * s.vy);
+          const float gnum = gt / s.den, gden = -gt * bt / s.den;
+          const float gvx = -bt * grx + (gx - s.ax) * gnum + 2.f * s.vx * gden;
+          const float gvy = -bt * gry + (gy - s.ay) * gnum + 2.f * s.vy * gden;
+          gax = -grx - s.vx * gnum - gvx; gay = -gry - s.vy * gnum - gvy;
+          gbx = gvx; gby = gvy;
+        }
+      }
     }
-    const int ja = children[bl], jb = parents[bl];
-    atomicAdd(&acc[ja * 2], gax); atomicAdd(&acc[ja * 2 + 1], gay);
-    atomicAdd(&acc[jb * 2], gbx); atomicAdd(&acc[jb * 2 + 1], gby);
+    rec_line[e] = bl;
+    rec_g[0][e] = gax; rec_g[1][e] = gay; rec_g[2][e] = gbx; rec_g[3][e] = gby;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int l = wave; l < L; l += kLineThreads / 64) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int e = lane; e < kRec; e += 64) {
+      if (rec_line[e] == l) { s0 += rec_g[0][e]; s1 += rec_g[1][e]; s2 += rec_g[2][e]; s3 += rec_g[3][e]; }
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+    if (lane == 0) { line_sum[l][0] = s0; line_sum[l][1] = s1; line_sum[l][2] = s2; line_sum[l][3] = s3; }
   }
   __syncthreads();
   float* o = partial + ((size_t)b * gridDim.x + blockIdx.x) * K * 2;
-  for (int i = threadIdx.x; i < K * 2; i += blockDim.x) o[i] = acc[i];
+  for (int i = threadIdx.x; i < K * 2; i += blockDim.x) {
+    const int j = i >> 1, c = i & 1;
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) {
+      if (children[l] == j) s += line_sum[l][c];
+      if (parents[l] == j) s += line_sum[l][2 + c];
+    }
+    o[i] = s;
+  }
 }
 
 __global__ void lines_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int K2, float* __restrict__ out) {

@@ -102,9 +102,14 @@ class Counter3DModel(torch.nn.Module):
         return v
 
     def forward(self, x, smpl_discriminator):
+        return self.finish(x, smpl_discriminator, *self.camera_passes(x))
+
+    def camera_passes(self, x, pseudo=True):
+        """Detector / geometry / mask part of the step for every camera (everything that does not involve the
+        discriminator).  `pseudo=False` leaves the pseudo-image branch to a later `pseudo_passes` call."""
         cams = _cams(x, self.cam_id_list)
         lc = self.loss_config
-        losses, out = {}, {}
+        out = {}
         ops_nn.prepack(self.regressor)                    # packed weights ready before the camera streams fork
         if self.physique_network is not None:
             ops_nn.prepack(self.physique_network)
@@ -115,10 +120,22 @@ class Counter3DModel(torch.nn.Module):
             for i, cam in enumerate(cams):
                 with fk.run(i):
                     per_cam['cam_{}'.format(cam)] = self._camera_pass(x, cam, lc, out)
-            if 'smpl_pseudo_img_loss' in lc:
+            if pseudo and 'smpl_pseudo_img_loss' in lc:
                 for i, cam in enumerate(cams):
                     with fk.run(i):
                         per_cam['cam_{}'.format(cam)]['pseudo'] = self._pseudo_pass(x, cam, out)
+        return per_cam, out
+
+    def pseudo_passes(self, x, per_cam, out):
+        if 'smpl_pseudo_img_loss' in self.loss_config:
+            for cam in _cams(x, self.cam_id_list):
+                per_cam['cam_{}'.format(cam)]['pseudo'] = self._pseudo_pass(x, cam, out)
+
+    def finish(self, x, smpl_discriminator, per_cam, out):
+        """Losses from the per-camera results (model.py:98-190)."""
+        cams = _cams(x, self.cam_id_list)
+        lc = self.loss_config
+        losses = {}
         kps = {k: v['kps'] for k, v in per_cam.items()}
         world = {k: v['world'] for k, v in per_cam.items()}
         if 'mono' not in cams:
@@ -181,23 +198,31 @@ class Counter3DDisc(torch.nn.Module):
         self.DISC_SUP_DIMENSION = cfg['smpl_disc_params'].get('disc_sup_dim', 3)
         self.use_aug = cfg['smpl_disc_params'].get('use_aug', False)
 
-    def forward(self, x, regressor):
+    def forward(self, x, regressor, preds=None):
+        """`preds` (optional, {cam_key: kps [B,Hy,K,3]}): detector outputs already computed on the same images with
+        the same weights (engine.TrainStep(dedupe=True)); the detector is then not run again here."""
         total = 0
         out = {}
         d = self.DISC_SUP_DIMENSION
         cams = _cams(x, self.cam_id_list)
-        preds, reals, inputs = {}, {}, []
-        ops_nn.prepack(regressor)
+        reals, inputs = {}, []
+        have = preds is not None
+        preds = {k: v.detach() for k, v in preds.items()} if have else {}
+        if not have:
+            ops_nn.prepack(regressor)
         with streams.fork() as fk:
             for i, cam in enumerate(cams):
                 key = 'cam_{}'.format(cam)
+                reals[key] = x[key + '_pseudo_joints']
+                if have:
+                    continue
                 # The reference builds (and discards) an autograd graph here (model.py:231, output detached at
                 # :243); only the values and the train-mode BN running-statistic updates matter, so no graph is
                 # recorded.  Each camera's detector runs on its own stream.
                 with fk.run(i), torch.no_grad():
                     pred, _ = regressor(x[key + '_img'])
                     streams.to_main(pred)
-                preds[key], reals[key] = pred, x[key + '_pseudo_joints']
+                preds[key] = pred
         for cam in cams:
             key = 'cam_{}'.format(cam)
             inputs += [preds[key][:, h, :, :d] for h in range(preds[key].shape[1])] + [reals[key][..., :d]]

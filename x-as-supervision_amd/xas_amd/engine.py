@@ -67,7 +67,13 @@ def _load_smpl(mp, smpl_arrays):
 class TrainStep:
     """One optimisation step = train.py:160-190.  Holds the two reducers (DDP equivalents)."""
 
-    def __init__(self, config, unsup_model, unsup_disc, opt_det, opt_disc, num_buckets=4):
+    def __init__(self, config, unsup_model, unsup_disc, opt_det, opt_disc, num_buckets=4, dedupe=False):
+        # dedupe: the reference runs the detector on the real images twice per step with IDENTICAL weights (once
+        # detached for the discriminator update, model.py:231, once for the generator losses, model.py:64).  With
+        # dedupe=True that forward is computed once; the batch-norm running-statistic updates of the skipped pass
+        # are replayed, so parameters AND buffers after the step are bit-identical (tests/test_gpu_model.py).
+        # Off by default: the benchmark runs the reference's 12 detector forwards per sample.
+        self.dedupe = dedupe
         self.model, self.disc = unsup_model, unsup_disc
         self.opt_det, self.opt_disc = opt_det, opt_disc
         interval = config['model_params']['loss_config']['smpl_disc_loss']['update_interval']
@@ -94,8 +100,24 @@ class TrainStep:
     def __call__(self, x):
         out = {}
         loss_disc, loss_kp, total = None, {}, None
-        if self.opt_disc is not None and self.cur_step % self.disc_every == 0:
-            loss_disc, info = self.disc(x, self.model.regressor)
+        do_disc = self.opt_disc is not None and self.cur_step % self.disc_every == 0
+        do_gen = self.cur_step % self.gen_every == 0
+        shared = None
+        if self.dedupe and do_disc and do_gen:
+            ops_nn.bn_log['on'], ops_nn.bn_log['calls'] = True, []
+            shared = self.model.camera_passes(x, pseudo=False)          # real-image passes, with autograd graph
+            ops_nn.bn_log['on'] = False
+            det_bufs = {b.data_ptr() for n, b in self.model.regressor.named_buffers() if n.endswith('running_mean')}
+            ops_nn.replay_bn_updates(det_bufs)                           # the pass the discriminator step would do
+            for m in self.model.regressor.modules():
+                c = getattr(m, '_counters', None)
+                if c is not None:
+                    for _ in range(len(self.model.cam_id_list)):
+                        c.bump()
+        if do_disc:
+            preds = {k: v['kps'] for k, v in shared[0].items()} if shared is not None else None
+            loss_disc, info = self.disc(x, self.model.regressor, preds) if preds is not None else \
+                self.disc(x, self.model.regressor)
             out.update(info)
             loss_disc = loss_disc.mean()
             if self.red_disc:
@@ -106,8 +128,12 @@ class TrainStep:
                 self.red_disc.finish()
             self.opt_disc.step()
             self.opt_disc.zero_grad()
-        if self.cur_step % self.gen_every == 0:
-            loss_kp, info = self.model(x, self.disc.smpl_discriminator)
+        if do_gen:
+            if shared is not None:
+                self.model.pseudo_passes(x, *shared)
+                loss_kp, info = self.model.finish(x, self.disc.smpl_discriminator, *shared)
+            else:
+                loss_kp, info = self.model(x, self.disc.smpl_discriminator)
             out.update(info)
             total = sum(v.mean() for v in loss_kp.values())
             if self.red_det:

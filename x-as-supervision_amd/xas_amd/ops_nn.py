@@ -236,6 +236,20 @@ def linear(x, weight, bias):
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 
+# Optional log of the batch statistics of every training-mode batch-norm call (engine.TrainStep(dedupe=True)
+# replays the running-statistic updates of a detector forward it does not repeat).
+bn_log = {'on': False, 'calls': []}
+
+
+def replay_bn_updates(only=None):
+    """Apply the logged running-statistic updates once more, in the logged order (`only`: data_ptr set of the
+    running_mean buffers to replay; others are dropped)."""
+    for mean, var, rm, rv, momentum, count in bn_log['calls']:
+        if only is not None and rm.data_ptr() not in only:
+            continue
+        call('xas_bn_update_running', ptr(mean), ptr(var), ptr(rm), ptr(rv), float(momentum), int(count), mean.numel())
+    bn_log['calls'] = []
+
 
 def _sync_stats(mean, var, count, group):
     """SyncBatchNorm statistic exchange: ONE all_gather of [mean | var | count] per layer
@@ -285,6 +299,8 @@ class _BatchNorm(torch.autograd.Function):
                 else:
                     call('xas_bn_update_running', ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
                          float(momentum), int(count), c)
+            if bn_log['on'] and running_mean is not None:
+                bn_log['calls'].append((mean, var, running_mean, running_var, momentum, count))
         else:
             mean, var = running_mean, running_var
         res = to_cl(residual) if residual is not None else None
