@@ -184,3 +184,51 @@ def model_params(stage='S1', cam_ids=(0, 1, 2, 3)):
         'flip_pairs': [[1, 4], [2, 5], [3, 6], [14, 11], [15, 12], [16, 13]],
         'line_select_ids': list(LINE_SELECT), 'body_width': 3.0,
         'loss_config': lc, 'cam_id_list': list(cam_ids)}
+
+
+def multiview_scene(B, cam_ids, seed, K=18, S=256, rect=2000.0, hypo=3, noise=0.01):
+    """A geometrically CONSISTENT multi-camera scene for the evaluation path: world joints projected into every
+    camera (pin-hole, crop affine, depth px), plus noisy multi-hypothesis 'detections' with some left/right swaps.
+    Returns (x, kps): x = batch dict of numpy arrays (camera parameters + `_joints` in pixel units, `world`),
+    kps = {cam_key: [B,hypo,K,3]} in the detector's normalised output range."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    world = rng.normal(0.0, 350.0, (B, K, 3))
+    world[:, 0] = rng.normal(0.0, 50.0, (B, 3))
+    x, kps = {'world': world.astype(np.float32)}, {}
+    pairs = ((1, 4), (2, 5), (3, 6), (14, 11), (15, 12), (16, 13))
+    for cam in cam_ids:
+        key = 'cam_%s' % cam
+        ti, km, pv, rw, tw = (np.zeros((B, 2, 3)), np.zeros((B, 3, 3)), np.zeros((B, 3)), np.zeros((B, 3, 3)),
+                              np.zeros((B, 3)))
+        joints = np.zeros((B, K, 3))
+        for b in range(B):
+            R = random_rotation(rng)
+            t = np.array([rng.uniform(-300, 300), rng.uniform(-300, 300), rng.uniform(4500, 5500)])
+            camp = world[b] @ R.T + t
+            fx, fy, cx, cy = rng.uniform(1100, 1200), rng.uniform(1100, 1200), rng.uniform(480, 540), rng.uniform(480, 540)
+            u, v = camp[:, 0] / camp[:, 2] * fx + cx, camp[:, 1] / camp[:, 2] * fy + cy
+            s, th = rng.uniform(0.24, 0.32), rng.uniform(-0.2, 0.2)
+            A = s * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+            off = np.array([S / 2, S / 2]) + rng.uniform(-6, 6, 2) - A @ np.array([u[0], v[0]])
+            uv = np.stack([u, v], 1) @ A.T + off
+            joints[b, :, :2] = uv
+            joints[b, :, 2] = (camp[:, 2] - camp[0, 2]) / (rect / S)
+            ti[b, :, :2], ti[b, :, 2] = A, off
+            km[b] = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]])
+            pv[b], rw[b], tw[b] = camp[0], R, t
+        f32 = lambda a: a.astype(np.float32)
+        x[key + '_joints'], x[key + '_trans_image'], x[key + '_k_mat'] = f32(joints), f32(ti), f32(km)
+        x[key + '_pelvis'], x[key + '_rot_world'], x[key + '_trans_world'] = f32(pv), f32(rw), f32(tw)
+        g = joints.copy()
+        g[..., :2] = g[..., :2] / (S - 1) * 2 - 1
+        g[..., 2] = g[..., 2] / (S - 1)
+        det = np.repeat(g[:, None], hypo, 1) + rng.normal(0, noise, (B, hypo, K, 3))
+        for h in range(1, hypo):
+            det[:, h, :, 2] += rng.normal(0, 0.08, (B, K))              # wrong-depth hypotheses
+        for b in range(B):                                              # mirrored detections: some joints, some hypotheses
+            for h in range(hypo):
+                for a, c in pairs:
+                    if rng.random() < 0.3:
+                        det[b, h, [a, c]] = det[b, h, [c, a]]
+        kps[key] = f32(det)
+    return x, kps

@@ -348,7 +348,69 @@ def g_sparse():
     save('sparse', adj=adj, edge_index=ei, edge_attr=ea, edge_index18=ei18, edge_attr18=ea18)
 
 
+# ----------------------------------------------------------------- 10. evaluation path
+def _ref_eval_modules():
+    """eval_utils.py imports matplotlib (present) and train_util (needs cv2 / tensorboard, absent) only for its
+    plotting helpers: an inert `train_util` module object is registered so that switch_points / per_act_mse can be
+    imported and called as they are.  metrics.py and modules/util.py import untouched."""
+    if 'train_util' not in sys.modules:
+        tu = types.ModuleType('train_util')
+        tu.pose_vis = lambda *a, **k: None
+        sys.modules['train_util'] = tu
+    import eval_utils as ref_eu
+    import metrics as ref_metrics
+    return ref_eu, ref_metrics
+
+
+def g_evalpath():
+    """Replays the body of Eval.eval (eval.py:111-204) with the reference's own switch_points, per_act_mse,
+    triangulation, convert_patch_to_world and metrics on a consistent synthetic multi-view scene."""
+    ref_eu, ref_m = _ref_eval_modules()
+    for tag, cams, mode, hypo in (('hm36_best', [0, 1, 2, 3], 'best', 3), ('mpi_confident', [0, 2, 4, 7, 8], 'confident', 3),
+                                  ('single', [0, 1], 'best', 1)):
+        xn, kn = gi.multiview_scene(4, cams, seed=300 + len(cams) + hypo, hypo=hypo)
+        x = {k: T(v) for k, v in xn.items()}
+        for c in cams:
+            x['cam_%d_img' % c] = torch.zeros(1, 3, 256, 256)            # only .shape is read (util.py:178)
+        out, sel, trans = {}, {}, {}
+        for c in cams:
+            m = 'cam_%d' % c
+            kp = T(kn[m]).clone()
+            k2 = kp.clone()[..., :2]
+            gt = x[m + '_joints'].clone()
+            gt[..., :2] = gt[..., :2] / (256.0 - 1) * 2 - 1
+            gt[..., 2] = gt[..., 2] / (256.0 - 1)
+            for h in range(kp.shape[1]):
+                k2[:, h, ...], _ = ref_eu.switch_points(k2[:, h, ...], gt[..., :2])
+                kp[:, h, ...], trans[m] = ref_eu.switch_points(kp[:, h, ...], gt, switch_all=False)
+            if mode == 'best' and kp.shape[1] > 1:
+                bi = (kp - gt[:, None, ...]).pow(2).sum(dim=-1).argmin(dim=1)
+                kp = torch.gather(kp, 1, bi[:, None, :, None].expand(-1, -1, -1, 3)).squeeze(1)
+                b2 = (k2 - gt[:, None, ..., :2]).pow(2).sum(dim=-1).argmin(dim=1)
+                k2 = torch.gather(k2, 1, b2[:, None, :, None].expand(-1, -1, -1, 2)).squeeze(1)
+            else:
+                kp, k2 = kp[:, 0, ...], k2[:, 0, ...]
+            sel[m] = kp
+            out['sel3d_' + m], out['sel2d_' + m], out['swapped_' + m] = kp, k2, trans[m]
+            out['err2d_' + m] = ref_eu.per_act_mse(k2, gt[..., :2])
+        tv = sum(trans['cam_%d' % c].float() for c in cams)
+        out['ambiguity'] = torch.min(tv, len(cams) - tv).mean()
+        gtw = ref_util.convert_patch_to_world(x['cam_0_joints'], x, 'cam_0', is_norm=False)
+        out['world_gt'] = gtw
+        mask = np.ones(gtw.shape[:2], dtype=bool)
+        preds = {'tri': ref_util.triangulation(sel, x, cams)}
+        for c in cams:
+            preds['view_cam_%d' % c] = ref_util.convert_patch_to_world(sel['cam_%d' % c], x, 'cam_%d' % c, is_norm=True)
+        for name, p in preds.items():
+            out[name] = p
+            for metric, al in (('mpjpe', 'none'), ('n-mpjpe', 'scale'), ('p-mpjpe', 'procrustes')):
+                out['%s_%s' % (metric, name)] = np.mean(ref_m.keypoint_mpjpe(p, gtw, mask, alignment=al), axis=1)
+            out['pck_' + name] = ref_m.keypoint_3d_pck(p / 1000.0, gtw / 1000.0, mask).mean()
+            out['auc_' + name] = ref_m.keypoint_3d_auc(p / 1000.0, gtw / 1000.0, mask)
+        save('evalpath_' + tag, **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['head', 'lines', 'geometry', 'losses', 'physique', 'detector', 'smpl', 'model', 'sparse']
+    which = sys.argv[1:] or ['head', 'lines', 'geometry', 'losses', 'physique', 'detector', 'smpl', 'model', 'sparse', 'evalpath']
     for w in which:
         globals()['g_' + w]()

@@ -89,7 +89,10 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ As, const fl
   float4 a[C::MI], b[C::NI];
 #pragma unroll
   for (int kk = 0; kk < BK / 8; ++kk) {
-    if (!(tune & 4096) || kk == 0) {        // ablation bit12: LDS fragments read once per K-step only
+#ifdef XAS_CONV_DIAG
+    if (!(tune & 4096) || kk == 0)          // ablation bit12 (diagnostic build): LDS fragments read once per K-step
+#endif
+    {
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
         a[mi] = *reinterpret_cast<const float4*>(As + (wm * C::WM + mi * 32 + i) * LDK + kk * 8 + h * 4);
@@ -253,6 +256,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     }
   };
 
+  // In-kernel phase stamps exist only in the diagnostic build (-DXAS_CONV_DIAG, tools/stamp_conv.py): even an
+  // untaken `if (stamp)` splits the K-loop into basic blocks, and hipcc then shuffles the 64 accumulator
+  // registers between AGPRs and VGPRs on every K-step.
+#ifdef XAS_CONV_DIAG
   unsigned long long t_store = 0, t_bar = 0, t_load = 0, t_mfma = 0, t0 = 0, t1 = 0;
   const bool stamp = p.dbg != nullptr;
 #define XAS_STAMP(acc_var)                                                     \
@@ -262,6 +269,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     __builtin_amdgcn_sched_barrier(0);                                         \
     acc_var += t1 - t0; t0 = t1;                                               \
   }
+#else
+#define XAS_STAMP(acc_var)
+#endif
 #define XAS_KSTEP(KS, BUF, RA, RB, MASK)                                                          \
   {                                                                                               \
     store_step(BUF, RA, RB, MASK);                                                                \
@@ -275,17 +285,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   }
   if (nk > 0) load_step(0, ra4_0, rb4_0, okmask_0);
   if (nk > 1) load_step(1, ra4_1, rb4_1, okmask_1);
+#ifdef XAS_CONV_DIAG
   if (stamp) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory"); }
-  for (int ks = 0; ks < nk; ks += 2) {
+#endif
+  // Two K-steps per trip with NO condition between them (an `if (ks + 1 < nk)` in the body makes hipcc carry the
+  // accumulators through VGPR phis: 64 v_accvgpr_read + 64 v_accvgpr_write per trip); an odd last step is peeled.
+  int ks = 0;
+  for (; ks + 1 < nk; ks += 2) {
     XAS_KSTEP(ks, 0, ra4_0, rb4_0, okmask_0)
-    if (ks + 1 < nk) XAS_KSTEP(ks + 1, 1, ra4_1, rb4_1, okmask_1)
+    XAS_KSTEP(ks + 1, 1, ra4_1, rb4_1, okmask_1)
   }
+  if (ks < nk) XAS_KSTEP(ks, 0, ra4_0, rb4_0, okmask_0)
 #undef XAS_KSTEP
 #undef XAS_STAMP
+#ifdef XAS_CONV_DIAG
   if (stamp && lane == 0) {
     atomicAdd(p.dbg + 0, t_store); atomicAdd(p.dbg + 1, t_bar); atomicAdd(p.dbg + 2, t_load);
     atomicAdd(p.dbg + 3, t_mfma); atomicAdd(p.dbg + 4, (unsigned long long)nk);
   }
+#endif
 
   if (C::MI == 1 && C::NI == 1) {
 #pragma unroll
