@@ -69,6 +69,7 @@ int xas_head_softargmax_bwd(const float* logits, const float* stats, const int64
 #define XAS_GEO_NORM 1
 #define XAS_GEO_MONO 2
 #define XAS_GEO_PATCH 4
+#define XAS_GEO_IMAGE 8   /* forward only: stop after patch -> image (u px, v px, depth mm), util.py:61-83 */
 int xas_patch_to_world_fwd(const float* kps, const float* trans_image, const float* k_mat,
                            const float* pelvis, const float* rot_world, const float* trans_world,
                            int B, int Hy, int K, float image_size, float rect_width, int flags,
@@ -265,6 +266,47 @@ int xas_smpl_lbs_fwd(const float* pose /*[B][72]*/, const float* betas /*[B][10]
  * ---------------------------------------------------------------------------------- */
 int xas_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                   float beta2, float eps, int step, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Evaluation path: hypothesis selection, triangulation, pose metrics.
+ * One evaluation batch stays on the device; nothing here synchronises with the host.
+ * ---------------------------------------------------------------------------------- */
+
+/* Left/right switch + hypothesis selection + 2-D error for ONE camera, one launch.
+ * Replaces eval_utils.py:7-30 (switch_points), eval.py:128-148 (per-hypothesis loop, best / confident
+ * selection by argmin + gather) and eval_utils.py:32-43 (per_act_mse).
+ * kps [B][Hy][K][C] (C = 2 or 3), joints [B][K][C] ground truth in PIXEL units unless
+ * XAS_EVAL_GT_NORMALISED; perm [K] = index of the mirrored joint (identity where none).
+ * Outputs (each may be NULL): sel3d [B][K][C] (selection by the C-dim squared error),
+ * sel2d [B][K][2] (selection by the 2-D squared error), err2d [B], swapped [B][K] (0/1, flags of the LAST
+ * hypothesis - what eval.py:132 keeps).  K <= 64. */
+#define XAS_EVAL_CONFIDENT 1      /* take hypothesis 0 (eval.py:144-146) instead of the best one */
+#define XAS_EVAL_SWITCH_ALL 2     /* one switch decision per sample (switch_points(switch_all=True)) */
+#define XAS_EVAL_GT_NORMALISED 4  /* joints already in the detector's output range */
+int xas_eval_select(const float* kps, const float* joints, const int* perm, int B, int Hy, int K, int C,
+                    float image_size, int flags, float* sel3d, float* sel2d, float* err2d,
+                    unsigned char* swapped, void* stream);
+
+/* P [B][3][4] = k_mat [B][3][3] * [rot_world [B][3][3] | trans_world [B][3]].  modules/util.py:188. */
+int xas_projection_matrix(const float* k_mat, const float* rot_world, const float* trans_world, int B, float* P,
+                          void* stream);
+
+/* Weighted DLT triangulation, replaces modules/util.py:198-230 (batch_triangulate: torch.linalg.svd of
+ * [B][K][2V][4]).  points [B][V][K][3] = (u, v, weight) image coordinates, P [B][V][3][4];
+ * out [B][K][4] = (X/w, Y/w, Z/w, mean weight).  V >= 2. */
+int xas_triangulate_dlt(const float* points, const float* P, int B, int V, int K, float* out, void* stream);
+
+/* Pose metrics, replaces metrics.py:5-244 (numpy, per-sample SVD on the host).
+ * pred, gt [N][K][3]; both are divided by in_div on load (eval.py:52-53 passes mm / 1000 for PCK / AUC);
+ * mask [N][K] (0/1) or NULL = all visible.  Outputs (each may be NULL):
+ *   err [3][N][K]       per-joint error * mask under alignment none / scale / procrustes
+ *   aligned [2][N][K][3] the scale- and procrustes-aligned predictions
+ *   pck [N][K]          100 where err[pck_align] < pck_threshold, * mask
+ *   auc_hits [N][31]    visible joints with err[pck_align] < linspace(0, 0.15, 31)[t]
+ * 3 <= K <= 64. */
+int xas_pose_metrics(const float* pred, const float* gt, const unsigned char* mask, int N, int K, float in_div,
+                     int pck_align, float pck_threshold, float* err, float* aligned, float* pck, int* auc_hits,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -18,16 +18,17 @@ struct CamParams {
 };
 
 __device__ __forceinline__ CamParams load_cam(const float* ti, const float* km, const float* pv, const float* rw,
-                                              const float* tw, int b) {
+                                              const float* tw, int b, bool full = true) {
   CamParams c;
   const float* A = ti + b * 6;
   const float a00 = A[0], a01 = A[1], a10 = A[3], a11 = A[4];
   const float det = a00 * a11 - a01 * a10;
   c.i00 = a11 / det; c.i01 = -a01 / det; c.i10 = -a10 / det; c.i11 = a00 / det;
   c.t0 = A[2]; c.t1 = A[5];
+  c.pz = pv[b * 3 + 2];
+  if (!full) return c;                               // XAS_GEO_IMAGE: intrinsics / extrinsics are not needed (may be NULL)
   const float* Kc = km + b * 9;
   c.fx = Kc[0]; c.fy = Kc[4]; c.cx = Kc[2]; c.cy = Kc[5];
-  c.pz = pv[b * 3 + 2];
   const float* R = rw + b * 9;
   const float m00 = R[4] * R[8] - R[5] * R[7], m01 = R[2] * R[7] - R[1] * R[8], m02 = R[1] * R[5] - R[2] * R[4];
   const float m10 = R[5] * R[6] - R[3] * R[8], m11 = R[0] * R[8] - R[2] * R[6], m12 = R[2] * R[3] - R[0] * R[5];
@@ -46,7 +47,7 @@ __global__ void patch_to_world_fwd_kernel(const float* __restrict__ kps, const f
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * HK) return;
   const int b = i / HK;
-  const CamParams c = load_cam(ti, km, pv, rw, tw, b);
+  const CamParams c = load_cam(ti, km, pv, rw, tw, b, !(flags & XAS_GEO_IMAGE));
   float p0 = kps[i * 3], p1 = kps[i * 3 + 1], p2 = kps[i * 3 + 2];
   if (flags & XAS_GEO_PATCH) {
     if (flags & XAS_GEO_NORM) {
@@ -58,6 +59,10 @@ __global__ void patch_to_world_fwd_kernel(const float* __restrict__ kps, const f
     p0 = c.i00 * du + c.i01 * dv;
     p1 = c.i10 * du + c.i11 * dv;
     p2 = p2 * (1.0f / S * rect) + c.pz;
+  }
+  if (flags & XAS_GEO_IMAGE) {                       // patch -> image only (triangulation input, util.py:180-182)
+    world[i * 3] = p0; world[i * 3 + 1] = p1; world[i * 3 + 2] = p2;
+    return;
   }
   float o0, o1, o2;
   if (flags & XAS_GEO_MONO) {
@@ -278,7 +283,8 @@ extern "C" int xas_patch_to_world_fwd(const float* kps, const float* trans_image
                                       const float* pelvis, const float* rot_world, const float* trans_world, int B,
                                       int Hy, int K, float image_size, float rect_width, int flags, float* world,
                                       void* stream) {
-  XAS_REQUIRE(kps && world && trans_image && k_mat && pelvis && rot_world && trans_world, "patch_to_world: null buffer");
+  XAS_REQUIRE(kps && world && trans_image && pelvis, "patch_to_world: null buffer");
+  XAS_REQUIRE((flags & XAS_GEO_IMAGE) || (k_mat && rot_world && trans_world), "patch_to_world: null camera buffer");
   XAS_REQUIRE(B > 0 && Hy > 0 && K > 0, "patch_to_world: bad shape B=%d Hy=%d K=%d", B, Hy, K);
   const int n = B * Hy * K;
   hipLaunchKernelGGL(patch_to_world_fwd_kernel, dim3(cdiv(n, 128)), dim3(128), 0, as_stream(stream), kps, trans_image,
@@ -294,6 +300,7 @@ extern "C" int xas_patch_to_world_bwd(const float* kps, const float* grad_world,
   XAS_REQUIRE(kps && grad_world && grad_kps && trans_image && k_mat && pelvis && rot_world && trans_world,
               "patch_to_world bwd: null buffer");
   XAS_REQUIRE(B > 0 && Hy > 0 && K > 0, "patch_to_world bwd: bad shape");
+  XAS_REQUIRE(!(flags & XAS_GEO_IMAGE), "patch_to_world bwd: XAS_GEO_IMAGE is a forward-only (evaluation) mode");
   const int n = B * Hy * K;
   hipLaunchKernelGGL(patch_to_world_bwd_kernel, dim3(cdiv(n, 128)), dim3(128), 0, as_stream(stream), kps, grad_world,
                      trans_image, k_mat, pelvis, rot_world, trans_world, B, Hy * K, image_size, rect_width, flags,

@@ -2,13 +2,13 @@
 
 Built here: `draw_lines` (+ the fused `draw_lines_max` the model actually consumes),
 `convert_patch_to_world` (all hypotheses in one launch, closed-form 2x2 / 3x3 inverses),
-`make_coordinate_grid`, `smpl_to_h36m`.  The eval-only helpers (triangulation, world->patch) and the
-reference's dead code (rule_transformation, my_truncated_normal, project_smpl_to_patch_kps has no caller)
-are outside the training step and not rebuilt.
+`make_coordinate_grid`, `smpl_to_h36m`, and for the evaluation path `convert_patch_to_image`,
+`triangulation` / `batch_triangulate` (device DLT, no batched SVD).  The reference's dead code
+(rule_transformation, my_truncated_normal, project_smpl_to_patch_kps has no caller) is not rebuilt.
 """
 import torch
 
-from xas_amd import ops_head
+from xas_amd import ops_eval, ops_head
 
 
 def make_coordinate_grid(spatial_size, type):
@@ -44,6 +44,34 @@ def convert_patch_to_world(keypoints, params, mode, is_norm=True, RECT_WIDTH=200
         keypoints, params['{}_trans_image'.format(mode)], params['{}_k_mat'.format(mode)],
         params['{}_pelvis'.format(mode)], params['{}_rot_world'.format(mode)], params['{}_trans_world'.format(mode)],
         image_size=size, rect_width=RECT_WIDTH, is_norm=is_norm, mono=mono, patch=patch)
+
+
+def convert_patch_to_image(kps, trans, image_depth, image_height, image_width, depth_scale, pelvis, is_norm=True):
+    """Patch -> image (u px, v px, depth mm), util.py:61-83.  The kernel takes the square patch size and the
+    metric box width; `depth_scale` is RECT_WIDTH / image size at every call site (util.py:180-182)."""
+    if not (image_depth == image_height == image_width):
+        raise RuntimeError('convert_patch_to_image: the patch must be a cube (D == H == W)')
+    return ops_eval.patch_to_image(kps, trans, pelvis, image_size=image_width, rect_width=depth_scale * image_width,
+                                   is_norm=is_norm)
+
+
+def batch_triangulate(keypoints_, Pall):
+    """keypoints_ [B,V,K,3] = (u, v, weight), Pall [B,V,3,4] -> [B,K,4] (util.py:198-230)."""
+    return ops_eval.triangulate_dlt(keypoints_, Pall)
+
+
+def triangulation(keypoints, params, cam_id_list, is_norm=True, RECT_WIDTH=2000):
+    """{cam_key: [B,K,3]} patch predictions of all cameras -> world joints [B,K,3] (util.py:171-196)."""
+    pts, pm = [], []
+    for cam_id in cam_id_list:
+        mode = 'cam_{}'.format(cam_id)
+        size = params['{}_img'.format(mode)].shape[-1]
+        pts.append(ops_eval.patch_to_image(keypoints[mode], params['{}_trans_image'.format(mode)],
+                                           params['{}_pelvis'.format(mode)], image_size=size, rect_width=RECT_WIDTH,
+                                           is_norm=is_norm))
+        pm.append(ops_eval.projection_matrix(params['{}_k_mat'.format(mode)], params['{}_rot_world'.format(mode)],
+                                             params['{}_trans_world'.format(mode)]))
+    return batch_triangulate(torch.stack(pts, dim=1), torch.stack(pm, dim=1))[..., :3]
 
 
 def smpl_to_h36m(verts, h36m_regressor):

@@ -67,6 +67,10 @@ SIGNATURES = {
     'xas_gln_bwd': ('pppppliifppppp', 'i'),
     'xas_smpl_lbs_fwd': ('ppppppppiiipppp', 'i'),
     'xas_adam_step': ('pppplffffip', 'i'),
+    'xas_eval_select': ('pppiiiifippppp', 'i'),
+    'xas_projection_matrix': ('pppipp', 'i'),
+    'xas_triangulate_dlt': ('ppiiipp', 'i'),
+    'xas_pose_metrics': ('pppiififppppp', 'i'),
 }
 
 

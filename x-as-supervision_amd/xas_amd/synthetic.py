@@ -86,3 +86,37 @@ def model_config(name='HM36_Multi_SurS1'):
           'lr_kp_detector': 1.0e-4 if s2 else 2.0e-4, 'lr_discriminator': 1.0e-4 if s2 else 2.0e-4,
           'checkpoint_freq': 2 if s2 else 20, 'patch_width': 256, 'patch_height': 256}
     return {'dataset_params': {'cam_id_list': cams}, 'model_params': mp, 'train_params': tp}
+
+
+def synthetic_eval_batch(B, cam_ids, device, seed=0, S=256, K=18, rect=2000.0):
+    """Evaluation batch with a geometrically CONSISTENT scene: one set of world joints seen by every camera
+    (pin-hole projection, crop affine, depth in patch pixels), so that triangulation and the world-space metrics
+    of eval.py:169-202 are meaningful.  Same keys as the dataloader contract plus `act` (eval.py:40-41)."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    r = lambda *s: torch.rand(*s, generator=gen, device=device)
+    world = 350.0 * torch.randn(B, K, 3, generator=gen, device=device)
+    world[:, 0] = 50.0 * torch.randn(B, 3, generator=gen, device=device)
+    x = {'act': ['act_%02d_subact_01_ca_01' % (2 + (seed + i) % 15) for i in range(B)]}
+    for cam in cam_ids:
+        key = 'cam_%s' % cam
+        R = _rotations(B, gen, device)
+        t = torch.stack([600 * r(B) - 300, 600 * r(B) - 300, 4500 + 1000 * r(B)], 1)
+        camp = torch.einsum('bij,bkj->bki', R, world) + t[:, None]
+        fx, fy, cx, cy = 1100 + 100 * r(B), 1100 + 100 * r(B), 480 + 60 * r(B), 480 + 60 * r(B)
+        uv = torch.stack([camp[..., 0] / camp[..., 2] * fx[:, None] + cx[:, None],
+                          camp[..., 1] / camp[..., 2] * fy[:, None] + cy[:, None]], -1)
+        scale, th = 0.24 + 0.08 * r(B), 0.4 * r(B) - 0.2
+        A = torch.stack([scale * torch.cos(th), -scale * torch.sin(th), scale * torch.sin(th), scale * torch.cos(th)], 1).view(B, 2, 2)
+        off = S / 2 + 12 * r(B, 2) - 6 - torch.einsum('bij,bj->bi', A, uv[:, 0])
+        ti = torch.cat([A, off[:, :, None]], dim=2)
+        joints = torch.cat([torch.einsum('bij,bkj->bki', A, uv) + off[:, None],
+                            ((camp[..., 2] - camp[:, :1, 2]) / (rect / S))[..., None]], dim=-1)
+        km = torch.zeros(B, 3, 3, device=device)
+        km[:, 0, 0], km[:, 1, 1], km[:, 2, 2], km[:, 0, 2], km[:, 1, 2] = fx, fy, 1.0, cx, cy
+        mask = _blob(B, S, gen, device)
+        x[key + '_mask'] = mask
+        x[key + '_img'] = r(B, 3, S, S) * mask
+        x[key + '_joints'], x[key + '_trans_image'], x[key + '_k_mat'] = joints, ti, km
+        x[key + '_pelvis'], x[key + '_rot_world'], x[key + '_trans_world'] = camp[:, 0].clone(), R, t
+    x['world'] = world
+    return x
