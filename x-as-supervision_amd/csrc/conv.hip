@@ -53,9 +53,10 @@ struct IgemmParams {
   int R, S, stride, pad;
   FastDiv div_hw, div_w;   // row -> (n, a, b) decode over the row grid
   int Hrow, Wrow;          // row grid (fwd: Ho x Wo; dgrad: per-phase grid, set in kernel)
-  int tune;                // experiment flags (xas_set_tuning): bit1 setprio around MFMAs, bit2 plain tile order
+  int tune;                // experiment flags (xas_set_tuning): bit2 plain tile order, bit5 plain K-loop, bit6 global-load kernel
   int nMt, nNt, mt_per_xcd;   // tile counts and M-tiles per XCD for the XCD-aware block order
   unsigned long long* dbg;    // diagnostic builds only: per-phase cycle sums (xas_set_debug_buffer)
+  long src_elems, wgt_elems;  // sizes of src / wgt (buffer-load kernel: range of the buffer descriptors)
 };
 
 static unsigned long long* g_dbg = nullptr;
@@ -129,7 +130,113 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ As, const fl
 // ------------------------------------------------------------------------------------
 // fwd (MODE 0) and dgrad (MODE 1)
 // ------------------------------------------------------------------------------------
-template <int BM, int BN, int MODE, int NBUF = 2>
+// One K-slice (8 k) of the block tile: fragment loads and the MFMAs that consume them, separately callable so the
+// pipelined K-loop can order them by hand.
+template <int BM, int BN>
+__device__ __forceinline__ void frag_load(const float* __restrict__ As, const float* __restrict__ Bs, int kk, int wm, int wn,
+                                          int lane, float4 (&a)[TileCfg<BM, BN>::MI], float4 (&b)[TileCfg<BM, BN>::NI]) {
+  using C = TileCfg<BM, BN>;
+  const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int mi = 0; mi < C::MI; ++mi)
+    a[mi] = *reinterpret_cast<const float4*>(As + (wm * C::WM + mi * 32 + i) * LDK + kk * 8 + h * 4);
+#pragma unroll
+  for (int ni = 0; ni < C::NI; ++ni)
+    b[ni] = *reinterpret_cast<const float4*>(Bs + (wn * C::WN + ni * 32 + i) * LDK + kk * 8 + h * 4);
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void mfma_slice(const float4 (&a)[TileCfg<BM, BN>::MI], const float4 (&b)[TileCfg<BM, BN>::NI],
+                                           f32x16 (&acc)[TileCfg<BM, BN>::MI][TileCfg<BM, BN>::NI], f32x16& acc2) {
+  using C = TileCfg<BM, BN>;
+  if (C::MI == 1 && C::NI == 1) {
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0].x, a[0].x, acc[0][0], 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0].y, a[0].y, acc2, 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0].z, a[0].z, acc[0][0], 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0].w, a[0].w, acc2, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni].x, a[mi].x, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni].y, a[mi].y, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni].z, a[mi].z, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni].w, a[mi].w, acc[mi][ni], 0, 0, 0);
+  }
+}
+
+// Scheduling hint for one K-slice of the pipelined loop: NMF MFMAs with NOTH memory operations of kind MASK
+// (0x100 LDS read, 0x200 LDS write, 0x020 global read) spread evenly between them.
+template <int NMF, int NOTH, int MASK>
+__device__ __forceinline__ void sched_mix() {
+  constexpr int G = NOTH > 0 ? (NMF / NOTH > 0 ? NMF / NOTH : 1) : NMF;
+  constexpr int USED = NOTH > 0 ? (G * NOTH < NMF ? G * NOTH : NMF) : 0;
+#pragma unroll
+  for (int i = 0; i < NOTH; ++i) {
+    if (i * G < NMF) __builtin_amdgcn_sched_group_barrier(0x008, G, 0);
+    __builtin_amdgcn_sched_group_barrier(MASK, 1, 0);
+  }
+  if (NMF - USED > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMF - USED, 0);
+}
+
+// Epilogue shared by the igemm kernels: accumulators -> global memory (+ bias), float4 per four output channels.
+template <int BM, int BN, int MODE>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&acc)[TileCfg<BM, BN>::MI][TileCfg<BM, BN>::NI],
+                                               f32x16& acc2, int m0, int n0, int wm, int wn, int lane, int Mrows, int HW,
+                                               int Wrow, int ph, int pw) {
+  using C = TileCfg<BM, BN>;
+  if (C::MI == 1 && C::NI == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
+  }
+  // ---- epilogue.  Accumulator layout (operands swapped): column = lane & 31 = pixel row m of the tile,
+  // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) = output channel -> registers 4g..4g+3 are four
+  // consecutive channels of one pixel: one 16-byte store each, row address computed once per lane.
+  const int pix_l = lane & 31, csub = 4 * (lane >> 5);
+  const bool vec_ok = (p.Cd & 3) == 0;
+#pragma unroll
+  for (int mi = 0; mi < C::MI; ++mi) {
+    const int m = m0 + wm * C::WM + mi * 32 + pix_l;
+    if (m >= Mrows) continue;
+    size_t orow;
+    if (MODE == 0) orow = (size_t)m;
+    else {
+      const int n = m / HW; const int rem = m - n * HW; const int a = rem / Wrow, b = rem - a * Wrow;
+      orow = ((size_t)n * p.Hd + (ph + p.stride * a)) * p.Wd + (pw + p.stride * b);
+    }
+    float* orow_p = p.out + orow * p.Cd;
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * C::WN + ni * 32 + 8 * g + csub;
+        float4 v = make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
+        if (vec_ok && n + 3 < p.Cd) {
+          if (MODE == 0 && p.bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+          }
+          *reinterpret_cast<float4*>(orow_p + n) = v;
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.Cd) orow_p[n + e] = vv[e] + ((MODE == 0 && p.bias) ? p.bias[n + e] : 0.f);
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int MODE, int NBUF = 2, bool PIPE = false>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   using C = TileCfg<BM, BN>;
   constexpr int APASS = BM / 32, BPASS = BN / 32;
@@ -272,17 +379,72 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #else
 #define XAS_STAMP(acc_var)
 #endif
+  // diagnostic build only: ablations of the K-loop after its first two steps (results are then wrong by design):
+  // tune bit3 = no further global loads, bit4 = no further LDS stores / barriers
+#ifdef XAS_CONV_DIAG
+#define XAS_ABL(bit, KS) ((p.tune & (bit)) && (KS) >= 2)
+#else
+#define XAS_ABL(bit, KS) false
+#endif
 #define XAS_KSTEP(KS, BUF, RA, RB, MASK)                                                          \
   {                                                                                               \
-    store_step(BUF, RA, RB, MASK);                                                                \
+    if (!XAS_ABL(16, KS)) store_step(BUF, RA, RB, MASK);                                          \
     XAS_STAMP(t_store)                                                                            \
-    __syncthreads();                                                                              \
+    if (!XAS_ABL(16, KS)) __syncthreads();                                                        \
     XAS_STAMP(t_bar)                                                                              \
-    if ((KS) + 2 < nk) load_step((KS) + 2, RA, RB, MASK);                                         \
+    if ((KS) + 2 < nk && !XAS_ABL(8, KS)) load_step((KS) + 2, RA, RB, MASK);                      \
     XAS_STAMP(t_load)                                                                             \
     mfma_tile<BM, BN>(As + (BUF) * BM * LDK, Bs + (BUF) * BN * LDK, acc, acc2, wm, wn, lane, p.tune); \
     XAS_STAMP(t_mfma)                                                                             \
   }
+  if constexpr (PIPE) {
+    // Pipelined K-loop.  The LDS stores of step ks+1 and the global loads of step ks+3 are issued INSIDE the MFMA
+    // sequence of step ks (the other LDS buffer is free as soon as every wave has passed this step's barrier), so a
+    // wave's only exposed work per K-step is the barrier and the first fragment read.  Loads past the last step are
+    // clamped to it (valid addresses, results never consumed) to keep the loop body free of branches.
+    constexpr int NMF = C::MI * C::NI * 4;                 // MFMAs per K-slice
+    constexpr int NRD = C::MI + C::NI;                     // fragment reads per K-slice
+    constexpr int NST = APASS + BPASS;                     // LDS stores == global loads per K-step
+    const int last = nk - 1;
+    auto pstep = [&](int buf, float4 (&ra4)[APASS], float4 (&rb4)[BPASS], unsigned& okmask, int ks_load) {
+      const float* a_s = As + buf * BM * LDK;
+      const float* b_s = Bs + buf * BN * LDK;
+      float4 fa0[C::MI], fb0[C::NI], fa1[C::MI], fb1[C::NI];
+      __syncthreads();
+      frag_load<BM, BN>(a_s, b_s, 0, wm, wn, lane, fa0, fb0);
+      frag_load<BM, BN>(a_s, b_s, 1, wm, wn, lane, fa1, fb1);
+      mfma_slice<BM, BN>(fa0, fb0, acc, acc2);
+      store_step(buf ^ 1, ra4, rb4, okmask);
+      frag_load<BM, BN>(a_s, b_s, 2, wm, wn, lane, fa0, fb0);
+      mfma_slice<BM, BN>(fa1, fb1, acc, acc2);
+      load_step(ks_load < last ? ks_load : last, ra4, rb4, okmask);
+      frag_load<BM, BN>(a_s, b_s, 3, wm, wn, lane, fa1, fb1);
+      mfma_slice<BM, BN>(fa0, fb0, acc, acc2);
+      mfma_slice<BM, BN>(fa1, fb1, acc, acc2);
+      // wanted issue order
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NRD, 0);            // slices 0 and 1
+      sched_mix<NMF, NST, 0x200>();                                       // slice 0 + LDS stores of the next step
+      sched_mix<NMF, NRD, 0x100>();                                       // slice 1 + fragments of slice 2
+      sched_mix<NMF, NST, 0x020>();                                       // slice 2 + global loads, then fragments of 3
+      __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);                // slice 3
+    };
+    if (nk > 0) {
+      load_step(0, ra4_0, rb4_0, okmask_0);
+      load_step(1 < last ? 1 : last, ra4_1, rb4_1, okmask_1);
+      store_step(0, ra4_0, rb4_0, okmask_0);
+      load_step(2 < last ? 2 : last, ra4_0, rb4_0, okmask_0);
+      int ks = 0;
+      for (; ks + 1 < nk; ks += 2) {
+        pstep(0, ra4_1, rb4_1, okmask_1, ks + 3);
+        pstep(1, ra4_0, rb4_0, okmask_0, ks + 4);
+      }
+      if (ks < nk) {
+        __syncthreads();
+        mfma_tile<BM, BN>(As, Bs, acc, acc2, wm, wn, lane, 0);
+      }
+    }
+  } else {
   if (nk > 0) load_step(0, ra4_0, rb4_0, okmask_0);
   if (nk > 1) load_step(1, ra4_1, rb4_1, okmask_1);
 #ifdef XAS_CONV_DIAG
@@ -296,7 +458,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     XAS_KSTEP(ks + 1, 1, ra4_1, rb4_1, okmask_1)
   }
   if (ks < nk) XAS_KSTEP(ks, 0, ra4_0, rb4_0, okmask_0)
+  }   // !PIPE
 #undef XAS_KSTEP
+#undef XAS_ABL
 #undef XAS_STAMP
 #ifdef XAS_CONV_DIAG
   if (stamp && lane == 0) {
@@ -305,46 +469,221 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   }
 #endif
 
-  if (C::MI == 1 && C::NI == 1) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
+  igemm_epilogue<BM, BN, MODE>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw);
+}
+
+// ------------------------------------------------------------------------------------
+// fwd / dgrad with BUFFER loads (the shipped path; igemm_kernel above stays as the fallback for tensors of 2 GiB
+// and more, whose byte offsets do not fit the scheme).
+//
+// In-kernel stamps (tools/stamp_conv.py) showed where the K-loop of igemm_kernel loses its time: not in the MFMAs
+// and not in memory latency, but in ISSUING the ~115 vector-ALU instructions per K-step that form 64-bit addresses,
+// clamp them and mask the staged registers - a wave that competes with the MFMA stream of the other wave on its
+// SIMD gets about one VALU issue slot per MFMA (64 cycles).  Here the address of every load is
+//     buffer base (SGPRs)  +  per-lane byte offset, FIXED for the whole tile (1 VGPR per staged row)
+//                          +  scalar offset of the (tap, channel chunk) of the K-step (SGPR, scalar ALU only)
+// and padding / ragged edges are handled by the buffer unit itself: a lane whose tap falls outside the image gets
+// the out-of-range offset 0x80000000 and the hardware returns zeros, so nothing is masked on the way to LDS.
+// Per K-step a wave issues 3 VALU per staged activation row (tap-validity bit -> offset select) and none for the
+// weights, against ~115 before.
+// ------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOB = 0x80000000u;
+
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+template <int BM, int BN, int MODE, bool PIPE>
+__global__ __launch_bounds__(256) void igemm_buf_kernel(IgemmParams p) {
+  using C = TileCfg<BM, BN>;
+  constexpr int APASS = BM / 32, BPASS = BN / 32;
+  extern __shared__ __align__(16) float lds[];
+  float* As = lds;                       // [2][BM][LDK]
+  float* Bs = lds + 2 * BM * LDK;        // [2][BN][LDK]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+  const int kq = tid & 7, lrow = tid >> 3;
+
+  int Hrow = p.Hrow, Wrow = p.Wrow;
+  int ph = 0, pw = 0, base_r = 0, base_s = 0, nr = p.R, ns = p.S, off_h = -p.pad, off_w = -p.pad, rstep = 1;
+  int sa = p.stride;
+  if (MODE == 1) {
+    const int st = p.stride;
+    ph = blockIdx.z / st; pw = blockIdx.z % st;
+    Hrow = (p.Hd - ph + st - 1) / st; Wrow = (p.Wd - pw + st - 1) / st;
+    base_r = (ph + p.pad) % st; base_s = (pw + p.pad) % st;
+    nr = base_r < p.R ? (p.R - base_r + st - 1) / st : 0;
+    ns = base_s < p.S ? (p.S - base_s + st - 1) / st : 0;
+    off_h = (ph + p.pad - base_r) / st; off_w = (pw + p.pad - base_s) / st;
+    rstep = st; sa = 1;
   }
-  // ---- epilogue.  Accumulator layout (operands swapped): column = lane & 31 = pixel row m of the tile,
-  // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) = output channel -> registers 4g..4g+3 are four
-  // consecutive channels of one pixel: one 16-byte store each, row address computed once per lane.
-  const int pix_l = lane & 31, csub = 4 * (lane >> 5);
-  const bool vec_ok = (p.Cd & 3) == 0;
+  const int Mrows = p.N * Hrow * Wrow;
+  int mt, nt;
+  if (p.tune & 4) { mt = blockIdx.x % p.nMt; nt = blockIdx.x / p.nMt; }
+  else {                                             // XCD-aware tile order, as igemm_kernel
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    mt = xcd * p.mt_per_xcd + q / p.nNt;
+    nt = q - (q / p.nNt) * p.nNt;
+    if (mt >= p.nMt) return;
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+  if (m0 >= Mrows) return;
+  const int HW = Hrow * Wrow;
+  const int cchunks = p.Cs / BK;
+  const int nk = nr * ns * cchunks;
+
+  // Offsets.  true element offset of (row j, tap, channel) = rbase[j] + delta(tap) + c, where
+  //   fwd  : delta = (jr*Ws + js)*Cs >= 0,           rbase >= -(pad*Ws + pad)*Cs
+  //   dgrad: delta = -(jr*Ws + js)*Cs <= 0,          rbase >= 0
+  // The buffer base is moved down by `bias` elements so that the per-lane part (rbase + min delta + bias) and the
+  // scalar part (delta - min delta + chunk) are both non-negative 32-bit byte offsets.
+  const long dmin = MODE == 0 ? 0l : -((long)(nr - 1) * p.Ws + (ns - 1)) * p.Cs;
+  const long rmin = MODE == 0 ? -((long)p.pad * p.Ws + p.pad) * p.Cs : 0l;
+  const long bias = -(rmin + dmin);
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src) - bias, 0, (int)((bias + p.src_elems) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, (int)(p.wgt_elems * 4), 0x00020000);
+
+  unsigned voffA[APASS], maskA[APASS], voffB[BPASS];
 #pragma unroll
-  for (int mi = 0; mi < C::MI; ++mi) {
-    const int m = m0 + wm * C::WM + mi * 32 + pix_l;
-    if (m >= Mrows) continue;
-    size_t orow;
-    if (MODE == 0) orow = (size_t)m;
-    else {
-      const int n = m / HW; const int rem = m - n * HW; const int a = rem / Wrow, b = rem - a * Wrow;
-      orow = ((size_t)n * p.Hd + (ph + p.stride * a)) * p.Wd + (pw + p.stride * b);
+  for (int j = 0; j < APASS; ++j) {
+    const int m = m0 + lrow + 32 * j;
+    voffA[j] = kOOB; maskA[j] = 0u;
+    if (m < Mrows) {
+      int n, a, b;
+      if (MODE == 0) { n = p.div_hw.div(m); const int rem = m - n * HW; a = p.div_w.div(rem); b = rem - a * Wrow; }
+      else { n = m / HW; const int rem = m - n * HW; a = rem / Wrow; b = rem - a * Wrow; }
+      const int ra = a * sa + off_h, rb = b * sa + off_w;
+      const long rbase = (((long)n * p.Hs + ra) * p.Ws + rb) * p.Cs;
+      voffA[j] = (unsigned)((rbase + dmin + bias + kq * 4) * 4);
+      unsigned colmask = 0u, msk = 0u;                 // bit (jr*ns + js) = tap inside the image
+      for (int js = 0; js < ns; ++js) {
+        const int ws = rb + (MODE == 0 ? js : -js);
+        colmask |= ((unsigned)ws < (unsigned)p.Ws ? 1u : 0u) << js;
+      }
+      for (int jr = 0; jr < nr; ++jr) {
+        const int hs = ra + (MODE == 0 ? jr : -jr);
+        if ((unsigned)hs < (unsigned)p.Hs) msk |= colmask << (jr * ns);
+      }
+      maskA[j] = msk;
     }
-    float* orow_p = p.out + orow * p.Cd;
+  }
+  const unsigned wrow_bytes = (unsigned)(p.R * p.S * p.Cs) * 4u;
 #pragma unroll
-    for (int ni = 0; ni < C::NI; ++ni) {
+  for (int j = 0; j < BPASS; ++j) {
+    const int n = n0 + lrow + 32 * j;
+    voffB[j] = n < p.Cd ? (unsigned)n * wrow_bytes + (unsigned)kq * 16u : kOOB;
+  }
+
+  f32x16 acc[C::MI][C::NI];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * C::WN + ni * 32 + 8 * g + csub;
-        float4 v = make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
-        if (vec_ok && n + 3 < p.Cd) {
-          if (MODE == 0 && p.bias) {
-            const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-          }
-          *reinterpret_cast<float4*>(orow_p + n) = v;
-        } else {
-          const float vv[4] = {v.x, v.y, v.z, v.w};
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.Cd) orow_p[n + e] = vv[e] + ((MODE == 0 && p.bias) ? p.bias[n + e] : 0.f);
-        }
+  for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+  f32x16 acc2;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+
+  // Load stream: K-steps are visited in order; (chunk, js, jr) advance with scalar ALU only and stop at the last
+  // step (further calls re-load it: valid addresses, values never consumed).
+  int ld_chunk = 0, ld_js = 0, ld_jr = 0, ld_left = nk;
+  float4 ra4_0[APASS], rb4_0[BPASS], ra4_1[APASS], rb4_1[BPASS];
+  auto load_next = [&](float4 (&ra4)[APASS], float4 (&rb4)[BPASS]) {
+    const int tap = ld_jr * ns + ld_js;
+    const int rel = MODE == 0 ? (ld_jr * p.Ws + ld_js) : ((nr - 1 - ld_jr) * p.Ws + (ns - 1 - ld_js));
+    const unsigned soffA = (unsigned)(rel * p.Cs + ld_chunk * BK) * 4u;
+    const int wtap = (base_r + rstep * ld_jr) * p.S + (base_s + rstep * ld_js);
+    const unsigned soffB = (unsigned)(wtap * p.Cs + ld_chunk * BK) * 4u;
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) {
+      const unsigned off = ((maskA[j] >> tap) & 1u) ? voffA[j] : kOOB;
+      ra4[j] = buf_load16(rsrcA, off, soffA);
+    }
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) rb4[j] = buf_load16(rsrcB, voffB[j], soffB);
+    const bool more = ld_left > 1;
+    ld_left -= more ? 1 : 0;
+    int c = ld_chunk + 1, s = ld_js, r = ld_jr;
+    if (c == cchunks) { c = 0; ++s; }
+    if (s == ns) { s = 0; ++r; }
+    ld_chunk = more ? c : ld_chunk; ld_js = more ? s : ld_js; ld_jr = more ? r : ld_jr;
+  };
+  auto store_step = [&](int buf, const float4 (&ra4)[APASS], const float4 (&rb4)[BPASS]) {
+    float* a = As + buf * BM * LDK;
+    float* b = Bs + buf * BN * LDK;
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) *reinterpret_cast<float4*>(a + (lrow + 32 * j) * LDK + kq * 4) = ra4[j];
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) *reinterpret_cast<float4*>(b + (lrow + 32 * j) * LDK + kq * 4) = rb4[j];
+  };
+
+  if (nk > 0) {
+    if constexpr (PIPE) {
+      // LDS stores of step ks+1 and loads of step ks+3 are issued inside the MFMA sequence of step ks.
+      constexpr int NMF = C::MI * C::NI * 4, NRD = C::MI + C::NI, NST = APASS + BPASS;
+      auto pstep = [&](int buf, float4 (&ra4)[APASS], float4 (&rb4)[BPASS]) {
+        const float* a_s = As + buf * BM * LDK;
+        const float* b_s = Bs + buf * BN * LDK;
+        float4 fa0[C::MI], fb0[C::NI], fa1[C::MI], fb1[C::NI];
+        __syncthreads();
+        frag_load<BM, BN>(a_s, b_s, 0, wm, wn, lane, fa0, fb0);
+        frag_load<BM, BN>(a_s, b_s, 1, wm, wn, lane, fa1, fb1);
+        mfma_slice<BM, BN>(fa0, fb0, acc, acc2);
+        store_step(buf ^ 1, ra4, rb4);
+        frag_load<BM, BN>(a_s, b_s, 2, wm, wn, lane, fa0, fb0);
+        mfma_slice<BM, BN>(fa1, fb1, acc, acc2);
+        load_next(ra4, rb4);
+        frag_load<BM, BN>(a_s, b_s, 3, wm, wn, lane, fa1, fb1);
+        mfma_slice<BM, BN>(fa0, fb0, acc, acc2);
+        mfma_slice<BM, BN>(fa1, fb1, acc, acc2);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NRD, 0);
+        sched_mix<NMF, NST, 0x200>();
+        sched_mix<NMF, NRD, 0x100>();
+        sched_mix<NMF, NST, 0x020>();
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+      };
+      load_next(ra4_0, rb4_0);                       // step 0
+      load_next(ra4_1, rb4_1);                       // step 1
+      store_step(0, ra4_0, rb4_0);
+      load_next(ra4_0, rb4_0);                       // step 2
+      int ks = 0;
+      for (; ks + 1 < nk; ks += 2) {
+        pstep(0, ra4_1, rb4_1);                      // computes ks, stores ks+1, loads ks+3
+        pstep(1, ra4_0, rb4_0);                      // computes ks+1, stores ks+2, loads ks+4
+      }
+      if (ks < nk) {
+        __syncthreads();
+        mfma_tile<BM, BN>(As, Bs, acc, acc2, wm, wn, lane, 0);
+      }
+    } else {
+      // store(ks) -> barrier -> issue loads(ks+2) -> MFMAs(ks); two K-steps per trip, odd last step peeled
+      load_next(ra4_0, rb4_0);
+      load_next(ra4_1, rb4_1);
+      int ks = 0;
+      for (; ks + 1 < nk; ks += 2) {
+        store_step(0, ra4_0, rb4_0);
+        __syncthreads();
+        load_next(ra4_0, rb4_0);
+        mfma_tile<BM, BN>(As, Bs, acc, acc2, wm, wn, lane, 0);
+        store_step(1, ra4_1, rb4_1);
+        __syncthreads();
+        load_next(ra4_1, rb4_1);
+        mfma_tile<BM, BN>(As + BM * LDK, Bs + BN * LDK, acc, acc2, wm, wn, lane, 0);
+      }
+      if (ks < nk) {
+        store_step(0, ra4_0, rb4_0);
+        __syncthreads();
+        mfma_tile<BM, BN>(As, Bs, acc, acc2, wm, wn, lane, 0);
       }
     }
   }
+  igemm_epilogue<BM, BN, MODE>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw);
 }
 
 // ------------------------------------------------------------------------------------
@@ -512,6 +851,158 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
       for (int ni = 0; ni < C::NI; ++ni) {
         const int nn = nn0 + wn * C::WN + ni * 32 + col_l;
         if (nn < p.KK) slab[(size_t)co * p.KK + nn] = acc[mi][ni][reg];
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// wgrad with BUFFER loads (shipped path for Cin % 4 == 0; wgrad_kernel above is the fallback).
+// Same tile / split / slab scheme, but the per-K-step vector-ALU work is cut from ~110 to ~35 instructions per wave
+// (see igemm_buf_kernel for why that is what bounds these kernels):
+//   dy tile : per-lane offset fixed for the whole tile, the pixel rows of a K-step come from a scalar offset,
+//             rows past the split end are cut off by the buffer range -> no VALU at all;
+//   x tile  : a thread stages ONE pixel per K-step (8 threads x BN/32 float4 each per pixel) so the
+//             pixel -> (n, ho, wo) decode is done once per K-step, from a scalar decode of the step's first pixel
+//             plus a per-thread constant; each float4 adds a precomputed (tap, channel) offset and is sent to the
+//             out-of-range offset when its tap falls outside the image (hardware returns zeros).
+// ------------------------------------------------------------------------------------
+template <int BM, int BN, int T>
+__global__ __launch_bounds__(256) void wgrad_buf_kernel(WgradParams p) {
+  using C = TileCfg<BM, BN>;
+  constexpr int LDA = BM + 4, LDB = BN + 32;         // LDB = 32 mod 64: the two 32-float rows of a b128 store group hit disjoint banks
+  constexpr int AQ = BM / 4, AROWS = 256 / AQ, APASS = WBK / AROWS;
+  constexpr int BPASS = BN / 32;                     // float4 per thread per K-step of the x tile
+  constexpr int GQ = BPASS / T;                      // float4 per tap group
+  static_assert(T >= 1 && T <= BPASS && BPASS % T == 0, "bad tap grouping");
+  extern __shared__ __align__(16) float lds[];
+  float* As = lds;                                   // [2][WBK][LDA]
+  float* Bs = lds + 2 * WBK * LDA;                   // [2][WBK][LDB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+  const int tile = blockIdx.x % p.ntiles, split = blockIdx.x / p.ntiles;
+  if (split >= p.nsplits) return;
+  const int co0 = (tile % p.nct) * BM, nn0 = (tile / p.nct) * BN;
+  const int mbeg = split * p.m_per_split, mend = min(p.M, mbeg + p.m_per_split);
+  const int HWo = p.Ho * p.Wo;
+
+  // ---- dy operand: per-lane offset fixed, K-step rows from a scalar offset, split end = buffer range
+  const int aq = tid % AQ, arow = tid / AQ;
+  const __amdgpu_buffer_rsrc_t rsrcA =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)((long)mend * p.Cout * 4), 0x00020000);
+  const unsigned voffA = (co0 + aq * 4 < p.Cout) ? (unsigned)(arow * p.Cout + co0 + aq * 4) * 4u : kOOB;
+  const unsigned passA = (unsigned)(AROWS * p.Cout) * 4u;
+
+  // ---- x operand: thread = (pixel brow of the K-step, float4 slot bq8); the BN columns of the tile are T groups
+  // of BN/T columns, each inside ONE filter tap (host guarantees Cin % (BN/T) == 0)
+  const int brow = tid >> 3, bq8 = tid & 7;
+  const long biasB = ((long)p.pad * p.Wi + p.pad) * p.Cin;
+  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x) - biasB, 0, (int)((biasB + (long)p.N * p.Hi * p.Wi * p.Cin) * 4), 0x00020000);
+  int tr[T], ts[T];
+  unsigned offG[T];                                  // ((tr*Wi + ts)*Cin + c)*4 + bias bytes of the group's first float4 of this thread
+#pragma unroll
+  for (int g = 0; g < T; ++g) {
+    const int nn = nn0 + g * (BN / T) + bq8 * 4;
+    const int nc = nn < p.KK ? nn : 0;               // columns past KK are never stored; any in-range address will do
+    const int tap = p.div_cin.div(nc), c = nc - tap * p.Cin;
+    tr[g] = p.div_s.div(tap); ts[g] = tap - tr[g] * p.S;
+    offG[g] = (unsigned)(((tr[g] * p.Wi + ts[g]) * p.Cin + c) * 4 + biasB * 4);
+  }
+  const int dh_r = brow / p.Wo, dw_r = brow - dh_r * p.Wo;     // this thread's pixel relative to the step's first pixel
+
+  f32x16 acc[C::MI][C::NI];
+#pragma unroll
+  for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  float4 ra4[APASS], rb4[BPASS];
+  auto load_step = [&](int mk) {                     // mk: first pixel of the K-step (uniform)
+    const unsigned soffA = (unsigned)mk * (unsigned)p.Cout * 4u;
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) ra4[j] = buf_load16(rsrcA, voffA, soffA + j * passA);
+    // scalar decode of the step's first pixel, then this thread's pixel with at most one carry per coordinate
+    const int n0 = p.div_hw.div(mk), rem = mk - n0 * HWo;
+    const int h0 = p.div_w.div(rem), w0 = rem - h0 * p.Wo;
+    int w = w0 + dw_r;
+    const int c1 = w >= p.Wo ? 1 : 0;
+    w -= c1 ? p.Wo : 0;
+    int h = h0 + dh_r + c1;
+    const int c2 = h >= p.Ho ? 1 : 0;
+    h -= c2 ? p.Ho : 0;
+    const int n = n0 + c2;
+    const int hb = h * p.stride - p.pad, wb = w * p.stride - p.pad;
+    const unsigned pix = (unsigned)(((n * p.Hi + hb) * p.Wi + wb) * p.Cin) * 4u;     // + bias stays >= 0 for valid taps
+#pragma unroll
+    for (int g = 0; g < T; ++g) {
+      const bool ok = (unsigned)(hb + tr[g]) < (unsigned)p.Hi && (unsigned)(wb + ts[g]) < (unsigned)p.Wi;
+      const unsigned off = ok ? pix + offG[g] : kOOB;
+#pragma unroll
+      for (int q = 0; q < GQ; ++q) rb4[g * GQ + q] = buf_load16(rsrcB, off, (unsigned)(q * 128));
+    }
+  };
+  auto store_step = [&](int buf) {
+    float* a = As + buf * WBK * LDA;
+    float* b = Bs + buf * WBK * LDB;
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) *reinterpret_cast<float4*>(a + (arow + AROWS * j) * LDA + aq * 4) = ra4[j];
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j)
+      *reinterpret_cast<float4*>(b + brow * LDB + (j / GQ) * (BN / T) + (bq8 + 8 * (j % GQ)) * 4) = rb4[j];
+  };
+
+  // MFMA operands: a wave with two 32-row tiles (MI == 2) takes tile rows 2i and 2i+1 for lane i, so both come from
+  // ONE 8-byte LDS read at a compile-time offset (no address arithmetic in the loop); same for the columns.
+  const int i = lane & 31, h = lane >> 5;
+  const int nsteps = (mend > mbeg) ? (mend - mbeg + WBK - 1) / WBK : 0;
+  if (nsteps > 0) load_step(mbeg);
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1;
+    store_step(buf);
+    __syncthreads();
+    if (st + 1 < nsteps) load_step(mbeg + (st + 1) * WBK);
+    const float* a = As + buf * WBK * LDA + h * LDA + wm * C::WM + C::MI * i;
+    const float* b = Bs + buf * WBK * LDB + h * LDB + wn * C::WN + C::NI * i;
+#pragma unroll
+    for (int kk = 0; kk < WBK / 2; ++kk) {
+      float av[C::MI], bv[C::NI];
+      if constexpr (C::MI == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(a + 2 * kk * LDA);
+        av[0] = t.x; av[1] = t.y;
+      } else {
+        av[0] = a[2 * kk * LDA];
+      }
+      if constexpr (C::NI == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(b + 2 * kk * LDB);
+        bv[0] = t.x; bv[1] = t.y;
+      } else {
+        bv[0] = b[2 * kk * LDB];
+      }
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+    }
+  }
+  static_assert(C::MI <= 2 && C::NI <= 2, "interleaved fragment scheme handles at most two tiles per wave and dimension");
+  float* slab = p.out + (size_t)split * p.Cout * p.KK;
+  const int col_l = lane & 31, rsub = 4 * (lane >> 5);
+#pragma unroll
+  for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int co = co0 + wm * C::WM + C::MI * ((reg & 3) + 8 * (reg >> 2) + rsub) + mi;
+      if (co >= p.Cout) continue;
+      const int nn = nn0 + wn * C::WN + C::NI * col_l;
+      float* o = slab + (size_t)co * p.KK + nn;
+      if constexpr (C::NI == 2) {
+        if (nn + 1 < p.KK) *reinterpret_cast<float2*>(o) = make_float2(acc[mi][0][reg], acc[mi][1][reg]);
+        else if (nn < p.KK) o[0] = acc[mi][0][reg];
+      } else {
+        if (nn < p.KK) o[0] = acc[mi][0][reg];
       }
     }
 }
@@ -832,12 +1323,12 @@ static int check_fwd_dims(const xas_conv_shape* s, const char* who) {
   return 0;
 }
 
-template <int BM, int BN, int MODE, int NBUF = 2>
+template <int BM, int BN, int MODE, int NBUF = 2, bool PIPE = false>
 static int launch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
   const size_t lds = (size_t)NBUF * (BM + BN) * LDK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, NBUF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, NBUF, PIPE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -845,9 +1336,41 @@ static int launch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStre
   q.nMt = (int)cdiv(Mrows_max, BM); q.nNt = (int)cdiv(p.Cd, BN); q.mt_per_xcd = (int)cdiv(q.nMt, 8);
   const unsigned nblk = (q.tune & 4) ? (unsigned)(q.nMt * q.nNt) : (unsigned)(8 * q.mt_per_xcd * q.nNt);
   dim3 grid(nblk, 1, (unsigned)phases);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, NBUF>), grid, dim3(256), lds, st, q);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, NBUF, PIPE>), grid, dim3(256), lds, st, q);
   XAS_LAUNCH_CHECK();
   return 0;
+}
+
+template <int BM, int BN, int MODE, bool PIPE>
+static int launch_igemm_buf(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
+  const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_buf_kernel<BM, BN, MODE, PIPE>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  IgemmParams q = p;
+  q.nMt = (int)cdiv(Mrows_max, BM); q.nNt = (int)cdiv(p.Cd, BN); q.mt_per_xcd = (int)cdiv(q.nMt, 8);
+  const unsigned nblk = (q.tune & 4) ? (unsigned)(q.nMt * q.nNt) : (unsigned)(8 * q.mt_per_xcd * q.nNt);
+  dim3 grid(nblk, 1, (unsigned)phases);
+  hipLaunchKernelGGL((igemm_buf_kernel<BM, BN, MODE, PIPE>), grid, dim3(256), lds, st, q);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+// Buffer-load kernel unless its 32-bit offset scheme cannot address the tensor (>= 2 GiB incl. the bias region, or a
+// tap window of more than 32 taps) or an experiment flag asks for the old kernel (tune bit6 = 64).
+template <int BM, int BN, int MODE>
+static int launch_tile(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
+  const long bias = ((long)(p.R + p.pad) * p.Ws + p.S + p.pad) * p.Cs;
+  const bool fits = (bias + p.src_elems) * 4 < 0x7fffff00l && p.wgt_elems * 4 < 0x7fffff00l && p.R * p.S <= 32;
+  if (fits && !(p.tune & 64)) {                       // tune bit5 (32): plain K-loop instead of the pipelined one
+    if (p.tune & 32) return launch_igemm_buf<BM, BN, MODE, false>(p, Mrows_max, phases, st);
+    return launch_igemm_buf<BM, BN, MODE, true>(p, Mrows_max, phases, st);
+  }
+  if (p.tune & 32) return launch_igemm<BM, BN, MODE, 2, false>(p, Mrows_max, phases, st);
+  return launch_igemm<BM, BN, MODE, 2, true>(p, Mrows_max, phases, st);
 }
 
 template <int MODE>
@@ -855,11 +1378,11 @@ static int dispatch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipSt
   if (p.Cd >= 96) {
     // small problems (layer3/4 at B=32: M = 8192 / 2048 rows): 128x128 tiles leave most of the 256 CUs idle
     const long blocks128 = cdiv(Mrows_max, 128) * cdiv(p.Cd, 128) * phases;
-    if (blocks128 <= 512) return launch_igemm<64, 64, MODE>(p, Mrows_max, phases, st);
-    return launch_igemm<128, 128, MODE>(p, Mrows_max, phases, st);
+    if (blocks128 <= 512) return launch_tile<64, 64, MODE>(p, Mrows_max, phases, st);
+    return launch_tile<128, 128, MODE>(p, Mrows_max, phases, st);
   }
-  if (p.Cd >= 48) return launch_igemm<128, 64, MODE>(p, Mrows_max, phases, st);
-  return launch_igemm<128, 32, MODE>(p, Mrows_max, phases, st);
+  if (p.Cd >= 48) return launch_tile<128, 64, MODE>(p, Mrows_max, phases, st);
+  return launch_tile<128, 32, MODE>(p, Mrows_max, phases, st);
 }
 
 }  // namespace xas
@@ -908,6 +1431,7 @@ extern "C" int xas_conv_fwd(const float* x, const float* w_packed, const float* 
   p.Hs = s->Hi; p.Ws = s->Wi; p.Cs = s->Cin; p.Hd = s->Ho; p.Wd = s->Wo; p.Cd = s->Cout;
   p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.Hrow = s->Ho; p.Wrow = s->Wo; p.tune = g_tune; p.dbg = g_dbg;
   p.div_hw.init((unsigned)(s->Ho * s->Wo)); p.div_w.init((unsigned)s->Wo);
+  p.src_elems = (long)p.N * p.Hs * p.Ws * p.Cs; p.wgt_elems = (long)p.Cd * p.R * p.S * p.Cs;
   return dispatch_igemm<0>(p, s->N * s->Ho * s->Wo, 1, st);
 }
 
@@ -946,6 +1470,7 @@ extern "C" int xas_conv_dgrad(const float* dy, const float* w_packed_t, float* d
   p.Hs = s->Ho; p.Ws = s->Wo; p.Cs = s->Cout; p.Hd = s->Hi; p.Wd = s->Wi; p.Cd = s->Cin;
   p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.tune = g_tune; p.dbg = g_dbg;
   const int Hp = (s->Hi + s->stride - 1) / s->stride, Wp = (s->Wi + s->stride - 1) / s->stride;
+  p.src_elems = (long)p.N * p.Hs * p.Ws * p.Cs; p.wgt_elems = (long)p.Cd * p.R * p.S * p.Cs;
   return dispatch_igemm<1>(p, s->N * Hp * Wp, s->stride * s->stride, st);
 }
 
@@ -1001,6 +1526,38 @@ static int launch_wgrad(const WgradParams& p, int splits, hipStream_t st) {
   hipLaunchKernelGGL((wgrad_kernel<BM, BN, VEC>), grid, dim3(256), lds, st, q);
   XAS_LAUNCH_CHECK();
   return 0;
+}
+
+template <int BM, int BN, int T>
+static int launch_wgrad_buf_t(const WgradParams& p, int splits, hipStream_t st) {
+  const size_t lds = (size_t)2 * WBK * ((BM + 4) + (BN + 32)) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_buf_kernel<BM, BN, T>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  WgradParams q = p;
+  q.nct = (int)cdiv(p.Cout, BM);
+  q.ntiles = q.nct * (int)cdiv(p.KK, BN);
+  q.nsplits = splits;
+  q.tune = g_tune;
+  dim3 grid((unsigned)(splits * q.ntiles));
+  hipLaunchKernelGGL((wgrad_buf_kernel<BM, BN, T>), grid, dim3(256), lds, st, q);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+// T = number of filter taps a BN-column tile can span: the smallest T in {1, 2, 4} with Cin % (BN / T) == 0
+template <int BM, int BN>
+static int launch_wgrad_buf(const WgradParams& p, int splits, hipStream_t st) {
+  if (p.Cin % BN == 0) return launch_wgrad_buf_t<BM, BN, 1>(p, splits, st);
+  if (p.Cin % (BN / 2) == 0) return launch_wgrad_buf_t<BM, BN, 2>(p, splits, st);
+  if constexpr (BN >= 128) {
+    if (p.Cin % (BN / 4) == 0) return launch_wgrad_buf_t<BM, BN, 4>(p, splits, st);
+  }
+  set_error("wgrad_buf: Cin=%d does not divide into tap groups of a %d-column tile", p.Cin, BN);
+  return 1;
 }
 
 static int conv_wgrad_impl(const float* x, const float* dy, float* dw_out, float* workspace, const xas_conv_shape* s,
@@ -1076,6 +1633,17 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
   XAS_REQUIRE(s->Cout % 4 == 0, "conv_wgrad: Cout=%d not supported by the MFMA path", s->Cout);
   const bool vec = (s->Cin % 4 == 0) && (((uintptr_t)x & 15) == 0);
   int rc;
+  // buffer-load kernel: 32-bit byte offsets (tensors < 2 GiB) and at most one carry per coordinate in the per-thread
+  // pixel decode (31 / Wo + 1 <= Ho); tune bit7 (128) forces the old kernel
+  const long xbytes = ((long)s->N * s->Hi * s->Wi + (long)s->pad * s->Wi + s->pad) * s->Cin * 4;
+  const long dybytes = (long)p.M * s->Cout * 4;
+  const bool buf_ok = vec && s->Cin % 32 == 0 && xbytes < 0x7fffff00l && dybytes < 0x7fffff00l && 31 / s->Wo + 1 <= s->Ho && !(g_tune & 128);
+  if (buf_ok) {
+    if (bm == 32) rc = launch_wgrad_buf<32, 128>(p, splits, st);
+    else if (bn == 64) rc = bm == 128 ? launch_wgrad_buf<128, 64>(p, splits, st) : launch_wgrad_buf<64, 64>(p, splits, st);
+    else if (bm == 128) rc = launch_wgrad_buf<128, 128>(p, splits, st);
+    else rc = launch_wgrad_buf<64, 128>(p, splits, st);
+  } else
   if (bm == 32) rc = vec ? launch_wgrad<32, 128, true>(p, splits, st) : launch_wgrad<32, 128, false>(p, splits, st);
   else if (bn == 64 && vec) rc = bm == 128 ? launch_wgrad<128, 64, true>(p, splits, st) : launch_wgrad<64, 64, true>(p, splits, st);
   else if (bm == 128) rc = vec ? launch_wgrad<128, 128, true>(p, splits, st) : launch_wgrad<128, 128, false>(p, splits, st);
