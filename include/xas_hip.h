@@ -167,11 +167,15 @@ int xas_bn_update_running(const float* mean, const float* var_biased, float* run
                           float* running_var, float momentum, long count, int C, void* stream);
 /* backward, step 1: dz = dy * act'(y); sum_dz[c], sum_dz_xhat[c]  (and dresidual = dz).
  * x may be NULL when the layer has an activation and no residual: xhat is then recovered from the saved output,
- * xhat = (act^-1(y) - beta) / gamma (needed only where dz != 0), one activation tensor less to read per pass. */
+ * xhat = (act^-1(y) - beta) / gamma (needed only where dz != 0), one activation tensor less to read per pass.
+ * See below for dbeta_acc / dgamma_acc. */
 int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy, const float* mean,
                       const float* var_biased, const float* gamma, const float* beta, float eps, int act,
                       long M, int C,
-                      float* sum_dz, float* sum_dz_xhat, float* workspace, void* stream);
+                      float* sum_dz, float* sum_dz_xhat, float* workspace,
+                      float* dbeta_acc, float* dgamma_acc, void* stream);
+/* dbeta_acc / dgamma_acc (both or neither, may be NULL): the parameter gradients sum_dz / sum_dz_xhat are ALSO added
+ * into these [C] buffers (the .grad arena of the optimizer), which saves the autograd accumulation kernels. */
 /* step 2: dx = gamma*invstd*(dz - sum_dz/cnt - xhat*sum_dz_xhat/cnt); dres = dz if != NULL.
  * x may be NULL only for the leaky-ReLU layers (invertible activation: xhat of every element from y). */
 int xas_bn_bwd_apply(const float* x, const float* y, const float* dy, const float* mean,

@@ -114,28 +114,32 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
 
 // partial: [nslab][2][C] -> out1[c], out2[c]; MODE 0 converts pivot sums to mean / biased var and, when
 // running buffers are given, applies the running-statistic update in the same launch.
-// Block = 64 channels x 16 slab lanes; slabs are summed in double, in a fixed order (deterministic).
+// Block = 64 channels x (blockDim.x / 64) slab lanes; slabs are summed in double, in a fixed order (deterministic).
+// Launched with 256 threads: a 1024-thread block needs 16 free wave slots on ONE compute unit, and while the
+// weight-gradient kernels of the side stream fill the chip this tiny kernel waited ~20 us for a CU to drain.
+constexpr int kFinalizeThreads = 256;
+
 template <int MODE>
 __global__ __launch_bounds__(1024) void col_finalize_kernel(const float* __restrict__ partial,
                                                            const float* __restrict__ x, int nslab, int C, long M,
                                                            float* __restrict__ out1, float* __restrict__ out2,
                                                            float* __restrict__ running_mean,
                                                            float* __restrict__ running_var, float momentum,
-                                                           float unbias) {
+                                                           float unbias, float* __restrict__ acc1 = nullptr,
+                                                           float* __restrict__ acc2 = nullptr) {
   __shared__ double r1[16][64], r2[16][64];
-  const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6;
+  const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6, nl = blockDim.x >> 6;
   const int c = blockIdx.x * 64 + cx;
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
-    for (int s = sy; s < nslab; s += 16) {
+    for (int s = sy; s < nslab; s += nl) {
       s1 += (double)partial[((size_t)s * 2) * C + c];
       s2 += (double)partial[((size_t)s * 2 + 1) * C + c];
     }
   r1[sy][cx] = s1; r2[sy][cx] = s2;
   __syncthreads();
   if (sy != 0 || c >= C) return;
-#pragma unroll
-  for (int k = 1; k < 16; ++k) { s1 += r1[k][cx]; s2 += r2[k][cx]; }
+  for (int k = 1; k < nl; ++k) { s1 += r1[k][cx]; s2 += r2[k][cx]; }
   if (MODE == 0) {
     const double m = s1 / (double)M;
     double v = s2 / (double)M - m * m;
@@ -150,6 +154,7 @@ __global__ __launch_bounds__(1024) void col_finalize_kernel(const float* __restr
   } else {
     out1[c] = (float)s1;
     out2[c] = (float)s2;
+    if (acc1) { acc1[c] += (float)s1; acc2[c] += (float)s2; }   // parameter gradients accumulated in place (.grad arena)
   }
 }
 
@@ -396,7 +401,7 @@ extern "C" int xas_bn_stats(const float* x, long M, int C, float* mean, float* v
   hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(g.nslab, g.ncb), dim3(256), 0, as_stream(stream), x, nullptr, nullptr,
                      nullptr, nullptr, 0.f, 0, M, C, g, workspace);
   XAS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_finalize_kernel<0>, dim3((unsigned)cdiv(C, 64)), dim3(1024), 0, as_stream(stream), workspace, x,
+  hipLaunchKernelGGL(col_finalize_kernel<0>, dim3((unsigned)cdiv(C, 64)), dim3(kFinalizeThreads), 0, as_stream(stream), workspace, x,
                      g.nslab, C, M, mean, var_biased, running_mean, running_var, momentum, unbias);
   XAS_LAUNCH_CHECK();
   return 0;
@@ -410,7 +415,7 @@ extern "C" int xas_col_sum(const float* x, long M, int C, float* out, float* wor
                      nullptr, nullptr, 0.f, 0, M, C, g, workspace);
   XAS_LAUNCH_CHECK();
   // second output (unused sums of the second accumulator) lands in workspace tail
-  hipLaunchKernelGGL(col_finalize_kernel<1>, dim3((unsigned)cdiv(C, 64)), dim3(1024), 0, as_stream(stream), workspace, x,
+  hipLaunchKernelGGL(col_finalize_kernel<1>, dim3((unsigned)cdiv(C, 64)), dim3(kFinalizeThreads), 0, as_stream(stream), workspace, x,
                      g.nslab, C, M, out, workspace + (size_t)g.nslab * 2 * C, nullptr, nullptr, 0.f, 1.f);
   XAS_LAUNCH_CHECK();
   return 0;
@@ -441,12 +446,14 @@ extern "C" int xas_bn_update_running(const float* mean, const float* var_biased,
 
 extern "C" int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy, const float* mean,
                                  const float* var_biased, const float* gamma, const float* beta, float eps, int act,
-                                 long M, int C, float* sum_dz, float* sum_dz_xhat, float* workspace, void* stream) {
+                                 long M, int C, float* sum_dz, float* sum_dz_xhat, float* workspace,
+                                 float* dbeta_acc, float* dgamma_acc, void* stream) {
   ColGeom g;
   if (col_geom(M, C, &g)) return 1;
   XAS_REQUIRE(dy && mean && var_biased && sum_dz && sum_dz_xhat && workspace && (act == 0 || y),
               "bn_bwd_reduce: null buffer");
   XAS_REQUIRE(x || (act != 0 && y && gamma && beta), "bn_bwd_reduce: without x the layer needs an activation, y, gamma, beta");
+  XAS_REQUIRE((dbeta_acc == nullptr) == (dgamma_acc == nullptr), "bn_bwd_reduce: gradient accumulators come in pairs");
   if (x) {
     hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(g.nslab, g.ncb), dim3(256), 0, as_stream(stream), x, y, dy, mean,
                        var_biased, eps, act, M, C, g, workspace);
@@ -455,8 +462,8 @@ extern "C" int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy
                        gamma, eps, act, M, C, g, workspace);
   }
   XAS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_finalize_kernel<1>, dim3((unsigned)cdiv(C, 64)), dim3(1024), 0, as_stream(stream), workspace, x,
-                     g.nslab, C, M, sum_dz, sum_dz_xhat, nullptr, nullptr, 0.f, 1.f);
+  hipLaunchKernelGGL(col_finalize_kernel<1>, dim3((unsigned)cdiv(C, 64)), dim3(kFinalizeThreads), 0, as_stream(stream), workspace, x,
+                     g.nslab, C, M, sum_dz, sum_dz_xhat, nullptr, nullptr, 0.f, 1.f, dbeta_acc, dgamma_acc);
   XAS_LAUNCH_CHECK();
   return 0;
 }

@@ -1007,22 +1007,23 @@ __global__ __launch_bounds__(256) void wgrad_buf_kernel(WgradParams p) {
     }
 }
 
-// Sum the split slabs (fixed order -> deterministic).  Block = 64 elements x 16 slab lanes, so a reduction
-// over hundreds of slabs is 16-way parallel instead of one long dependent chain per element.
+// Sum the split slabs (fixed order -> deterministic).  Block = 64 elements x (blockDim.x / 64) slab lanes, so a
+// reduction over hundreds of slabs is several-way parallel instead of one long dependent chain per element.
+// kSlabThreads = 256 by default (4 lanes): 1024-thread blocks are hard to place while other kernels fill the CUs.
 // unpack != 0: element i is a packed index [co][r][s][ci] and is written to OIHW [co][ci][r][s].
 __global__ __launch_bounds__(1024) void slab_reduce_kernel2(const float* __restrict__ slabs, int splits, long n,
                                                             int unpack, int Cin, int R, int S,
                                                             float* __restrict__ out) {
   __shared__ float red[16][64];
-  const int ex = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const int ex = threadIdx.x & 63, ly = threadIdx.x >> 6, nl = blockDim.x >> 6;
   const long i = (long)blockIdx.x * 64 + ex;
   float acc = 0.f;
   if (i < n)
-    for (int k = ly; k < splits; k += 16) acc += slabs[(size_t)k * n + i];
+    for (int k = ly; k < splits; k += nl) acc += slabs[(size_t)k * n + i];
   red[ly][ex] = acc;
   __syncthreads();
   if (ly != 0 || i >= n) return;
-  for (int k = 1; k < 16; ++k) acc += red[k][ex];
+  for (int k = 1; k < nl; ++k) acc += red[k][ex];
   long o = i;
   if (unpack & 1) {
     long t = i;
@@ -1474,6 +1475,8 @@ extern "C" int xas_conv_dgrad(const float* dy, const float* w_packed_t, float* d
   return dispatch_igemm<1>(p, s->N * Hp * Wp, s->stride * s->stride, st);
 }
 
+static inline unsigned slab_threads() { return (g_tune & 16384) ? 1024u : 256u; }   // tune bit14: old 1024-thread blocks
+
 static void wgrad_plan(const xas_conv_shape* s, int* bm, int* bn, int* splits, int* mps) {
   const long KK = (long)s->R * s->S * s->Cin, M = (long)s->N * s->Ho * s->Wo;
   *bm = s->Cout >= 96 ? 128 : (s->Cout > 32 ? 64 : 32);
@@ -1598,10 +1601,10 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
     XAS_LAUNCH_CHECK();
     const long n = (long)C * 9;
     if (oihw || !cout1) {
-      hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, workspace, chunks, n,
+      hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(n, 64)), dim3(slab_threads()), 0, st, workspace, chunks, n,
                          accumulate ? 2 : 0, 1, 1, 1, dw_packed);
     } else {          // packed [1][tap][c] wanted: treat the [c][tap] sums as an "OIHW" with Cout=1 and repack
-      hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, workspace, chunks, n, 0, 1, 1, 1,
+      hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(n, 64)), dim3(slab_threads()), 0, st, workspace, chunks, n, 0, 1, 1, 1,
                          workspace + (size_t)chunks * n);
       XAS_LAUNCH_CHECK();
       hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, workspace + (size_t)chunks * n,
@@ -1616,7 +1619,7 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
     hipLaunchKernelGGL(wgrad_cout1_kernel, dim3((unsigned)cdiv(KK, 64), (unsigned)chunks), dim3(64), 0, st, x, dy,
                        workspace, *s, kCout1Chunk);
     XAS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(KK, 64)), dim3(1024), 0, st, workspace, chunks, (long)KK,
+    hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(KK, 64)), dim3(slab_threads()), 0, st, workspace, chunks, (long)KK,
                        rflag, s->Cin, s->R, s->S, dw_packed);
     XAS_LAUNCH_CHECK();
     return 0;
@@ -1651,7 +1654,7 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
   if (rc) return rc;
   const long n = (long)s->Cout * p.KK;
   if (oihw || splits > 1) {
-    hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, workspace, splits, n,
+    hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(n, 64)), dim3(slab_threads()), 0, st, workspace, splits, n,
                        rflag, s->Cin, s->R, s->S, dw_packed);
     XAS_LAUNCH_CHECK();
   }

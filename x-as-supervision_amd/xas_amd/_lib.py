@@ -44,7 +44,7 @@ SIGNATURES = {
     'xas_col_sum': ('plippp', 'i'),
     'xas_bn_apply': ('ppppppfilipp', 'i'),
     'xas_bn_update_running': ('ppppflip', 'i'),
-    'xas_bn_bwd_reduce': ('pppppppfilipppp', 'i'),
+    'xas_bn_bwd_reduce': ('pppppppfilipppppp', 'i'),
     'xas_bn_bwd_apply': ('pppppppppfilidppp', 'i'),
     'xas_maxpool3x3s2_fwd': ('piiiippp', 'i'),
     'xas_maxpool3x3s2_bwd': ('ppiiiipp', 'i'),

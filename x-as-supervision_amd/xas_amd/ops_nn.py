@@ -326,11 +326,21 @@ class _BatchNorm(torch.autograd.Function):
         dev = x.device
         sdz = torch.empty(2 * c, device=dev, dtype=torch.float32)
         ws = torch.empty(query('xas_bn_workspace_floats', M, c), device=dev, dtype=torch.float32)
+        # parameter gradients (LOCAL sums: the gradient all-reduce averages them later) go straight into the
+        # optimizer's .grad arena when there is one, instead of through two autograd accumulation kernels per layer
+        gg, gb = gamma.grad, beta.grad
+        direct = (ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and gg is not None and gb is not None
+                  and gg.is_contiguous() and gb.is_contiguous() and gg.dtype == torch.float32 and gb.dtype == torch.float32)
         call('xas_bn_bwd_reduce', None if xfree_reduce else ptr(x), ptr(y), ptr(dy), ptr(mean), ptr(var), ptr(gamma),
-             ptr(beta), eps, act, M, c, ptr(sdz), ptr(sdz[c:]), ptr(ws))
-        dgamma, dbeta = sdz[c:], sdz[:c]                      # local sums: DDP averages parameter grads later
+             ptr(beta), eps, act, M, c, ptr(sdz), ptr(sdz[c:]), ptr(ws), ptr(gb) if direct else None,
+             ptr(gg) if direct else None)
+        if direct:
+            dgamma = dbeta = None
+        else:
+            dgamma, dbeta = sdz[c:], sdz[:c]
         if group is not None:
-            dgamma, dbeta = dgamma.clone(), dbeta.clone()
+            if not direct:
+                dgamma, dbeta = dgamma.clone(), dbeta.clone()
             dist.all_reduce(sdz, group=group)                 # one coalesced 2C message per layer
         dx = torch.empty_like(y)
         dres = torch.empty_like(y) if has_res else None
