@@ -21,7 +21,8 @@ static int col_geom(long M, int C, ColGeom* g) {
   while (cb < 256 && C % (cb * 2) == 0) cb *= 2;
   g->CB = cb;
   g->TX = g->CB / 4; g->TY = 256 / g->TX; g->ncb = C / g->CB;
-  long want = 256 / g->ncb;                  // ~1 block per CU in total; keeps the finalize pass short
+  static const long kWant[4] = {256, 512, 128, 64};           // tune bits 15-16 (experiment)
+  long want = kWant[(tune_flags() >> 15) & 3] / g->ncb;         // ~1 block per CU in total; keeps the finalize pass short
   long maxslab = cdiv(M, (long)g->TY * 8);   // at least 8 rows per thread
   if (want > maxslab) want = maxslab;
   if (want < 1) want = 1;
@@ -131,11 +132,23 @@ __global__ __launch_bounds__(1024) void col_finalize_kernel(const float* __restr
   const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6, nl = blockDim.x >> 6;
   const int c = blockIdx.x * 64 + cx;
   double s1 = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int s = sy; s < nslab; s += nl) {
+  if (c < C) {
+    int s = sy;
+    for (; s + 7 * nl < nslab; s += 8 * nl) {          // 16 independent loads in flight per lane, summed in slab order
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a[u] = partial[((size_t)(s + u * nl) * 2) * C + c];
+        b[u] = partial[((size_t)(s + u * nl) * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s1 += (double)a[u]; s2 += (double)b[u]; }
+    }
+    for (; s < nslab; s += nl) {
       s1 += (double)partial[((size_t)s * 2) * C + c];
       s2 += (double)partial[((size_t)s * 2 + 1) * C + c];
     }
+  }
   r1[sy][cx] = s1; r2[sy][cx] = s2;
   __syncthreads();
   if (sy != 0 || c >= C) return;

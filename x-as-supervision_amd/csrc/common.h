@@ -9,6 +9,7 @@
 namespace xas {
 
 void set_error(const char* fmt, ...);
+int tune_flags();   // xas_set_tuning value (experiments only; 0 = shipped configuration)
 
 #define XAS_REQUIRE(cond, ...)        \
   do {                                \

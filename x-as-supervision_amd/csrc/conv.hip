@@ -62,6 +62,7 @@ struct IgemmParams {
 static unsigned long long* g_dbg = nullptr;
 
 static int g_tune = 0;
+int tune_flags() { return g_tune; }
 
 // ------------------------------------------------------------------------------------
 // shared MFMA core: As[BM][LDK], Bs[BN][LDK] -> acc
@@ -1018,8 +1019,17 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel2(const float* __restr
   const int ex = threadIdx.x & 63, ly = threadIdx.x >> 6, nl = blockDim.x >> 6;
   const long i = (long)blockIdx.x * 64 + ex;
   float acc = 0.f;
-  if (i < n)
-    for (int k = ly; k < splits; k += nl) acc += slabs[(size_t)k * n + i];
+  if (i < n) {
+    int k = ly;
+    for (; k + 7 * nl < splits; k += 8 * nl) {         // 8 independent loads in flight per lane, summed in slab order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = slabs[(size_t)(k + u * nl) * n + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; k < splits; k += nl) acc += slabs[(size_t)k * n + i];
+  }
   red[ly][ex] = acc;
   __syncthreads();
   if (ly != 0 || i >= n) return;
