@@ -121,14 +121,16 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
 constexpr int kFinalizeThreads = 256;
 
 template <int MODE>
-__global__ __launch_bounds__(1024) void col_finalize_kernel(const float* __restrict__ partial,
+__global__ __launch_bounds__(kFinalizeThreads) void col_finalize_kernel(const float* __restrict__ partial,
                                                            const float* __restrict__ x, int nslab, int C, long M,
                                                            float* __restrict__ out1, float* __restrict__ out2,
                                                            float* __restrict__ running_mean,
                                                            float* __restrict__ running_var, float momentum,
                                                            float unbias, float* __restrict__ acc1 = nullptr,
                                                            float* __restrict__ acc2 = nullptr) {
-  __shared__ double r1[16][64], r2[16][64];
+  // 4 KB of LDS, not 16: while two weight-gradient blocks (2 x 74 KB) sit on every CU, a block asking for 16 KB has to
+  // wait for one of them to retire (seen as 25 us launches of this 5 us kernel in the backward pass)
+  __shared__ double r1[kFinalizeThreads / 64][64], r2[kFinalizeThreads / 64][64];
   const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6, nl = blockDim.x >> 6;
   const int c = blockIdx.x * 64 + cx;
   double s1 = 0.0, s2 = 0.0;

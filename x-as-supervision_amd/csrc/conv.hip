@@ -1543,12 +1543,13 @@ static int launch_wgrad(const WgradParams& p, int splits, hipStream_t st) {
 
 template <int BM, int BN, int T>
 static int launch_wgrad_buf_t(const WgradParams& p, int splits, hipStream_t st) {
-  const size_t lds = (size_t)2 * WBK * ((BM + 4) + (BN + 32)) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  size_t lds = (size_t)2 * WBK * ((BM + 4) + (BN + 32)) * sizeof(float);
+  if ((g_tune & 131072) && lds < 84 * 1024) lds = 84 * 1024;     // experiment (bit17): one block per CU
+  static size_t attr_set = 0;
+  if (attr_set < lds) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_buf_kernel<BM, BN, T>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+    attr_set = lds;
   }
   WgradParams q = p;
   q.nct = (int)cdiv(p.Cout, BM);
