@@ -880,7 +880,14 @@ __global__ __launch_bounds__(256) void wgrad_buf_kernel(WgradParams p) {
   float* Bs = lds + 2 * WBK * LDA;                   // [2][WBK][LDB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
-  const int tile = blockIdx.x % p.ntiles, split = blockIdx.x / p.ntiles;
+  int tile, split;
+  if (!(p.tune & 8192)) {                    // default: tiles fastest, dealt round-robin over the XCDs
+    tile = blockIdx.x % p.ntiles; split = blockIdx.x / p.ntiles;
+  } else {                                   // experiment (bit13): all tiles of a pixel split on ONE XCD (shared L2)
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    split = xcd + 8 * (q / p.ntiles);
+    tile = q - (q / p.ntiles) * p.ntiles;
+  }
   if (split >= p.nsplits) return;
   const int co0 = (tile % p.nct) * BM, nn0 = (tile / p.nct) * BN;
   const int mbeg = split * p.m_per_split, mend = min(p.M, mbeg + p.m_per_split);
@@ -1556,7 +1563,7 @@ static int launch_wgrad_buf_t(const WgradParams& p, int splits, hipStream_t st) 
   q.ntiles = q.nct * (int)cdiv(p.KK, BN);
   q.nsplits = splits;
   q.tune = g_tune;
-  dim3 grid((unsigned)(splits * q.ntiles));
+  dim3 grid((unsigned)((g_tune & 8192) ? 8 * cdiv(splits, 8) * q.ntiles : splits * q.ntiles));
   hipLaunchKernelGGL((wgrad_buf_kernel<BM, BN, T>), grid, dim3(256), lds, st, q);
   XAS_LAUNCH_CHECK();
   return 0;
