@@ -1137,52 +1137,68 @@ __device__ __forceinline__ bool thin_src(const ThinParams& p, int h, int w, int 
   return (unsigned)*hs < (unsigned)p.H && (unsigned)*ws < (unsigned)p.W;
 }
 
+// Thread = (pixel, 4-channel slot): the C/4 lanes of a pixel read one contiguous C*4-byte row per tap (coalesced),
+// keep their 9 weight vectors in registers, and a block walks kThinPasses pixel groups.  (The first version gave a
+// thread a whole pixel: 64 lanes x 16 B at a C*4-byte stride per load instruction, 0.9 TB/s.)
+constexpr int kThinPasses = 8;
+
 __global__ __launch_bounds__(256) void thin_vec2scalar_kernel(const float* __restrict__ V, const float* __restrict__ Wt,
                                                               const float* __restrict__ bias, float* __restrict__ out,
                                                               ThinParams p) {
-  __shared__ float4 wl[9 * 16];
-  const int C4 = p.C / 4;
-  for (int e = threadIdx.x; e < 9 * C4; e += blockDim.x) wl[e] = reinterpret_cast<const float4*>(Wt)[e];
-  __syncthreads();
-  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long M = (long)p.N * p.H * p.W;
-  if (m >= M) return;
-  const int w = m % p.W; const long t = m / p.W; const int h = t % p.H; const int n = t / p.H;
-  float acc = bias ? bias[0] : 0.f;
+  const int C4 = p.C / 4, ppb = 256 / C4;                      // lanes per pixel (power of two <= 16), pixels per pass
+  const int cq = threadIdx.x % C4, pl = threadIdx.x / C4;
+  float4 wv[9];
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    int hs, ws;
-    if (!thin_src(p, h, w, tap / 3, tap % 3, &hs, &ws)) continue;
-    const float4* v = reinterpret_cast<const float4*>(V + (((size_t)n * p.H + hs) * p.W + ws) * p.C);
-    for (int c = 0; c < C4; ++c) {
-      const float4 a = v[c], b = wl[tap * C4 + c];
-      acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+  for (int tap = 0; tap < 9; ++tap) wv[tap] = reinterpret_cast<const float4*>(Wt)[tap * C4 + cq];
+  const long M = (long)p.N * p.H * p.W;
+  const float b0 = bias ? bias[0] : 0.f;
+  for (int pass = 0; pass < kThinPasses; ++pass) {
+    const long m = ((long)blockIdx.x * kThinPasses + pass) * ppb + pl;
+    const bool on = m < M;
+    const long mm = on ? m : 0;
+    const int w = mm % p.W; const long t = mm / p.W; const int h = t % p.H; const int n = t / p.H;
+    float acc = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      int hs, ws;
+      if (!thin_src(p, h, w, tap / 3, tap % 3, &hs, &ws)) continue;
+      const float4 a = *reinterpret_cast<const float4*>(V + (((size_t)n * p.H + hs) * p.W + ws) * p.C + cq * 4);
+      acc = fmaf(a.x, wv[tap].x, acc); acc = fmaf(a.y, wv[tap].y, acc);
+      acc = fmaf(a.z, wv[tap].z, acc); acc = fmaf(a.w, wv[tap].w, acc);
     }
+    for (int o = C4 >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);     // the C4 lanes of a pixel are adjacent
+    if (on && cq == 0) out[m] = acc + b0;
   }
-  out[m] = acc;
 }
 
 // Wct: [C][9] (packed [C][R][S][1])
 __global__ __launch_bounds__(256) void thin_scalar2vec_kernel(const float* __restrict__ S, const float* __restrict__ Wct,
                                                               const float* __restrict__ bias, float* __restrict__ out,
                                                               ThinParams p) {
-  const int C4 = p.C / 4;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long M = (long)p.N * p.H * p.W;
-  if (i >= M * C4) return;
-  const int c = (int)(i % C4) * 4;
-  const long m = i / C4;
-  const int w = m % p.W; const long t = m / p.W; const int h = t % p.H; const int n = t / p.H;
-  float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0, 0, 0, 0);
+  const int C4 = p.C / 4, ppb = 256 / C4;
+  const int cq = threadIdx.x % C4, pl = threadIdx.x / C4;
+  const int c = cq * 4;
+  float4 wv[9];
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    int hs, ws;
-    if (!thin_src(p, h, w, tap / 3, tap % 3, &hs, &ws)) continue;
-    const float sv = S[((size_t)n * p.H + hs) * p.W + ws];
-    acc.x = fmaf(sv, Wct[(c + 0) * 9 + tap], acc.x); acc.y = fmaf(sv, Wct[(c + 1) * 9 + tap], acc.y);
-    acc.z = fmaf(sv, Wct[(c + 2) * 9 + tap], acc.z); acc.w = fmaf(sv, Wct[(c + 3) * 9 + tap], acc.w);
+  for (int tap = 0; tap < 9; ++tap)
+    wv[tap] = make_float4(Wct[(c + 0) * 9 + tap], Wct[(c + 1) * 9 + tap], Wct[(c + 2) * 9 + tap], Wct[(c + 3) * 9 + tap]);
+  const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0, 0, 0, 0);
+  const long M = (long)p.N * p.H * p.W;
+  for (int pass = 0; pass < kThinPasses; ++pass) {
+    const long m = ((long)blockIdx.x * kThinPasses + pass) * ppb + pl;
+    if (m >= M) break;
+    const int w = m % p.W; const long t = m / p.W; const int h = t % p.H; const int n = t / p.H;
+    float4 acc = b4;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      int hs, ws;
+      if (!thin_src(p, h, w, tap / 3, tap % 3, &hs, &ws)) continue;
+      const float sv = S[((size_t)n * p.H + hs) * p.W + ws];
+      acc.x = fmaf(sv, wv[tap].x, acc.x); acc.y = fmaf(sv, wv[tap].y, acc.y);
+      acc.z = fmaf(sv, wv[tap].z, acc.z); acc.w = fmaf(sv, wv[tap].w, acc.w);
+    }
+    *reinterpret_cast<float4*>(out + m * p.C + c) = acc;
   }
-  *reinterpret_cast<float4*>(out + m * p.C + c) = acc;
 }
 
 // slabs[chunk][c][tap];  scalar_at_src = 0: S = dy[m], V = x[src(m,tap)]   (wgrad Cout = 1)
@@ -1233,6 +1249,7 @@ static bool thin_ok(const xas_conv_shape* s, int C) {
          (256 % (C / 4)) == 0 && s->Ho == s->Hi && s->Wo == s->Wi;
 }
 constexpr int kThinChunk = 2048;
+static inline unsigned thin_grid(long M, int C) { return (unsigned)cdiv(M, (long)kThinPasses * (256 / (C / 4))); }
 
 // ------------------------------------------------------------------------------------
 // direct (VALU) fallbacks for shapes the MFMA tiles do not cover (Cin = 1 / 3, Cout = 1)
@@ -1425,14 +1442,14 @@ extern "C" int xas_conv_fwd(const float* x, const float* w_packed, const float* 
   if (s->Cout == 1 && thin_ok(s, s->Cin)) {
     ThinParams tp{s->N, s->Hi, s->Wi, s->Cin, s->pad, 0};
     const long M = (long)s->N * s->Hi * s->Wi;
-    hipLaunchKernelGGL(thin_vec2scalar_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, x, w_packed, bias, y, tp);
+    hipLaunchKernelGGL(thin_vec2scalar_kernel, dim3(thin_grid(M, s->Cin)), dim3(256), 0, st, x, w_packed, bias, y, tp);
     XAS_LAUNCH_CHECK();
     return 0;
   }
   if (s->Cin == 1 && thin_ok(s, s->Cout)) {
     ThinParams tp{s->N, s->Hi, s->Wi, s->Cout, s->pad, 0};
     const long M = (long)s->N * s->Hi * s->Wi;
-    hipLaunchKernelGGL(thin_scalar2vec_kernel, dim3((unsigned)cdiv(M * (s->Cout / 4), 256)), dim3(256), 0, st, x, w_packed,
+    hipLaunchKernelGGL(thin_scalar2vec_kernel, dim3(thin_grid(M, s->Cout)), dim3(256), 0, st, x, w_packed,
                        bias, y, tp);
     XAS_LAUNCH_CHECK();
     return 0;
@@ -1464,14 +1481,14 @@ extern "C" int xas_conv_dgrad(const float* dy, const float* w_packed_t, float* d
   if (s->Cin == 1 && thin_ok(s, s->Cout)) {          // dx[m] = sum dy[src] . wt[0][tap][:]
     ThinParams tp{s->N, s->Hi, s->Wi, s->Cout, s->pad, 1};
     const long M = (long)s->N * s->Hi * s->Wi;
-    hipLaunchKernelGGL(thin_vec2scalar_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, st, dy, w_packed_t, nullptr, dx, tp);
+    hipLaunchKernelGGL(thin_vec2scalar_kernel, dim3(thin_grid(M, s->Cout)), dim3(256), 0, st, dy, w_packed_t, nullptr, dx, tp);
     XAS_LAUNCH_CHECK();
     return 0;
   }
   if (s->Cout == 1 && thin_ok(s, s->Cin)) {          // dx[m][ci] = sum dy[src] * wt[ci][tap]
     ThinParams tp{s->N, s->Hi, s->Wi, s->Cin, s->pad, 1};
     const long M = (long)s->N * s->Hi * s->Wi;
-    hipLaunchKernelGGL(thin_scalar2vec_kernel, dim3((unsigned)cdiv(M * (s->Cin / 4), 256)), dim3(256), 0, st, dy,
+    hipLaunchKernelGGL(thin_scalar2vec_kernel, dim3(thin_grid(M, s->Cin)), dim3(256), 0, st, dy,
                        w_packed_t, nullptr, dx, tp);
     XAS_LAUNCH_CHECK();
     return 0;
