@@ -31,12 +31,12 @@ static int col_geom(long M, int C, ColGeom* g) {
   return 0;
 }
 
-template <int MODE>   // 0: stats of x around pivot ; 1: bn backward sums ; 2: plain column sums of x ;
+template <int MODE, int UNR = 4>   // 0: stats of x around pivot ; 1: bn backward sums ; 2: plain column sums of x ;
                       // 3: bn backward sums WITHOUT x: xhat = (z - beta)/gamma with z recovered from y (act != 0)
-__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                         const float* __restrict__ dy, const float* __restrict__ mean,
-                                                         const float* __restrict__ var, float eps, int act, long M,
-                                                         int C, ColGeom g, float* __restrict__ partial) {
+__device__ __forceinline__ void col_reduce_body(const float* __restrict__ x, const float* __restrict__ y,
+                                                const float* __restrict__ dy, const float* __restrict__ mean,
+                                                const float* __restrict__ var, float eps, int act, long M,
+                                                int C, ColGeom g, float* __restrict__ partial) {
   __shared__ float4 red[2][256];
   const int tx = threadIdx.x % g.TX, ty = threadIdx.x / g.TX;
   const int c = blockIdx.y * g.CB + tx * 4;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
     const float4 v = *reinterpret_cast<const float4*>(var + c);
     p1 = make_float4(rsqrtf(v.x + eps), rsqrtf(v.y + eps), rsqrtf(v.z + eps), rsqrtf(v.w + eps));
   }
-#pragma unroll 4
+#pragma unroll UNR
   for (long r = r0 + ty; r < r1; r += g.TY) {
     if (MODE == 3) {
       float4 g4 = *reinterpret_cast<const float4*>(dy + r * C + c);
@@ -111,6 +111,24 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
     *reinterpret_cast<float4*>(o) = red[0][tx];
     *reinterpret_cast<float4*>(o + C) = red[1][tx];
   }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ dy, const float* __restrict__ mean,
+                                                         const float* __restrict__ var, float eps, int act, long M,
+                                                         int C, ColGeom g, float* __restrict__ partial) {
+  col_reduce_body<MODE, 4>(x, y, dy, mean, var, eps, act, M, C, g, partial);
+}
+
+// Same kernel compiled for at most 64 VGPRs (the shipped one for the backward sums): in the backward pass it runs beside two
+// weight-gradient blocks per CU, which leave 112 VGPRs per SIMD lane - room for two lean waves instead of one.
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void col_reduce_lean_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                            const float* __restrict__ mean, const float* __restrict__ var, float eps, int act, long M,
+                            int C, ColGeom g, float* __restrict__ partial) {
+  col_reduce_body<MODE, 2>(x, y, dy, mean, var, eps, act, M, C, g, partial);
 }
 
 // partial: [nslab][2][C] -> out1[c], out2[c]; MODE 0 converts pivot sums to mean / biased var and, when
@@ -469,12 +487,13 @@ extern "C" int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy
               "bn_bwd_reduce: null buffer");
   XAS_REQUIRE(x || (act != 0 && y && gamma && beta), "bn_bwd_reduce: without x the layer needs an activation, y, gamma, beta");
   XAS_REQUIRE((dbeta_acc == nullptr) == (dgamma_acc == nullptr), "bn_bwd_reduce: gradient accumulators come in pairs");
+  const bool lean = (tune_flags() & 262144) == 0;      // shipped: the <= 64-VGPR build (tune bit18 selects the 86-VGPR one)
   if (x) {
-    hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(g.nslab, g.ncb), dim3(256), 0, as_stream(stream), x, y, dy, mean,
-                       var_biased, eps, act, M, C, g, workspace);
+    hipLaunchKernelGGL(lean ? col_reduce_lean_kernel<1> : col_reduce_kernel<1>, dim3(g.nslab, g.ncb), dim3(256), 0,
+                       as_stream(stream), x, y, dy, mean, var_biased, eps, act, M, C, g, workspace);
   } else {            // x-free form: xhat recovered from the saved output (one activation tensor less to read)
-    hipLaunchKernelGGL(col_reduce_kernel<3>, dim3(g.nslab, g.ncb), dim3(256), 0, as_stream(stream), y, y, dy, beta,
-                       gamma, eps, act, M, C, g, workspace);
+    hipLaunchKernelGGL(lean ? col_reduce_lean_kernel<3> : col_reduce_kernel<3>, dim3(g.nslab, g.ncb), dim3(256), 0,
+                       as_stream(stream), y, y, dy, beta, gamma, eps, act, M, C, g, workspace);
   }
   XAS_LAUNCH_CHECK();
   hipLaunchKernelGGL(col_finalize_kernel<1>, dim3((unsigned)cdiv(C, 64)), dim3(kFinalizeThreads), 0, as_stream(stream), workspace, x,
