@@ -21,6 +21,7 @@ for p in (ROOT, os.path.join(ROOT, 'x-as-supervision_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC only on this driver: RCCL needs it (multi-process runs)
 import torch
 import torch.distributed as dist
 

@@ -17,6 +17,8 @@ import os
 from argparse import ArgumentParser
 
 import numpy as np
+
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC (RCCL between processes) on this driver
 import torch
 import yaml
 from torch.distributed import destroy_process_group, init_process_group

@@ -16,6 +16,8 @@ from argparse import ArgumentParser
 from time import gmtime, strftime
 
 import numpy as np
+
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC (RCCL between processes) on this driver
 import torch
 import yaml
 from torch.distributed import destroy_process_group, init_process_group
