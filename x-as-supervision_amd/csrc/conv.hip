@@ -867,7 +867,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 //             plus a per-thread constant; each float4 adds a precomputed (tap, channel) offset and is sent to the
 //             out-of-range offset when its tap falls outside the image (hardware returns zeros).
 // ------------------------------------------------------------------------------------
-template <int BM, int BN, int T>
+template <int BM, int BN, int T, bool PIPE>
 __global__ __launch_bounds__(256) void wgrad_buf_kernel(WgradParams p) {
   using C = TileCfg<BM, BN>;
   constexpr int LDA = BM + 4, LDB = BN + 32;         // LDB = 32 mod 64: the two 32-float rows of a b128 store group hit disjoint banks
@@ -926,8 +926,7 @@ __global__ __launch_bounds__(256) void wgrad_buf_kernel(WgradParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  float4 ra4[APASS], rb4[BPASS];
-  auto load_step = [&](int mk) {                     // mk: first pixel of the K-step (uniform)
+  auto load_step = [&](int mk, float4 (&ra4)[APASS], float4 (&rb4)[BPASS]) {   // mk: first pixel of the K-step (uniform)
     const unsigned soffA = (unsigned)mk * (unsigned)p.Cout * 4u;
 #pragma unroll
     for (int j = 0; j < APASS; ++j) ra4[j] = buf_load16(rsrcA, voffA, soffA + j * passA);
@@ -951,7 +950,7 @@ __global__ __launch_bounds__(256) void wgrad_buf_kernel(WgradParams p) {
       for (int q = 0; q < GQ; ++q) rb4[g * GQ + q] = buf_load16(rsrcB, off, (unsigned)(q * 128));
     }
   };
-  auto store_step = [&](int buf) {
+  auto store_step = [&](int buf, const float4 (&ra4)[APASS], const float4 (&rb4)[BPASS]) {
     float* a = As + buf * WBK * LDA;
     float* b = Bs + buf * WBK * LDB;
 #pragma unroll
@@ -962,15 +961,10 @@ __global__ __launch_bounds__(256) void wgrad_buf_kernel(WgradParams p) {
   };
 
   // MFMA operands: a wave with two 32-row tiles (MI == 2) takes tile rows 2i and 2i+1 for lane i, so both come from
-  // ONE 8-byte LDS read at a compile-time offset (no address arithmetic in the loop); same for the columns.
+  // ONE 8-byte LDS read at a compile-time offset; same for the columns.
   const int i = lane & 31, h = lane >> 5;
   const int nsteps = (mend > mbeg) ? (mend - mbeg + WBK - 1) / WBK : 0;
-  if (nsteps > 0) load_step(mbeg);
-  for (int st = 0; st < nsteps; ++st) {
-    const int buf = st & 1;
-    store_step(buf);
-    __syncthreads();
-    if (st + 1 < nsteps) load_step(mbeg + (st + 1) * WBK);
+  auto mfma_step = [&](int buf) {
     const float* a = As + buf * WBK * LDA + h * LDA + wm * C::WM + C::MI * i;
     const float* b = Bs + buf * WBK * LDB + h * LDB + wn * C::WN + C::NI * i;
 #pragma unroll
@@ -993,6 +987,52 @@ __global__ __launch_bounds__(256) void wgrad_buf_kernel(WgradParams p) {
 #pragma unroll
         for (int ni = 0; ni < C::NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+    }
+  };
+  float4 ra4_0[APASS], rb4_0[BPASS];
+  if constexpr (PIPE) {
+    // Two register sets, loads three K-steps ahead; the LDS stores of step st+1 and the loads of step st+3 are issued
+    // inside the MFMA sequence of step st (see igemm_buf_kernel).  Steps past the end re-load the last one.
+    float4 ra4_1[APASS], rb4_1[BPASS];
+    const int last = nsteps - 1;
+    auto mk_of = [&](int st) { return mbeg + (st < last ? st : last) * WBK; };
+    auto pstep = [&](int buf, float4 (&ra4)[APASS], float4 (&rb4)[BPASS], int st_load) {
+      __syncthreads();
+      mfma_step(buf);
+      store_step(buf ^ 1, ra4, rb4);
+      load_step(mk_of(st_load), ra4, rb4);
+      constexpr int NMF = C::MI * C::NI, NST = APASS + BPASS;
+#pragma unroll
+      for (int kk = 0; kk < WBK / 2; ++kk) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+        if (kk < NST) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        else if (kk - NST < NST) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    };
+    if (nsteps > 0) {
+      load_step(mk_of(0), ra4_0, rb4_0);
+      load_step(mk_of(1), ra4_1, rb4_1);
+      store_step(0, ra4_0, rb4_0);
+      load_step(mk_of(2), ra4_0, rb4_0);
+      int st = 0;
+      for (; st + 1 < nsteps; st += 2) {
+        pstep(0, ra4_1, rb4_1, st + 3);
+        pstep(1, ra4_0, rb4_0, st + 4);
+      }
+      if (st < nsteps) {
+        __syncthreads();
+        mfma_step(0);
+      }
+    }
+  } else {
+    if (nsteps > 0) load_step(mbeg, ra4_0, rb4_0);
+    for (int st = 0; st < nsteps; ++st) {
+      const int buf = st & 1;
+      store_step(buf, ra4_0, rb4_0);
+      __syncthreads();
+      if (st + 1 < nsteps) load_step(mbeg + (st + 1) * WBK, ra4_0, rb4_0);
+      mfma_step(buf);
     }
   }
   static_assert(C::MI <= 2 && C::NI <= 2, "interleaved fragment scheme handles at most two tiles per wave and dimension");
@@ -1565,13 +1605,14 @@ static int launch_wgrad(const WgradParams& p, int splits, hipStream_t st) {
   return 0;
 }
 
-template <int BM, int BN, int T>
+template <int BM, int BN, int T, bool PIPE = true>
 static int launch_wgrad_buf_t(const WgradParams& p, int splits, hipStream_t st) {
+  if (PIPE && (g_tune & 524288)) return launch_wgrad_buf_t<BM, BN, T, false>(p, splits, st);   // tune bit19: plain K-loop
   size_t lds = (size_t)2 * WBK * ((BM + 4) + (BN + 32)) * sizeof(float);
   if ((g_tune & 131072) && lds < 84 * 1024) lds = 84 * 1024;     // experiment (bit17): one block per CU
   static size_t attr_set = 0;
   if (attr_set < lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_buf_kernel<BM, BN, T>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_buf_kernel<BM, BN, T, PIPE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = lds;
   }
@@ -1581,7 +1622,7 @@ static int launch_wgrad_buf_t(const WgradParams& p, int splits, hipStream_t st) 
   q.nsplits = splits;
   q.tune = g_tune;
   dim3 grid((unsigned)((g_tune & 8192) ? 8 * cdiv(splits, 8) * q.ntiles : splits * q.ntiles));
-  hipLaunchKernelGGL((wgrad_buf_kernel<BM, BN, T>), grid, dim3(256), lds, st, q);
+  hipLaunchKernelGGL((wgrad_buf_kernel<BM, BN, T, PIPE>), grid, dim3(256), lds, st, q);
   XAS_LAUNCH_CHECK();
   return 0;
 }
