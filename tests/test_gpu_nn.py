@@ -60,6 +60,22 @@ def test_conv2d_fwd_bwd(n, cin, h, w, cout, k, stride, pad):
     assert rel(m.bias.grad, bc.grad) < 3e-6
 
 
+@pytest.mark.parametrize('tune,what', [(32, 'plain K-loop, buffer loads'), (64 | 128, 'global-load kernels (>= 2 GiB fallback)'),
+                                       (64 | 128 | 32, 'global-load kernels, plain loop'), (524288, 'plain weight-gradient loop'),
+                                       (8192, 'XCD-grouped weight-gradient order')])
+def test_conv_kernel_variants(tune, what):
+    """Every conv kernel variant that stays in the library (fallbacks for tensors the 32-bit buffer offsets cannot
+    address, the non-pipelined loops, the alternative block order) gives the same results as the shipped ones."""
+    from xas_amd import _lib
+    try:
+        _lib.query('xas_set_tuning', tune)
+        for case in (CONV_CASES[1], CONV_CASES[2], CONV_CASES[3], CONV_CASES[8], (2, 64, 40, 24, 160, 3, 1, 1)):
+            test_conv2d_fwd_bwd(*case)
+        test_conv_transpose2d(2, 256, 8, 256)
+    finally:
+        _lib.query('xas_set_tuning', 0)
+
+
 @pytest.mark.parametrize('h,w', [(64, 64), (50, 70), (256, 256)])
 def test_stem_conv_mfma(h, w):
     """7x7 s2 p3, 3 -> 64, no bias: the dedicated MFMA stem kernel (resnet.py:16)."""
