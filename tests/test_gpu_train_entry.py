@@ -40,3 +40,13 @@ def test_train_entry_synthetic(tmp_path):
     # resume (finetune mode restarts at epoch 0 in a new directory)
     r = subprocess.run(base + ['--checkpoint', str(ckpt), '--finetune'], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
+    # evaluate the checkpoint with the mirrored eval entry (synthetic consistent scene): result file as the reference's
+    ev = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
+          '--master-port', '29542', os.path.join(PKG, 'eval.py'), '--config', str(cfg_path), '--checkpoint', str(ckpt),
+          '--synthetic', '2', '--batch_size', '2', '--multi_hypo', 'best']
+    r = subprocess.run(ev, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = (tmp_path / 'log' / runs[0] / 'eval' / 'eval_result.txt').read_text().split('\n')
+    assert res[0].startswith('2D MSE: ') and any(l.startswith('TRI P-MPJPE: ') for l in res)
+    assert '--------select---------' in res
+    assert 'Ambiguity Ratio' in r.stdout

@@ -85,7 +85,8 @@ def model_config(name='HM36_Multi_SurS1'):
     tp = {'num_epochs': 15 if s2 else 50, 'batch_size': 32, 'epoch_milestones': [40],
           'lr_kp_detector': 1.0e-4 if s2 else 2.0e-4, 'lr_discriminator': 1.0e-4 if s2 else 2.0e-4,
           'checkpoint_freq': 2 if s2 else 20, 'patch_width': 256, 'patch_height': 256}
-    return {'dataset_params': {'cam_id_list': cams}, 'model_params': mp, 'train_params': tp}
+    ds = {'name': 'mpi_inf_3dhp' if name.startswith('MPI') else 'hm36'}           # config/*.yaml:3-4 (eval.py:73 reads it)
+    return {'dataset_params': {'dataset': ds, 'cam_id_list': cams}, 'model_params': mp, 'train_params': tp}
 
 
 def synthetic_eval_batch(B, cam_ids, device, seed=0, S=256, K=18, rect=2000.0):
