@@ -964,23 +964,32 @@ __global__ __launch_bounds__(256) void wgrad_buf_kernel(WgradParams p) {
   // ONE 8-byte LDS read at a compile-time offset; same for the columns.
   const int i = lane & 31, h = lane >> 5;
   const int nsteps = (mend > mbeg) ? (mend - mbeg + WBK - 1) / WBK : 0;
+  // Even and odd k-pairs are addressed from two bases whose distance the compiler cannot see: otherwise it merges
+  // neighbouring fragment reads into ds_read2 (8-bit offsets) and then needs a v_add per pair to move the base,
+  // 16-22 VALU instructions per K-step; this way every read is one ds_read with a 16-bit immediate offset.
+  int odd_a = 2 * LDA, odd_b = 2 * LDB;
+  asm volatile("" : "+v"(odd_a), "+v"(odd_b));
   auto mfma_step = [&](int buf) {
     const float* a = As + buf * WBK * LDA + h * LDA + wm * C::WM + C::MI * i;
     const float* b = Bs + buf * WBK * LDB + h * LDB + wn * C::WN + C::NI * i;
+    const float* a2 = a + odd_a;
+    const float* b2 = b + odd_b;
 #pragma unroll
     for (int kk = 0; kk < WBK / 2; ++kk) {
       float av[C::MI], bv[C::NI];
+      const float* ap = (kk & 1) ? a2 + (kk - 1) * 2 * LDA : a + kk * 2 * LDA;
+      const float* bp = (kk & 1) ? b2 + (kk - 1) * 2 * LDB : b + kk * 2 * LDB;
       if constexpr (C::MI == 2) {
-        const float2 t = *reinterpret_cast<const float2*>(a + 2 * kk * LDA);
+        const float2 t = *reinterpret_cast<const float2*>(ap);
         av[0] = t.x; av[1] = t.y;
       } else {
-        av[0] = a[2 * kk * LDA];
+        av[0] = ap[0];
       }
       if constexpr (C::NI == 2) {
-        const float2 t = *reinterpret_cast<const float2*>(b + 2 * kk * LDB);
+        const float2 t = *reinterpret_cast<const float2*>(bp);
         bv[0] = t.x; bv[1] = t.y;
       } else {
-        bv[0] = b[2 * kk * LDB];
+        bv[0] = bp[0];
       }
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
