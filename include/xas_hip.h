@@ -27,7 +27,16 @@ extern "C" {
 #endif
 
 const char* xas_last_error(void);
-/* kernel-tuning experiment flags (benchmarks only; 0 = shipped configuration) */
+/* Kernel-tuning experiment flags for A/B measurements (tools/ab_step.py, tools/bench_conv.py); 0 = the shipped
+ * configuration, results are identical under every flag (tests/test_gpu_nn.py::test_conv_kernel_variants).
+ *   4       plain (not XCD-aware) tile order in fwd / dgrad
+ *   32      plain K-loop in fwd / dgrad instead of the pipelined one      524288  same for the weight gradient
+ *   64      global-load fwd / dgrad kernels (the >= 2 GiB fallback)       128     same for the weight gradient
+ *   256/512 weight-gradient split target 512 / 256 blocks (768: 2048)     1024    force 64x64 weight-gradient tiles
+ *   8192    all tiles of a weight-gradient pixel split on one XCD         16384   1024-thread slab-reduce blocks
+ *   32768 / 65536 / 98304  column-reduce slab target 512 / 128 / 64       131072  one weight-gradient block per CU
+ *   262144  86-VGPR build of the backward column sums
+ *   8, 16, 4096  K-loop ablations, diagnostic build only (tools/build_diag.py) */
 int xas_set_tuning(int flags);
 /* diagnostic builds: device buffer of 8 uint64 that the igemm kernels add per-phase cycle sums to (NULL = off) */
 int xas_set_debug_buffer(void* device_ptr);
