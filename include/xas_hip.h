@@ -177,7 +177,8 @@ int xas_bn_update_running(const float* mean, const float* var_biased, float* run
 /* backward, step 1: dz = dy * act'(y); sum_dz[c], sum_dz_xhat[c]  (and dresidual = dz).
  * x may be NULL when the layer has an activation and no residual: xhat is then recovered from the saved output,
  * xhat = (act^-1(y) - beta) / gamma (needed only where dz != 0), one activation tensor less to read per pass.
- * See below for dbeta_acc / dgamma_acc. */
+ * y may be NULL instead (x, gamma, beta given, no residual): the activation mask is then re-derived from x with the
+ * forward's exact arithmetic and the backward never reads y.  See below for dbeta_acc / dgamma_acc. */
 int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy, const float* mean,
                       const float* var_biased, const float* gamma, const float* beta, float eps, int act,
                       long M, int C,

@@ -10,6 +10,12 @@
 
 namespace xas {
 
+// z = (x - mean) * (rstd * gamma) + beta with a FIXED operation order (no compiler-chosen contraction), so the
+// backward kernels that re-derive the ReLU mask from x reproduce the forward decision bit for bit.
+__device__ __forceinline__ float bn_affine(float x, float m, float rs_g, float b) {
+  return __fmaf_rn(__fsub_rn(x, m), rs_g, b);
+}
+
 // ---------------------------------------------------------------- column reductions
 // x is [M][C]; a block owns CB = min(C,256) channels (TX = CB/4 lanes along C) and a slab
 // of rows; it emits per channel sum(f1), sum(f2) of two per-element functions.
@@ -33,10 +39,13 @@ static int col_geom(long M, int C, ColGeom* g) {
 
 template <int MODE, int UNR = 4>   // 0: stats of x around pivot ; 1: bn backward sums ; 2: plain column sums of x ;
                       // 3: bn backward sums WITHOUT x: xhat = (z - beta)/gamma with z recovered from y (act != 0)
+                      // 4: bn backward sums WITHOUT y: the activation mask is re-derived from x (`y` carries gamma,
+                      //    `aux` carries beta)
 __device__ __forceinline__ void col_reduce_body(const float* __restrict__ x, const float* __restrict__ y,
                                                 const float* __restrict__ dy, const float* __restrict__ mean,
                                                 const float* __restrict__ var, float eps, int act, long M,
-                                                int C, ColGeom g, float* __restrict__ partial) {
+                                                int C, ColGeom g, float* __restrict__ partial,
+                                                const float* __restrict__ aux = nullptr) {
   __shared__ float4 red[2][256];
   const int tx = threadIdx.x % g.TX, ty = threadIdx.x / g.TX;
   const int c = blockIdx.y * g.CB + tx * 4;
@@ -44,7 +53,15 @@ __device__ __forceinline__ void col_reduce_body(const float* __restrict__ x, con
   const long r1 = min(M, r0 + g.rows_per_slab);
   float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
   float4 p0, p1;   // MODE 0: pivot ; MODE 1: mean, invstd
-  if (MODE == 0) {
+  float4 rsg = make_float4(0, 0, 0, 0), bt = make_float4(0, 0, 0, 0);      // MODE 4: rstd * gamma, beta
+  if (MODE == 4) {
+    p0 = *reinterpret_cast<const float4*>(mean + c);
+    const float4 v = *reinterpret_cast<const float4*>(var + c);
+    p1 = make_float4(rsqrtf(v.x + eps), rsqrtf(v.y + eps), rsqrtf(v.z + eps), rsqrtf(v.w + eps));
+    const float4 gm = *reinterpret_cast<const float4*>(y + c);
+    rsg = make_float4(__fmul_rn(p1.x, gm.x), __fmul_rn(p1.y, gm.y), __fmul_rn(p1.z, gm.z), __fmul_rn(p1.w, gm.w));
+    bt = *reinterpret_cast<const float4*>(aux + c);
+  } else if (MODE == 0) {
     p0 = *reinterpret_cast<const float4*>(x + c);          // pivot = first row
     p1 = p0;
   } else if (MODE == 2) {
@@ -76,6 +93,16 @@ __device__ __forceinline__ void col_reduce_body(const float* __restrict__ x, con
       continue;
     }
     const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c);
+    if (MODE == 4) {
+      float4 g4 = *reinterpret_cast<const float4*>(dy + r * C + c);
+      const float neg = act == 1 ? 0.f : 0.01f;
+      g4.x *= bn_affine(xv.x, p0.x, rsg.x, bt.x) > 0.f ? 1.f : neg; g4.y *= bn_affine(xv.y, p0.y, rsg.y, bt.y) > 0.f ? 1.f : neg;
+      g4.z *= bn_affine(xv.z, p0.z, rsg.z, bt.z) > 0.f ? 1.f : neg; g4.w *= bn_affine(xv.w, p0.w, rsg.w, bt.w) > 0.f ? 1.f : neg;
+      s1.x += g4.x; s1.y += g4.y; s1.z += g4.z; s1.w += g4.w;
+      s2.x = fmaf(g4.x, (xv.x - p0.x) * p1.x, s2.x); s2.y = fmaf(g4.y, (xv.y - p0.y) * p1.y, s2.y);
+      s2.z = fmaf(g4.z, (xv.z - p0.z) * p1.z, s2.z); s2.w = fmaf(g4.w, (xv.w - p0.w) * p1.w, s2.w);
+      continue;
+    }
     if (MODE == 2) {
       s1.x += xv.x; s1.y += xv.y; s1.z += xv.z; s1.w += xv.w;
     } else if (MODE == 0) {
@@ -117,8 +144,9 @@ template <int MODE>
 __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ dy, const float* __restrict__ mean,
                                                          const float* __restrict__ var, float eps, int act, long M,
-                                                         int C, ColGeom g, float* __restrict__ partial) {
-  col_reduce_body<MODE, 4>(x, y, dy, mean, var, eps, act, M, C, g, partial);
+                                                         int C, ColGeom g, float* __restrict__ partial,
+                                                         const float* __restrict__ aux = nullptr) {
+  col_reduce_body<MODE, 4>(x, y, dy, mean, var, eps, act, M, C, g, partial, aux);
 }
 
 // Same kernel compiled for at most 64 VGPRs (the shipped one for the backward sums): in the backward pass it runs beside two
@@ -127,8 +155,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void col_reduce_lean_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                             const float* __restrict__ mean, const float* __restrict__ var, float eps, int act, long M,
-                            int C, ColGeom g, float* __restrict__ partial) {
-  col_reduce_body<MODE, 2>(x, y, dy, mean, var, eps, act, M, C, g, partial);
+                            int C, ColGeom g, float* __restrict__ partial, const float* __restrict__ aux = nullptr) {
+  col_reduce_body<MODE, 2>(x, y, dy, mean, var, eps, act, M, C, g, partial, aux);
 }
 
 // partial: [nslab][2][C] -> out1[c], out2[c]; MODE 0 converts pivot sums to mean / biased var and, when
@@ -205,10 +233,10 @@ __global__ void bn_apply_kernel(const float4* __restrict__ x, const float* __res
     const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
     const float4 xv = x[i];
     float4 o;
-    o.x = (xv.x - m.x) * (rsqrtf(v.x + eps) * g.x) + b.x;
-    o.y = (xv.y - m.y) * (rsqrtf(v.y + eps) * g.y) + b.y;
-    o.z = (xv.z - m.z) * (rsqrtf(v.z + eps) * g.z) + b.z;
-    o.w = (xv.w - m.w) * (rsqrtf(v.w + eps) * g.w) + b.w;
+    o.x = bn_affine(xv.x, m.x, __fmul_rn(rsqrtf(v.x + eps), g.x), b.x);
+    o.y = bn_affine(xv.y, m.y, __fmul_rn(rsqrtf(v.y + eps), g.y), b.y);
+    o.z = bn_affine(xv.z, m.z, __fmul_rn(rsqrtf(v.z + eps), g.z), b.z);
+    o.w = bn_affine(xv.w, m.w, __fmul_rn(rsqrtf(v.w + eps), g.w), b.w);
     if (res) { const float4 r = res[i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
     o.x = act_fwd(o.x, act); o.y = act_fwd(o.y, act); o.z = act_fwd(o.z, act); o.w = act_fwd(o.w, act);
     y[i] = o;
@@ -228,11 +256,19 @@ __global__ void bn_bwd_apply_kernel(const float4* __restrict__ x, const float4* 
     const float4 a = *reinterpret_cast<const float4*>(sdz + c), b = *reinterpret_cast<const float4*>(sdzx + c);
     float4 dz = dy[i];
     float4 yv = make_float4(0, 0, 0, 0);
-    if (act) {
+    if (act && y) {
       yv = y[i];
       const float neg = act == 1 ? 0.f : 0.01f;
       dz.x *= yv.x > 0.f ? 1.f : neg; dz.y *= yv.y > 0.f ? 1.f : neg;
       dz.z *= yv.z > 0.f ? 1.f : neg; dz.w *= yv.w > 0.f ? 1.f : neg;
+    } else if (act) {                                      // y not read: the mask is re-derived from x (no residual)
+      const float4 xv = x[i];
+      const float4 bt = *reinterpret_cast<const float4*>(beta + c);
+      const float neg = act == 1 ? 0.f : 0.01f;
+      dz.x *= bn_affine(xv.x, m.x, __fmul_rn(rsqrtf(v.x + eps), g.x), bt.x) > 0.f ? 1.f : neg;
+      dz.y *= bn_affine(xv.y, m.y, __fmul_rn(rsqrtf(v.y + eps), g.y), bt.y) > 0.f ? 1.f : neg;
+      dz.z *= bn_affine(xv.z, m.z, __fmul_rn(rsqrtf(v.z + eps), g.z), bt.z) > 0.f ? 1.f : neg;
+      dz.w *= bn_affine(xv.w, m.w, __fmul_rn(rsqrtf(v.w + eps), g.w), bt.w) > 0.f ? 1.f : neg;
     }
     if (dres) dres[i] = dz;
     float4 xh;                                             // normalised input
@@ -483,17 +519,21 @@ extern "C" int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy
                                  float* dbeta_acc, float* dgamma_acc, void* stream) {
   ColGeom g;
   if (col_geom(M, C, &g)) return 1;
-  XAS_REQUIRE(dy && mean && var_biased && sum_dz && sum_dz_xhat && workspace && (act == 0 || y),
-              "bn_bwd_reduce: null buffer");
+  XAS_REQUIRE(dy && mean && var_biased && sum_dz && sum_dz_xhat && workspace && (act == 0 || y || (x && gamma && beta)),
+              "bn_bwd_reduce: null buffer (an activation needs y, or x with gamma and beta)");
   XAS_REQUIRE(x || (act != 0 && y && gamma && beta), "bn_bwd_reduce: without x the layer needs an activation, y, gamma, beta");
   XAS_REQUIRE((dbeta_acc == nullptr) == (dgamma_acc == nullptr), "bn_bwd_reduce: gradient accumulators come in pairs");
   const bool lean = (tune_flags() & 262144) == 0;      // shipped: the <= 64-VGPR build (tune bit18 selects the 86-VGPR one)
+  if (x && act != 0 && y == nullptr) {   // y-free form: activation mask re-derived from x (layers without a residual)
+    hipLaunchKernelGGL(lean ? col_reduce_lean_kernel<4> : col_reduce_kernel<4>, dim3(g.nslab, g.ncb), dim3(256), 0,
+                       as_stream(stream), x, gamma, dy, mean, var_biased, eps, act, M, C, g, workspace, beta);
+  } else
   if (x) {
     hipLaunchKernelGGL(lean ? col_reduce_lean_kernel<1> : col_reduce_kernel<1>, dim3(g.nslab, g.ncb), dim3(256), 0,
-                       as_stream(stream), x, y, dy, mean, var_biased, eps, act, M, C, g, workspace);
+                       as_stream(stream), x, y, dy, mean, var_biased, eps, act, M, C, g, workspace, (const float*)nullptr);
   } else {            // x-free form: xhat recovered from the saved output (one activation tensor less to read)
     hipLaunchKernelGGL(lean ? col_reduce_lean_kernel<3> : col_reduce_kernel<3>, dim3(g.nslab, g.ncb), dim3(256), 0,
-                       as_stream(stream), y, y, dy, beta, gamma, eps, act, M, C, g, workspace);
+                       as_stream(stream), y, y, dy, beta, gamma, eps, act, M, C, g, workspace, (const float*)nullptr);
   }
   XAS_LAUNCH_CHECK();
   hipLaunchKernelGGL(col_finalize_kernel<1>, dim3((unsigned)cdiv(C, 64)), dim3(kFinalizeThreads), 0, as_stream(stream), workspace, x,
@@ -506,8 +546,9 @@ extern "C" int xas_bn_bwd_apply(const float* x, const float* y, const float* dy,
                                 const float* var_biased, const float* gamma, const float* beta, const float* sum_dz,
                                 const float* sum_dz_xhat, float eps, int act, long M, int C, double count, float* dx,
                                 float* dresidual, void* stream) {
-  XAS_REQUIRE(dy && mean && var_biased && gamma && sum_dz && sum_dz_xhat && dx && (act == 0 || y),
-              "bn_bwd_apply: null buffer");
+  XAS_REQUIRE(dy && mean && var_biased && gamma && sum_dz && sum_dz_xhat && dx && (act == 0 || y || (x && beta)),
+              "bn_bwd_apply: null buffer (an activation needs y, or x with beta)");
+  XAS_REQUIRE(y || !dresidual || act == 0, "bn_bwd_apply: the y-free form is for layers without a residual");
   XAS_REQUIRE(x || (act == 2 && y && beta),
               "bn_bwd_apply: without x the layer needs an INVERTIBLE activation (leaky ReLU), y and beta: dx needs xhat "
               "of every element, also where ReLU clipped the output");

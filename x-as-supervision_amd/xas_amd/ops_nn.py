@@ -1,6 +1,8 @@
 """Layer ops (conv / conv-transpose / linear / batch-norm / pool / upsample / sigmoid) as
 autograd Functions over the C ABI.  Activations are torch channels_last tensors: logically
 [N,C,H,W] like the reference, physically NHWC like the kernels want."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -310,16 +312,19 @@ class _BatchNorm(torch.autograd.Function):
         #   reduce pass (sums of dz and dz*xhat): only elements with dz != 0 matter -> any activation, no residual;
         #   apply pass (dx needs xhat of EVERY element): only an invertible activation (leaky ReLU); then x is
         #   not kept alive at all.
-        xfree_reduce = training and act != ACT_NONE and residual is None
-        xfree_apply = xfree_reduce and act == ACT_LEAKY
-        ctx.save_for_backward(y if xfree_apply else x, y, mean, var, gamma, beta)
-        ctx.cfg = (M, c, float(eps), act, count, group, training, residual is not None, xfree_reduce, xfree_apply)
+        #   ReLU without residual: neither pass reads y - the mask is re-derived from x (2 reads + 1 write in the apply
+        #   pass instead of 3 + 1).
+        xfree_reduce = training and act == ACT_LEAKY and residual is None
+        xfree_apply = xfree_reduce
+        yfree = training and act == ACT_RELU and residual is None and os.environ.get('XAS_BN_YFREE', '1') == '1'
+        ctx.save_for_backward(y if xfree_apply else x, x if yfree else y, mean, var, gamma, beta)
+        ctx.cfg = (M, c, float(eps), act, count, group, training, residual is not None, xfree_reduce, xfree_apply, yfree)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, mean, var, gamma, beta = ctx.saved_tensors
-        M, c, eps, act, count, group, training, has_res, xfree_reduce, xfree_apply = ctx.cfg
+        M, c, eps, act, count, group, training, has_res, xfree_reduce, xfree_apply, yfree = ctx.cfg
         if not training:
             raise RuntimeError('batch-norm backward in eval mode is not part of the training path')
         dy = to_cl(dy)
@@ -331,7 +336,7 @@ class _BatchNorm(torch.autograd.Function):
         gg, gb = gamma.grad, beta.grad
         direct = (ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and gg is not None and gb is not None
                   and gg.is_contiguous() and gb.is_contiguous() and gg.dtype == torch.float32 and gb.dtype == torch.float32)
-        call('xas_bn_bwd_reduce', None if xfree_reduce else ptr(x), ptr(y), ptr(dy), ptr(mean), ptr(var), ptr(gamma),
+        call('xas_bn_bwd_reduce', None if xfree_reduce else ptr(x), None if yfree else ptr(y), ptr(dy), ptr(mean), ptr(var), ptr(gamma),
              ptr(beta), eps, act, M, c, ptr(sdz), ptr(sdz[c:]), ptr(ws), ptr(gb) if direct else None,
              ptr(gg) if direct else None)
         if direct:
@@ -344,7 +349,7 @@ class _BatchNorm(torch.autograd.Function):
             dist.all_reduce(sdz, group=group)                 # one coalesced 2C message per layer
         dx = torch.empty_like(y)
         dres = torch.empty_like(y) if has_res else None
-        call('xas_bn_bwd_apply', None if xfree_apply else ptr(x), ptr(y), ptr(dy), ptr(mean), ptr(var), ptr(gamma),
+        call('xas_bn_bwd_apply', None if xfree_apply else ptr(x), None if yfree else ptr(y), ptr(dy), ptr(mean), ptr(var), ptr(gamma),
              ptr(beta), ptr(sdz), ptr(sdz[c:]), eps, act, M, c, float(count), ptr(dx), ptr(dres))
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
 
