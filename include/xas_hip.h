@@ -130,6 +130,9 @@ int xas_conv_fwd(const float* x, const float* w_packed, const float* bias, float
  * with roles swapped.  w_packed_t: [Cin][R][S][Cout] (xas_pack_weight transposed=1). */
 int xas_conv_dgrad(const float* dy, const float* w_packed_t, float* dx,
                    const xas_conv_shape* s, void* stream);
+/* Same, but dx += result: the residual-branch gradient is already in dx (one read-modify-write instead of a
+ * separate gradient-accumulation kernel per bottleneck).  MFMA path only (Cout % 32 == 0, Cin % 4 == 0, Cin >= 16). */
+int xas_conv_dgrad_acc(const float* dy, const float* w_packed_t, float* dx, const xas_conv_shape* shape, void* stream);
 /* dw_packed [Cout][R][S][Cin] (+)= sum_n,ho,wo dy * x ; workspace for split-K partials. */
 size_t xas_conv_wgrad_workspace_floats(const xas_conv_shape* s);
 int xas_conv_wgrad(const float* x, const float* dy, float* dw_packed, float* workspace,

@@ -57,6 +57,7 @@ struct IgemmParams {
   int nMt, nNt, mt_per_xcd;   // tile counts and M-tiles per XCD for the XCD-aware block order
   unsigned long long* dbg;    // diagnostic builds only: per-phase cycle sums (xas_set_debug_buffer)
   long src_elems, wgt_elems;  // sizes of src / wgt (buffer-load kernel: range of the buffer descriptors)
+  int accumulate;             // epilogue: out += result (residual gradient already in the buffer)
 };
 
 static unsigned long long* g_dbg = nullptr;
@@ -226,11 +227,16 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
             const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
             v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
           }
+          if (p.accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(orow_p + n);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
           *reinterpret_cast<float4*>(orow_p + n) = v;
         } else {
           const float vv[4] = {v.x, v.y, v.z, v.w};
           for (int e = 0; e < 4; ++e)
-            if (n + e < p.Cd) orow_p[n + e] = vv[e] + ((MODE == 0 && p.bias) ? p.bias[n + e] : 0.f);
+            if (n + e < p.Cd)
+              orow_p[n + e] = vv[e] + ((MODE == 0 && p.bias) ? p.bias[n + e] : 0.f) + (p.accumulate ? orow_p[n + e] : 0.f);
         }
       }
     }
@@ -1519,9 +1525,24 @@ extern "C" int xas_conv_fwd(const float* x, const float* w_packed, const float* 
   return dispatch_igemm<0>(p, s->N * s->Ho * s->Wo, 1, st);
 }
 
+static int conv_dgrad_impl(const float* dy, const float* w_packed_t, float* dx, const xas_conv_shape* s, void* stream,
+                           int accumulate);
+
 extern "C" int xas_conv_dgrad(const float* dy, const float* w_packed_t, float* dx, const xas_conv_shape* s,
                               void* stream) {
+  return conv_dgrad_impl(dy, w_packed_t, dx, s, stream, 0);
+}
+
+extern "C" int xas_conv_dgrad_acc(const float* dy, const float* w_packed_t, float* dx, const xas_conv_shape* s,
+                                  void* stream) {
+  return conv_dgrad_impl(dy, w_packed_t, dx, s, stream, 1);
+}
+
+static int conv_dgrad_impl(const float* dy, const float* w_packed_t, float* dx, const xas_conv_shape* s, void* stream,
+                           int accumulate) {
   if (check_shape(s, "conv_dgrad")) return 1;
+  XAS_REQUIRE(!accumulate || (s->Cout % BK == 0 && s->Cin >= 16 && s->Cin % 4 == 0 && !(s->Cin == 1 || s->Cout == 1)),
+              "conv_dgrad_acc: only the MFMA path accumulates (Cout %% 32 == 0, Cin %% 4 == 0, Cin >= 16)");
   XAS_REQUIRE(dy && w_packed_t && dx, "conv_dgrad: null buffer");
   // valid for the conv (Hi -> Ho) and for ConvTranspose2d forward (Ho given, Hi = (Ho-1)*stride - 2*pad + R)
   XAS_REQUIRE((s->Ho - 1) * s->stride - 2 * s->pad + s->R <= s->Hi && (s->Wo - 1) * s->stride - 2 * s->pad + s->S <= s->Wi,
@@ -1553,6 +1574,7 @@ extern "C" int xas_conv_dgrad(const float* dy, const float* w_packed_t, float* d
   p.src = dy; p.wgt = w_packed_t; p.bias = nullptr; p.out = dx; p.N = s->N;
   p.Hs = s->Ho; p.Ws = s->Wo; p.Cs = s->Cout; p.Hd = s->Hi; p.Wd = s->Wi; p.Cd = s->Cin;
   p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.tune = g_tune; p.dbg = g_dbg;
+  p.accumulate = accumulate;
   const int Hp = (s->Hi + s->stride - 1) / s->stride, Wp = (s->Wi + s->stride - 1) / s->stride;
   p.src_elems = (long)p.N * p.Hs * p.Ws * p.Cs; p.wgt_elems = (long)p.Cd * p.R * p.S * p.Cs;
   return dispatch_igemm<1>(p, s->N * Hp * Wp, s->stride * s->stride, st);

@@ -11,7 +11,11 @@ are rank-local BatchNorm2d.
 import torch.nn as nn
 
 from xas_amd import layers as L
-from xas_amd.ops_nn import ACT_NONE, ACT_RELU, from_nchw
+import os
+
+from xas_amd.ops_nn import ACT_NONE, ACT_RELU, bottleneck, from_nchw
+
+FUSED_BLOCKS = os.environ.get('XAS_FUSED_BLOCKS', '1') == '1'     # one autograd node per bottleneck (ops_nn._Bottleneck)
 
 
 class Bottleneck(nn.Module):
@@ -28,8 +32,13 @@ class Bottleneck(nn.Module):
         self.bn3 = L.BatchNorm2d(planes * 4, act=ACT_RELU)      # applied after the residual add
         self.downsample = downsample
         self.stride = stride
+        self._fused_params = None
 
     def forward(self, x):
+        if FUSED_BLOCKS and x.is_cuda:
+            if self._fused_params is None:
+                self._fused_params = tuple(self.parameters())
+            return bottleneck(x, self)
         skip = x if self.downsample is None else self.downsample(x)
         y = self.bn1(self.conv1(x))
         y = self.bn2(self.conv2(y))

@@ -33,6 +33,7 @@ SIGNATURES = {
     'xas_draw_lines_max_bwd': ('plliippiufipppp', 'i'),
     'xas_conv_fwd': ('ppppsp', 'i'),
     'xas_conv_dgrad': ('pppsp', 'i'),
+    'xas_conv_dgrad_acc': ('pppsp', 'i'),
     'xas_conv_wgrad_workspace_floats': ('s', 'z'),
     'xas_conv_wgrad': ('ppppsp', 'i'),
     'xas_conv_wgrad_oihw': ('ppppsp', 'i'),

@@ -79,10 +79,14 @@ class BatchNorm2d(nn.Module):
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
         self._nbt_shared = False       # True once a parent owns the counter (share_batch_counters)
 
-    def forward(self, x, residual=None):
-        group = None
+    def sync_group(self):
+        """Process group of the statistic exchange, or None for a rank-local norm."""
         if self.sync and self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            group = dist.group.WORLD
+            return dist.group.WORLD
+        return None
+
+    def count_batch(self):
+        """num_batches_tracked += 1 unless a parent owns the counter (SharedBatchCounters)."""
         if self.training and not self._nbt_shared:
             from . import streams
             if streams.forked():
@@ -90,6 +94,10 @@ class BatchNorm2d(nn.Module):
                     self.num_batches_tracked += 1
             else:
                 self.num_batches_tracked += 1
+
+    def forward(self, x, residual=None):
+        group = self.sync_group()
+        self.count_batch()
         return F.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, residual, self.training,
                             self.momentum, self.eps, self.act, group)
 

@@ -160,6 +160,122 @@ def conv2d(x, weight, bias, stride, pad, cache):
     return _Conv2d.apply(x, weight, bias, stride, pad, cache)
 
 
+def _conv_forward(x, weight, stride, pad, cache):
+    """Bias-free convolution -> (y, shape descriptor)."""
+    n, ci, hi, wi = x.shape
+    co, ci2, r, s = weight.shape
+    if ci != ci2:
+        raise RuntimeError('conv2d: input has %d channels, weight expects %d' % (ci, ci2))
+    ho, wo = (hi + 2 * pad - r) // stride + 1, (wi + 2 * pad - s) // stride + 1
+    shp = _shape(n, hi, wi, ci, co, r, s, stride, pad, ho, wo)
+    y = empty_cl(n, co, ho, wo, x)
+    call('xas_conv_fwd', ptr(x), ptr(cache.get(weight, 0)), None, ptr(y), shp)
+    return y, shp
+
+
+def _conv_backward(x, weight, dy, shp, cache, need_dx, need_dw, acc_into=None):
+    """-> (dx, dw).  acc_into: a gradient buffer of x's shape that already holds the other branch's gradient; the
+    data gradient is added to it in the kernel epilogue.  dw is None when it went straight into weight.grad."""
+    dx = dw = None
+    if need_dx:
+        if acc_into is not None:
+            dx = acc_into
+            call('xas_conv_dgrad_acc', ptr(dy), ptr(cache.get(weight, 1)), ptr(dx), shp)
+        else:
+            dx = torch.empty_like(x)
+            call('xas_conv_dgrad', ptr(dy), ptr(cache.get(weight, 1)), ptr(dx), shp)
+    if need_dw and not _wgrad_into_grad(x, dy, shp, weight):
+        dw = _wgrad(x, dy, shp, weight.shape)
+    return dx, dw
+
+
+class _Bottleneck(torch.autograd.Function):
+    """conv1-bn1-relu, conv2-bn2-relu, conv3-bn3 (+ skip | downsample conv-bn), add, relu as ONE autograd node
+    (torchvision Bottleneck v1.5, the block the reference imports at integral_base_modules/resnet.py:2).  Same kernels
+    and the same arithmetic as the layer-by-layer path; what the node buys is the backward order under our control:
+    the skip gradient produced by bn3's backward is the buffer conv1's data gradient accumulates into
+    (xas_conv_dgrad_acc), so the block-input gradient needs no separate addition pass, and the host walks 1 autograd
+    node per block instead of 6-8."""
+
+    @staticmethod
+    def forward(ctx, x, blk, *params):
+        x = to_cl(x)
+        convs = [blk.conv1, blk.conv2, blk.conv3]
+        bns = [blk.bn1, blk.bn2, blk.bn3]
+        ds = blk.downsample
+        for bn in bns + ([ds[1]] if ds is not None else []):
+            bn.count_batch()
+        saved, cfgs, shps = [], [], []
+        skip = x
+        if ds is not None:
+            yd, shp_d = _conv_forward(x, ds[0].weight, ds[0].stride, ds[0].padding, ds[0]._cache)
+            skip, sv, cf = _bn_forward(yd, ds[1].weight, ds[1].bias, ds[1].running_mean, ds[1].running_var, None,
+                                       ds[1].training, ds[1].momentum, ds[1].eps, ds[1].act, ds[1].sync_group())
+            saved.append(sv); cfgs.append(cf); shps.append(shp_d)
+        a = x
+        acts = [x]
+        for i in range(3):
+            y, shp = _conv_forward(a, convs[i].weight, convs[i].stride, convs[i].padding, convs[i]._cache)
+            a, sv, cf = _bn_forward(y, bns[i].weight, bns[i].bias, bns[i].running_mean, bns[i].running_var,
+                                    skip if i == 2 else None, bns[i].training, bns[i].momentum, bns[i].eps, bns[i].act, None)
+            saved.append(sv); cfgs.append(cf); shps.append(shp)
+            acts.append(a)
+        flat = [t for sv in saved for t in sv]
+        ctx.save_for_backward(x, acts[1], acts[2], *flat)
+        ctx.blk, ctx.cfgs, ctx.shps, ctx.has_ds = blk, cfgs, shps, ds is not None
+        return a
+
+    @staticmethod
+    def backward(ctx, dout):
+        blk = ctx.blk
+        x, a1, a2, *flat = ctx.saved_tensors
+        saved = [tuple(flat[4 * i:4 * i + 4]) for i in range(len(flat) // 4)]
+        cfgs, shps = ctx.cfgs, ctx.shps
+        o = 1 if ctx.has_ds else 0                    # index of conv1's entries
+        convs = [blk.conv1, blk.conv2, blk.conv3]
+        bns = [blk.bn1, blk.bn2, blk.bn3]
+        ins = [x, a1, a2]
+        pgrads = {}
+
+        def bn_b(idx, bn, dy):
+            dx, dg, db, dres = _bn_backward(saved[idx], cfgs[idx], bn.weight, bn.bias, dy, True)
+            if dg is not None:
+                pgrads[id(bn.weight)], pgrads[id(bn.bias)] = dg, db
+            return dx, dres
+
+        g, dskip = bn_b(o + 2, bns[2], dout)          # dskip: gradient of the skip branch (= dz of the block output)
+        for i in (2, 1):
+            g, dw = _conv_backward(ins[i], convs[i].weight, g, shps[o + i], convs[i]._cache, True, True)
+            if dw is not None:
+                pgrads[id(convs[i].weight)] = dw
+            g, _ = bn_b(o + i - 1, bns[i - 1], g)
+        need_dx = ctx.needs_input_grad[0]
+        if ctx.has_ds:
+            ds = blk.downsample
+            gd, _ = bn_b(0, ds[1], dskip)
+            dx, dw = _conv_backward(x, ds[0].weight, gd, shps[0], ds[0]._cache, need_dx, True)
+            if dw is not None:
+                pgrads[id(ds[0].weight)] = dw
+            acc = dx
+        else:
+            acc = dskip
+        dx, dw = _conv_backward(x, convs[0].weight, g, shps[o], convs[0]._cache, need_dx, True,
+                                acc_into=acc if (need_dx and _can_accumulate(shps[o])) else None)
+        if dw is not None:
+            pgrads[id(convs[0].weight)] = dw
+        if need_dx and dx is not acc:
+            dx = dx + acc
+        return (dx if need_dx else None, None) + tuple(pgrads.get(id(p)) for p in ctx.blk._fused_params)
+
+
+def _can_accumulate(shp):
+    return shp.Cout % 32 == 0 and shp.Cin % 4 == 0 and shp.Cin >= 16
+
+
+def bottleneck(x, blk):
+    return _Bottleneck.apply(x, blk, *blk._fused_params)
+
+
 class _ConvTranspose2d(torch.autograd.Function):
     """y = conv_transpose2d(x, weight[Cin_t, Cout_t, R, S], stride, pad) == data-gradient of the conv
     whose OIHW weight has the same memory layout (deconv_head.py:27-29)."""
@@ -269,88 +385,102 @@ def _sync_stats(mean, var, count, group):
     return gm.contiguous(), gv.clamp_min_(0).contiguous()
 
 
+def _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, group):
+    """-> (y, saved tensors (x|y, y|x, mean, var), cfg) - the body of _BatchNorm.forward, also used by _Bottleneck."""
+    x = to_cl(x)
+    n, c, h, w = x.shape
+    M = n * h * w
+    dev = x.device
+    count = float(M)
+    if training:
+        mean = torch.empty(c, device=dev, dtype=torch.float32)
+        var = torch.empty(c, device=dev, dtype=torch.float32)
+        ws = torch.empty(query('xas_bn_workspace_floats', M, c), device=dev, dtype=torch.float32)
+        fuse_running = group is None and running_mean is not None and not streams.forked()
+        call('xas_bn_stats', ptr(x), M, c, ptr(mean), ptr(var), ptr(ws),
+             ptr(running_mean) if fuse_running else None, ptr(running_var) if fuse_running else None,
+             float(momentum), int(M))
+        if group is not None:
+            mean, var = _sync_stats(mean, var, M, group)
+            count = float(M) * dist.get_world_size(group)     # equal per-rank batches (train.py:274)
+        if running_mean is not None and not fuse_running:
+            if streams.forked():
+                # order-dependent update: serialised on the bookkeeping stream in host program order
+                book, cur = streams.book_stream(), torch.cuda.current_stream()
+                book.wait_stream(cur)
+                with torch.cuda.stream(book):
+                    call('xas_bn_update_running', ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
+                         float(momentum), int(count), c)
+                mean.record_stream(book)
+                var.record_stream(book)
+            else:
+                call('xas_bn_update_running', ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
+                     float(momentum), int(count), c)
+        if bn_log['on'] and running_mean is not None:
+            bn_log['calls'].append((mean, var, running_mean, running_var, momentum, count))
+    else:
+        mean, var = running_mean, running_var
+    res = to_cl(residual) if residual is not None else None
+    y = torch.empty_like(x)
+    call('xas_bn_apply', ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(res), float(eps), act, M, c, ptr(y))
+    # Backward traffic: which of x / y the backward passes need
+    #   leaky ReLU, no residual : neither pass reads x (xhat recovered from the invertible output y);
+    #   ReLU, no residual       : neither pass reads y (the mask is re-derived from x: 2 reads + 1 write in the apply
+    #                             pass instead of 3 + 1);
+    #   otherwise               : both.
+    xfree = training and act == ACT_LEAKY and residual is None
+    yfree = training and act == ACT_RELU and residual is None and os.environ.get('XAS_BN_YFREE', '1') == '1'
+    saved = (y if xfree else x, x if yfree else y, mean, var)
+    cfg = (M, c, float(eps), act, count, group, training, residual is not None, xfree, yfree)
+    return y, saved, cfg
+
+
+def _bn_backward(saved, cfg, gamma, beta, dy, want_param_grads):
+    """-> (dx, dgamma, dbeta, dres); dgamma / dbeta are None when they were accumulated straight into gamma.grad /
+    beta.grad (LOCAL sums: the gradient all-reduce averages them later), which saves two autograd accumulation kernels
+    per layer."""
+    x, y, mean, var = saved
+    M, c, eps, act, count, group, training, has_res, xfree, yfree = cfg
+    if not training:
+        raise RuntimeError('batch-norm backward in eval mode is not part of the training path')
+    dy = to_cl(dy)
+    dev = x.device
+    sdz = torch.empty(2 * c, device=dev, dtype=torch.float32)
+    ws = torch.empty(query('xas_bn_workspace_floats', M, c), device=dev, dtype=torch.float32)
+    gg, gb = gamma.grad, beta.grad
+    direct = (want_param_grads and gg is not None and gb is not None and gg.is_contiguous() and gb.is_contiguous()
+              and gg.dtype == torch.float32 and gb.dtype == torch.float32)
+    call('xas_bn_bwd_reduce', None if xfree else ptr(x), None if yfree else ptr(y), ptr(dy), ptr(mean), ptr(var), ptr(gamma),
+         ptr(beta), eps, act, M, c, ptr(sdz), ptr(sdz[c:]), ptr(ws), ptr(gb) if direct else None,
+         ptr(gg) if direct else None)
+    if direct:
+        dgamma = dbeta = None
+    else:
+        dgamma, dbeta = sdz[c:], sdz[:c]
+    if group is not None:
+        if not direct:
+            dgamma, dbeta = dgamma.clone(), dbeta.clone()
+        dist.all_reduce(sdz, group=group)                 # one coalesced 2C message per layer
+    dx = torch.empty_like(y)
+    dres = torch.empty_like(y) if has_res else None
+    call('xas_bn_bwd_apply', None if xfree else ptr(x), None if yfree else ptr(y), ptr(dy), ptr(mean), ptr(var), ptr(gamma),
+         ptr(beta), ptr(sdz), ptr(sdz[c:]), eps, act, M, c, float(count), ptr(dx), ptr(dres))
+    return dx, dgamma, dbeta, dres
+
+
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, group):
-        x = to_cl(x)
-        n, c, h, w = x.shape
-        M = n * h * w
-        dev = x.device
-        count = float(M)
-        if training:
-            mean = torch.empty(c, device=dev, dtype=torch.float32)
-            var = torch.empty(c, device=dev, dtype=torch.float32)
-            ws = torch.empty(query('xas_bn_workspace_floats', M, c), device=dev, dtype=torch.float32)
-            fuse_running = group is None and running_mean is not None and not streams.forked()
-            call('xas_bn_stats', ptr(x), M, c, ptr(mean), ptr(var), ptr(ws),
-                 ptr(running_mean) if fuse_running else None, ptr(running_var) if fuse_running else None,
-                 float(momentum), int(M))
-            if group is not None:
-                mean, var = _sync_stats(mean, var, M, group)
-                count = float(M) * dist.get_world_size(group)     # equal per-rank batches (train.py:274)
-            if running_mean is not None and not fuse_running:
-                if streams.forked():
-                    # order-dependent update: serialised on the bookkeeping stream in host program order
-                    book, cur = streams.book_stream(), torch.cuda.current_stream()
-                    book.wait_stream(cur)
-                    with torch.cuda.stream(book):
-                        call('xas_bn_update_running', ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
-                             float(momentum), int(count), c)
-                    mean.record_stream(book)
-                    var.record_stream(book)
-                else:
-                    call('xas_bn_update_running', ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
-                         float(momentum), int(count), c)
-            if bn_log['on'] and running_mean is not None:
-                bn_log['calls'].append((mean, var, running_mean, running_var, momentum, count))
-        else:
-            mean, var = running_mean, running_var
-        res = to_cl(residual) if residual is not None else None
-        y = torch.empty_like(x)
-        call('xas_bn_apply', ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(res), float(eps), act, M, c, ptr(y))
-        # Backward without re-reading x where xhat can be recovered from the saved output y:
-        #   reduce pass (sums of dz and dz*xhat): only elements with dz != 0 matter -> any activation, no residual;
-        #   apply pass (dx needs xhat of EVERY element): only an invertible activation (leaky ReLU); then x is
-        #   not kept alive at all.
-        #   ReLU without residual: neither pass reads y - the mask is re-derived from x (2 reads + 1 write in the apply
-        #   pass instead of 3 + 1).
-        xfree_reduce = training and act == ACT_LEAKY and residual is None
-        xfree_apply = xfree_reduce
-        yfree = training and act == ACT_RELU and residual is None and os.environ.get('XAS_BN_YFREE', '1') == '1'
-        ctx.save_for_backward(y if xfree_apply else x, x if yfree else y, mean, var, gamma, beta)
-        ctx.cfg = (M, c, float(eps), act, count, group, training, residual is not None, xfree_reduce, xfree_apply, yfree)
+        y, saved, cfg = _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, group)
+        ctx.save_for_backward(*saved, gamma, beta)
+        ctx.cfg = cfg
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, var, gamma, beta = ctx.saved_tensors
-        M, c, eps, act, count, group, training, has_res, xfree_reduce, xfree_apply, yfree = ctx.cfg
-        if not training:
-            raise RuntimeError('batch-norm backward in eval mode is not part of the training path')
-        dy = to_cl(dy)
-        dev = x.device
-        sdz = torch.empty(2 * c, device=dev, dtype=torch.float32)
-        ws = torch.empty(query('xas_bn_workspace_floats', M, c), device=dev, dtype=torch.float32)
-        # parameter gradients (LOCAL sums: the gradient all-reduce averages them later) go straight into the
-        # optimizer's .grad arena when there is one, instead of through two autograd accumulation kernels per layer
-        gg, gb = gamma.grad, beta.grad
-        direct = (ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and gg is not None and gb is not None
-                  and gg.is_contiguous() and gb.is_contiguous() and gg.dtype == torch.float32 and gb.dtype == torch.float32)
-        call('xas_bn_bwd_reduce', None if xfree_reduce else ptr(x), None if yfree else ptr(y), ptr(dy), ptr(mean), ptr(var), ptr(gamma),
-             ptr(beta), eps, act, M, c, ptr(sdz), ptr(sdz[c:]), ptr(ws), ptr(gb) if direct else None,
-             ptr(gg) if direct else None)
-        if direct:
-            dgamma = dbeta = None
-        else:
-            dgamma, dbeta = sdz[c:], sdz[:c]
-        if group is not None:
-            if not direct:
-                dgamma, dbeta = dgamma.clone(), dbeta.clone()
-            dist.all_reduce(sdz, group=group)                 # one coalesced 2C message per layer
-        dx = torch.empty_like(y)
-        dres = torch.empty_like(y) if has_res else None
-        call('xas_bn_bwd_apply', None if xfree_apply else ptr(x), None if yfree else ptr(y), ptr(dy), ptr(mean), ptr(var), ptr(gamma),
-             ptr(beta), ptr(sdz), ptr(sdz[c:]), eps, act, M, c, float(count), ptr(dx), ptr(dres))
+        *saved, gamma, beta = ctx.saved_tensors
+        dx, dgamma, dbeta, dres = _bn_backward(tuple(saved), ctx.cfg, gamma, beta, dy,
+                                               ctx.needs_input_grad[1] and ctx.needs_input_grad[2])
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
 
 

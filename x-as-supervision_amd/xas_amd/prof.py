@@ -4,7 +4,8 @@ import torch
 
 from . import _lib
 
-CONV_ENTRIES = ('xas_conv_fwd', 'xas_conv_dgrad', 'xas_conv_wgrad', 'xas_conv_wgrad_oihw', 'xas_conv_wgrad_acc')
+CONV_ENTRIES = ('xas_conv_fwd', 'xas_conv_dgrad', 'xas_conv_dgrad_acc', 'xas_conv_wgrad', 'xas_conv_wgrad_oihw',
+                'xas_conv_wgrad_acc')
 
 
 def conv_flops(shape):
@@ -43,7 +44,7 @@ class KernelTimer:
         if shape is not None:
             if name == 'xas_conv_fwd':
                 mfma = (shape.Cin % 32 == 0 and shape.Cout >= 16) or (shape.Cin == 3 and shape.R == 7 and shape.Cout == 64)
-            elif name == 'xas_conv_dgrad':
+            elif name in ('xas_conv_dgrad', 'xas_conv_dgrad_acc'):
                 mfma = shape.Cout % 32 == 0 and shape.Cin >= 16
             else:
                 mfma = shape.Cout != 1
