@@ -210,7 +210,7 @@ class Counter3DDisc(torch.nn.Module):
         preds = {k: v.detach() for k, v in preds.items()} if have else {}
         if not have:
             ops_nn.prepack(regressor)
-        with streams.fork() as fk:
+        with streams.fork(streams.NUM_NOGRAD) as fk:
             for i, cam in enumerate(cams):
                 key = 'cam_{}'.format(cam)
                 reals[key] = x[key + '_pseudo_joints']

@@ -9,28 +9,37 @@ Order-dependent state is kept deterministic:
   * batch-norm running statistics and `num_batches_tracked` are updated on ONE bookkeeping stream in host
     program order (camera 0 first), exactly the order of the single-stream reference;
   * packed weight copies are (re)built on the main stream before the cameras fork.
-The fan-out is OFF by default (XAS_CAM_STREAMS=1): at B=32 the kernels of one camera already fill the chip and
-extra streams only add contention (tools/ab_step.py: 306 ms/step with 1 stream, 312 with 2, 321 with 4); the
-weight-gradient side stream of ops_nn is what pays (327 -> 306 ms).
+The fan-out of the passes that are followed by a backward is OFF by default (XAS_CAM_STREAMS=1): at B=32 the kernels
+of one camera already fill the chip and in the backward the extra streams meet the weight-gradient stream
+(tools/ab_step.py: 1 stream 258 ms/step, 4 streams 259); the weight-gradient side stream of ops_nn is what pays
+(327 -> 306 ms at the time).  The gradient-free detector passes of the discriminator step DO fan out over 4 streams
+(XAS_NOGRAD_STREAMS): batch-norm kernels of one camera fill the matrix-pipe gaps of another, 257.5 -> 253.9 ms/step;
+in data-parallel runs they stay on one stream so that the SyncBatchNorm collectives are issued from a single stream.
 """
 import os
 
 import torch
+import torch.distributed
 
 NUM = max(1, int(os.environ.get('XAS_CAM_STREAMS', '1')))   # measured on MI355X: 1 -> 306 ms/step, 2 -> 312, 4 -> 321
+# Fan-out of the gradient-free detector passes of the discriminator step (no backward follows, so the extra streams do
+# not meet the weight-gradient stream): tools/ab_step.py on MI355X: 1 -> 257.5 ms/step, 2 -> 259.0, 3 -> 253.8, 4 -> 253.9.
+NUM_NOGRAD = max(1, int(os.environ.get('XAS_NOGRAD_STREAMS', '4')))
+_num = [NUM]
 _cam = []
 _book = [None]
 _active = [False]          # True while camera streams are forked (BN bookkeeping must use the book stream)
+_main = [None]             # the stream that forked (consumer of what the camera streams produce)
 
 
 def enabled():
-    return NUM > 1 and torch.cuda.is_available()
+    return _num[0] > 1 and torch.cuda.is_available()
 
 
 def cam_stream(i):
-    while len(_cam) < NUM:
+    while len(_cam) < _num[0]:
         _cam.append(torch.cuda.Stream())
-    return _cam[i % NUM]
+    return _cam[i % _num[0]]
 
 
 def book_stream():
@@ -47,9 +56,17 @@ class fork:
     """Context: camera streams may be used inside; on exit the main stream waits for all of them and for the
     bookkeeping stream."""
 
+    def __init__(self, num=None):
+        self.num = NUM if num is None else num
+        if num is not None and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            self.num = NUM      # data-parallel runs keep the SyncBatchNorm collectives on one stream
+
     def __enter__(self):
         self.main = torch.cuda.current_stream()
+        self.prev, _num[0] = _num[0], self.num
         _active[0] = enabled()
+        _main[0] = self.main
         if _active[0]:
             book_stream().wait_stream(self.main)
         return self
@@ -68,13 +85,15 @@ class fork:
                 self.main.wait_stream(s)
             self.main.wait_stream(book_stream())
         _active[0] = False
+        _num[0] = self.prev
+        _main[0] = None
 
 
 def to_main(*tensors):
     """Tell the caching allocator that tensors produced on a camera stream are consumed on the main stream."""
     if not enabled():
         return
-    main = torch.cuda.current_stream()
+    main = _main[0] if _main[0] is not None else torch.cuda.current_stream()
     for t in tensors:
         if t is not None and t.is_cuda:
             t.record_stream(main)
