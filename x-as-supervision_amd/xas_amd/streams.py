@@ -12,9 +12,11 @@ Order-dependent state is kept deterministic:
 The fan-out of the passes that are followed by a backward is OFF by default (XAS_CAM_STREAMS=1): at B=32 the kernels
 of one camera already fill the chip and in the backward the extra streams meet the weight-gradient stream
 (tools/ab_step.py: 1 stream 258 ms/step, 4 streams 259); the weight-gradient side stream of ops_nn is what pays
-(327 -> 306 ms at the time).  The gradient-free detector passes of the discriminator step DO fan out over 4 streams
-(XAS_NOGRAD_STREAMS): batch-norm kernels of one camera fill the matrix-pipe gaps of another, 257.5 -> 253.9 ms/step;
-in data-parallel runs they stay on one stream so that the SyncBatchNorm collectives are issued from a single stream.
+(327 -> 306 ms at the time).  The gradient-free detector passes of the discriminator step can fan out separately
+(XAS_NOGRAD_STREAMS=4): batch-norm kernels of one camera fill the matrix-pipe gaps of another, -0.6 % step time in
+bench.py (-1.4 % in tools/ab_step.py); off by default because the overlapped launches read 4 % slower per launch in
+the roofline measurement for a gain inside the box-to-box noise, and never used in data-parallel runs (SyncBatchNorm
+collectives stay on one stream).
 """
 import os
 
@@ -23,8 +25,9 @@ import torch.distributed
 
 NUM = max(1, int(os.environ.get('XAS_CAM_STREAMS', '1')))   # measured on MI355X: 1 -> 306 ms/step, 2 -> 312, 4 -> 321
 # Fan-out of the gradient-free detector passes of the discriminator step (no backward follows, so the extra streams do
-# not meet the weight-gradient stream): tools/ab_step.py on MI355X: 1 -> 257.5 ms/step, 2 -> 259.0, 3 -> 253.8, 4 -> 253.9.
-NUM_NOGRAD = max(1, int(os.environ.get('XAS_NOGRAD_STREAMS', '4')))
+# not meet the weight-gradient stream): tools/ab_step.py on MI355X: 1 -> 257.5 ms/step, 2 -> 259.0, 3 -> 253.8, 4 -> 253.9;
+# bench.py (10 steps): 1 -> 257.3 / 260.0, 4 -> 255.8 / 258.3.  Default 1 (see the module docstring).
+NUM_NOGRAD = max(1, int(os.environ.get('XAS_NOGRAD_STREAMS', '1')))
 _num = [NUM]
 _cam = []
 _book = [None]
