@@ -71,3 +71,25 @@ def test_no_cpu_fallback():
     from xas_amd import ops_head
     with pytest.raises(RuntimeError):
         ops_head.softargmax_multi(torch.zeros(1, 32, 16, 16), 2, 3, 15)
+
+
+def test_argument_checks_return_errors_without_a_gpu():
+    """Every entry point validates its arguments BEFORE touching the device: status 1 and a message, no launch."""
+    import ctypes
+    from xas_amd import _lib
+    lib = _lib.load()
+    one = ctypes.c_void_p(16)                       # any non-null pointer: never dereferenced on these paths
+    err = lambda: lib.xas_last_error().decode()
+    f = _lib.fn
+    assert f('xas_eval_select')(one, one, one, 2, 3, 65, 3, 256.0, 0, None, None, None, None, None) == 1
+    assert 'K <= 64' in err()
+    assert f('xas_eval_select')(one, one, one, 2, 3, 18, 4, 256.0, 0, None, None, None, None, None) == 1
+    assert f('xas_triangulate_dlt')(one, one, 2, 1, 18, one, None) == 1 and '2 views' in err()
+    assert f('xas_pose_metrics')(one, one, None, 2, 2, 1.0, 0, 0.15, None, None, None, None, None) == 1
+    assert f('xas_pose_metrics')(one, one, None, 2, 18, 1.0, 3, 0.15, None, None, None, None, None) == 1
+    assert f('xas_projection_matrix')(None, one, one, 2, one, None) == 1
+    shp = _lib.ConvShape(2, 8, 8, 3, 64, 3, 3, 1, 1, 8, 8)         # Cin = 3: not on the accumulating MFMA path
+    assert f('xas_conv_dgrad_acc')(one, one, one, ctypes.byref(shp), None) == 1 and 'MFMA path' in err()
+    assert f('xas_bn_bwd_reduce')(None, None, one, one, one, None, None, 1e-5, 1, 64, 64, one, one, one, None, None, None) == 1
+    assert f('xas_bn_bwd_apply')(None, one, one, one, one, one, None, one, one, 1e-5, 1, 64, 64, 64.0, one, None, None) == 1
+    assert 'invertible' in err().lower() or 'null buffer' in err()
