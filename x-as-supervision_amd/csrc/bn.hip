@@ -182,15 +182,25 @@ __global__ __launch_bounds__(kFinalizeThreads) void col_finalize_kernel(const fl
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
     int s = sy;
-    for (; s + 7 * nl < nslab; s += 8 * nl) {          // 16 independent loads in flight per lane, summed in slab order
-      float a[8], b[8];
+    for (; s + 15 * nl < nslab; s += 16 * nl) {        // 32 independent loads in flight per lane, summed in slab order
+      float a[16], b[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         a[u] = partial[((size_t)(s + u * nl) * 2) * C + c];
         b[u] = partial[((size_t)(s + u * nl) * 2 + 1) * C + c];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { s1 += (double)a[u]; s2 += (double)b[u]; }
+      for (int u = 0; u < 16; ++u) { s1 += (double)a[u]; s2 += (double)b[u]; }
+    }
+    for (; s + 3 * nl < nslab; s += 4 * nl) {
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = partial[((size_t)(s + u * nl) * 2) * C + c];
+        b[u] = partial[((size_t)(s + u * nl) * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s1 += (double)a[u]; s2 += (double)b[u]; }
     }
     for (; s < nslab; s += nl) {
       s1 += (double)partial[((size_t)s * 2) * C + c];
