@@ -267,3 +267,31 @@ def test_detector_single_hypothesis():
     k1, _ = hip(x.cuda())
     assert k1.shape == (2, 1, 18, 3)
     assert maxabs(k1, T(golden('detector_single')['kps'])) < 1e-4
+
+
+def test_conv_random_shapes():
+    """Randomised sweep of the MFMA conv path (buffer-load kernels): channel counts in multiples of 32 and a few that
+    are not, odd spatial sizes, strides 1-2, pads 0-2, kernel 1-4 - forward, data gradient and weight gradient against
+    torch on the CPU.  Catches tile-tail / padding / tap-mask indexing errors that the fixed layer shapes never hit."""
+    import random
+    rng = random.Random(20251003)
+    done = 0
+    while done < 28:
+        n = rng.choice([1, 2, 3])
+        cin = rng.choice([32, 64, 96, 160, 16, 48])
+        cout = rng.choice([32, 64, 96, 128, 192, 16, 40])
+        k = rng.choice([1, 2, 3, 4])
+        stride = rng.choice([1, 2])
+        pad = rng.choice([0, 1, 2])
+        h, w = rng.randint(5, 23), rng.randint(5, 23)
+        if pad >= k or (h + 2 * pad - k) < 0 or (w + 2 * pad - k) < 0:
+            continue
+        test_conv2d_fwd_bwd(n, cin, h, w, cout, k, stride, pad)
+        done += 1
+
+
+def test_conv_transpose_random_shapes():
+    import random
+    rng = random.Random(7)
+    for _ in range(8):
+        test_conv_transpose2d(rng.choice([1, 2]), rng.choice([32, 64, 128]), rng.randint(3, 11), rng.choice([32, 64, 96]))
