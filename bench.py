@@ -200,7 +200,7 @@ def main():
                 f.write('entry (N,Hi,Wi,Cin,Cout,R,stride) launches ms_total TFLOP/s\n')
                 for name, sig, n, ms_, tf in timer.by_shape():
                     f.write('%-16s %-36s %5d %9.3f %7.2f\n' % (name, sig, n, ms_, tf))
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only (the other ranks would sit in a barrier)
             threads = host_threads()
             log('timing the CPU oracle step (B=8) on %d host threads' % threads)
             line['cpu_baseline'] = cpu_baseline(args.workload, threads)
