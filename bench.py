@@ -64,6 +64,20 @@ def cpu_baseline(workload, threads):
             'sample': '1 full disc+gen step incl. Adam, %s, B=%d, fp32, oracle on torch CPU (%.1f s)' % (workload, B, dt)}
 
 
+def launch_ranks(n):
+    """Run this script as n ranks of a single-node torchrun job (child process; no exec, no GPU use here)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -80,7 +94,14 @@ def main():
     ap.add_argument('--shape-report', default=None, help='write a per-conv-shape timing table to this file')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: this parent has not touched the GPU; it starts N fresh ranks (one per GPU, RCCL)
+        # as a child torchrun job and exits with its code.  Rank 0 of the child prints the JSON line.
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d; launch with --nproc-per-node %d (or drop WORLD_SIZE and '
+                         'let bench.py start the ranks itself)' % (args.gpus, world, args.gpus))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():

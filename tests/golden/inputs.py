@@ -163,6 +163,32 @@ def smpl_buffers(seed, V=6890):
                 posedirs=f32(0.01 * rng.standard_normal((V, 3, 207))),
                 J_regressor=f32(jr), weights=f32(w), h36m_regressor=f32(hr))
 
+def seeded_state_dict(keys, shapes, seed, gain=1.0):
+    """The values seeded_fill_ gives a module whose state dict has exactly these keys / shapes IN THIS ORDER
+    (used to load a golden's parameter set into a module whose registration order may differ)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name, shape in zip(keys, shapes):
+        shape = tuple(shape)
+        leaf = name.rsplit('.', 1)[-1]
+        if leaf == 'num_batches_tracked':
+            continue
+        if leaf == 'running_mean':
+            out[name] = torch.zeros(shape)
+        elif leaf == 'running_var':
+            out[name] = torch.ones(shape)
+        elif len(shape) >= 2:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            out[name] = torch.randn(shape, generator=g) * (gain * (2.0 / fan_in) ** 0.5)
+        elif leaf == 'weight':
+            out[name] = 0.6 + 0.8 * torch.rand(shape, generator=g)
+        else:
+            out[name] = 0.1 * torch.randn(shape, generator=g)
+    return out
+
 
 def model_params(stage='S1', cam_ids=(0, 1, 2, 3)):
     """model_params section of config/HM36_Multi_SurS1.yaml:30-87 / SurS2 (values only)."""

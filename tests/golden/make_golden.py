@@ -194,7 +194,13 @@ def g_losses():
     kp3 = f(4, 18, 3) * 500
     kp2 = f(4, 18, 2)
     lg3, lg2, gt2 = f(4, 3, 1), f(4, 1), f(4, 1)
-    save('losses', m=m, gt=gt, w=w, kp3=kp3, kp2=kp2, lg3=lg3, lg2=lg2, gt2=gt2,
+    # d(loss.mean())/dmask of the four modes (the trainer reduces every loss with .mean(), train.py:182)
+    grads = {}
+    for tag, kw in (('plain', {}), ('w', {'weight': w}), ('clip', {'use_clip': True}), ('w_clip', {'weight': w, 'use_clip': True})):
+        mm = m.clone().requires_grad_(True)
+        ref_loss.compute_mask_reconstruction_loss(mm, gt, **kw).mean().backward()
+        grads['grad_' + tag] = mm.grad
+    save('losses', m=m, gt=gt, w=w, kp3=kp3, kp2=kp2, lg3=lg3, lg2=lg2, gt2=gt2, **grads,
          recon_plain=ref_loss.compute_mask_reconstruction_loss(m, gt),
          recon_w=ref_loss.compute_mask_reconstruction_loss(m, gt, weight=w),
          recon_clip=ref_loss.compute_mask_reconstruction_loss(m, gt, use_clip=True),
@@ -300,36 +306,163 @@ class LinearDisc(nn.Module):
         return self.fc(kp.reshape(kp.shape[0], -1))
 
 
+def _wiring_case(tag, yaml_name, cams, edit=None, seed=83, phys_probe=False):
+    cfg = yaml.load(open(os.path.join(REF, 'config', yaml_name + '.yaml')), Loader=yaml.FullLoader)
+    mp = cfg['model_params']
+    mp['cam_id_list'] = cams
+    if edit is not None:
+        edit(mp)
+    reg = _ref_detector(True)
+    phys = PhysiqueMaskGenerator(mp['physique_mask_generator_params']['layers'])
+    phys.load_state_dict(gi.seeded_fill_(onets.PhysiqueNet([32, 64, 128]), seed=81).state_dict())
+    disc = gi.seeded_fill_(LinearDisc(), seed=82)
+    gen = ref_model.Counter3DModel(mp, reg, None, None, phys)
+    dis = ref_model.Counter3DDisc(mp, disc, None, None)
+    gen.train(), dis.train()
+    x = {k: T(v) for k, v in gi.synthetic_batch(2, cams, seed=seed).items()}
+    loss_d, _ = dis(x, gen.regressor)
+    loss_d.mean().backward()
+    gd = disc.fc.weight.grad.clone()
+    disc.zero_grad()
+    losses, out = gen(x, dis.smpl_discriminator)
+    tot = sum(v.mean() for v in losses.values())
+    tot.backward()
+    p = dict(reg.named_parameters())
+    last = 'cam_%d' % cams[-1]
+    arrays = {'loss_disc': loss_d, 'grad_disc_w': gd, 'total': tot,
+              'g_conv1': p['net.backbone.conv1.weight'].grad, 'g_fin_b': p['net.head.features.9.bias'].grad,
+              'g_phys_dec4_w': phys.decoder[4].weight.grad, 'g_disc_after_gen': disc.fc.weight.grad,
+              'pose_3d_cam_0': out['pose_3d_depth_cam_%d' % cams[0]], 'kp_gt_world': out['kp_gt_world'],
+              'mask_line_sub': out['mask_heatmap_line_' + last][:, :, ::4, ::4]}
+    if phys_probe:
+        arrays['g_phys_enc0_w'] = phys.encoder[0][0].weight.grad
+        arrays['g_l1c2'] = p['net.backbone.layer1.0.conv2.weight'].grad[:8]
+    for k, v in losses.items():
+        arrays['loss_' + k] = v.mean()
+        arrays['shape_' + k] = np.array(list(v.shape), np.int64)
+    save('model_' + tag, **arrays)
+
+
+def _weighted_masks(mp):
+    """HM36_Multi_SurS1 with the two mask losses switched ON (the shipped weight 0.0 hides them from any golden):
+    geodesic weight maps in use (use_dis_map: True as shipped), weights as in the S2 stage."""
+    mp['loss_config']['recons_loss']['weight'] = 0.02
+    mp['loss_config']['physique_recons_loss']['weight'] = 0.02
+
+
 def g_model():
-    for tag in ('HM36_Multi_SurS1', 'HM36_Multi_SurS2'):
-        cfg = yaml.load(open(os.path.join(REF, 'config', tag + '.yaml')), Loader=yaml.FullLoader)
-        mp = cfg['model_params']
-        mp['cam_id_list'] = [0, 1]            # two cameras keep the CPU run short
-        reg = _ref_detector(True)
-        phys = PhysiqueMaskGenerator(mp['physique_mask_generator_params']['layers'])
-        phys.load_state_dict(gi.seeded_fill_(onets.PhysiqueNet([32, 64, 128]), seed=81).state_dict())
-        disc = gi.seeded_fill_(LinearDisc(), seed=82)
-        gen = ref_model.Counter3DModel(mp, reg, None, None, phys)
-        dis = ref_model.Counter3DDisc(mp, disc, None, None)
-        gen.train(), dis.train()
-        x = {k: T(v) for k, v in gi.synthetic_batch(2, [0, 1], seed=83).items()}
-        loss_d, _ = dis(x, gen.regressor)
-        loss_d.mean().backward()
-        gd = disc.fc.weight.grad.clone()
-        disc.zero_grad()
-        losses, out = gen(x, dis.smpl_discriminator)
-        tot = sum(v.mean() for v in losses.values())
-        tot.backward()
-        p = dict(reg.named_parameters())
-        arrays = {'loss_disc': loss_d, 'grad_disc_w': gd, 'total': tot,
-                  'g_conv1': p['net.backbone.conv1.weight'].grad, 'g_fin_b': p['net.head.features.9.bias'].grad,
-                  'g_phys_dec4_w': phys.decoder[4].weight.grad, 'g_disc_after_gen': disc.fc.weight.grad,
-                  'pose_3d_cam_0': out['pose_3d_depth_cam_0'], 'kp_gt_world': out['kp_gt_world'],
-                  'mask_line_sub': out['mask_heatmap_line_cam_1'][:, :, ::4, ::4]}
-        for k, v in losses.items():
-            arrays['loss_' + k] = v.mean()
-            arrays['shape_' + k] = np.array(list(v.shape), np.int64)
-        save('model_' + tag, **arrays)
+    _wiring_case('HM36_Multi_SurS1', 'HM36_Multi_SurS1', [0, 1])       # two cameras keep the CPU run short
+    _wiring_case('HM36_Multi_SurS2', 'HM36_Multi_SurS2', [0, 1])
+
+
+def g_model2():
+    _wiring_case('HM36_Multi_SurS1_wmask', 'HM36_Multi_SurS1', [0, 1], edit=_weighted_masks, phys_probe=True)
+    _wiring_case('MPI_Multi_SurS1', 'MPI_Multi_SurS1', [0, 2, 4, 7, 8], seed=84)      # the YAML's own camera list
+    _wiring_case('HM36_Multi_SynthS2', 'HM36_Multi_SynthS2', [0, 1], seed=85)
+
+
+# ----------------------------------------------------------------- 8b. the YAML files as data
+def g_configs():
+    """model_params / train_params / cam_id_list of every shipped YAML, as JSON (xas_amd.synthetic.model_config is
+    asserted equal to these: tests/test_configs.py)."""
+    import json
+    out = {}
+    for fn in sorted(os.listdir(os.path.join(REF, 'config'))):
+        cfg = yaml.load(open(os.path.join(REF, 'config', fn)), Loader=yaml.FullLoader)
+        out[fn[:-5]] = {'model_params': cfg['model_params'], 'train_params': cfg['train_params'],
+                        'cam_id_list': cfg['dataset_params']['cam_id_list'],
+                        'dataset_name': cfg['dataset_params']['dataset']['name'],
+                        'geodesic_param_list': cfg['dataset_params']['geodesic_param_list']}
+    with open(os.path.join(HERE, 'configs.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print('wrote configs.json', list(out))
+
+
+# ----------------------------------------------------------------- 8c. the reference's discriminator classes
+class _PygSAGEConv(nn.Module):
+    """torch_geometric 2.5.3 SAGEConv(aggr='mean', root_weight=True, bias=True) restated on edge lists:
+    out_i = lin_l(mean_{(j -> i) in E} x_j) + lin_r(x_i); lin_l carries the bias, lin_r has none;
+    edge_index[0] = source j, edge_index[1] = target i (flow 'source_to_target')."""
+
+    def __init__(self, in_channels, out_channels, aggr='mean'):
+        super().__init__()
+        assert aggr == 'mean'
+        self.lin_l = nn.Linear(in_channels, out_channels, bias=True)
+        self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
+
+    def forward(self, x, edge_index):
+        src, dst = edge_index[0], edge_index[1]
+        agg = torch.zeros_like(x).index_add_(0, dst, x[src])
+        deg = torch.zeros(x.shape[0], dtype=x.dtype).index_add_(0, dst, torch.ones(src.shape[0], dtype=x.dtype))
+        return self.lin_l(agg / deg.clamp_min(1.0)[:, None]) + self.lin_r(x)
+
+
+class _PygLayerNorm(nn.Module):
+    """torch_geometric 2.5.3 norm.LayerNorm(in_channels, eps=1e-5, affine=True, mode='graph') called without `batch`:
+    x - mean over ALL nodes and channels, divided by (std(unbiased=False) + eps), then the per-channel affine."""
+
+    def __init__(self, in_channels, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(in_channels))
+        self.bias = nn.Parameter(torch.zeros(in_channels))
+
+    def forward(self, x):
+        x = x - x.mean()
+        return x / (x.std(unbiased=False) + self.eps) * self.weight + self.bias
+
+
+def _install_pyg_shims():
+    tg = types.ModuleType('torch_geometric')
+    tgn = types.ModuleType('torch_geometric.nn')
+    norm = types.ModuleType('torch_geometric.nn.norm')
+    norm.LayerNorm = _PygLayerNorm
+    tgn.SAGEConv, tgn.norm = _PygSAGEConv, norm
+    tgn.GCNConv = type('GCNConv', (nn.Module,), {})        # imported by gcn.py:3, never constructed by the shipped configs
+    tg.nn = tgn
+    sys.modules.update({'torch_geometric': tg, 'torch_geometric.nn': tgn, 'torch_geometric.nn.norm': norm})
+
+
+def g_disc():
+    """modules/discriminator.py + modules/gcn.py imported UNCHANGED with the two PyG primitives restated above: pins the
+    reference's own positional encoding, adjacency / edge list, bone vectors, residual order and FFN header."""
+    _install_pyg_shims()
+    from modules.discriminator import GCNDiscriminatorDecouple, GCNSAGEDiscriminator
+    cfg = yaml.load(open(os.path.join(REF, 'config', 'HM36_Multi_SurS2.yaml')), Loader=yaml.FullLoader)['model_params']
+    p17, c17 = ref_model.cal_links(cfg['parent_ids'], cfg['line_select_ids'], use_root=False, extension=False)
+    rng = np.random.Generator(np.random.PCG64(91))
+    for tag, cls in (('decouple', GCNDiscriminatorDecouple), ('sage', GCNSAGEDiscriminator)):
+        ref = cls(cfg['smpl_disc_params'])
+        gi.seeded_fill_(ref, seed=92)
+        ref.parent_ids, ref.child_ids = p17, c17
+        out = {'keys': np.array(list(ref.state_dict().keys())),
+               'shapes': np.array([str(list(v.shape)) for v in ref.state_dict().values()])}
+        for B in (2, 5):
+            kp = T((0.4 * rng.standard_normal((B, 18, 3))).astype(np.float32))
+            for mode in ('eval', 'train_p0'):
+                ref.train(mode != 'eval')
+                if hasattr(ref.header, 'dropout'):
+                    ref.header.dropout.p = 0.0
+                ref.zero_grad()
+                x = kp.clone().requires_grad_(True)
+                y = ref(x)
+                gw = T(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+                (y * gw).sum().backward()
+                pre = '%s_B%d_' % (mode, B)
+                prm = dict(ref.named_parameters())
+                first = 'joint_input_layer.weight' if tag == 'decouple' else 'input_layer.weight'
+                gcn = 'joint_gcn' if tag == 'decouple' else 'gcn'
+                out.update({pre + 'kp': kp, pre + 'logits': y, pre + 'grad_out': gw, pre + 'grad_kp': x.grad,
+                            pre + 'g_in_w': prm[first].grad, pre + 'g_sage_l': prm[gcn + '.0.gc1.lin_l.weight'].grad,
+                            pre + 'g_sage_r': prm[gcn + '.1.gc2.lin_r.weight'].grad, pre + 'g_ln_w': prm[gcn + '.2.ln1.weight'].grad,
+                            pre + 'g_ln_b': prm[gcn + '.0.ln2.bias'].grad})
+                if tag == 'decouple':
+                    out.update({pre + 'g_bone_in_b': prm['bone_input_layer.bias'].grad,
+                                pre + 'g_head2_w': prm['header.layer2.weight'].grad,
+                                pre + 'g_head1_w_sub': prm['header.layer1.weight'].grad[::16, ::64]})
+                else:
+                    out[pre + 'g_head_w'] = prm['header.weight'].grad
+        save('disc_' + tag, **out)
 
 
 # ----------------------------------------------------------------- 9. dense -> sparse known answer
@@ -411,6 +544,7 @@ def g_evalpath():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['head', 'lines', 'geometry', 'losses', 'physique', 'detector', 'smpl', 'model', 'sparse', 'evalpath']
+    which = sys.argv[1:] or ['head', 'lines', 'geometry', 'losses', 'physique', 'detector', 'smpl', 'model', 'model2', 'configs',
+                             'disc', 'sparse', 'evalpath']
     for w in which:
         globals()['g_' + w]()

@@ -85,6 +85,49 @@ def test_gcn_discriminator_vs_oracle(B):
     assert maxabs(hip(kp.cuda()), ora(kp)) < 2e-5 * max(1.0, float(yo.abs().max()))
 
 
+@pytest.mark.parametrize('tag', ['decouple', 'sage'])
+def test_gcn_discriminators_vs_reference_golden(tag):
+    """HIP GCNDiscriminatorDecouple / GCNSAGEDiscriminator against goldens written by the REFERENCE's own
+    modules/discriminator.py + modules/gcn.py (imported unchanged, the two torch_geometric primitives restated:
+    tests/golden/make_golden.py g_disc): logits, input gradient, parameter gradients, eval and train (dropout 0)."""
+    import ast
+    from modules.discriminator import GCNDiscriminatorDecouple, GCNSAGEDiscriminator
+    from modules.model import cal_links
+    g = golden('disc_' + tag)
+    cfg = gi.model_params('S2')['smpl_disc_params']
+    hip = (GCNDiscriminatorDecouple if tag == 'decouple' else GCNSAGEDiscriminator)(cfg)
+    keys = g['keys'].tolist()
+    shapes = [ast.literal_eval(s) for s in g['shapes'].tolist()]
+    assert sorted(hip.state_dict().keys()) == sorted(keys)               # reference checkpoints load unchanged
+    hip.load_state_dict(gi.seeded_state_dict(keys, shapes, 92), strict=True)
+    hip.parent_ids, hip.child_ids = cal_links(gi.HM36_PARENTS, gi.LINE_SELECT, use_root=False, extension=False)
+    hip.cuda()
+    if tag == 'decouple':
+        hip.header.p = 0.0
+    gcn = 'joint_gcn' if tag == 'decouple' else 'gcn'
+    first = 'joint_input_layer.weight' if tag == 'decouple' else 'input_layer.weight'
+    probes = [('g_in_w', first), ('g_sage_l', gcn + '.0.gc1.lin_l.weight'), ('g_sage_r', gcn + '.1.gc2.lin_r.weight'),
+              ('g_ln_w', gcn + '.2.ln1.weight'), ('g_ln_b', gcn + '.0.ln2.bias')]
+    probes += [('g_bone_in_b', 'bone_input_layer.bias'), ('g_head2_w', 'header.layer2.weight')] if tag == 'decouple' \
+        else [('g_head_w', 'header.weight')]
+    for B in (2, 5):
+        for mode in ('eval', 'train_p0'):
+            hip.train(mode != 'eval')
+            hip.zero_grad()
+            pre = '%s_B%d_' % (mode, B)
+            x = T(g[pre + 'kp']).cuda().requires_grad_(True)
+            y = hip(x)
+            ref = T(g[pre + 'logits'])
+            assert maxabs(y, ref) < 2e-5 * max(1.0, float(ref.abs().max())), (tag, pre)
+            (y * T(g[pre + 'grad_out']).cuda()).sum().backward()
+            assert rel(x.grad, T(g[pre + 'grad_kp'])) < 1e-4, (tag, pre)
+            p = dict(hip.named_parameters())
+            for gk, name in probes:
+                assert rel(p[name].grad, T(g[pre + gk])) < 2e-4, (tag, pre, name)
+            if tag == 'decouple':
+                assert rel(p['header.layer1.weight'].grad[::16, ::64], T(g[pre + 'g_head1_w_sub'])) < 2e-4
+
+
 def test_discriminator_groups_equal_separate_calls():
     """forward_groups == one call per input (graph-LayerNorm statistics stay per input), values and grads."""
     hip, _ = _discs(seed=11)
@@ -231,42 +274,120 @@ def _hip_models(stage, cam_ids):
     return reg.cuda().train(), phys.cuda().train(), ora_reg.train(), ora_phys.train()
 
 
-@pytest.mark.parametrize('stage', ['S1', 'S2'])
-def test_model_wiring_vs_golden(stage):
+def _check_wiring(gname, cfg, cams, seed, tol_loss=3e-4):
+    """Counter3DDisc + Counter3DModel on the HIP path vs a golden written by the imported reference classes
+    (tests/golden/make_golden.py: _wiring_case): every loss value, outputs, selected gradients."""
     from modules.model import Counter3DDisc, Counter3DModel
-    g = golden('model_HM36_Multi_Sur' + stage)
-    cfg = gi.model_params(stage, cam_ids=(0, 1))
-    reg, phys, _, _ = _hip_models(stage, (0, 1))
+    g = golden(gname)
+    reg, phys, _, _ = _hip_models(None, cams)
     disc = gi.seeded_fill_(LinearDisc(), seed=82).cuda()
     gen = Counter3DModel(cfg, reg, None, None, phys)
     dis = Counter3DDisc(cfg, disc, None, None)
-    x = {k: T(v).cuda() for k, v in gi.synthetic_batch(2, [0, 1], seed=83).items()}
+    x = {k: T(v).cuda() for k, v in gi.synthetic_batch(2, list(cams), seed=seed).items()}
     ld, info = dis(x, gen.regressor)
     assert abs(float(ld) - float(g['loss_disc'])) < 1e-5 + 2e-4 * abs(float(g['loss_disc']))
     ld.mean().backward()
     assert rel(disc.fc.weight.grad, T(g['grad_disc_w'])) < 2e-3 or float(T(g['grad_disc_w']).norm()) == 0
     disc.zero_grad()
     losses, out = gen(x, dis.smpl_discriminator)
+    assert sorted('loss_' + k for k in losses) == sorted(k for k in g.files if k.startswith('loss_') and k != 'loss_disc')
     for k, v in losses.items():
         ref = float(g['loss_' + k])
-        assert abs(float(v.mean()) - ref) < 1e-5 + 3e-4 * abs(ref), (k, float(v.mean()), ref)
+        assert abs(float(v.mean()) - ref) < 1e-5 + tol_loss * abs(ref), (k, float(v.mean()), ref)
     tot = sum(v.mean() for v in losses.values())
-    assert abs(float(tot) - float(g['total'])) < 1e-5 + 3e-4 * abs(float(g['total']))
+    assert abs(float(tot) - float(g['total'])) < 1e-5 + tol_loss * abs(float(g['total']))
     tot.backward()
-    w = out['pose_3d_depth_cam_0']
-    assert maxabs(w, T(g['pose_3d_cam_0'])) < 0.2                # mm, |coords| ~ 1e3..1e4
+    c0, cl = 'cam_%d' % cams[0], 'cam_%d' % cams[-1]
+    assert maxabs(out['pose_3d_depth_' + c0], T(g['pose_3d_cam_0'])) < 0.2      # mm, |coords| ~ 1e3..1e4
     assert maxabs(out['kp_gt_world'], T(g['kp_gt_world'])) < 0.05
-    assert maxabs(out['mask_heatmap_line_cam_1'][:, :, ::4, ::4], T(g['mask_line_sub'])) < 2e-4
+    assert maxabs(out['mask_heatmap_line_' + cl][:, :, ::4, ::4], T(g['mask_line_sub'])) < 2e-4
     p = dict(reg.named_parameters())
     assert rel(p['net.head.features.9.bias'].grad, T(g['g_fin_b'])) < 3e-2
     assert rel(p['net.backbone.conv1.weight'].grad, T(g['g_conv1'])) < 5e-2
     if float(T(g['g_phys_dec4_w']).norm()) > 0:
         assert rel(phys.decoder[4].weight.grad, T(g['g_phys_dec4_w'])) < 3e-2
-    for key in ('pose_2d_pred_cam_0_ori', 'depth_map_cam_0', 'pose_3d_gt_cam_0_pseudo', 'mask_physique_cam_0',
-                'pose_2d_pred_cam_1_pseudo'):
+    for key in ('pose_2d_pred_%s_ori' % c0, 'depth_map_' + c0, 'pose_3d_gt_%s_pseudo' % c0, 'mask_physique_' + c0,
+                'pose_2d_pred_%s_pseudo' % cl):
         assert key in out
-    for key in ('pose_smpl_2d_cam_0', 'pose_smpl_3d_cam_1', 'smpl_logits_cam_0', 'pred_logits_cam_1'):
+    for key in ('pose_smpl_2d_' + c0, 'pose_smpl_3d_' + cl, 'smpl_logits_' + c0, 'pred_logits_' + cl):
         assert key in info
+    return g, reg, phys
+
+
+@pytest.mark.parametrize('stage', ['S1', 'S2'])
+def test_model_wiring_vs_golden(stage):
+    _check_wiring('model_HM36_Multi_Sur' + stage, gi.model_params(stage, cam_ids=(0, 1)), (0, 1), 83)
+
+
+def _yaml_params(name, cams):
+    from xas_amd.synthetic import model_config
+    mp = model_config(name)['model_params']          # equal to the YAML (tests/test_configs.py)
+    mp['cam_id_list'] = list(cams)
+    return mp
+
+
+def test_model_wiring_weighted_mask_losses():
+    """HM36_Multi_SurS1 with NON-zero recons / physique_recons weights and use_dis_map: True: the geodesic-weighted
+    mask-loss kernels (xas_mask_loss_fwd/bwd modes 2 and 3) and everything upstream of them (line renderer backward,
+    physique net backward) are visible to the golden; with the shipped weight 0.0 they are multiplied away."""
+    mp = _yaml_params('HM36_Multi_SurS1', (0, 1))
+    assert mp['loss_config']['recons_loss']['use_dis_map'] and mp['loss_config']['physique_recons_loss']['use_dis_map']
+    mp['loss_config']['recons_loss']['weight'] = 0.02
+    mp['loss_config']['physique_recons_loss']['weight'] = 0.02
+    g, reg, phys = _check_wiring('model_HM36_Multi_SurS1_wmask', mp, (0, 1), 83)
+    assert float(g['loss_reconstruction']) > 1e-4 and float(g['loss_physique_recons']) > 1e-4
+    assert float(T(g['g_phys_dec4_w']).norm()) > 0
+    assert rel(phys.encoder[0][0].weight.grad, T(g['g_phys_enc0_w'])) < 3e-2
+    assert rel(dict(reg.named_parameters())['net.backbone.layer1.0.conv2.weight'].grad[:8], T(g['g_l1c2'])) < 5e-2
+
+
+def test_model_wiring_mpi_five_cameras():
+    """MPI_Multi_SurS1 (BASELINE config 4) with its own camera list [0, 2, 4, 7, 8]."""
+    cams = (0, 2, 4, 7, 8)
+    _check_wiring('model_MPI_Multi_SurS1', _yaml_params('MPI_Multi_SurS1', cams), cams, 84)
+
+
+def test_model_wiring_synth_s2():
+    """HM36_Multi_SynthS2 (BASELINE config 5): S2 losses, smpl_pseudo_img_loss.weight 1.0."""
+    _check_wiring('model_HM36_Multi_SynthS2', _yaml_params('HM36_Multi_SynthS2', (0, 1)), (0, 1), 85)
+
+
+@pytest.mark.parametrize('name,batch', [('MPI_Multi_SurS1', 2), ('HM36_Multi_SynthS2', 3)])
+def test_train_step_other_configs(name, batch):
+    """Full TrainStep (real GCN discriminator, fused Adam, weight-gradient side stream) on the MPI camera list and on
+    the SynthS2 configuration: losses of the first step equal the CPU oracle step on the same batch."""
+    from oracle import step as ostep
+    from oracle.nets import GCNDecouple
+    from xas_amd import engine
+    from xas_amd.synthetic import model_config
+    cfg = model_config(name)
+    mp = cfg['model_params']
+    cams = mp['cam_id_list']
+    torch.manual_seed(5)
+    model, disc, od, odisc = engine.prepare_model(cfg)
+    oreg = gi.seeded_fill_(ostep.Regressor(**mp['detector_params']), seed=61)
+    with torch.no_grad():
+        oreg.net.head.features[9].bias.copy_(T(gi.planted_depth_bias(18, 64, seed=62)))
+    from oracle.nets import PhysiqueNet
+    ophys = gi.seeded_fill_(PhysiqueNet([32, 64, 128]), seed=81)
+    ogcn = gi.seeded_fill_(GCNDecouple(mp['smpl_disc_params']), seed=9)
+    model.regressor.load_state_dict(oreg.state_dict())
+    model.physique_network.load_state_dict(ophys.state_dict())
+    disc.smpl_discriminator.load_state_dict(ogcn.state_dict())
+    model.cuda().train(), disc.cuda().train()
+    disc.smpl_discriminator.header.p = 0.0
+    ogcn.parent_ids, ogcn.child_ids = disc.parent_ids, disc.child_ids
+    step = engine.TrainStep(cfg, model, disc, od, odisc)
+    o_det = torch.optim.Adam(list(oreg.parameters()) + list(ophys.parameters()), lr=od.param_groups[0]['lr'], betas=(0.5, 0.999))
+    o_disc = torch.optim.Adam(ogcn.parameters(), lr=odisc.param_groups[0]['lr'], betas=(0.5, 0.999))
+    xn = gi.synthetic_batch(batch, cams, seed=95)
+    ld, lk, tot, _ = step({k: T(v).cuda() for k, v in xn.items()})
+    old, olk = ostep.train_step(mp, oreg.train(), ophys.train(), ogcn, o_det, o_disc, {k: T(v) for k, v in xn.items()})
+    assert abs(float(ld) - float(old)) < 1e-5 + 3e-4 * abs(float(old)), (float(ld), float(old))
+    assert sorted(lk) == sorted(olk)
+    for k in olk:
+        assert abs(float(lk[k].mean()) - float(olk[k])) < 1e-5 + 3e-4 * abs(float(olk[k])), (k, float(lk[k].mean()), float(olk[k]))
+    assert torch.isfinite(od.param_arena).all() and torch.isfinite(odisc.param_arena).all()
 
 
 def test_full_train_step_vs_oracle():

@@ -64,14 +64,14 @@ class LinearDisc(nn.Module):
         return self.fc(kp.reshape(kp.shape[0], -1))
 
 
-def _run_model(stage):
+def _run_model(stage, gname=None, cfg=None, cams=(0, 1), seed=83):
     from oracle.nets import PhysiqueNet
-    g = golden('model_HM36_Multi_Sur' + stage)
-    cfg = gi.model_params(stage, cam_ids=(0, 1))
+    g = golden(gname or 'model_HM36_Multi_Sur' + stage)
+    cfg = cfg or gi.model_params(stage, cam_ids=(0, 1))
     reg = make_regressor().train()
     phys = gi.seeded_fill_(PhysiqueNet([32, 64, 128]), seed=81).train()
     disc = gi.seeded_fill_(LinearDisc(), seed=82)
-    x = {k: T(v) for k, v in gi.synthetic_batch(2, [0, 1], seed=83).items()}
+    x = {k: T(v) for k, v in gi.synthetic_batch(2, list(cams), seed=seed).items()}
     ld = ostep.discriminator_loss(cfg, reg, disc, x)
     close(ld, g['loss_disc'], 1e-5, 1e-4)
     ld.mean().backward()
@@ -84,8 +84,8 @@ def _run_model(stage):
     tot = sum(v.mean() for v in losses.values())
     close(tot, g['total'], 1e-5, 2e-4)
     tot.backward()
-    close(aux['world']['cam_0'][:, 0], g['pose_3d_cam_0'], 0.05, 1e-5)
-    close(aux['recon']['cam_1'][:, :, ::4, ::4], g['mask_line_sub'], 1e-4)
+    close(aux['world']['cam_%d' % cams[0]][:, 0], g['pose_3d_cam_0'], 0.05, 1e-5)
+    close(aux['recon']['cam_%d' % cams[-1]][:, :, ::4, ::4], g['mask_line_sub'], 1e-4)
     p = dict(reg.named_parameters())
     rel = lambda a, b: float((a - T(b)).norm() / (T(b).norm() + 1e-30))
     assert rel(p['net.backbone.conv1.weight'].grad, g['g_conv1']) < 5e-3
@@ -101,3 +101,27 @@ def test_model_wiring_s1():
 
 def test_model_wiring_s2():
     _run_model('S2')
+
+
+def _yaml_params(name, cams):
+    from xas_amd.synthetic import model_config           # pure Python, equal to the YAML (tests/test_configs.py)
+    mp = model_config(name)['model_params']
+    mp['cam_id_list'] = list(cams)
+    return mp
+
+
+def test_model_wiring_s1_weighted_mask_losses():
+    """S1 with non-zero mask-loss weights and use_dis_map: True (the shipped 0.0 hides those terms)."""
+    mp = _yaml_params('HM36_Multi_SurS1', (0, 1))
+    mp['loss_config']['recons_loss']['weight'] = 0.02
+    mp['loss_config']['physique_recons_loss']['weight'] = 0.02
+    _run_model(None, 'model_HM36_Multi_SurS1_wmask', mp)
+
+
+def test_model_wiring_synth_s2():
+    _run_model(None, 'model_HM36_Multi_SynthS2', _yaml_params('HM36_Multi_SynthS2', (0, 1)), seed=85)
+
+
+def test_model_wiring_mpi_five_cameras():
+    cams = (0, 2, 4, 7, 8)
+    _run_model(None, 'model_MPI_Multi_SurS1', _yaml_params('MPI_Multi_SurS1', cams), cams, seed=84)

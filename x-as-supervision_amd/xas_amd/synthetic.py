@@ -61,18 +61,27 @@ def synthetic_batch(B, cam_ids, device, seed=0, S=256, K=18):
     return x
 
 
+CONFIG_NAMES = ('HM36_Multi_SurS1', 'HM36_Multi_SurS2', 'HM36_Multi_SynthS1', 'HM36_Multi_SynthS2',
+                'MPI_Multi_SurS1', 'MPI_Multi_SurS2', 'MPI_Multi_SynthS2')
+
+
 def model_config(name='HM36_Multi_SurS1'):
-    """model/train parameters of the shipped YAMLs (config/HM36_Multi_SurS1.yaml:30-106 and the SurS2 / MPI /
-    Synth variants, which differ in the fields set below).  Real runs load the YAML itself (train.py)."""
-    s2 = name.endswith('S2')
-    cams = [0, 2, 4, 7, 8] if name.startswith('MPI') else [0, 1, 2, 3]
+    """dataset / model / train parameters of the shipped YAMLs (config/HM36_Multi_SurS1.yaml:1-106 and its six
+    siblings, which differ only in the fields set below; asserted equal to the YAML contents in
+    tests/test_configs.py).  Real runs load the YAML itself (train.py); benchmarks and tests have no config dir."""
+    if name not in CONFIG_NAMES:
+        raise KeyError('unknown config %r (known: %s)' % (name, ', '.join(CONFIG_NAMES)))
+    mpi, s2, synth = name.startswith('MPI'), name.endswith('S2'), 'Synth' in name
+    cams = [0, 2, 4, 7, 8] if mpi else [0, 1, 2, 3]
     lc = {'recons_loss': {'use_dis_map': not s2, 'weight': 0.02 if s2 else 0.0},
           'physique_recons_loss': {'use_dis_map': not s2, 'weight': 0.02 if s2 else 0.0},
-          'smpl_pseudo_img_loss': {'weight': 1.0 if name.startswith('MPI') else 3.0}}
+          'smpl_pseudo_img_loss': {'weight': 1.0 if (synth or name == 'MPI_Multi_SurS1') else 3.0}}
     if s2:
-        lc['symmetry_loss'] = {'weight': {'bone': 0.1, 'kp': 0.1, 'kp_2d': 0.0}}
-    lc['smpl_disc_loss'] = {'weight': 0.5 if s2 else 0.0, 'update_interval': 1}
-    lc['smpl_gen_loss'] = {'weight': 0.5 if s2 else 0.0}
+        sym = 0.05 if mpi else 0.1
+        lc['symmetry_loss'] = {'weight': {'bone': sym, 'kp': sym, 'kp_2d': 0.0}}
+    adv = (1.0 if mpi else 0.5) if s2 else 0.0
+    lc['smpl_disc_loss'] = {'weight': adv, 'update_interval': 1}
+    lc['smpl_gen_loss'] = {'weight': adv}
     mp = {'detector_params': {'name': 'resnet_multi', 'num_kp': 18, 'depth_dim': 64, 'num_hypo': 3, 'neighbor_size': 15},
           'smpl_disc_params': {'name': 'res_sage_gcn_decouple', 'input_dim': 128, 'hidden_dim': 128, 'output_dim': 128,
                                'num_node': 18, 'disc_sup_dim': 3, 'num_layers': 2, 'use_self_loop': True, 'use_pe': True},
@@ -82,11 +91,19 @@ def model_config(name='HM36_Multi_SurS1'):
           'child_ids': list(range(18)),
           'flip_pairs': [[1, 4], [2, 5], [3, 6], [14, 11], [15, 12], [16, 13]],
           'line_select_ids': list(range(17)), 'body_width': 3.0, 'loss_config': lc, 'cam_id_list': cams}
-    tp = {'num_epochs': 15 if s2 else 50, 'batch_size': 32, 'epoch_milestones': [40],
+    if s2:
+        epochs = (10 if name == 'MPI_Multi_SurS2' else 15)
+    else:
+        epochs = 80 if mpi else 50
+    tp = {'num_epochs': epochs, 'batch_size': 32, 'epoch_milestones': [70] if name == 'MPI_Multi_SurS1' else [40],
           'lr_kp_detector': 1.0e-4 if s2 else 2.0e-4, 'lr_discriminator': 1.0e-4 if s2 else 2.0e-4,
-          'checkpoint_freq': 2 if s2 else 20, 'patch_width': 256, 'patch_height': 256}
-    ds = {'name': 'mpi_inf_3dhp' if name.startswith('MPI') else 'hm36'}           # config/*.yaml:3-4 (eval.py:73 reads it)
-    return {'dataset_params': {'dataset': ds, 'cam_id_list': cams}, 'model_params': mp, 'train_params': tp}
+          'checkpoint_freq': 2 if s2 else 20, 'patch_width': 256, 'patch_height': 256,
+          'rect_3d_width': 2000, 'rect_3d_height': 2000,
+          'aug': {'scale_factor': 0.0, 'rot_factor': 0, 'color_factor': 0.0, 'rot_aug_rate': 0.0, 'flip_aug_rate': 0.0,
+                  'do_flip_aug': False}}
+    ds = {'name': 'mpi_inf_3dhp' if mpi else 'hm36'}           # config/*.yaml:3-4 (eval.py:73 reads it)
+    return {'dataset_params': {'dataset': ds, 'cam_id_list': cams, 'geodesic_param_list': [2, 1, 3, 20, 0.0]},
+            'model_params': mp, 'train_params': tp}
 
 
 def synthetic_eval_batch(B, cam_ids, device, seed=0, S=256, K=18, rect=2000.0):
