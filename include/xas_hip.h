@@ -52,14 +52,15 @@ int xas_abi_version(void);
  * neighbor == 0 : single-hypothesis head (plain expectation along depth).
  * kps      [B][num_hypo][K][3]   normalised to [-1,1)
  * z_idx    [B][K][num_hypo] int64 (depth-peak bins, 1..D-2; ties: lower index first)
- * depth_prob_map [K][D]          (depth marginal of sample 0)
+ * depth_prob_map [groups][K][D]  (depth marginal of the FIRST sample of each of `groups` equal sub-batches:
+ *                                 sample 0 for groups = 1, multi.py:45; one per camera in a camera-batched pass)
  * stats    [B][K][XAS_HEAD_STATS] saved for backward (lse, X, Y, Z_h, S_h ...)
  * partial  workspace, xas_head_workspace_floats(B,K,D) floats
  * ---------------------------------------------------------------------------------- */
 #define XAS_HEAD_STATS 16
 size_t xas_head_workspace_floats(int B, int K, int D);
 int xas_head_softargmax_fwd(const float* logits, int B, int K, int D, int num_hypo, int neighbor,
-                            float* kps, int64_t* z_idx, float* depth_prob_map, float* stats,
+                            float* kps, int64_t* z_idx, float* depth_prob_map, int groups, float* stats,
                             float* partial, void* stream);
 /* grad_logits [B][H][W][K*D] = d loss / d logits given grad_kps [B][num_hypo][K][3].
  * coef: workspace of B*K*(4+D) floats. */
@@ -155,45 +156,58 @@ int xas_unpack_weight(const float* packed, float* oihw, int Cout, int Cin, int R
  * Replaces ATen batch_norm_stats / batch_norm_elemt / batch_norm_backward_{reduce,elemt}
  * behind nn.BatchNorm2d and nn.SyncBatchNorm (resnet.py:18,40, deconv_head.py:30,
  * physique_network.py:18,25,33).
- * stats step : per-channel (mean, M2) partials -> mean, biased var (Chan combine).
- * The host may all-gather (mean, var, count) across ranks between the two steps for
- * SyncBatchNorm (one coalesced message per layer).
+ * GROUPS.  The M rows may be `groups` independent batches of M / groups consecutive rows, each normalised with
+ * its own statistics: the camera-batched step sends the images of all cameras through the detector as one
+ * tensor while every camera keeps its own batch statistics and its own running-statistic update, exactly as
+ * the reference's per-camera calls (model.py:64,147,231).  Statistics are [groups][C]; groups = 1 is the plain
+ * layer.  Running statistics receive one update per group, in group order.
+ * stats step : slab partials (sums around a pivot row) are combined by the LAST-ARRIVING block of the same
+ * launch (ticket counter, fixed summation order: deterministic), no separate finalize launch.
+ * The host may all-gather (mean | var | count) across ranks between the two steps for SyncBatchNorm (one
+ * coalesced message per layer for all groups) and merge with xas_bn_sync_merge.
  * act: 0 none, 1 relu, 2 leaky-relu(0.01).
  * ---------------------------------------------------------------------------------- */
-size_t xas_bn_workspace_floats(long M, int C);
-/* running_mean/var != NULL (rank-local norms): the running-statistic update (momentum, unbiased variance
- * from `count`) is fused into the finalize launch; pass NULL for SyncBatchNorm and call
- * xas_bn_update_running after the statistic exchange. */
-int xas_bn_stats(const float* x, long M, int C, float* mean, float* var_biased,
-                 float* workspace, float* running_mean, float* running_var, float momentum,
+size_t xas_bn_workspace_floats(long M, int C, int groups);
+/* mean[g*out_stride + c], var_biased[g*out_stride + c] (out_stride >= C, multiple of 4 floats; C for dense [G][C]).
+ * count_out != NULL: count_out[g*out_stride] = M / groups as float (the count slot of a packed SyncBatchNorm
+ * message [mean | var | count]: pass mean = msg, var = msg + C, count_out = msg + 2C, out_stride = 2C + 4).
+ * running_mean/var != NULL (rank-local norms): the running-statistic updates (momentum, unbiased variance
+ * from `count`) are applied in the same launch; pass NULL for SyncBatchNorm (xas_bn_sync_merge updates them). */
+int xas_bn_stats(const float* x, long M, int C, int groups, float* mean, float* var_biased, long out_stride,
+                 float* count_out, float* workspace, float* running_mean, float* running_var, float momentum,
                  long count, void* stream);
+/* SyncBatchNorm merge (torch/nn/modules/_functions.py SyncBatchNorm.forward: batch_norm_gather_stats_with_counts):
+ * gathered [world][groups][msg_stride] with mean at +0, biased var at +C, count at +2C of each message;
+ * count-weighted merge in double -> mean, var_biased [groups][C]; running statistics (may be NULL) updated once per
+ * group in group order with the global count. */
+int xas_bn_sync_merge(const float* gathered, int world, int groups, int C, long msg_stride, float* mean,
+                      float* var_biased, float* running_mean, float* running_var, float momentum, void* stream);
 /* out[c] = sum_m x[m][c]  (bias gradients: deconv_head.py:34, physique_network.py:17, discriminator.py:11);
- * workspace: xas_bn_workspace_floats(M, C) */
+ * workspace: xas_bn_workspace_floats(M, C, 1) */
 int xas_col_sum(const float* x, long M, int C, float* out, float* workspace, void* stream);
-/* y = act(gamma*(x-mean)*rsqrt(var+eps)+beta [+ residual]) */
+/* y = act(gamma*(x-mean_g)*rsqrt(var_g+eps)+beta [+ residual]); mean / var_biased: [groups][C] */
 int xas_bn_apply(const float* x, const float* mean, const float* var_biased, const float* gamma,
-                 const float* beta, const float* residual, float eps, int act, long M, int C,
+                 const float* beta, const float* residual, float eps, int act, long M, int C, int groups,
                  float* y, void* stream);
-/* running = (1-momentum)*running + momentum*stat; var uses the unbiased estimate n/(n-1). */
+/* running = (1-momentum)*running + momentum*stat_g for g = 0..groups-1; var uses the unbiased estimate n/(n-1). */
 int xas_bn_update_running(const float* mean, const float* var_biased, float* running_mean,
-                          float* running_var, float momentum, long count, int C, void* stream);
-/* backward, step 1: dz = dy * act'(y); sum_dz[c], sum_dz_xhat[c]  (and dresidual = dz).
+                          float* running_var, float momentum, long count, int C, int groups, void* stream);
+/* backward, step 1: dz = dy * act'(y); sums[g][0][c] = sum_dz, sums[g][1][c] = sum_dz_xhat  ([groups][2][C]).
  * x may be NULL when the layer has an activation and no residual: xhat is then recovered from the saved output,
  * xhat = (act^-1(y) - beta) / gamma (needed only where dz != 0), one activation tensor less to read per pass.
  * y may be NULL instead (x, gamma, beta given, no residual): the activation mask is then re-derived from x with the
- * forward's exact arithmetic and the backward never reads y.  See below for dbeta_acc / dgamma_acc. */
+ * forward's exact arithmetic and the backward never reads y.
+ * dbeta_acc / dgamma_acc (both or neither, may be NULL): the parameter gradients (sums over all groups) are ALSO
+ * added into these [C] buffers (the .grad arena of the optimizer), which saves the autograd accumulation kernels. */
 int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy, const float* mean,
                       const float* var_biased, const float* gamma, const float* beta, float eps, int act,
-                      long M, int C,
-                      float* sum_dz, float* sum_dz_xhat, float* workspace,
+                      long M, int C, int groups, float* sums, float* workspace,
                       float* dbeta_acc, float* dgamma_acc, void* stream);
-/* dbeta_acc / dgamma_acc (both or neither, may be NULL): the parameter gradients sum_dz / sum_dz_xhat are ALSO added
- * into these [C] buffers (the .grad arena of the optimizer), which saves the autograd accumulation kernels. */
-/* step 2: dx = gamma*invstd*(dz - sum_dz/cnt - xhat*sum_dz_xhat/cnt); dres = dz if != NULL.
- * x may be NULL only for the leaky-ReLU layers (invertible activation: xhat of every element from y). */
+/* step 2: dx = gamma*invstd_g*(dz - sum_dz_g/cnt - xhat*sum_dz_xhat_g/cnt); dres = dz if != NULL; cnt = rows per
+ * group (x world size for SyncBatchNorm).  x may be NULL only for the leaky-ReLU layers (invertible activation). */
 int xas_bn_bwd_apply(const float* x, const float* y, const float* dy, const float* mean,
-                     const float* var_biased, const float* gamma, const float* beta, const float* sum_dz,
-                     const float* sum_dz_xhat, float eps, int act, long M, int C, double count,
+                     const float* var_biased, const float* gamma, const float* beta, const float* sums,
+                     float eps, int act, long M, int C, int groups, double count,
                      float* dx, float* dresidual, void* stream);
 
 /* 3x3 stride-2 pad-1 max pool (resnet.py:20), NHWC. idx: int8 argmax tap 0..8 for backward */

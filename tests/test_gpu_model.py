@@ -390,8 +390,31 @@ def test_train_step_other_configs(name, batch):
     assert torch.isfinite(od.param_arena).all() and torch.isfinite(odisc.param_arena).all()
 
 
+def _sync_oracle_to_hip(pairs, hip_opt, ora_opt):
+    """Copy parameters and Adam state of the HIP modules into the oracle's, so that the next step starts from the
+    SAME state on both sides.  (One Adam step moves every weight by ~lr * sign(g): where g ~ 0 the sign is decided by
+    fp32 rounding, and unsynchronised trajectories drift apart chaotically - measured: 3e-5 ... 2e-1 after two steps
+    depending on nothing but the summation order inside the batch-norm reductions.)"""
+    sd = hip_opt.state_dict()['state']
+    hip_params = [p for g in hip_opt.param_groups for p in g['params']]
+    index = {id(p): i for i, p in enumerate(hip_params)}
+    with torch.no_grad():
+        for hip_mod, ora_mod in pairs:
+            op = dict(ora_mod.named_parameters())
+            for name, p in hip_mod.named_parameters():
+                q = op[name]
+                q.copy_(p.detach().cpu())
+                st = sd[index[id(p)]]
+                ost = ora_opt.state[q]
+                ost['exp_avg'].copy_(st['exp_avg'].cpu())
+                ost['exp_avg_sq'].copy_(st['exp_avg_sq'].cpu())
+                assert float(ost['step']) == float(st['step'])
+
+
 def test_full_train_step_vs_oracle():
-    """disc + gen step with the real GCN discriminator and Adam: losses of two consecutive steps."""
+    """disc + gen step with the real GCN discriminator and Adam against the CPU oracle step, three consecutive steps.
+    After each step the oracle is re-synchronised to the HIP state (parameters + Adam moments), so every step is an
+    exact one-step comparison from identical state with non-trivial optimizer state from the second step on."""
     from modules.discriminator import GCNDiscriminatorDecouple
     from modules.model import Counter3DDisc, Counter3DModel
     from oracle import step as ostep
@@ -416,13 +439,16 @@ def test_full_train_step_vs_oracle():
     xn = gi.synthetic_batch(2, [0, 1], seed=91)
     xg = {k: T(v).cuda() for k, v in xn.items()}
     xc = {k: T(v) for k, v in xn.items()}
-    for it in range(2):
+    for it in range(3):
         ld, lk, tot, _ = step(xg)
         old, olk = ostep.train_step(cfg, oreg, ophys, odisc, o_det, o_disc, xc)
-        tol = 3e-4 if it == 0 else 2e-2     # step 2 sees weights after one Adam step (sign-like update: chaotic where g ~ 0)
-        assert abs(float(ld) - float(old)) < 1e-5 + tol * abs(float(old)), (it, float(ld), float(old))
+        assert abs(float(ld) - float(old)) < 1e-5 + 3e-4 * abs(float(old)), (it, float(ld), float(old))
         for k in olk:
+            # smpl_gen is evaluated with the discriminator AFTER this step's update (one Adam step from identical state)
+            tol = 3e-3 if k == 'smpl_gen' else 3e-4
             assert abs(float(lk[k].mean()) - float(olk[k])) < 1e-5 + tol * abs(float(olk[k])), (it, k, float(lk[k].mean()), float(olk[k]))
+        _sync_oracle_to_hip([(reg, oreg), (phys, ophys)], opt_det, o_det)
+        _sync_oracle_to_hip([(disc, odisc)], opt_disc, o_disc)
     assert torch.isfinite(opt_det.param_arena).all()
 
 

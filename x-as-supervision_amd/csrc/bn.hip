@@ -17,40 +17,99 @@ __device__ __forceinline__ float bn_affine(float x, float m, float rs_g, float b
 }
 
 // ---------------------------------------------------------------- column reductions
-// x is [M][C]; a block owns CB = min(C,256) channels (TX = CB/4 lanes along C) and a slab
-// of rows; it emits per channel sum(f1), sum(f2) of two per-element functions.
-struct ColGeom { int TX, TY, CB, ncb, nslab; long rows_per_slab; };
+// x is [M][C] = `G` independent groups of Mg = M / G consecutive rows (the camera-batched step sends the images of
+// all cameras through the detector as ONE tensor; every camera keeps its own batch statistics, exactly as the
+// reference's per-camera calls, model.py:64,147).  A block owns CB = min(C,256) channels (TX = CB/4 lanes along C)
+// and a slab of rows of ONE group; it emits per channel sum(f1), sum(f2) of two per-element functions.
+// The finalize pass is folded into the same launch: the block that arrives LAST at a ticket counter (one counter
+// per channel block) sums the slab partials of all groups in a fixed order (deterministic) and writes the results
+// (rocprof, round 1: 1 262 separate finalize launches per step were pure latency, 13 ms).
+struct ColGeom { int TX, TY, CB, ncb, nslab, G; long rows_per_slab, Mg; };
 
-static int col_geom(long M, int C, ColGeom* g) {
+static int col_geom(long M, int C, int G, ColGeom* g) {
   XAS_REQUIRE(M > 0 && C >= 4 && C % 4 == 0, "column reduce: channel count %d must be a positive multiple of 4", C);
-  int cb = 4;                                  // largest power of two <= 256 dividing C
-  while (cb < 256 && C % (cb * 2) == 0) cb *= 2;
-  g->CB = cb;
+  XAS_REQUIRE(G >= 1 && G <= 64 && M % G == 0, "column reduce: %ld rows do not split into %d equal groups", M, G);
+  // largest power of two <= 64 dividing C: a 64-channel block still moves 256-byte row segments, and the block that
+  // finalizes a channel block reads G * nslab * 512 B of partials (one CU pulls ~100 GB/s: keep that in the tens of KB)
+  int cb = 4;
+  while (cb < 64 && C % (cb * 2) == 0) cb *= 2;
+  g->CB = cb; g->G = G; g->Mg = M / G;
   g->TX = g->CB / 4; g->TY = 256 / g->TX; g->ncb = C / g->CB;
   static const long kWant[4] = {256, 512, 128, 64};           // tune bits 15-16 (experiment)
-  long want = kWant[(tune_flags() >> 15) & 3] / g->ncb;         // ~1 block per CU in total; keeps the finalize pass short
-  long maxslab = cdiv(M, (long)g->TY * 8);   // at least 8 rows per thread
+  long want = kWant[(tune_flags() >> 15) & 3] * (G > 1 ? 2 : 1) / ((long)g->ncb * G);   // ~1-2 blocks per CU in total
+  long maxslab = cdiv(g->Mg, (long)g->TY * 8);   // at least 8 rows per thread
   if (want > maxslab) want = maxslab;
   if (want < 1) want = 1;
-  g->rows_per_slab = cdiv(M, want);
-  g->nslab = (int)cdiv(M, g->rows_per_slab);
+  g->rows_per_slab = cdiv(g->Mg, want);
+  g->nslab = (int)cdiv(g->Mg, g->rows_per_slab);
   return 0;
 }
 
-template <int MODE, int UNR = 4>   // 0: stats of x around pivot ; 1: bn backward sums ; 2: plain column sums of x ;
+// Ticket counters of the folded finalize: a zero-initialised pool per device; a launch takes `ncb` consecutive words,
+// the last arriver of each word resets it, so a word is zero again whenever a later launch re-uses it (launches that
+// share a word are thousands of launches apart).
+constexpr int kTicketWords = 65536;
+static unsigned* g_tickets[16] = {};
+static unsigned g_ticket_next[16] = {};
+
+static unsigned* take_tickets(int n) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!g_tickets[dev]) {
+    unsigned* p = nullptr;
+    if (hipMalloc(&p, kTicketWords * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, kTicketWords * sizeof(unsigned)) != hipSuccess) return nullptr;
+    g_tickets[dev] = p;
+  }
+  if (g_ticket_next[dev] + (unsigned)n > (unsigned)kTicketWords) g_ticket_next[dev] = 0;
+  unsigned* r = g_tickets[dev] + g_ticket_next[dev];
+  g_ticket_next[dev] += (unsigned)n;
+  return r;
+}
+
+struct ColArgs {
+  const float* x; const float* y; const float* dy; const float* mean; const float* var; const float* aux;
+  float eps; int act; long M; int C; ColGeom g;
+  float* partial;              // [G][nslab][2][C]
+  unsigned* ticket;            // [ncb]
+  // finalize
+  float* out1; float* out2;    // group g writes out1[g * out_stride + c], out2[g * out_stride + c]
+  long out_stride;
+  float* count_out;            // != null: count_out[g * out_stride] = rows per group (SyncBatchNorm message)
+  float* running_mean; float* running_var; float momentum, unbias;
+  float* acc1; float* acc2;    // != null: acc1[c] += sum over groups of out1 ... (parameter gradients, in place)
+};
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+// write-through (sc1) store / L1-bypassing load of a float4 at a per-lane byte offset of ONE wave-uniform buffer: the
+// slab partials cross workgroups inside one launch
+__device__ __forceinline__ void store_wt(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
+  const u32x4_t u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)byte_off, 0, 16);          // aux 16 = sc1
+}
+__device__ __forceinline__ float4 load_wt(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16);
+  return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
+
+template <int MODE, int UNR = 4, int FL = 4>   // 0: stats of x around pivot ; 1: bn backward sums ; 2: plain column sums of x ;
                       // 3: bn backward sums WITHOUT x: xhat = (z - beta)/gamma with z recovered from y (act != 0)
                       // 4: bn backward sums WITHOUT y: the activation mask is re-derived from x (`y` carries gamma,
                       //    `aux` carries beta)
-__device__ __forceinline__ void col_reduce_body(const float* __restrict__ x, const float* __restrict__ y,
-                                                const float* __restrict__ dy, const float* __restrict__ mean,
-                                                const float* __restrict__ var, float eps, int act, long M,
-                                                int C, ColGeom g, float* __restrict__ partial,
-                                                const float* __restrict__ aux = nullptr) {
-  __shared__ float4 red[2][256];
+__device__ __forceinline__ void col_reduce_body(const ColArgs& a) {
+  __shared__ __align__(16) float4 red[2][256];         // 8 KB, also the double scratch of the finalize tail
+  const ColGeom& g = a.g;
+  const float* __restrict__ x = a.x; const float* __restrict__ y = a.y; const float* __restrict__ dy = a.dy;
+  const int C = a.C, act = a.act;
+  const float eps = a.eps;
   const int tx = threadIdx.x % g.TX, ty = threadIdx.x / g.TX;
   const int c = blockIdx.y * g.CB + tx * 4;
-  const long r0 = (long)blockIdx.x * g.rows_per_slab;
-  const long r1 = min(M, r0 + g.rows_per_slab);
+  const int grp = blockIdx.z;
+  const float* mean = a.mean ? a.mean + (size_t)grp * C : nullptr;      // per-group statistics / parameters
+  const float* var = a.var ? a.var + (size_t)grp * C : nullptr;
+  const long r0 = grp * g.Mg + (long)blockIdx.x * g.rows_per_slab;
+  const long r1 = min((grp + 1) * g.Mg, r0 + g.rows_per_slab);
   float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
   float4 p0, p1;   // MODE 0: pivot ; MODE 1: mean, invstd
   float4 rsg = make_float4(0, 0, 0, 0), bt = make_float4(0, 0, 0, 0);      // MODE 4: rstd * gamma, beta
@@ -60,15 +119,15 @@ __device__ __forceinline__ void col_reduce_body(const float* __restrict__ x, con
     p1 = make_float4(rsqrtf(v.x + eps), rsqrtf(v.y + eps), rsqrtf(v.z + eps), rsqrtf(v.w + eps));
     const float4 gm = *reinterpret_cast<const float4*>(y + c);
     rsg = make_float4(__fmul_rn(p1.x, gm.x), __fmul_rn(p1.y, gm.y), __fmul_rn(p1.z, gm.z), __fmul_rn(p1.w, gm.w));
-    bt = *reinterpret_cast<const float4*>(aux + c);
+    bt = *reinterpret_cast<const float4*>(a.aux + c);
   } else if (MODE == 0) {
-    p0 = *reinterpret_cast<const float4*>(x + c);          // pivot = first row
+    p0 = *reinterpret_cast<const float4*>(x + (size_t)grp * g.Mg * C + c);          // pivot = first row of the group
     p1 = p0;
   } else if (MODE == 2) {
     p0 = make_float4(0, 0, 0, 0); p1 = p0;
-  } else if (MODE == 3) {                                  // `mean` carries beta, `var` carries gamma
-    p0 = *reinterpret_cast<const float4*>(mean + c);
-    const float4 gm = *reinterpret_cast<const float4*>(var + c);
+  } else if (MODE == 3) {                                  // `aux` carries beta, `y`-side parameter pointer: see launcher
+    p0 = *reinterpret_cast<const float4*>(a.aux + c);                                 // beta
+    const float4 gm = *reinterpret_cast<const float4*>(a.x + c);                      // gamma (x unused in this mode)
     p1 = make_float4(gm.x != 0.f ? 1.f / gm.x : 0.f, gm.y != 0.f ? 1.f / gm.y : 0.f, gm.z != 0.f ? 1.f / gm.z : 0.f,
                      gm.w != 0.f ? 1.f / gm.w : 0.f);
   } else {
@@ -106,9 +165,9 @@ __device__ __forceinline__ void col_reduce_body(const float* __restrict__ x, con
     if (MODE == 2) {
       s1.x += xv.x; s1.y += xv.y; s1.z += xv.z; s1.w += xv.w;
     } else if (MODE == 0) {
-      const float a = xv.x - p0.x, b = xv.y - p0.y, cc = xv.z - p0.z, d = xv.w - p0.w;
-      s1.x += a; s1.y += b; s1.z += cc; s1.w += d;
-      s2.x = fmaf(a, a, s2.x); s2.y = fmaf(b, b, s2.y); s2.z = fmaf(cc, cc, s2.z); s2.w = fmaf(d, d, s2.w);
+      const float a0 = xv.x - p0.x, b = xv.y - p0.y, cc = xv.z - p0.z, d = xv.w - p0.w;
+      s1.x += a0; s1.y += b; s1.z += cc; s1.w += d;
+      s2.x = fmaf(a0, a0, s2.x); s2.y = fmaf(b, b, s2.y); s2.z = fmaf(cc, cc, s2.z); s2.w = fmaf(d, d, s2.w);
     } else {
       float4 g4 = *reinterpret_cast<const float4*>(dy + r * C + c);
       if (act) {
@@ -126,141 +185,223 @@ __device__ __forceinline__ void col_reduce_body(const float* __restrict__ x, con
   __syncthreads();
   for (int s = g.TY >> 1; s > 0; s >>= 1) {
     if (ty < s) {
-      const float4 a = red[0][threadIdx.x + s * g.TX], b = red[1][threadIdx.x + s * g.TX];
+      const float4 u0 = red[0][threadIdx.x + s * g.TX], v0 = red[1][threadIdx.x + s * g.TX];
       float4& u = red[0][threadIdx.x]; float4& v = red[1][threadIdx.x];
-      u.x += a.x; u.y += a.y; u.z += a.z; u.w += a.w;
-      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      u.x += u0.x; u.y += u0.y; u.z += u0.z; u.w += u0.w;
+      v.x += v0.x; v.y += v0.y; v.z += v0.z; v.w += v0.w;
     }
     __syncthreads();
   }
+  // ---- publish this block's partial sums (write-through), then take a ticket -------------------------------------
+  const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+      a.partial, 0, (int)((size_t)g.G * g.nslab * 2 * C * sizeof(float)), 0x00020000);
   if (ty == 0) {
-    float* o = partial + ((size_t)blockIdx.x * 2) * C + c;
-    *reinterpret_cast<float4*>(o) = red[0][tx];
-    *reinterpret_cast<float4*>(o + C) = red[1][tx];
+    const unsigned o = (unsigned)(((((size_t)grp * g.nslab + blockIdx.x) * 2) * C + c) * sizeof(float));
+    store_wt(prs, o, red[0][tx]);
+    store_wt(prs, o + (unsigned)C * 4u, red[1][tx]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores ...
+  __syncthreads();                                          // ... before one lane signals for the workgroup
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    const unsigned total = (unsigned)(g.nslab * g.G);
+    const unsigned old = __hip_atomic_fetch_add(a.ticket + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old == total - 1u;
+    if (last) {
+      __hip_atomic_store(a.ticket + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for re-use
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // drop this CU's stale L1 lines (other blocks' partials)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+
+  // ---- finalize (last arriver of this channel block): all groups, slabs summed in slab order in double ------------
+  double* dred = reinterpret_cast<double*>(&red[0][0]);     // [256][4] doubles = 8 KB
+  const int nl = g.TY;                                      // slab lanes (same thread layout as the reduction)
+  float4 accg1 = make_float4(0, 0, 0, 0), accg2 = make_float4(0, 0, 0, 0);      // sums over groups (parameter gradients)
+  float4 rm = make_float4(0, 0, 0, 0), rv = make_float4(0, 0, 0, 0);
+  if (MODE == 0 && a.running_mean && ty == 0) {
+    rm = *reinterpret_cast<const float4*>(a.running_mean + c);
+    rv = *reinterpret_cast<const float4*>(a.running_var + c);
+  }
+  for (int gi = 0; gi < g.G; ++gi) {
+    double d1[4] = {0, 0, 0, 0}, d2[4] = {0, 0, 0, 0};
+    const unsigned base = (unsigned)((((size_t)gi * g.nslab * 2) * C + c) * sizeof(float));
+    const unsigned slab_b = 2u * (unsigned)C * 4u, half_b = (unsigned)C * 4u;
+    int s = ty;
+    for (; s + (FL - 1) * nl < g.nslab; s += FL * nl) {      // 2 * FL independent 16-byte loads in flight per lane
+      float4 u[FL], v[FL];
+#pragma unroll
+      for (int k = 0; k < FL; ++k) {
+        u[k] = load_wt(prs, base + (unsigned)(s + k * nl) * slab_b);
+        v[k] = load_wt(prs, base + (unsigned)(s + k * nl) * slab_b + half_b);
+      }
+#pragma unroll
+      for (int k = 0; k < FL; ++k) {
+        d1[0] += (double)u[k].x; d1[1] += (double)u[k].y; d1[2] += (double)u[k].z; d1[3] += (double)u[k].w;
+        d2[0] += (double)v[k].x; d2[1] += (double)v[k].y; d2[2] += (double)v[k].z; d2[3] += (double)v[k].w;
+      }
+    }
+    for (; s < g.nslab; s += nl) {
+      const float4 u = load_wt(prs, base + (unsigned)s * slab_b), v = load_wt(prs, base + (unsigned)s * slab_b + half_b);
+      d1[0] += (double)u.x; d1[1] += (double)u.y; d1[2] += (double)u.z; d1[3] += (double)u.w;
+      d2[0] += (double)v.x; d2[1] += (double)v.y; d2[2] += (double)v.z; d2[3] += (double)v.w;
+    }
+    // cross-lane sums over the slab lanes, fixed order, first sums then second sums through the same 8 KB
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dred[(size_t)threadIdx.x * 4 + e] = half ? d2[e] : d1[e];
+      __syncthreads();
+      if (ty == 0) {
+        for (int k = 1; k < nl; ++k)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const double t = dred[(size_t)(k * g.TX + tx) * 4 + e];
+            if (half) d2[e] += t; else d1[e] += t;
+          }
+      }
+    }
+    if (ty != 0) continue;
+    float* o1 = a.out1 + (size_t)gi * a.out_stride + c;
+    float* o2 = a.out2 + (size_t)gi * a.out_stride + c;
+    if (MODE == 0) {
+      const float4 pv = *reinterpret_cast<const float4*>(x + (size_t)gi * g.Mg * C + c);
+      const float piv[4] = {pv.x, pv.y, pv.z, pv.w};
+      float mf[4], vf[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double m = d1[e] / (double)g.Mg;
+        double v = d2[e] / (double)g.Mg - m * m;
+        if (v < 0.0) v = 0.0;
+        mf[e] = (float)((double)piv[e] + m); vf[e] = (float)v;
+      }
+      *reinterpret_cast<float4*>(o1) = make_float4(mf[0], mf[1], mf[2], mf[3]);
+      *reinterpret_cast<float4*>(o2) = make_float4(vf[0], vf[1], vf[2], vf[3]);
+      if (a.running_mean) {                                  // one update per group, in group order = the order of the
+        const float mo = a.momentum, ub = a.unbias;          // reference's per-camera calls
+        rm.x = (1.f - mo) * rm.x + mo * mf[0]; rm.y = (1.f - mo) * rm.y + mo * mf[1];
+        rm.z = (1.f - mo) * rm.z + mo * mf[2]; rm.w = (1.f - mo) * rm.w + mo * mf[3];
+        rv.x = (1.f - mo) * rv.x + mo * (vf[0] * ub); rv.y = (1.f - mo) * rv.y + mo * (vf[1] * ub);
+        rv.z = (1.f - mo) * rv.z + mo * (vf[2] * ub); rv.w = (1.f - mo) * rv.w + mo * (vf[3] * ub);
+      }
+    } else {
+      const float4 f1 = make_float4((float)d1[0], (float)d1[1], (float)d1[2], (float)d1[3]);
+      const float4 f2 = make_float4((float)d2[0], (float)d2[1], (float)d2[2], (float)d2[3]);
+      *reinterpret_cast<float4*>(o1) = f1;
+      *reinterpret_cast<float4*>(o2) = f2;
+      accg1.x += f1.x; accg1.y += f1.y; accg1.z += f1.z; accg1.w += f1.w;
+      accg2.x += f2.x; accg2.y += f2.y; accg2.z += f2.z; accg2.w += f2.w;
+    }
+    if (a.count_out && blockIdx.y == 0 && tx == 0) a.count_out[(size_t)gi * a.out_stride] = (float)g.Mg;
+  }
+  if (ty != 0) return;
+  if (MODE == 0 && a.running_mean) {
+    *reinterpret_cast<float4*>(a.running_mean + c) = rm;
+    *reinterpret_cast<float4*>(a.running_var + c) = rv;
+  }
+  if (MODE != 0 && a.acc1) {                                 // parameter gradients accumulated in place (.grad arena)
+    float4 t1 = *reinterpret_cast<const float4*>(a.acc1 + c), t2 = *reinterpret_cast<const float4*>(a.acc2 + c);
+    t1.x += accg1.x; t1.y += accg1.y; t1.z += accg1.z; t1.w += accg1.w;
+    t2.x += accg2.x; t2.y += accg2.y; t2.z += accg2.z; t2.w += accg2.w;
+    *reinterpret_cast<float4*>(a.acc1 + c) = t1;
+    *reinterpret_cast<float4*>(a.acc2 + c) = t2;
   }
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                         const float* __restrict__ dy, const float* __restrict__ mean,
-                                                         const float* __restrict__ var, float eps, int act, long M,
-                                                         int C, ColGeom g, float* __restrict__ partial,
-                                                         const float* __restrict__ aux = nullptr) {
-  col_reduce_body<MODE, 4>(x, y, dy, mean, var, eps, act, M, C, g, partial, aux);
+__global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs a) {
+  col_reduce_body<MODE, 4, 4>(a);
 }
 
 // Same kernel compiled for at most 64 VGPRs (the shipped one for the backward sums): in the backward pass it runs beside two
 // weight-gradient blocks per CU, which leave 112 VGPRs per SIMD lane - room for two lean waves instead of one.
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void col_reduce_lean_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
-                            const float* __restrict__ mean, const float* __restrict__ var, float eps, int act, long M,
-                            int C, ColGeom g, float* __restrict__ partial, const float* __restrict__ aux = nullptr) {
-  col_reduce_body<MODE, 2>(x, y, dy, mean, var, eps, act, M, C, g, partial, aux);
+void col_reduce_lean_kernel(ColArgs a) {
+  col_reduce_body<MODE, 2, 2>(a);
 }
 
-// partial: [nslab][2][C] -> out1[c], out2[c]; MODE 0 converts pivot sums to mean / biased var and, when
-// running buffers are given, applies the running-statistic update in the same launch.
-// Block = 64 channels x (blockDim.x / 64) slab lanes; slabs are summed in double, in a fixed order (deterministic).
-// Launched with 256 threads: a 1024-thread block needs 16 free wave slots on ONE compute unit, and while the
-// weight-gradient kernels of the side stream fill the chip this tiny kernel waited ~20 us for a CU to drain.
-constexpr int kFinalizeThreads = 256;
-
-template <int MODE>
-__global__ __launch_bounds__(kFinalizeThreads) void col_finalize_kernel(const float* __restrict__ partial,
-                                                           const float* __restrict__ x, int nslab, int C, long M,
-                                                           float* __restrict__ out1, float* __restrict__ out2,
-                                                           float* __restrict__ running_mean,
-                                                           float* __restrict__ running_var, float momentum,
-                                                           float unbias, float* __restrict__ acc1 = nullptr,
-                                                           float* __restrict__ acc2 = nullptr) {
-  // 4 KB of LDS, not 16: while two weight-gradient blocks (2 x 74 KB) sit on every CU, a block asking for 16 KB has to
-  // wait for one of them to retire (seen as 25 us launches of this 5 us kernel in the backward pass)
-  __shared__ double r1[kFinalizeThreads / 64][64], r2[kFinalizeThreads / 64][64];
-  const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6, nl = blockDim.x >> 6;
-  const int c = blockIdx.x * 64 + cx;
-  double s1 = 0.0, s2 = 0.0;
-  if (c < C) {
-    int s = sy;
-    for (; s + 15 * nl < nslab; s += 16 * nl) {        // 32 independent loads in flight per lane, summed in slab order
-      float a[16], b[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        a[u] = partial[((size_t)(s + u * nl) * 2) * C + c];
-        b[u] = partial[((size_t)(s + u * nl) * 2 + 1) * C + c];
-      }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) { s1 += (double)a[u]; s2 += (double)b[u]; }
+// SyncBatchNorm: merge the per-rank statistics of every group.  gathered: [world][G][msg_stride] = mean | biased var |
+// count (| padding) per (rank, group).  Count-weighted merge in double (Chan et al.: total M2 = sum n_i (var_i + (mean_i - mean)^2)),
+// then the running-statistic update of each group in group order with the GLOBAL count.
+__global__ void bn_sync_merge_kernel(const float* __restrict__ gathered, int world, int G, int C, long msg_stride,
+                                     float* __restrict__ mean, float* __restrict__ var,
+                                     float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const size_t stride = (size_t)msg_stride;
+  float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+  for (int g = 0; g < G; ++g) {
+    double n = 0.0, mu = 0.0;
+    for (int r = 0; r < world; ++r) {
+      const float* p = gathered + ((size_t)r * G + g) * stride;
+      const double cnt = (double)p[2 * C];
+      n += cnt; mu += cnt * (double)p[c];
     }
-    for (; s + 3 * nl < nslab; s += 4 * nl) {
-      float a[4], b[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        a[u] = partial[((size_t)(s + u * nl) * 2) * C + c];
-        b[u] = partial[((size_t)(s + u * nl) * 2 + 1) * C + c];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { s1 += (double)a[u]; s2 += (double)b[u]; }
+    mu /= n;
+    double m2 = 0.0;
+    for (int r = 0; r < world; ++r) {
+      const float* p = gathered + ((size_t)r * G + g) * stride;
+      const double d = (double)p[c] - mu;
+      m2 += (double)p[2 * C] * ((double)p[C + c] + d * d);
     }
-    for (; s < nslab; s += nl) {
-      s1 += (double)partial[((size_t)s * 2) * C + c];
-      s2 += (double)partial[((size_t)s * 2 + 1) * C + c];
-    }
-  }
-  r1[sy][cx] = s1; r2[sy][cx] = s2;
-  __syncthreads();
-  if (sy != 0 || c >= C) return;
-  for (int k = 1; k < nl; ++k) { s1 += r1[k][cx]; s2 += r2[k][cx]; }
-  if (MODE == 0) {
-    const double m = s1 / (double)M;
-    double v = s2 / (double)M - m * m;
-    if (v < 0.0) v = 0.0;
-    const float mean_f = (float)((double)x[c] + m), var_f = (float)v;
-    out1[c] = mean_f;
-    out2[c] = var_f;
+    const float mf = (float)mu, vf = (float)(m2 / n);
+    mean[(size_t)g * C + c] = mf;
+    var[(size_t)g * C + c] = vf;
     if (running_mean) {
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean_f;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (var_f * unbias);
+      const float unbias = n > 1.0 ? (float)(n / (n - 1.0)) : 1.f;
+      rm = (1.f - momentum) * rm + momentum * mf;
+      rv = (1.f - momentum) * rv + momentum * (vf * unbias);
     }
-  } else {
-    out1[c] = (float)s1;
-    out2[c] = (float)s2;
-    if (acc1) { acc1[c] += (float)s1; acc2[c] += (float)s2; }   // parameter gradients accumulated in place (.grad arena)
   }
+  if (running_mean) { running_mean[c] = rm; running_var[c] = rv; }
 }
 
 __device__ __forceinline__ float act_fwd(float v, int act) {
   return act == 0 ? v : (act == 1 ? fmaxf(v, 0.f) : (v > 0.f ? v : 0.01f * v));
 }
 
+// grid.y = group: the rows of group g use mean / var row g ([G][C]); n4g = float4 elements per group
 __global__ void bn_apply_kernel(const float4* __restrict__ x, const float* __restrict__ mean,
                                 const float* __restrict__ var, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, const float4* __restrict__ res, float eps, int act,
-                                long n4, int C4, float4* __restrict__ y) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+                                long n4g, int C4, float4* __restrict__ y) {
+  const long goff = (long)blockIdx.y * n4g;
+  mean += (size_t)blockIdx.y * C4 * 4; var += (size_t)blockIdx.y * C4 * 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4g; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4) * 4;
     const float4 m = *reinterpret_cast<const float4*>(mean + c), v = *reinterpret_cast<const float4*>(var + c);
     const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
-    const float4 xv = x[i];
+    const float4 xv = x[goff + i];
     float4 o;
     o.x = bn_affine(xv.x, m.x, __fmul_rn(rsqrtf(v.x + eps), g.x), b.x);
     o.y = bn_affine(xv.y, m.y, __fmul_rn(rsqrtf(v.y + eps), g.y), b.y);
     o.z = bn_affine(xv.z, m.z, __fmul_rn(rsqrtf(v.z + eps), g.z), b.z);
     o.w = bn_affine(xv.w, m.w, __fmul_rn(rsqrtf(v.w + eps), g.w), b.w);
-    if (res) { const float4 r = res[i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+    if (res) { const float4 r = res[goff + i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
     o.x = act_fwd(o.x, act); o.y = act_fwd(o.y, act); o.z = act_fwd(o.z, act); o.w = act_fwd(o.w, act);
-    y[i] = o;
+    y[goff + i] = o;
   }
 }
 
+// grid.y = group; sums: [G][2][C] = sum_dz | sum_dz_xhat of each group
 __global__ void bn_bwd_apply_kernel(const float4* __restrict__ x, const float4* __restrict__ y,
                                     const float4* __restrict__ dy, const float* __restrict__ mean,
                                     const float* __restrict__ var, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, const float* __restrict__ sdz,
-                                    const float* __restrict__ sdzx, float eps, int act, long n4, int C4,
+                                    const float* __restrict__ beta, const float* __restrict__ sums,
+                                    float eps, int act, long n4g, int C4,
                                     float inv_count, float4* __restrict__ dx, float4* __restrict__ dres) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
+  const long goff = (long)blockIdx.y * n4g;
+  mean += (size_t)blockIdx.y * C4 * 4; var += (size_t)blockIdx.y * C4 * 4;
+  const float* sdz = sums + (size_t)blockIdx.y * C4 * 8;
+  const float* sdzx = sdz + (size_t)C4 * 4;
+  for (long ii = (long)blockIdx.x * blockDim.x + threadIdx.x; ii < n4g; ii += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(ii % C4) * 4;
+    const long i = goff + ii;
     const float4 m = *reinterpret_cast<const float4*>(mean + c), v = *reinterpret_cast<const float4*>(var + c);
     const float4 g = *reinterpret_cast<const float4*>(gamma + c);
     const float4 a = *reinterpret_cast<const float4*>(sdz + c), b = *reinterpret_cast<const float4*>(sdzx + c);
@@ -303,12 +444,17 @@ __global__ void bn_bwd_apply_kernel(const float4* __restrict__ x, const float4* 
   }
 }
 
+// one update per group, in group order (mean / var: [G][C])
 __global__ void bn_running_kernel(const float* mean, const float* var, float* rm, float* rv, float momentum,
-                                  float unbias, int C) {
+                                  float unbias, int C, int G) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  rm[c] = (1.f - momentum) * rm[c] + momentum * mean[c];
-  rv[c] = (1.f - momentum) * rv[c] + momentum * (var[c] * unbias);
+  float m = rm[c], v = rv[c];
+  for (int g = 0; g < G; ++g) {
+    m = (1.f - momentum) * m + momentum * mean[(size_t)g * C + c];
+    v = (1.f - momentum) * v + momentum * (var[(size_t)g * C + c] * unbias);
+  }
+  rm[c] = m; rv[c] = v;
 }
 
 // ---------------------------------------------------------------- max pool 3x3 s2 p1
@@ -495,109 +641,141 @@ static inline unsigned ew_grid(long n, int per_block = 256) {
 
 using namespace xas;
 
-extern "C" size_t xas_bn_workspace_floats(long M, int C) {
+extern "C" size_t xas_bn_workspace_floats(long M, int C, int groups) {
   ColGeom g;
-  if (col_geom(M, C, &g)) return 0;
-  return (size_t)g.nslab * 2 * C + C;
+  if (col_geom(M, C, groups, &g)) return 0;
+  return (size_t)g.G * g.nslab * 2 * C + C;
 }
 
-extern "C" int xas_bn_stats(const float* x, long M, int C, float* mean, float* var_biased, float* workspace,
-                            float* running_mean, float* running_var, float momentum, long count, void* stream) {
+static inline unsigned ew_grid_g(long n_per_group, int groups) {
+  long b = cdiv(n_per_group, 256);
+  const long cap = groups > 1 ? cdiv(4096, groups) : 4096;
+  return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+static int col_args(ColArgs* a, const ColGeom& g, long M, int C, float* workspace) {
+  a->M = M; a->C = C; a->g = g; a->partial = workspace;
+  a->ticket = take_tickets(g.ncb);
+  XAS_REQUIRE(a->ticket != nullptr, "column reduce: could not allocate the ticket counters");
+  XAS_REQUIRE((size_t)g.G * g.nslab * 2 * C * sizeof(float) < 0x7fffff00ul, "column reduce: partial buffer too large");
+  return 0;
+}
+
+extern "C" int xas_bn_stats(const float* x, long M, int C, int groups, float* mean, float* var_biased, long out_stride,
+                            float* count_out, float* workspace, float* running_mean, float* running_var, float momentum,
+                            long count, void* stream) {
   ColGeom g;
-  if (col_geom(M, C, &g)) return 1;
-  XAS_REQUIRE(x && mean && var_biased && workspace, "bn_stats: null buffer");
+  if (col_geom(M, C, groups, &g)) return 1;
+  XAS_REQUIRE(x && mean && var_biased && workspace && out_stride >= C, "bn_stats: null buffer / bad stride");
   XAS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats: running buffers come in pairs");
-  const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
-  hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(g.nslab, g.ncb), dim3(256), 0, as_stream(stream), x, nullptr, nullptr,
-                     nullptr, nullptr, 0.f, 0, M, C, g, workspace);
+  XAS_REQUIRE((((uintptr_t)mean | (uintptr_t)var_biased) & 15) == 0 && out_stride % 4 == 0,
+              "bn_stats: outputs must be 16-byte aligned (out_stride a multiple of 4 floats)");
+  ColArgs a{};
+  if (col_args(&a, g, M, C, workspace)) return 1;
+  a.x = x; a.out1 = mean; a.out2 = var_biased; a.out_stride = out_stride; a.count_out = count_out;
+  a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum;
+  a.unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
+  hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(g.nslab, g.ncb, g.G), dim3(256), 0, as_stream(stream), a);
   XAS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_finalize_kernel<0>, dim3((unsigned)cdiv(C, 64)), dim3(kFinalizeThreads), 0, as_stream(stream), workspace, x,
-                     g.nslab, C, M, mean, var_biased, running_mean, running_var, momentum, unbias);
+  return 0;
+}
+
+extern "C" int xas_bn_sync_merge(const float* gathered, int world, int groups, int C, long msg_stride, float* mean,
+                                 float* var_biased, float* running_mean, float* running_var, float momentum,
+                                 void* stream) {
+  XAS_REQUIRE(gathered && mean && var_biased && world >= 1 && groups >= 1 && C >= 1 && msg_stride >= 2 * (long)C + 1,
+              "bn_sync_merge: bad arguments");
+  XAS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_sync_merge: running buffers come in pairs");
+  hipLaunchKernelGGL(bn_sync_merge_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, as_stream(stream), gathered, world,
+                     groups, C, msg_stride, mean, var_biased, running_mean, running_var, momentum);
   XAS_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int xas_col_sum(const float* x, long M, int C, float* out, float* workspace, void* stream) {
   ColGeom g;
-  if (col_geom(M, C, &g)) return 1;
+  if (col_geom(M, C, 1, &g)) return 1;
   XAS_REQUIRE(x && out && workspace, "col_sum: null buffer");
-  hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(g.nslab, g.ncb), dim3(256), 0, as_stream(stream), x, nullptr, nullptr,
-                     nullptr, nullptr, 0.f, 0, M, C, g, workspace);
-  XAS_LAUNCH_CHECK();
-  // second output (unused sums of the second accumulator) lands in workspace tail
-  hipLaunchKernelGGL(col_finalize_kernel<1>, dim3((unsigned)cdiv(C, 64)), dim3(kFinalizeThreads), 0, as_stream(stream), workspace, x,
-                     g.nslab, C, M, out, workspace + (size_t)g.nslab * 2 * C, nullptr, nullptr, 0.f, 1.f);
+  ColArgs a{};
+  if (col_args(&a, g, M, C, workspace)) return 1;
+  a.x = x; a.out1 = out; a.out2 = workspace + (size_t)g.nslab * 2 * C;     // second sums are unused: workspace tail
+  a.out_stride = C;
+  hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(g.nslab, g.ncb, 1), dim3(256), 0, as_stream(stream), a);
   XAS_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int xas_bn_apply(const float* x, const float* mean, const float* var_biased, const float* gamma,
-                            const float* beta, const float* residual, float eps, int act, long M, int C, float* y,
-                            void* stream) {
+                            const float* beta, const float* residual, float eps, int act, long M, int C, int groups,
+                            float* y, void* stream) {
   XAS_REQUIRE(x && mean && var_biased && gamma && beta && y, "bn_apply: null buffer");
-  XAS_REQUIRE(M > 0 && C >= 4 && C % 4 == 0 && act >= 0 && act <= 2, "bn_apply: bad shape M=%ld C=%d act=%d", M, C, act);
-  const long n4 = M * (C / 4);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, as_stream(stream),
+  XAS_REQUIRE(M > 0 && C >= 4 && C % 4 == 0 && act >= 0 && act <= 2 && groups >= 1 && M % groups == 0,
+              "bn_apply: bad shape M=%ld C=%d act=%d groups=%d", M, C, act, groups);
+  const long n4g = (M / groups) * (C / 4);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid_g(n4g, groups), groups), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float4*>(x), mean, var_biased, gamma, beta,
-                     reinterpret_cast<const float4*>(residual), eps, act, n4, C / 4, reinterpret_cast<float4*>(y));
+                     reinterpret_cast<const float4*>(residual), eps, act, n4g, C / 4, reinterpret_cast<float4*>(y));
   XAS_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int xas_bn_update_running(const float* mean, const float* var_biased, float* running_mean,
-                                     float* running_var, float momentum, long count, int C, void* stream) {
-  XAS_REQUIRE(mean && var_biased && running_mean && running_var && C > 0 && count > 0, "bn_update_running: bad arguments");
+                                     float* running_var, float momentum, long count, int C, int groups, void* stream) {
+  XAS_REQUIRE(mean && var_biased && running_mean && running_var && C > 0 && count > 0 && groups >= 1,
+              "bn_update_running: bad arguments");
   const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
   hipLaunchKernelGGL(bn_running_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, as_stream(stream), mean, var_biased,
-                     running_mean, running_var, momentum, unbias, C);
+                     running_mean, running_var, momentum, unbias, C, groups);
   XAS_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy, const float* mean,
                                  const float* var_biased, const float* gamma, const float* beta, float eps, int act,
-                                 long M, int C, float* sum_dz, float* sum_dz_xhat, float* workspace,
+                                 long M, int C, int groups, float* sums, float* workspace,
                                  float* dbeta_acc, float* dgamma_acc, void* stream) {
   ColGeom g;
-  if (col_geom(M, C, &g)) return 1;
-  XAS_REQUIRE(dy && mean && var_biased && sum_dz && sum_dz_xhat && workspace && (act == 0 || y || (x && gamma && beta)),
+  if (col_geom(M, C, groups, &g)) return 1;
+  XAS_REQUIRE(dy && mean && var_biased && sums && workspace && (act == 0 || y || (x && gamma && beta)),
               "bn_bwd_reduce: null buffer (an activation needs y, or x with gamma and beta)");
   XAS_REQUIRE(x || (act != 0 && y && gamma && beta), "bn_bwd_reduce: without x the layer needs an activation, y, gamma, beta");
   XAS_REQUIRE((dbeta_acc == nullptr) == (dgamma_acc == nullptr), "bn_bwd_reduce: gradient accumulators come in pairs");
   const bool lean = (tune_flags() & 262144) == 0;      // shipped: the <= 64-VGPR build (tune bit18 selects the 86-VGPR one)
+  ColArgs a{};
+  if (col_args(&a, g, M, C, workspace)) return 1;
+  a.dy = dy; a.mean = mean; a.var = var_biased; a.eps = eps; a.act = act;
+  a.out1 = sums; a.out2 = sums + C; a.out_stride = 2 * (long)C;            // [G][2][C]
+  a.acc1 = dbeta_acc; a.acc2 = dgamma_acc;
+  const dim3 grid(g.nslab, g.ncb, g.G);
   if (x && act != 0 && y == nullptr) {   // y-free form: activation mask re-derived from x (layers without a residual)
-    hipLaunchKernelGGL(lean ? col_reduce_lean_kernel<4> : col_reduce_kernel<4>, dim3(g.nslab, g.ncb), dim3(256), 0,
-                       as_stream(stream), x, gamma, dy, mean, var_biased, eps, act, M, C, g, workspace, beta);
-  } else
-  if (x) {
-    hipLaunchKernelGGL(lean ? col_reduce_lean_kernel<1> : col_reduce_kernel<1>, dim3(g.nslab, g.ncb), dim3(256), 0,
-                       as_stream(stream), x, y, dy, mean, var_biased, eps, act, M, C, g, workspace, (const float*)nullptr);
+    a.x = x; a.y = gamma; a.aux = beta;
+    hipLaunchKernelGGL(lean ? col_reduce_lean_kernel<4> : col_reduce_kernel<4>, grid, dim3(256), 0, as_stream(stream), a);
+  } else if (x) {
+    a.x = x; a.y = y;
+    hipLaunchKernelGGL(lean ? col_reduce_lean_kernel<1> : col_reduce_kernel<1>, grid, dim3(256), 0, as_stream(stream), a);
   } else {            // x-free form: xhat recovered from the saved output (one activation tensor less to read)
-    hipLaunchKernelGGL(lean ? col_reduce_lean_kernel<3> : col_reduce_kernel<3>, dim3(g.nslab, g.ncb), dim3(256), 0,
-                       as_stream(stream), y, y, dy, beta, gamma, eps, act, M, C, g, workspace, (const float*)nullptr);
+    a.x = gamma; a.y = y; a.aux = beta;
+    hipLaunchKernelGGL(lean ? col_reduce_lean_kernel<3> : col_reduce_kernel<3>, grid, dim3(256), 0, as_stream(stream), a);
   }
-  XAS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_finalize_kernel<1>, dim3((unsigned)cdiv(C, 64)), dim3(kFinalizeThreads), 0, as_stream(stream), workspace, x,
-                     g.nslab, C, M, sum_dz, sum_dz_xhat, nullptr, nullptr, 0.f, 1.f, dbeta_acc, dgamma_acc);
   XAS_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int xas_bn_bwd_apply(const float* x, const float* y, const float* dy, const float* mean,
-                                const float* var_biased, const float* gamma, const float* beta, const float* sum_dz,
-                                const float* sum_dz_xhat, float eps, int act, long M, int C, double count, float* dx,
+                                const float* var_biased, const float* gamma, const float* beta, const float* sums,
+                                float eps, int act, long M, int C, int groups, double count, float* dx,
                                 float* dresidual, void* stream) {
-  XAS_REQUIRE(dy && mean && var_biased && gamma && sum_dz && sum_dz_xhat && dx && (act == 0 || y || (x && beta)),
+  XAS_REQUIRE(dy && mean && var_biased && gamma && sums && dx && (act == 0 || y || (x && beta)),
               "bn_bwd_apply: null buffer (an activation needs y, or x with beta)");
   XAS_REQUIRE(y || !dresidual || act == 0, "bn_bwd_apply: the y-free form is for layers without a residual");
   XAS_REQUIRE(x || (act == 2 && y && beta),
               "bn_bwd_apply: without x the layer needs an INVERTIBLE activation (leaky ReLU), y and beta: dx needs xhat "
               "of every element, also where ReLU clipped the output");
-  XAS_REQUIRE(M > 0 && C >= 4 && C % 4 == 0 && count > 0, "bn_bwd_apply: bad shape");
-  const long n4 = M * (C / 4);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, as_stream(stream),
+  XAS_REQUIRE(M > 0 && C >= 4 && C % 4 == 0 && count > 0 && groups >= 1 && M % groups == 0, "bn_bwd_apply: bad shape");
+  const long n4g = (M / groups) * (C / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid_g(n4g, groups), groups), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(y),
-                     reinterpret_cast<const float4*>(dy), mean, var_biased, gamma, beta, sum_dz, sum_dz_xhat, eps, act, n4,
+                     reinterpret_cast<const float4*>(dy), mean, var_biased, gamma, beta, sums, eps, act, n4g,
                      C / 4, (float)(1.0 / count), reinterpret_cast<float4*>(dx), reinterpret_cast<float4*>(dresidual));
   XAS_LAUNCH_CHECK();
   return 0;

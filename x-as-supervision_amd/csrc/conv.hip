@@ -1479,6 +1479,19 @@ static int dispatch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipSt
 
 using namespace xas;
 
+// Images per launch so that a gathered tensor stays below the 2 GiB range of the 32-bit buffer offsets (camera-batched
+// passes: the logits of 128+ images are 2.4 GB and more).  Images are independent in all three convolution passes, so
+// a larger batch is processed as several launches over image ranges (weight gradients: the later ones accumulate).
+static int images_per_launch(int N, long elems_per_image_a, long elems_per_image_b) {
+  const long lim = (0x7fffff00l / 4) - (1l << 22);            // leave room for the padding region in front of the tensor
+  const long per = elems_per_image_a > elems_per_image_b ? elems_per_image_a : elems_per_image_b;
+  if ((long)N * per < lim || N <= 1) return N;
+  long n = lim / per;
+  if (n < 1) n = 1;
+  const long launches = cdiv(N, n);
+  return (int)cdiv(N, launches);                               // equal-sized ranges
+}
+
 extern "C" int xas_set_tuning(int flags) { g_tune = flags; return 0; }
 extern "C" int xas_set_debug_buffer(void* p) { g_dbg = reinterpret_cast<unsigned long long*>(p); return 0; }
 
@@ -1486,6 +1499,19 @@ extern "C" int xas_conv_fwd(const float* x, const float* w_packed, const float* 
                             const xas_conv_shape* s, void* stream) {
   if (check_shape(s, "conv_fwd") || check_fwd_dims(s, "conv_fwd")) return 1;
   XAS_REQUIRE(x && w_packed && y, "conv_fwd: null buffer");
+  {
+    const long xi = (long)s->Hi * s->Wi * s->Cin, yi = (long)s->Ho * s->Wo * s->Cout;
+    const int per = images_per_launch(s->N, xi, 0);
+    if (per < s->N) {
+      for (int n0 = 0; n0 < s->N; n0 += per) {
+        xas_conv_shape part = *s;
+        part.N = s->N - n0 < per ? s->N - n0 : per;
+        const int rc = xas_conv_fwd(x + (size_t)n0 * xi, w_packed, bias, y + (size_t)n0 * yi, &part, stream);
+        if (rc) return rc;
+      }
+      return 0;
+    }
+  }
   hipStream_t st = as_stream(stream);
   if (s->Cin == 3 && s->R == 7 && s->S == 7 && s->stride == 2 && s->pad == 3 && s->Cout == ST_CO && bias == nullptr) {
     const int tiles = (int)(cdiv(s->Ho, ST_TH) * cdiv(s->Wo, ST_TW));
@@ -1547,6 +1573,19 @@ static int conv_dgrad_impl(const float* dy, const float* w_packed_t, float* dx, 
   // valid for the conv (Hi -> Ho) and for ConvTranspose2d forward (Ho given, Hi = (Ho-1)*stride - 2*pad + R)
   XAS_REQUIRE((s->Ho - 1) * s->stride - 2 * s->pad + s->R <= s->Hi && (s->Wo - 1) * s->stride - 2 * s->pad + s->S <= s->Wi,
               "conv_dgrad: Hi/Wi (%d,%d) too small for Ho/Wo (%d,%d)", s->Hi, s->Wi, s->Ho, s->Wo);
+  {
+    const long xi = (long)s->Hi * s->Wi * s->Cin, yi = (long)s->Ho * s->Wo * s->Cout;
+    const int per = images_per_launch(s->N, yi, 0);
+    if (per < s->N) {
+      for (int n0 = 0; n0 < s->N; n0 += per) {
+        xas_conv_shape part = *s;
+        part.N = s->N - n0 < per ? s->N - n0 : per;
+        const int rc = conv_dgrad_impl(dy + (size_t)n0 * yi, w_packed_t, dx + (size_t)n0 * xi, &part, stream, accumulate);
+        if (rc) return rc;
+      }
+      return 0;
+    }
+  }
   hipStream_t st = as_stream(stream);
   if (s->Cin == 1 && thin_ok(s, s->Cout)) {          // dx[m] = sum dy[src] . wt[0][tap][:]
     ThinParams tp{s->N, s->Hi, s->Wi, s->Cout, s->pad, 1};
@@ -1694,6 +1733,20 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
   if (check_shape(s, "conv_wgrad")) return 1;
   XAS_REQUIRE(x && dy && dw_packed && workspace, "conv_wgrad: null buffer");
   XAS_REQUIRE(s->Cout % 4 == 0 || s->Cout == 1, "conv_wgrad: Cout=%d must be a multiple of 4 (or 1)", s->Cout);
+  {
+    const long xi = (long)s->Hi * s->Wi * s->Cin, yi = (long)s->Ho * s->Wo * s->Cout;
+    const int per = images_per_launch(s->N, xi, yi);
+    if (per < s->N && (oihw || accumulate)) {            // the packed single-slab form (linear layers) is never this large
+      for (int n0 = 0; n0 < s->N; n0 += per) {
+        xas_conv_shape part = *s;
+        part.N = s->N - n0 < per ? s->N - n0 : per;
+        const int rc = conv_wgrad_impl(x + (size_t)n0 * xi, dy + (size_t)n0 * yi, dw_packed, workspace, &part, stream, oihw,
+                                       accumulate || n0 > 0);
+        if (rc) return rc;
+      }
+      return 0;
+    }
+  }
   hipStream_t st = as_stream(stream);
   if ((s->Cout == 1 && thin_ok(s, s->Cin)) || (s->Cin == 1 && thin_ok(s, s->Cout))) {
     // slabs [chunk][c][tap] == OIHW order for both cases ([1][Cin][3][3] resp. [Cout][1][3][3]); the packed

@@ -121,7 +121,7 @@ __global__ void head_partial_kernel(const float4* __restrict__ logits, float* __
 
 __global__ void head_finalize_kernel(const float* __restrict__ partial, HeadGeom g, int num_hypo, int neighbor,
                                      float* __restrict__ kps, int64_t* __restrict__ z_idx,
-                                     float* __restrict__ depth_prob_map, float* __restrict__ stats) {
+                                     float* __restrict__ depth_prob_map, int dmap_every, float* __restrict__ stats) {
   const int b = blockIdx.x / g.K, k = blockIdx.x % g.K;
   const int d = threadIdx.x;                  // one wave; lane = depth bin
   const bool live = d < g.D;
@@ -141,7 +141,7 @@ __global__ void head_finalize_kernel(const float* __restrict__ partial, HeadGeom
   const float pz = live ? sd / S : 0.f;
   const float X = SX / S, Y = SY / S;
   float* st = stats + ((size_t)b * g.K + k) * XAS_HEAD_STATS;
-  if (b == 0 && live) depth_prob_map[k * g.D + d] = pz;
+  if (b % dmap_every == 0 && live) depth_prob_map[((size_t)(b / dmap_every) * g.K + k) * g.D + d] = pz;
   const float fD = (float)g.D;
   const float xn = X / fD * 2.f - 1.f, yn = Y / fD * 2.f - 1.f;
   if (d == 0) { st[0] = M + __logf(S); st[1] = X; st[2] = Y; }
@@ -246,7 +246,7 @@ extern "C" size_t xas_head_workspace_floats(int B, int K, int D) {
 }
 
 extern "C" int xas_head_softargmax_fwd(const float* logits, int B, int K, int D, int num_hypo, int neighbor,
-                                       float* kps, int64_t* z_idx, float* depth_prob_map, float* stats,
+                                       float* kps, int64_t* z_idx, float* depth_prob_map, int groups, float* stats,
                                        float* partial, void* stream) {
   HeadGeom g;
   if (make_geom(B, K, D, &g)) return 1;
@@ -255,13 +255,14 @@ extern "C" int xas_head_softargmax_fwd(const float* logits, int B, int K, int D,
   XAS_REQUIRE(neighbor >= 0 && (neighbor > 0 || num_hypo == 1), "head fwd: single-hypothesis mode needs num_hypo == 1");
   XAS_REQUIRE(neighbor == 0 || (z_idx != nullptr && num_hypo <= D - 2), "head fwd: z_idx required / too many hypotheses");
   XAS_REQUIRE(((uintptr_t)logits & 15) == 0, "head fwd: logits must be 16-byte aligned");
+  XAS_REQUIRE(groups >= 1 && B % groups == 0, "head fwd: B=%d does not split into %d groups", B, groups);
   const size_t lds = (size_t)g.R * K * g.rec * sizeof(float);
   XAS_REQUIRE(lds <= 64 * 1024, "head fwd: LDS %zu too large", lds);
   hipLaunchKernelGGL(head_partial_kernel, dim3(g.nchunk, B), dim3(g.C4 * g.R), lds, as_stream(stream),
                      reinterpret_cast<const float4*>(logits), partial, g);
   XAS_LAUNCH_CHECK();
   hipLaunchKernelGGL(head_finalize_kernel, dim3(B * K), dim3(64), 0, as_stream(stream), partial, g, num_hypo,
-                     neighbor, kps, z_idx, depth_prob_map, stats);
+                     neighbor, kps, z_idx, depth_prob_map, B / groups, stats);
   XAS_LAUNCH_CHECK();
   return 0;
 }

@@ -3,7 +3,7 @@ softmax over D*H*W and the plain three-axis expectation, fused into one HIP redu
 import torch.nn as nn
 
 from modules.integral_base_modules.network import get_default_network_config, get_pose_net
-from xas_amd import ops_head
+from xas_amd import ops_head, ops_nn
 
 
 class KPDetector3D(nn.Module):
@@ -19,3 +19,9 @@ class KPDetector3D(nn.Module):
     def forward(self, x):
         kps, depth_prob_map = ops_head.softargmax_single(self.net(x), self.num_kp)
         return kps, depth_prob_map          # kps [B, 1, num_kp, 3], aligned with the multi-hypothesis layout
+
+    def forward_groups(self, x, groups):
+        """`groups` consecutive reference calls as one camera-batched pass (see KPDetector3DMulti.forward_groups)."""
+        with ops_nn.bn_groups(groups):
+            heatmap = self.net(x)
+        return ops_head.softargmax_single(heatmap, self.num_kp, groups=groups)

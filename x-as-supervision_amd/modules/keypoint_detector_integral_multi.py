@@ -8,7 +8,7 @@ passes over a 604 MB tensor.  Ties between equal peak scores resolve to the lowe
 import torch.nn as nn
 
 from modules.integral_base_modules.network import get_default_network_config, get_pose_net
-from xas_amd import ops_head
+from xas_amd import ops_head, ops_nn
 
 
 class KPDetector3DMulti(nn.Module):
@@ -27,5 +27,16 @@ class KPDetector3DMulti(nn.Module):
     def forward(self, x):
         heatmap = self.net(x)
         kps, depth_prob_map, idx = ops_head.softargmax_multi(heatmap, self.num_kp, self.num_hypo, self.neighbor_size)
+        self.last_peak_indices = idx
+        return kps, depth_prob_map
+
+    def forward_groups(self, x, groups):
+        """The reference's `groups` consecutive calls forward(x[0:B]), forward(x[B:2B]), ... as ONE pass over the
+        concatenated batch: convolutions see G*B images, every batch-norm layer keeps per-call statistics and applies
+        its running-statistic updates in call order (ops_nn.bn_groups).  -> kps [G*B, Hy, K, 3], depth maps [G, K, D]."""
+        with ops_nn.bn_groups(groups):
+            heatmap = self.net(x)
+        kps, depth_prob_map, idx = ops_head.softargmax_multi(heatmap, self.num_kp, self.num_hypo, self.neighbor_size,
+                                                            groups=groups)
         self.last_peak_indices = idx
         return kps, depth_prob_map

@@ -7,12 +7,14 @@ the `smpl_gen` input subtracts HYPOTHESIS 0 (model.py:124 indexes axis 1) and is
 regressor receives no adversarial gradient; symmetry / pseudo losses take the min over hypotheses of
 batch means; zero-weight losses are still computed and back-propagated.
 """
+import os
+
 import torch
 
 from modules.base_losses.loss_func import (compute_disc_loss, compute_mask_reconstruction_loss,
                                            compute_supervision_min, compute_symmetry_min)
 from modules.util import convert_patch_to_world, draw_lines_max, random_rotation_3D
-from xas_amd import ops_nn, streams
+from xas_amd import ops_nn
 
 
 def cal_links(parent_ids, line_select_ids=None, use_root=False, extension=True):
@@ -44,6 +46,37 @@ def _to_world(kps, x, key, mono):
     return convert_patch_to_world(kps, x, key, is_norm=True)
 
 
+# Camera batching (MI355X: 288 GB of HBM): the reference calls the detector once per camera (model.py:64,147,231) and
+# the physique net once per camera (model.py:81).  Here the images of all cameras go through the network as ONE tensor
+# [G*B, ...]: 4x larger GEMMs for the small late layers, 4x fewer launches and SyncBatchNorm messages.  Every batch-norm
+# layer still normalises each camera's B images with their own statistics and applies the running-statistic updates
+# in camera order (ops_nn.bn_groups), so the arithmetic is that of the per-camera calls.  XAS_CAM_BATCH=0 restores one
+# call per camera; XAS_CAM_BATCH_MAX caps the number of cameras per pass.
+CAM_BATCH = os.environ.get('XAS_CAM_BATCH', '1') == '1'
+CAM_BATCH_MAX = max(1, int(os.environ.get('XAS_CAM_BATCH_MAX', '8')))
+
+
+def _grouped(net, tensors):
+    """[net(t) for t in tensors] (results as a list), camera-batched when the network offers forward_groups."""
+    if not (CAM_BATCH and len(tensors) > 1 and hasattr(net, 'forward_groups')
+            and all(t.shape == tensors[0].shape for t in tensors)):
+        return [net(t) for t in tensors]
+    res = []
+    B = tensors[0].shape[0]
+    per_pass = max(1, min(CAM_BATCH_MAX, 384 // max(1, B)))     # logits of a pass: G*B*64*64*1152 elements < 2^31
+    for lo in range(0, len(tensors), per_pass):
+        part = tensors[lo:lo + per_pass]
+        G = len(part)
+        y = net.forward_groups(torch.cat(part, dim=0) if G > 1 else part[0], G)
+        if isinstance(y, tuple):                         # detector: (kps [G*B, ...], depth maps [G, K, D])
+            kps, dmap = y
+            dmap = dmap.reshape(G, *dmap.shape[-2:])
+            res += [(kps[g * B:(g + 1) * B], dmap[g]) for g in range(G)]
+        else:
+            res += [y[g * B:(g + 1) * B] for g in range(G)]
+    return res
+
+
 class Counter3DModel(torch.nn.Module):
     def __init__(self, cfg, regressor, smpl_layer, h36m_regressor, physique_network=None):
         super().__init__()
@@ -60,47 +93,6 @@ class Counter3DModel(torch.nn.Module):
         self.DISC_SUP_DIMENSION = cfg['smpl_disc_params'].get('disc_sup_dim', 3)
         self.use_aug = cfg['smpl_disc_params'].get('use_aug', False)
 
-    def _camera_pass(self, x, cam, lc, out):
-        """Everything of one camera that does not need the other cameras: detector, geometry, mask renderer,
-        physique net, mask losses, pseudo-image branch.  Runs on that camera's HIP stream."""
-        key = 'cam_{}'.format(cam)
-        img = x[key + '_img']
-        r = {}
-        kps, depth_map = self.regressor(img)
-        assert kps.dim() == 4, "use aligned multi-hypothesis settings"
-        out['pose_2d_pred_{}_ori'.format(key)] = kps[[0], 0].detach().clone()
-        out['depth_map_{}'.format(key)] = depth_map
-        world = _to_world(kps, x, key, cam == 'mono')                  # [B, Hy, K, 3], one launch
-        out['pose_3d_depth_{}'.format(key)] = world[:, 0].detach().clone()
-        # multi-hypothesis only changes z, so one mask per camera (hypothesis 0's x, y)
-        recon = draw_lines_max(kps[:, 0, :, :2], img.shape[-1], self.parent_ids, self.child_ids, self.body_width)
-        out['mask_heatmap_line_{}'.format(key)] = recon.detach()
-        r.update(kps=kps, world=world, recon=recon)
-        if 'physique_recons_loss' in lc and self.physique_network is not None:
-            phys = self.physique_network(recon)
-            out['mask_physique_{}'.format(key)] = phys[[0]].detach()
-            r['phys'] = compute_mask_reconstruction_loss(
-                phys, x[key + '_mask'], weight=x[key + '_geodesic_dis'] if lc['physique_recons_loss']['use_dis_map'] else None)
-        if 'recons_loss' in lc:
-            r['recons'] = compute_mask_reconstruction_loss(
-                recon, x[key + '_mask'], weight=x[key + '_geodesic_dis'] if lc['recons_loss']['use_dis_map'] else None,
-                use_clip=True)
-        streams.to_main(*[v for v in r.values() if isinstance(v, torch.Tensor)])
-        return r
-
-    def _pseudo_pass(self, x, cam, out):
-        """Pseudo-image branch of one camera (model.py:145-164): detector on the synthetic image, supervised by
-        its joints, min over hypotheses of the batch-mean error."""
-        key = 'cam_{}'.format(cam)
-        pred, _ = self.regressor(x[key + '_pseudo_img'])
-        gt = x[key + '_pseudo_joints']
-        out['pose_2d_pred_{}_pseudo'.format(key)] = pred[[0], 0].detach().clone()
-        out['pose_3d_pred_{}_pseudo'.format(key)] = _to_world(pred[:, 0].detach(), x, key, True)[[0]]
-        out['pose_3d_gt_{}_pseudo'.format(key)] = _to_world(gt, x, key, True)[[0]]
-        v = compute_supervision_min(pred, gt)
-        streams.to_main(v)
-        return v
-
     def forward(self, x, smpl_discriminator):
         return self.finish(x, smpl_discriminator, *self.camera_passes(x))
 
@@ -110,26 +102,55 @@ class Counter3DModel(torch.nn.Module):
         cams = _cams(x, self.cam_id_list)
         lc = self.loss_config
         out = {}
-        ops_nn.prepack(self.regressor)                    # packed weights ready before the camera streams fork
+        ops_nn.prepack(self.regressor)
         if self.physique_network is not None:
             ops_nn.prepack(self.physique_network)
+        keys = ['cam_{}'.format(c) for c in cams]
+        # detector on the real image of every camera (model.py:64); call order = camera order fixes the order of the
+        # batch-norm running-statistic updates
+        dets = _grouped(self.regressor, [x[k + '_img'] for k in keys])
         per_cam = {}
-        with streams.fork() as fk:
-            # host enqueue order (real images of every camera, then the pseudo images) is the reference's
-            # order of detector calls: it fixes the order of the batch-norm running-statistic updates
-            for i, cam in enumerate(cams):
-                with fk.run(i):
-                    per_cam['cam_{}'.format(cam)] = self._camera_pass(x, cam, lc, out)
-            if pseudo and 'smpl_pseudo_img_loss' in lc:
-                for i, cam in enumerate(cams):
-                    with fk.run(i):
-                        per_cam['cam_{}'.format(cam)]['pseudo'] = self._pseudo_pass(x, cam, out)
+        for cam, key, (kps, depth_map) in zip(cams, keys, dets):
+            assert kps.dim() == 4, "use aligned multi-hypothesis settings"
+            out['pose_2d_pred_{}_ori'.format(key)] = kps[[0], 0].detach().clone()
+            out['depth_map_{}'.format(key)] = depth_map
+            world = _to_world(kps, x, key, cam == 'mono')                  # [B, Hy, K, 3], one launch
+            out['pose_3d_depth_{}'.format(key)] = world[:, 0].detach().clone()
+            # multi-hypothesis only changes z, so one mask per camera (hypothesis 0's x, y)
+            recon = draw_lines_max(kps[:, 0, :, :2], x[key + '_img'].shape[-1], self.parent_ids, self.child_ids,
+                                   self.body_width)
+            out['mask_heatmap_line_{}'.format(key)] = recon.detach()
+            per_cam[key] = dict(kps=kps, world=world, recon=recon)
+        if 'physique_recons_loss' in lc and self.physique_network is not None:
+            use_w = lc['physique_recons_loss']['use_dis_map']
+            for key, phys in zip(keys, _grouped(self.physique_network, [per_cam[k]['recon'] for k in keys])):
+                out['mask_physique_{}'.format(key)] = phys[[0]].detach()
+                per_cam[key]['phys'] = compute_mask_reconstruction_loss(
+                    phys, x[key + '_mask'], weight=x[key + '_geodesic_dis'] if use_w else None)
+        if 'recons_loss' in lc:
+            use_w = lc['recons_loss']['use_dis_map']
+            for key in keys:
+                per_cam[key]['recons'] = compute_mask_reconstruction_loss(
+                    per_cam[key]['recon'], x[key + '_mask'], weight=x[key + '_geodesic_dis'] if use_w else None,
+                    use_clip=True)
+        if pseudo:
+            self.pseudo_passes(x, per_cam, out)
         return per_cam, out
 
     def pseudo_passes(self, x, per_cam, out):
-        if 'smpl_pseudo_img_loss' in self.loss_config:
-            for cam in _cams(x, self.cam_id_list):
-                per_cam['cam_{}'.format(cam)]['pseudo'] = self._pseudo_pass(x, cam, out)
+        """Pseudo-image branch (model.py:145-164): detector on the synthetic image of every camera, supervised by its
+        joints, min over hypotheses of the batch-mean error."""
+        if 'smpl_pseudo_img_loss' not in self.loss_config:
+            return
+        cams = _cams(x, self.cam_id_list)
+        keys = ['cam_{}'.format(c) for c in cams]
+        dets = _grouped(self.regressor, [x[k + '_pseudo_img'] for k in keys])
+        for key, (pred, _) in zip(keys, dets):
+            gt = x[key + '_pseudo_joints']
+            out['pose_2d_pred_{}_pseudo'.format(key)] = pred[[0], 0].detach().clone()
+            out['pose_3d_pred_{}_pseudo'.format(key)] = _to_world(pred[:, 0].detach(), x, key, True)[[0]]
+            out['pose_3d_gt_{}_pseudo'.format(key)] = _to_world(gt, x, key, True)[[0]]
+            per_cam[key]['pseudo'] = compute_supervision_min(pred, gt)
 
     def finish(self, x, smpl_discriminator, per_cam, out):
         """Losses from the per-camera results (model.py:98-190)."""
@@ -205,24 +226,17 @@ class Counter3DDisc(torch.nn.Module):
         out = {}
         d = self.DISC_SUP_DIMENSION
         cams = _cams(x, self.cam_id_list)
-        reals, inputs = {}, []
-        have = preds is not None
-        preds = {k: v.detach() for k, v in preds.items()} if have else {}
-        if not have:
+        keys = ['cam_{}'.format(c) for c in cams]
+        reals, inputs = {k: x[k + '_pseudo_joints'] for k in keys}, []
+        if preds is not None:
+            preds = {k: v.detach() for k, v in preds.items()}
+        else:
+            # The reference builds (and discards) an autograd graph here (model.py:231, output detached at :243);
+            # only the values and the train-mode BN running-statistic updates matter, so no graph is recorded.
             ops_nn.prepack(regressor)
-        with streams.fork(streams.NUM_NOGRAD) as fk:
-            for i, cam in enumerate(cams):
-                key = 'cam_{}'.format(cam)
-                reals[key] = x[key + '_pseudo_joints']
-                if have:
-                    continue
-                # The reference builds (and discards) an autograd graph here (model.py:231, output detached at
-                # :243); only the values and the train-mode BN running-statistic updates matter, so no graph is
-                # recorded.  Each camera's detector runs on its own stream.
-                with fk.run(i), torch.no_grad():
-                    pred, _ = regressor(x[key + '_img'])
-                    streams.to_main(pred)
-                preds[key] = pred
+            with torch.no_grad():
+                dets = _grouped(regressor, [x[k + '_img'] for k in keys])
+            preds = {k: kp for k, (kp, _) in zip(keys, dets)}
         for cam in cams:
             key = 'cam_{}'.format(cam)
             inputs += [preds[key][:, h, :, :d] for h in range(preds[key].shape[1])] + [reals[key][..., :d]]

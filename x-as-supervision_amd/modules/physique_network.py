@@ -38,3 +38,9 @@ class PhysiqueMaskGenerator(nn.Module):
 
     def forward(self, input):
         return F.sigmoid(self.decoder(self.encoder(input)))
+
+    def forward_groups(self, input, groups):
+        """`groups` consecutive reference calls on equal sub-batches as ONE pass (per-call batch-norm statistics and
+        running-statistic updates in call order: ops_nn.bn_groups)."""
+        with F.bn_groups(groups):
+            return F.sigmoid(self.decoder(self.encoder(input)))

@@ -24,7 +24,7 @@ SIGNATURES = {
     'xas_set_tuning': ('i', 'i'),
     'xas_set_debug_buffer': ('p', 'i'),
     'xas_head_workspace_floats': ('iii', 'z'),
-    'xas_head_softargmax_fwd': ('piiiiipppppp', 'i'),
+    'xas_head_softargmax_fwd': ('piiiiipppippp', 'i'),
     'xas_head_softargmax_bwd': ('ppppiiiiippp', 'i'),
     'xas_patch_to_world_fwd': ('ppppppiiiffipp', 'i'),
     'xas_patch_to_world_bwd': ('pppppppiiiffipp', 'i'),
@@ -40,13 +40,14 @@ SIGNATURES = {
     'xas_conv_wgrad_acc': ('ppppsp', 'i'),
     'xas_pack_weight': ('ppiiiiip', 'i'),
     'xas_unpack_weight': ('ppiiiiip', 'i'),
-    'xas_bn_workspace_floats': ('li', 'z'),
-    'xas_bn_stats': ('plipppppflp', 'i'),
+    'xas_bn_workspace_floats': ('lii', 'z'),
+    'xas_bn_stats': ('pliipplppppflp', 'i'),
+    'xas_bn_sync_merge': ('piiilppppfp', 'i'),
     'xas_col_sum': ('plippp', 'i'),
-    'xas_bn_apply': ('ppppppfilipp', 'i'),
-    'xas_bn_update_running': ('ppppflip', 'i'),
-    'xas_bn_bwd_reduce': ('pppppppfilipppppp', 'i'),
-    'xas_bn_bwd_apply': ('pppppppppfilidppp', 'i'),
+    'xas_bn_apply': ('ppppppfiliipp', 'i'),
+    'xas_bn_update_running': ('ppppfliip', 'i'),
+    'xas_bn_bwd_reduce': ('pppppppfiliippppp', 'i'),
+    'xas_bn_bwd_apply': ('ppppppppfiliidppp', 'i'),
     'xas_maxpool3x3s2_fwd': ('piiiippp', 'i'),
     'xas_maxpool3x3s2_bwd': ('ppiiiipp', 'i'),
     'xas_upsample2x_fwd': ('piiiipp', 'i'),

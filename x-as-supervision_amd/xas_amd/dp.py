@@ -3,16 +3,25 @@ train.py:87-88, whose reducer all-reduces 25 MB buckets on the NCCL stream).
 
 MI355X-first design: gradients already live in ONE contiguous arena per optimizer (optim.FusedAdam), laid
 out in parameter-registration order.  Backward produces gradients roughly in reverse order, so the arena is
-cut into a few large buckets from the tail; a post-accumulate-grad hook on the LAST parameter to become
-ready in each bucket (counted) launches that bucket's all-reduce on a side HIP stream behind an event, so the
-collective overlaps the rest of backward.  xGMI is point-to-point (7 links x ~153 GB/s): a handful of large
-messages beats many small ones, so the default is 4 buckets of ~35 MB for the 139 MB generator arena.
-`finish()` makes the compute stream wait for the side stream and divides by world size (mean) inside the
-wait, before the optimizer step.
+cut into a few large buckets from the tail.  A bucket's all-reduce is launched on a side HIP stream as soon as
+every member's gradient of this step is complete:
+  * parameters whose gradient autograd accumulates (biases, linear layers) report through a
+    post-accumulate-grad hook;
+  * conv weights (weight-gradient side stream) and batch-norm parameters (reduce kernel) are accumulated into the
+    arena by the kernels themselves; ops_nn counts their forward uses and reports a parameter when its last backward
+    contribution of the step has been launched (ops_nn.grad_ready).
+The communication stream waits for an event on the compute stream AND one on the weight-gradient stream, so the
+collective overlaps the rest of backward.  How much overlaps is limited by the step itself: every detector
+parameter receives contributions from each detector backward pass, so a bucket is complete only inside the LAST
+pass.  xGMI is point-to-point (7 links x ~153 GB/s): a handful of large messages beats many small ones, so the
+default is 4 buckets of ~35 MB for the 139 MB generator arena.  `finish()` joins the weight-gradient stream,
+launches whatever is left, waits, and divides by world size (mean) before the optimizer step.
 
 Works with any torch.distributed backend: `nccl` (= RCCL on ROCm) on GPUs, `gloo` in the CPU tests.
-Buffers are NOT broadcast every forward (the reference's broadcast_buffers=True re-sends 19 MB of constant
-SMPL arrays per call): BN running statistics are synchronised once per step instead (`sync_buffers`).
+Buffers are NOT broadcast every forward (the reference's broadcast_buffers=True re-sends 19 MB of constant SMPL
+arrays per call): SyncBatchNorm layers keep identical running statistics on every rank by construction (global
+statistics), the in-block BatchNorm2d layers are rank-local exactly as in the reference; `sync_buffers` aligns all
+buffers ONCE when the step object is built (engine.TrainStep.__init__).
 """
 import torch
 import torch.distributed as dist
@@ -50,28 +59,46 @@ class GradReducer:
         if arena.is_cuda and use_side_stream:
             self.stream = torch.cuda.Stream()
         self._hooks = []
+        self._index = {}
         for j, p in enumerate(params):
             if j in self._member_bucket:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(j)))
+                self._index[id(p)] = j
         self._armed = False
+        if arena.is_cuda:
+            from . import ops_nn
+            ops_nn.track_grad_uses(True)       # count forward uses of kernel-accumulated parameters from now on
+
+    def _member_ready(self, j):
+        if not self._armed:
+            return
+        b = self.buckets[self._member_bucket[j]]
+        b['ready'] += 1
+        if b['ready'] == len(b['members']) and not b.get('launched'):
+            self._launch(b)
 
     def _make_hook(self, j):
         def hook(_p):
-            if not self._armed:
-                return
-            b = self.buckets[self._member_bucket[j]]
-            b['ready'] += 1
-            if b['ready'] == len(b['members']):
-                self._launch(b)
+            self._member_ready(j)
         return hook
+
+    def notify(self, p):
+        """ops_nn.grad_ready: the kernels have launched the last contribution to p.grad of this step."""
+        j = self._index.get(id(p))
+        if j is not None:
+            self._member_ready(j)
 
     def _launch(self, b):
         view = self.arena[b['lo']:b['hi']]
         if self.stream is not None:
+            from . import ops_nn
             ev = torch.cuda.Event()
             ev.record()                                   # gradients of this bucket are complete on the compute stream
+            ev_side = ops_nn.side_stream_event()          # ... and on the weight-gradient stream
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
+                if ev_side is not None:
+                    self.stream.wait_event(ev_side)
                 work = dist.all_reduce(view, group=self.group, async_op=True)
         else:
             work = dist.all_reduce(view, group=self.group, async_op=True)
@@ -86,12 +113,20 @@ class GradReducer:
             b['ready'] = 0
             b['launched'] = False
         self._armed = True
+        if self.arena.is_cuda:
+            from . import ops_nn
+            ops_nn._uses['hook'] = self.notify
 
     def finish(self):
         """Wait for all buckets (launching any whose hooks never fired: unused parameters), then average."""
         if not self.enabled:
             return
         self._armed = False
+        if self.arena.is_cuda:
+            from . import ops_nn
+            ops_nn._uses['hook'] = None
+            ops_nn._uses['pending'].clear()
+            ops_nn.join_side_stream()          # weight gradients still in flight on the side stream
         for b in self.buckets:
             if not b.get('launched'):
                 self._launch(b)

@@ -86,14 +86,16 @@ class BatchNorm2d(nn.Module):
         return None
 
     def count_batch(self):
-        """num_batches_tracked += 1 unless a parent owns the counter (SharedBatchCounters)."""
+        """num_batches_tracked += number of camera groups in this call (1 for a plain call) unless a parent owns the
+        counter (SharedBatchCounters): a camera-batched pass stands for that many reference calls."""
         if self.training and not self._nbt_shared:
             from . import streams
+            n = F.current_groups()
             if streams.forked():
                 with torch.cuda.stream(streams.book_stream()):
-                    self.num_batches_tracked += 1
+                    self.num_batches_tracked += n
             else:
-                self.num_batches_tracked += 1
+                self.num_batches_tracked += n
 
     def forward(self, x, residual=None):
         group = self.sync_group()
@@ -136,8 +138,9 @@ class SharedBatchCounters:
         if not ok:                      # first use, or the buffers were replaced (.to(), load_state_dict)
             self._bind()
         from . import streams
+        n = F.current_groups()          # a camera-batched pass counts once per camera
         if streams.forked():            # concurrent camera streams: serialise the read-modify-write
             with torch.cuda.stream(streams.book_stream()):
-                self.arena += 1
+                self.arena += n
         else:
-            self.arena += 1
+            self.arena += n

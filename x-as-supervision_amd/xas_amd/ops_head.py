@@ -19,7 +19,7 @@ def _nhwc_storage(logits):
 
 class _SoftArgmax(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, num_kp, num_hypo, neighbor):
+    def forward(ctx, logits, num_kp, num_hypo, neighbor, groups):
         logits = _nhwc_storage(logits)
         B, C, H, W = logits.shape
         D = C // num_kp
@@ -28,11 +28,11 @@ class _SoftArgmax(torch.autograd.Function):
         dev = logits.device
         kps = torch.empty(B, num_hypo, num_kp, 3, device=dev, dtype=torch.float32)
         z_idx = torch.empty(B, num_kp, num_hypo, device=dev, dtype=torch.int64)
-        dmap = torch.empty(num_kp, D, device=dev, dtype=torch.float32)
+        dmap = torch.empty(groups, num_kp, D, device=dev, dtype=torch.float32)
         stats = torch.empty(B, num_kp, HEAD_STATS, device=dev, dtype=torch.float32)
         ws = torch.empty(query('xas_head_workspace_floats', B, num_kp, D), device=dev, dtype=torch.float32)
         call('xas_head_softargmax_fwd', ptr(logits), B, num_kp, D, num_hypo, neighbor, ptr(kps), ptr(z_idx),
-             ptr(dmap), ptr(stats), ptr(ws))
+             ptr(dmap), groups, ptr(stats), ptr(ws))
         ctx.save_for_backward(logits, stats, z_idx)
         ctx.cfg = (num_kp, D, num_hypo, neighbor)
         ctx.mark_non_differentiable(z_idx, dmap)
@@ -48,19 +48,20 @@ class _SoftArgmax(torch.autograd.Function):
         coef = torch.empty(B * K * (4 + D), device=logits.device, dtype=torch.float32)
         call('xas_head_softargmax_bwd', ptr(logits), ptr(stats), ptr(z_idx), ptr(g_kps), B, K, D, Hy, nb,
              ptr(grad), ptr(coef))
-        return grad, None, None, None
+        return grad, None, None, None, None
 
 
-def softargmax_multi(logits, num_kp, num_hypo, neighbor_size):
-    """-> kps [B,num_hypo,K,3], depth_prob_map [K,D], z_idx [B,K,num_hypo] int64
-    (keypoint_detector_integral_multi.py:66-88)."""
-    return _SoftArgmax.apply(logits, num_kp, num_hypo, neighbor_size)
+def softargmax_multi(logits, num_kp, num_hypo, neighbor_size, groups=1):
+    """-> kps [B,num_hypo,K,3], depth_prob_map [K,D] ([groups,K,D] for groups > 1: first sample of each sub-batch),
+    z_idx [B,K,num_hypo] int64  (keypoint_detector_integral_multi.py:66-88)."""
+    kps, dmap, idx = _SoftArgmax.apply(logits, num_kp, num_hypo, neighbor_size, groups)
+    return kps, (dmap[0] if groups == 1 else dmap), idx
 
 
-def softargmax_single(logits, num_kp):
-    """-> kps [B,1,K,3], depth_prob_map [K,D]  (keypoint_detector_integral.py:45-65)."""
-    kps, dmap, _ = _SoftArgmax.apply(logits, num_kp, 1, 0)
-    return kps, dmap
+def softargmax_single(logits, num_kp, groups=1):
+    """-> kps [B,1,K,3], depth_prob_map [K,D] ([groups,K,D] for groups > 1)  (keypoint_detector_integral.py:45-65)."""
+    kps, dmap, _ = _SoftArgmax.apply(logits, num_kp, 1, 0, groups)
+    return kps, (dmap[0] if groups == 1 else dmap)
 
 
 class _PatchToWorld(torch.autograd.Function):

@@ -13,6 +13,27 @@ from ._lib import ConvShape, call, ptr, query
 CL = torch.channels_last
 _weights_epoch = [0]          # bumped by the fused optimizer (raw-pointer updates bypass tensor._version)
 
+# Camera-batched passes: the images of G cameras travel through a network as ONE tensor [G*B, ...] while every
+# batch-norm layer keeps separate statistics per camera (G groups of B images), exactly as the reference's G separate
+# calls (model.py:64,147,231).  `bn_groups(G)` is entered by the grouped forward of the detector / physique net.
+_groups = [1]
+
+
+class bn_groups:
+    def __init__(self, groups):
+        self.groups = int(groups)
+
+    def __enter__(self):
+        self.prev, _groups[0] = _groups[0], self.groups
+        return self
+
+    def __exit__(self, *exc):
+        _groups[0] = self.prev
+
+
+def current_groups():
+    return _groups[0]
+
 
 def bump_weights_epoch():
     _weights_epoch[0] += 1
@@ -40,6 +61,49 @@ def join_side_stream():
         _side['dirty'] = False
 
 
+def side_stream_event():
+    """An event that completes when every weight gradient launched so far has been added to the gradient arena
+    (None when the side stream is idle).  The data-parallel reducer makes its communication stream wait on it."""
+    if _side['dirty'] and _side['stream'] is not None:
+        ev = torch.cuda.Event()
+        ev.record(_side['stream'])
+        return ev
+    return None
+
+
+# ---- gradient readiness for the data-parallel reducer ------------------------------------------------------------
+# Conv weight gradients (side stream) and batch-norm parameter gradients (reduce kernel) are added to the gradient
+# arena by the kernels themselves, so autograd's post-accumulate hooks never fire for them.  Every forward use of such
+# a parameter that will be followed by a backward is counted; each backward contribution counts down; at zero the
+# parameter's gradient of this step is complete and the reducer (dp.GradReducer) is told, so a bucket can be
+# all-reduced while the rest of backward still runs.
+_uses = {'on': False, 'pending': {}, 'hook': None}
+
+
+def track_grad_uses(on=True):
+    _uses['on'] = bool(on)
+    _uses['pending'].clear()
+
+
+def note_use(p):
+    if _uses['on'] and p is not None:
+        k = id(p)
+        _uses['pending'][k] = _uses['pending'].get(k, 0) + 1
+
+
+def grad_ready(p):
+    if not _uses['on']:
+        return
+    k = id(p)
+    left = _uses['pending'].get(k, 0) - 1
+    if left > 0:
+        _uses['pending'][k] = left
+        return
+    _uses['pending'].pop(k, None)
+    if _uses['hook'] is not None:
+        _uses['hook'](p)
+
+
 def _wgrad_into_grad(x, dy, shp, weight):
     """Accumulate the OIHW weight gradient into weight.grad on the side stream; False if not applicable."""
     g = weight.grad
@@ -53,6 +117,7 @@ def _wgrad_into_grad(x, dy, shp, weight):
     x.record_stream(side)
     dy.record_stream(side)
     _side['dirty'] = True
+    grad_ready(weight)
     return True
 
 
@@ -103,7 +168,7 @@ class _PackCache:
 
 def _col_sum(t2d_ptr_tensor, M, C):
     out = torch.empty(C, device=t2d_ptr_tensor.device, dtype=torch.float32)
-    ws = torch.empty(query('xas_bn_workspace_floats', M, C), device=out.device, dtype=torch.float32)
+    ws = torch.empty(query('xas_bn_workspace_floats', M, C, 1), device=out.device, dtype=torch.float32)
     call('xas_col_sum', ptr(t2d_ptr_tensor), M, C, ptr(out), ptr(ws))
     return out
 
@@ -138,6 +203,8 @@ class _Conv2d(torch.autograd.Function):
         call('xas_conv_fwd', ptr(x), ptr(cache.get(weight, 0)), ptr(bias), ptr(y), shp)
         ctx.save_for_backward(x, weight)
         ctx.shp, ctx.cache, ctx.has_bias = shp, cache, bias is not None
+        if ctx.needs_input_grad[1]:
+            note_use(weight)
         return y
 
     @staticmethod
@@ -223,6 +290,10 @@ class _Bottleneck(torch.autograd.Function):
         flat = [t for sv in saved for t in sv]
         ctx.save_for_backward(x, acts[1], acts[2], *flat)
         ctx.blk, ctx.cfgs, ctx.shps, ctx.has_ds = blk, cfgs, shps, ds is not None
+        if _uses['on']:
+            for p, need in zip(params, ctx.needs_input_grad[2:]):
+                if need:
+                    note_use(p)
         return a
 
     @staticmethod
@@ -294,6 +365,8 @@ class _ConvTranspose2d(torch.autograd.Function):
         call('xas_conv_dgrad', ptr(x), ptr(cache.get(weight, 1)), ptr(y), shp)
         ctx.save_for_backward(x, weight)
         ctx.shp, ctx.cache = shp, cache
+        if ctx.needs_input_grad[1]:
+            note_use(weight)
         return y
 
     @staticmethod
@@ -362,67 +435,85 @@ bn_log = {'on': False, 'calls': []}
 def replay_bn_updates(only=None):
     """Apply the logged running-statistic updates once more, in the logged order (`only`: data_ptr set of the
     running_mean buffers to replay; others are dropped)."""
-    for mean, var, rm, rv, momentum, count in bn_log['calls']:
+    for mean, var, rm, rv, momentum, count, groups in bn_log['calls']:
         if only is not None and rm.data_ptr() not in only:
             continue
-        call('xas_bn_update_running', ptr(mean), ptr(var), ptr(rm), ptr(rv), float(momentum), int(count), mean.numel())
+        call('xas_bn_update_running', ptr(mean), ptr(var), ptr(rm), ptr(rv), float(momentum), int(count), mean.shape[-1],
+             int(groups))
     bn_log['calls'] = []
 
 
 def _sync_stats(mean, var, count, group):
-    """SyncBatchNorm statistic exchange: ONE all_gather of [mean | var | count] per layer
-    (torch issues all_gather of mean/invstd/count: _functions.SyncBatchNorm.forward)."""
+    """SyncBatchNorm statistic merge with torch ops (any device; the HIP path uses xas_bn_sync_merge on the packed
+    message instead): all_gather of [mean | var | count], count-weighted merge in float64
+    (torch: _functions.SyncBatchNorm.forward -> batch_norm_gather_stats_with_counts)."""
     world = dist.get_world_size(group)
     C = mean.numel()
     packed = torch.cat([mean, var, mean.new_tensor([float(count)])])
     gathered = torch.empty(world * (2 * C + 1), device=mean.device, dtype=torch.float32)
     dist.all_gather_into_tensor(gathered, packed, group=group)
-    g = gathered.view(world, 2 * C + 1)
+    g = gathered.view(world, 2 * C + 1).double()
     cnt = g[:, 2 * C:]                                    # [world,1]
     total = cnt.sum()
     gm = (g[:, :C] * cnt).sum(0) / total
-    gv = ((g[:, C:2 * C] + g[:, :C] ** 2) * cnt).sum(0) / total - gm * gm
-    return gm.contiguous(), gv.clamp_min_(0).contiguous()
+    gv = ((g[:, C:2 * C] + (g[:, :C] - gm) ** 2) * cnt).sum(0) / total
+    return gm.float().contiguous(), gv.float().contiguous()
 
 
 def _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, group):
-    """-> (y, saved tensors (x|y, y|x, mean, var), cfg) - the body of _BatchNorm.forward, also used by _Bottleneck."""
+    """-> (y, saved tensors (x|y, y|x, mean, var), cfg) - the body of _BatchNorm.forward, also used by _Bottleneck.
+    The batch is `current_groups()` independent sub-batches (cameras): statistics are [G, C]."""
     x = to_cl(x)
     n, c, h, w = x.shape
+    G = _groups[0]
+    if n % G:
+        raise RuntimeError('batch of %d images does not split into %d camera groups' % (n, G))
     M = n * h * w
+    Mg = M // G
     dev = x.device
-    count = float(M)
+    count = float(Mg)
     if training:
-        mean = torch.empty(c, device=dev, dtype=torch.float32)
-        var = torch.empty(c, device=dev, dtype=torch.float32)
-        ws = torch.empty(query('xas_bn_workspace_floats', M, c), device=dev, dtype=torch.float32)
-        fuse_running = group is None and running_mean is not None and not streams.forked()
-        call('xas_bn_stats', ptr(x), M, c, ptr(mean), ptr(var), ptr(ws),
-             ptr(running_mean) if fuse_running else None, ptr(running_var) if fuse_running else None,
-             float(momentum), int(M))
-        if group is not None:
-            mean, var = _sync_stats(mean, var, M, group)
-            count = float(M) * dist.get_world_size(group)     # equal per-rank batches (train.py:274)
-        if running_mean is not None and not fuse_running:
-            if streams.forked():
+        ws = torch.empty(query('xas_bn_workspace_floats', M, c, G), device=dev, dtype=torch.float32)
+        if group is None:
+            mean = torch.empty(G, c, device=dev, dtype=torch.float32)
+            var = torch.empty(G, c, device=dev, dtype=torch.float32)
+            fuse_running = running_mean is not None and not streams.forked()
+            call('xas_bn_stats', ptr(x), M, c, G, ptr(mean), ptr(var), c, None, ptr(ws),
+                 ptr(running_mean) if fuse_running else None, ptr(running_var) if fuse_running else None,
+                 float(momentum), int(Mg))
+            if running_mean is not None and not fuse_running:
                 # order-dependent update: serialised on the bookkeeping stream in host program order
                 book, cur = streams.book_stream(), torch.cuda.current_stream()
                 book.wait_stream(cur)
                 with torch.cuda.stream(book):
                     call('xas_bn_update_running', ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
-                         float(momentum), int(count), c)
+                         float(momentum), int(Mg), c, G)
                 mean.record_stream(book)
                 var.record_stream(book)
-            else:
-                call('xas_bn_update_running', ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
-                     float(momentum), int(count), c)
+        else:
+            # SyncBatchNorm: the stats kernel writes [mean | var | count | pad] per group straight into the message,
+            # ONE all-gather per layer carries all groups, one kernel merges (count-weighted, double) and updates the
+            # running statistics with the global count
+            world = dist.get_world_size(group)
+            stride = 2 * c + 4
+            msg = torch.empty(G, stride, device=dev, dtype=torch.float32)
+            call('xas_bn_stats', ptr(x), M, c, G, ptr(msg), ptr(msg[:, c:]), stride, ptr(msg[:, 2 * c:]), ptr(ws),
+                 None, None, float(momentum), int(Mg))
+            gathered = torch.empty(world * G * stride, device=dev, dtype=torch.float32)     # [world][G][stride]
+            dist.all_gather_into_tensor(gathered, msg.view(-1), group=group)
+            mean = torch.empty(G, c, device=dev, dtype=torch.float32)
+            var = torch.empty(G, c, device=dev, dtype=torch.float32)
+            call('xas_bn_sync_merge', ptr(gathered), world, G, c, stride, ptr(mean), ptr(var),
+                 ptr(running_mean), ptr(running_var), float(momentum))
+            count = float(Mg) * world                          # equal per-rank batches (train.py:274)
         if bn_log['on'] and running_mean is not None:
-            bn_log['calls'].append((mean, var, running_mean, running_var, momentum, count))
+            bn_log['calls'].append((mean, var, running_mean, running_var, momentum, count, G))
     else:
-        mean, var = running_mean, running_var
+        mean = running_mean.reshape(1, c).expand(G, c).contiguous() if G > 1 else running_mean
+        var = running_var.reshape(1, c).expand(G, c).contiguous() if G > 1 else running_var
     res = to_cl(residual) if residual is not None else None
     y = torch.empty_like(x)
-    call('xas_bn_apply', ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(res), float(eps), act, M, c, ptr(y))
+    call('xas_bn_apply', ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(res), float(eps), act, M, c, G, ptr(y))
     # Backward traffic: which of x / y the backward passes need
     #   leaky ReLU, no residual : neither pass reads x (xhat recovered from the invertible output y);
     #   ReLU, no residual       : neither pass reads y (the mask is re-derived from x: 2 reads + 1 write in the apply
@@ -431,7 +522,7 @@ def _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, m
     xfree = training and act == ACT_LEAKY and residual is None
     yfree = training and act == ACT_RELU and residual is None and os.environ.get('XAS_BN_YFREE', '1') == '1'
     saved = (y if xfree else x, x if yfree else y, mean, var)
-    cfg = (M, c, float(eps), act, count, group, training, residual is not None, xfree, yfree)
+    cfg = (M, c, float(eps), act, count, group, training, residual is not None, xfree, yfree, G)
     return y, saved, cfg
 
 
@@ -440,31 +531,30 @@ def _bn_backward(saved, cfg, gamma, beta, dy, want_param_grads):
     beta.grad (LOCAL sums: the gradient all-reduce averages them later), which saves two autograd accumulation kernels
     per layer."""
     x, y, mean, var = saved
-    M, c, eps, act, count, group, training, has_res, xfree, yfree = cfg
+    M, c, eps, act, count, group, training, has_res, xfree, yfree, G = cfg
     if not training:
         raise RuntimeError('batch-norm backward in eval mode is not part of the training path')
     dy = to_cl(dy)
     dev = x.device
-    sdz = torch.empty(2 * c, device=dev, dtype=torch.float32)
-    ws = torch.empty(query('xas_bn_workspace_floats', M, c), device=dev, dtype=torch.float32)
+    sums = torch.empty(G, 2, c, device=dev, dtype=torch.float32)          # [g][0] = sum dz, [g][1] = sum dz * xhat
+    ws = torch.empty(query('xas_bn_workspace_floats', M, c, G), device=dev, dtype=torch.float32)
     gg, gb = gamma.grad, beta.grad
     direct = (want_param_grads and gg is not None and gb is not None and gg.is_contiguous() and gb.is_contiguous()
               and gg.dtype == torch.float32 and gb.dtype == torch.float32)
     call('xas_bn_bwd_reduce', None if xfree else ptr(x), None if yfree else ptr(y), ptr(dy), ptr(mean), ptr(var), ptr(gamma),
-         ptr(beta), eps, act, M, c, ptr(sdz), ptr(sdz[c:]), ptr(ws), ptr(gb) if direct else None,
-         ptr(gg) if direct else None)
+         ptr(beta), eps, act, M, c, G, ptr(sums), ptr(ws), ptr(gb) if direct else None, ptr(gg) if direct else None)
     if direct:
         dgamma = dbeta = None
+        grad_ready(gamma)
+        grad_ready(beta)
     else:
-        dgamma, dbeta = sdz[c:], sdz[:c]
+        dgamma, dbeta = sums[:, 1].sum(0), sums[:, 0].sum(0)              # local sums (before the exchange)
     if group is not None:
-        if not direct:
-            dgamma, dbeta = dgamma.clone(), dbeta.clone()
-        dist.all_reduce(sdz, group=group)                 # one coalesced 2C message per layer
+        dist.all_reduce(sums, group=group)                # one coalesced message per layer (all groups)
     dx = torch.empty_like(y)
     dres = torch.empty_like(y) if has_res else None
     call('xas_bn_bwd_apply', None if xfree else ptr(x), None if yfree else ptr(y), ptr(dy), ptr(mean), ptr(var), ptr(gamma),
-         ptr(beta), ptr(sdz), ptr(sdz[c:]), eps, act, M, c, float(count), ptr(dx), ptr(dres))
+         ptr(beta), ptr(sums), eps, act, M, c, G, float(count), ptr(dx), ptr(dres))
     return dx, dgamma, dbeta, dres
 
 
@@ -474,6 +564,9 @@ class _BatchNorm(torch.autograd.Function):
         y, saved, cfg = _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, group)
         ctx.save_for_backward(*saved, gamma, beta)
         ctx.cfg = cfg
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            note_use(gamma)
+            note_use(beta)
         return y
 
     @staticmethod
