@@ -148,7 +148,9 @@ def main():
     sync()
     # HIP events bracket every conv-family launch of the LAST timed step (1 818 launches): bracketing all K steps cost
     # ~4 % of the headline (two event packets per launch on the queue), one step costs < 1 %.
-    timer = KernelTimer()
+    from xas_amd.prof import CONV_ENTRIES
+    HEAD = ('xas_head_softargmax_fwd', 'xas_head_softargmax_bwd')
+    timer = KernelTimer(CONV_ENTRIES + HEAD)
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == args.steps - 1:
@@ -179,16 +181,18 @@ def main():
     samples = world * args.batch * args.steps
     if rank == 0:
         summ = timer.summary()
+        head = {k: summ.pop(k) for k in list(summ) if k.startswith('xas_head_')}
         mfma = {k: v for k, v in summ.items() if not k.endswith(':direct')}
         fl = sum(v['flops'] for v in mfma.values())
         ms = sum(v['ms'] for v in mfma.values())
         n_launch = sum(v['launches'] for v in mfma.values())
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r01_conv_traffic.json')
+        tpath = os.path.join(ROOT, 'profiles', 'r02_conv_traffic.json')
         if os.path.exists(tpath) and args.workload == 'HM36_Multi_SurS1' and args.batch == 32:
             with open(tpath) as tf:
-                traffic = json.load(tf).get('bytes_per_launch')   # PMC passes of this same command (see file)
+                pmc = json.load(tf)
+                traffic = pmc.get('bytes_per_launch')   # PMC passes of this same command (see file)
         line = {
             'metric': 'images/sec %s 256px bs%d (full disc+gen training step)' % (args.workload, args.batch),
             'value': samples * per_sample / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
@@ -216,10 +220,28 @@ def main():
                                           'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 else 0.0}
                                       for k, v in summ.items()}},
         }
+        # soft-argmax head (HBM bound): entry-point time (partial + finalize kernels) of the calls in the event-timed step
+        hd = {}
+        for k, v in head.items():
+            if v['ms'] > 0:
+                tbs = v['flops'] / (v['ms'] * 1e-3) / 1e12
+                hd[k.replace('xas_head_softargmax_', '').replace(':direct', '')] = {
+                    'launches': v['launches'], 'us_per_launch': v['ms'] * 1e3 / v['launches'],
+                    'algorithmic_MB_per_launch': v['flops'] / v['launches'] / 1e6, 'achieved_TBps': tbs, 'frac_of_8TBps': tbs / 8.0}
+        line['roofline']['head'] = dict(hd, kernel='head_partial_kernel + head_finalize_kernel (fwd), head_bwd_coef_kernel + '
+                                        'head_bwd_kernel (bwd)', bound='hbm', peak_TBps=8.0,
+                                        note='logits of one camera-batched pass (%d images x 18.87 MB): read once forward, read + '
+                                             'written backward' % (args.batch * len(cams)))
+        if traffic is not None:
+            line['roofline']['mfma_busy_pct_pmc'] = pmc.get('mfma_busy_pct')
         if args.shape_report:
             with open(args.shape_report, 'w') as f:
                 f.write('entry (N,Hi,Wi,Cin,Cout,R,stride) launches ms_total TFLOP/s\n')
                 for name, sig, n, ms_, tf in timer.by_shape():
+                    f.write('%-16s %-36s %5d %9.3f %7.2f\n' % (name, sig, n, ms_, tf))
+            with open(args.shape_report + '.serial', 'w') as f:       # the extra step without stream overlap
+                f.write('entry (N,Hi,Wi,Cin,Cout,R,stride) launches ms_total TFLOP/s\n')
+                for name, sig, n, ms_, tf in serial.by_shape():
                     f.write('%-16s %-36s %5d %9.3f %7.2f\n' % (name, sig, n, ms_, tf))
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only (the other ranks would sit in a barrier)
             threads = host_threads()

@@ -1,0 +1,79 @@
+"""The RCCL (`nccl` backend) code path of the data-parallel step on ONE GPU: a world-size-1 nccl process group with
+XAS_FORCE_DP=1 drives every collective call of the path through RCCL - parameter broadcast, packed SyncBatchNorm
+all-gather + merge kernel, backward all-reduce, bucketed gradient all-reduce on the communication stream (own
+communicator, launched from the readiness hooks during backward).  With one rank the exchange must be the identity:
+the step must equal the step without a process group."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(mode, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for p in (ROOT, os.path.join(ROOT, 'x-as-supervision_amd'), os.path.join(ROOT, 'tests', 'golden')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    if mode == 'nccl':
+        os.environ['XAS_FORCE_DP'] = '1'
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    from xas_amd import engine
+    from xas_amd.synthetic import model_config, synthetic_batch
+    cfg = model_config('HM36_Multi_SurS2')
+    cfg['model_params']['cam_id_list'] = [0, 1]
+    torch.manual_seed(7)
+    model, disc, od, odisc = engine.prepare_model(cfg)
+    model.cuda().train(), disc.cuda().train()
+    disc.smpl_discriminator.header.p = 0.0
+    step = engine.TrainStep(cfg, model, disc, od, odisc, num_buckets=3)
+    if mode == 'nccl':
+        assert step.red_det is not None and step.red_det.enabled and len(step.red_det.buckets) >= 2
+        assert dist.get_backend(step.red_det.group) == 'nccl'
+        launched = []
+        orig = step.red_det._launch
+        step.red_det._launch = lambda b: (launched.append(step.red_det._armed), orig(b))[1]
+    x = synthetic_batch(2, [0, 1], torch.device('cuda'), seed=21)
+    losses = []
+    for _ in range(2):
+        ld, lk, tot, _o = step(x)
+        losses.append((float(ld.detach()), float(tot.detach())))
+    torch.cuda.synchronize()
+    sd = model.state_dict()
+    ret[mode] = (losses, od.param_arena.double().sum().item(), od.param_arena.double().abs().sum().item(),
+                 odisc.param_arena.double().sum().item(), sd['regressor.net.backbone.bn1.running_mean'].double().sum().item(),
+                 sd['regressor.net.backbone.bn1.running_var'].double().sum().item(),
+                 (sum(launched), len(launched)) if mode == 'nccl' else None)
+    if mode == 'nccl':
+        dist.destroy_process_group()
+
+
+def test_nccl_world1_step_equals_plain_step():
+    ctx = mp.get_context('spawn')
+    ret = ctx.Manager().dict()
+    for mode in ('plain', 'nccl'):
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        p = ctx.Process(target=_worker, args=(mode, port, ret))
+        p.start()
+        p.join(600)
+        assert p.exitcode == 0, mode
+    a, b = ret['plain'], ret['nccl']
+    early, total = b[6]
+    assert total == 2 * 3 and early >= 1                     # 3 buckets per generator step; some launched from the hooks
+    for (la, ta), (lb, tb) in zip(a[0], b[0]):
+        assert abs(la - lb) <= 1e-6 * max(1.0, abs(la)) and abs(ta - tb) <= 1e-5 * max(1.0, abs(ta))
+    # identity exchange: parameters and synchronised running statistics agree with the plain step (the merge kernel
+    # re-derives mean / var from the gathered message: same values up to one rounding)
+    assert abs(a[1] - b[1]) <= 1e-6 * abs(a[2]) and abs(a[3] - b[3]) <= 1e-9 + 1e-6 * abs(a[3])
+    assert abs(a[4] - b[4]) <= 1e-6 * max(1.0, abs(a[4])) and abs(a[5] - b[5]) <= 1e-6 * max(1.0, abs(a[5]))

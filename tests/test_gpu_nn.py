@@ -62,7 +62,7 @@ def test_conv2d_fwd_bwd(n, cin, h, w, cout, k, stride, pad):
 
 @pytest.mark.parametrize('tune,what', [(32, 'plain K-loop, buffer loads'), (64 | 128, 'global-load kernels (>= 2 GiB fallback)'),
                                        (64 | 128 | 32, 'global-load kernels, plain loop'), (524288, 'plain weight-gradient loop'),
-                                       (8192, 'XCD-grouped weight-gradient order')])
+                                       (8192, 'plain (not XCD-grouped) weight-gradient block order')])
 def test_conv_kernel_variants(tune, what):
     """Every conv kernel variant that stays in the library (fallbacks for tensors the 32-bit buffer offsets cannot
     address, the non-pipelined loops, the alternative block order) gives the same results as the shipped ones."""

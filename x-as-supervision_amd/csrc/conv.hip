@@ -216,6 +216,19 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
       orow = ((size_t)n * p.Hd + (ph + p.stride * a)) * p.Wd + (pw + p.stride * b);
     }
     float* orow_p = p.out + orow * p.Cd;
+    // accumulating form (out += result): ALL the old values of this row are requested before the first one is used -
+    // one load at a time (load, wait, add, store) left the epilogue waiting out a full memory round trip per float4
+    // (rocprof: xas_conv_dgrad_acc at 46 TFLOP/s against 104 for the same shapes without the accumulation)
+    float4 prev[C::NI][4];
+    if (p.accumulate && vec_ok) {
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wn * C::WN + ni * 32 + 8 * g + csub;
+          prev[ni][g] = *reinterpret_cast<const float4*>(orow_p + (n + 3 < p.Cd ? n : p.Cd - 4));   // clamped: unconditional load
+        }
+    }
 #pragma unroll
     for (int ni = 0; ni < C::NI; ++ni) {
 #pragma unroll
@@ -228,7 +241,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
             v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
           }
           if (p.accumulate) {
-            const float4 o = *reinterpret_cast<const float4*>(orow_p + n);
+            const float4 o = prev[ni][g];
             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
           }
           *reinterpret_cast<float4*>(orow_p + n) = v;
@@ -887,12 +900,19 @@ __global__ __launch_bounds__(256) void wgrad_buf_kernel(WgradParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
   int tile, split;
-  if (!(p.tune & 8192)) {                    // default: tiles fastest, dealt round-robin over the XCDs
+  if (p.tune & 8192) {                       // experiment (bit13): tiles fastest, dealt round-robin over the XCDs
     tile = blockIdx.x % p.ntiles; split = blockIdx.x / p.ntiles;
-  } else {                                   // experiment (bit13): all tiles of a pixel split on ONE XCD (shared L2)
+  } else {
+    // XCD-grouped order.  A group = the KK-tiles of one (pixel split, Cout tile): they read the SAME dy tile and the
+    // same x pixels (the taps of a 3x3 filter shift by one pixel).  Workgroups are dealt round-robin over the 8 XCDs,
+    // so group g runs on XCD g % 8: its operands are fetched into ONE L2 (round 1 dealt the tiles of a split over
+    // all eight L2s: 2.04x the algorithmic HBM bytes).  Placement only affects speed.
+    const int nkt = p.ntiles / p.nct;
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    split = xcd + 8 * (q / p.ntiles);
-    tile = q - (q / p.ntiles) * p.ntiles;
+    const int grp = xcd + 8 * (q / nkt);                      // group index = split * nct + co-tile
+    const int kt = q - (q / nkt) * nkt;
+    split = grp / p.nct;
+    tile = (grp - split * p.nct) + kt * p.nct;                // tile = co-tile + nct * kk-tile
   }
   if (split >= p.nsplits) return;
   const int co0 = (tile % p.nct) * BM, nn0 = (tile / p.nct) * BN;
@@ -1184,7 +1204,21 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 struct ThinParams {
   int N, H, W, C;       // pixel grid (same for both sides: stride 1, 'same' padding) and vector width
   int pad, flip;
+  FastDiv div_w, div_hw;   // pixel index -> (n, h, w) without 64-bit divisions (they cost ~100 instructions each)
 };
+
+static ThinParams thin_params(int N, int H, int W, int C, int pad, int flip) {
+  ThinParams t{N, H, W, C, pad, flip, {}, {}};
+  t.div_w.init((unsigned)W);
+  t.div_hw.init((unsigned)(H * W));
+  return t;
+}
+
+__device__ __forceinline__ void thin_decode(const ThinParams& p, unsigned m, int* n, int* h, int* w) {
+  const unsigned nn = p.div_hw.div(m), rem = m - nn * (unsigned)(p.H * p.W);
+  const unsigned hh = p.div_w.div(rem);
+  *n = (int)nn; *h = (int)hh; *w = (int)(rem - hh * (unsigned)p.W);
+}
 
 __device__ __forceinline__ bool thin_src(const ThinParams& p, int h, int w, int r, int q, int* hs, int* ws) {
   *hs = p.flip ? h + p.pad - r : h - p.pad + r;
@@ -1205,13 +1239,13 @@ __global__ __launch_bounds__(256) void thin_vec2scalar_kernel(const float* __res
   float4 wv[9];
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) wv[tap] = reinterpret_cast<const float4*>(Wt)[tap * C4 + cq];
-  const long M = (long)p.N * p.H * p.W;
+  const unsigned M = (unsigned)(p.N * p.H * p.W);
   const float b0 = bias ? bias[0] : 0.f;
   for (int pass = 0; pass < kThinPasses; ++pass) {
-    const long m = ((long)blockIdx.x * kThinPasses + pass) * ppb + pl;
+    const unsigned m = ((unsigned)blockIdx.x * kThinPasses + pass) * ppb + pl;
     const bool on = m < M;
-    const long mm = on ? m : 0;
-    const int w = mm % p.W; const long t = mm / p.W; const int h = t % p.H; const int n = t / p.H;
+    int n, h, w;
+    thin_decode(p, on ? m : 0u, &n, &h, &w);
     float acc = 0.f;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -1238,11 +1272,12 @@ __global__ __launch_bounds__(256) void thin_scalar2vec_kernel(const float* __res
   for (int tap = 0; tap < 9; ++tap)
     wv[tap] = make_float4(Wct[(c + 0) * 9 + tap], Wct[(c + 1) * 9 + tap], Wct[(c + 2) * 9 + tap], Wct[(c + 3) * 9 + tap]);
   const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0, 0, 0, 0);
-  const long M = (long)p.N * p.H * p.W;
+  const unsigned M = (unsigned)(p.N * p.H * p.W);
   for (int pass = 0; pass < kThinPasses; ++pass) {
-    const long m = ((long)blockIdx.x * kThinPasses + pass) * ppb + pl;
+    const unsigned m = ((unsigned)blockIdx.x * kThinPasses + pass) * ppb + pl;
     if (m >= M) break;
-    const int w = m % p.W; const long t = m / p.W; const int h = t % p.H; const int n = t / p.H;
+    int n, h, w;
+    thin_decode(p, m, &n, &h, &w);
     float4 acc = b4;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -1252,7 +1287,7 @@ __global__ __launch_bounds__(256) void thin_scalar2vec_kernel(const float* __res
       acc.x = fmaf(sv, wv[tap].x, acc.x); acc.y = fmaf(sv, wv[tap].y, acc.y);
       acc.z = fmaf(sv, wv[tap].z, acc.z); acc.w = fmaf(sv, wv[tap].w, acc.w);
     }
-    *reinterpret_cast<float4*>(out + m * p.C + c) = acc;
+    *reinterpret_cast<float4*>(out + (size_t)m * p.C + c) = acc;
   }
 }
 
@@ -1264,15 +1299,16 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
   __shared__ float4 red[256];
   const int C4 = p.C / 4, lanes = 256 / C4;
   const int cq = threadIdx.x % C4, pl = threadIdx.x / C4;
-  const long M = (long)p.N * p.H * p.W;
-  const long mbeg = (long)blockIdx.x * m_per_chunk, mend = min(M, mbeg + m_per_chunk);
+  const unsigned M = (unsigned)(p.N * p.H * p.W);
+  const unsigned mbeg = (unsigned)blockIdx.x * (unsigned)m_per_chunk, mend = min(M, mbeg + (unsigned)m_per_chunk);
   float4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = make_float4(0, 0, 0, 0);
-  for (long m = mbeg + pl; m < mend; m += lanes) {
-    const int w = m % p.W; const long t = m / p.W; const int h = t % p.H; const int n = t / p.H;
+  for (unsigned m = mbeg + pl; m < mend; m += lanes) {
+    int n, h, w;
+    thin_decode(p, m, &n, &h, &w);
     float s0 = 0.f; float4 v0 = make_float4(0, 0, 0, 0);
-    if (!scalar_at_src) s0 = S[m]; else v0 = *reinterpret_cast<const float4*>(V + m * p.C + cq * 4);
+    if (!scalar_at_src) s0 = S[m]; else v0 = *reinterpret_cast<const float4*>(V + (size_t)m * p.C + cq * 4);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       int hs, ws;
@@ -1468,7 +1504,8 @@ static int dispatch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipSt
   if (p.Cd >= 96) {
     // small problems (layer3/4 at B=32: M = 8192 / 2048 rows): 128x128 tiles leave most of the 256 CUs idle
     const long blocks128 = cdiv(Mrows_max, 128) * cdiv(p.Cd, 128) * phases;
-    if (blocks128 <= 512) return launch_tile<64, 64, MODE>(p, Mrows_max, phases, st);
+    const long thr = (p.tune >> 20) & 1 ? 256 : ((p.tune >> 21) & 1 ? 384 : 512);     // experiment: tune bits 20 / 21
+    if (blocks128 <= thr) return launch_tile<64, 64, MODE>(p, Mrows_max, phases, st);
     return launch_tile<128, 128, MODE>(p, Mrows_max, phases, st);
   }
   if (p.Cd >= 48) return launch_tile<128, 64, MODE>(p, Mrows_max, phases, st);
@@ -1521,14 +1558,14 @@ extern "C" int xas_conv_fwd(const float* x, const float* w_packed, const float* 
     return 0;
   }
   if (s->Cout == 1 && thin_ok(s, s->Cin)) {
-    ThinParams tp{s->N, s->Hi, s->Wi, s->Cin, s->pad, 0};
+    const ThinParams tp = thin_params(s->N, s->Hi, s->Wi, s->Cin, s->pad, 0);
     const long M = (long)s->N * s->Hi * s->Wi;
     hipLaunchKernelGGL(thin_vec2scalar_kernel, dim3(thin_grid(M, s->Cin)), dim3(256), 0, st, x, w_packed, bias, y, tp);
     XAS_LAUNCH_CHECK();
     return 0;
   }
   if (s->Cin == 1 && thin_ok(s, s->Cout)) {
-    ThinParams tp{s->N, s->Hi, s->Wi, s->Cout, s->pad, 0};
+    const ThinParams tp = thin_params(s->N, s->Hi, s->Wi, s->Cout, s->pad, 0);
     const long M = (long)s->N * s->Hi * s->Wi;
     hipLaunchKernelGGL(thin_scalar2vec_kernel, dim3(thin_grid(M, s->Cout)), dim3(256), 0, st, x, w_packed,
                        bias, y, tp);
@@ -1588,14 +1625,14 @@ static int conv_dgrad_impl(const float* dy, const float* w_packed_t, float* dx, 
   }
   hipStream_t st = as_stream(stream);
   if (s->Cin == 1 && thin_ok(s, s->Cout)) {          // dx[m] = sum dy[src] . wt[0][tap][:]
-    ThinParams tp{s->N, s->Hi, s->Wi, s->Cout, s->pad, 1};
+    const ThinParams tp = thin_params(s->N, s->Hi, s->Wi, s->Cout, s->pad, 1);
     const long M = (long)s->N * s->Hi * s->Wi;
     hipLaunchKernelGGL(thin_vec2scalar_kernel, dim3(thin_grid(M, s->Cout)), dim3(256), 0, st, dy, w_packed_t, nullptr, dx, tp);
     XAS_LAUNCH_CHECK();
     return 0;
   }
   if (s->Cout == 1 && thin_ok(s, s->Cin)) {          // dx[m][ci] = sum dy[src] * wt[ci][tap]
-    ThinParams tp{s->N, s->Hi, s->Wi, s->Cin, s->pad, 1};
+    const ThinParams tp = thin_params(s->N, s->Hi, s->Wi, s->Cin, s->pad, 1);
     const long M = (long)s->N * s->Hi * s->Wi;
     hipLaunchKernelGGL(thin_scalar2vec_kernel, dim3(thin_grid(M, s->Cin)), dim3(256), 0, st, dy,
                        w_packed_t, nullptr, dx, tp);
@@ -1635,6 +1672,10 @@ static void wgrad_plan(const xas_conv_shape* s, int* bm, int* bn, int* splits, i
   const long maxsp = M / 256 > 0 ? M / 256 : 1;    // >= 8 K-steps per block
   if (sp > maxsp) sp = maxsp;
   if (sp < 1) sp = 1;
+  if (!(g_tune & 8192)) {                          // XCD-grouped order: (splits x Cout tiles) groups, 8 XCDs -> keep them balanced
+    const long nct = cdiv(s->Cout, *bm);
+    while (sp > 1 && (sp * nct) % 8 != 0 && (sp * nct) > 8) --sp;
+  }
   long per = cdiv(M, sp);
   per = cdiv(per, WBK) * WBK;
   *mps = (int)per;
@@ -1691,7 +1732,7 @@ static int launch_wgrad_buf_t(const WgradParams& p, int splits, hipStream_t st) 
   q.ntiles = q.nct * (int)cdiv(p.KK, BN);
   q.nsplits = splits;
   q.tune = g_tune;
-  dim3 grid((unsigned)((g_tune & 8192) ? 8 * cdiv(splits, 8) * q.ntiles : splits * q.ntiles));
+  dim3 grid((unsigned)((g_tune & 8192) ? splits * q.ntiles : 8 * cdiv((long)splits * q.nct, 8) * (q.ntiles / q.nct)));
   hipLaunchKernelGGL((wgrad_buf_kernel<BM, BN, T, PIPE>), grid, dim3(256), lds, st, q);
   XAS_LAUNCH_CHECK();
   return 0;
@@ -1753,7 +1794,7 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
     // layouts are [1][tap][c] resp. [c][tap]
     const bool cout1 = s->Cout == 1;
     const int C = cout1 ? s->Cin : s->Cout;
-    ThinParams tp{s->N, s->Hi, s->Wi, C, s->pad, 0};
+    const ThinParams tp = thin_params(s->N, s->Hi, s->Wi, C, s->pad, 0);
     const long M = (long)s->N * s->Hi * s->Wi;
     const int chunks = (int)cdiv(M, kThinChunk);
     hipLaunchKernelGGL(thin_wgrad_kernel, dim3(chunks), dim3(256), 0, st, cout1 ? dy : x, cout1 ? x : dy, workspace, tp,

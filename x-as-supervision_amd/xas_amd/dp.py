@@ -5,11 +5,12 @@ MI355X-first design: gradients already live in ONE contiguous arena per optimize
 out in parameter-registration order.  Backward produces gradients roughly in reverse order, so the arena is
 cut into a few large buckets from the tail.  A bucket's all-reduce is launched on a side HIP stream as soon as
 every member's gradient of this step is complete:
-  * parameters whose gradient autograd accumulates (biases, linear layers) report through a
-    post-accumulate-grad hook;
-  * conv weights (weight-gradient side stream) and batch-norm parameters (reduce kernel) are accumulated into the
-    arena by the kernels themselves; ops_nn counts their forward uses and reports a parameter when its last backward
-    contribution of the step has been launched (ops_nn.grad_ready).
+  * every parameter reports through a post-accumulate-grad hook (torch runs the leaf's AccumulateGrad node, and its
+    hooks, once all backward nodes that use the parameter have run - also when those nodes returned no gradient
+    because the kernels added it to the arena themselves);
+  * conv weights (weight-gradient side stream) and batch-norm parameters (reduce kernel) are ALSO reported by ops_nn,
+    which counts their forward uses and reports a parameter when its last backward contribution of the step has been
+    launched (ops_nn.grad_ready): this does not rely on the hook behaviour for gradient-less returns.
 The communication stream waits for an event on the compute stream AND one on the weight-gradient stream, so the
 collective overlaps the rest of backward.  How much overlaps is limited by the step itself: every detector
 parameter receives contributions from each detector backward pass, so a bucket is complete only inside the LAST
@@ -23,16 +24,30 @@ arrays per call): SyncBatchNorm layers keep identical running statistics on ever
 statistics), the in-block BatchNorm2d layers are rank-local exactly as in the reference; `sync_buffers` aligns all
 buffers ONCE when the step object is built (engine.TrainStep.__init__).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
+def dp_active(group=None):
+    """True when the data-parallel exchange code should run: a process group with more than one rank, or
+    XAS_FORCE_DP=1 with an initialised group of ANY size (a single-GPU box can then drive every RCCL call of the
+    path - all-reduce, all-gather, broadcast - through a world-size-1 `nccl` group: tests/test_gpu_nccl.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get('XAS_FORCE_DP', '0') == '1'
+
+
 class GradReducer:
-    def __init__(self, arena, params, offsets, num_buckets=4, group=None, use_side_stream=True):
+    def __init__(self, arena, params, offsets, num_buckets=4, group=None, use_side_stream=True, own_group=True):
         self.arena = arena
-        self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.enabled = self.world > 1
+        self.enabled = dp_active(group)
+        # The gradient buckets travel on their OWN communicator: on RCCL a communicator's collectives run in issue order on
+        # one internal stream, and a 35 MB bucket all-reduce launched early must not sit in front of the latency-bound
+        # SyncBatchNorm exchanges that the rest of backward is waiting for (default group).
+        self.group = dist.new_group() if (self.enabled and group is None and own_group) else group
         self.pending = []
         self.stream = None
         if not self.enabled:
@@ -51,7 +66,7 @@ class GradReducer:
         for lo, hi, first_idx in bounds:
             members = [j for j, o in enumerate(offsets) if lo <= o < hi and params[j].requires_grad]
             if members and hi > lo:
-                self.buckets.append(dict(lo=lo, hi=hi, members=members, ready=0))
+                self.buckets.append(dict(lo=lo, hi=hi, members=members, seen=set()))
         self._member_bucket = {}
         for bi, b in enumerate(self.buckets):
             for j in b['members']:
@@ -63,18 +78,23 @@ class GradReducer:
         for j, p in enumerate(params):
             if j in self._member_bucket:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(j)))
-                self._index[id(p)] = j
+                self._index[p.data_ptr()] = j
         self._armed = False
         if arena.is_cuda:
             from . import ops_nn
-            ops_nn.track_grad_uses(True)       # count forward uses of kernel-accumulated parameters from now on
+            # count forward uses of kernel-accumulated parameters from now on (XAS_DP_NOTIFY=0: every bucket waits for finish())
+            ops_nn.track_grad_uses(os.environ.get('XAS_DP_NOTIFY', '1') == '1')
 
     def _member_ready(self, j):
+        """Parameter j has received its last gradient contribution of this backward.  A parameter may be reported
+        twice - by ops_nn.grad_ready when the kernels that accumulate into the arena have been launched, and by the
+        autograd hook (torch calls post-accumulate hooks of a leaf even when the custom Function returned no gradient
+        for it) - so members are kept as a set."""
         if not self._armed:
             return
         b = self.buckets[self._member_bucket[j]]
-        b['ready'] += 1
-        if b['ready'] == len(b['members']) and not b.get('launched'):
+        b['seen'].add(j)
+        if len(b['seen']) == len(b['members']) and not b.get('launched'):
             self._launch(b)
 
     def _make_hook(self, j):
@@ -84,7 +104,7 @@ class GradReducer:
 
     def notify(self, p):
         """ops_nn.grad_ready: the kernels have launched the last contribution to p.grad of this step."""
-        j = self._index.get(id(p))
+        j = self._index.get(p.data_ptr())
         if j is not None:
             self._member_ready(j)
 
@@ -110,7 +130,7 @@ class GradReducer:
         if not self.enabled:
             return
         for b in self.buckets:
-            b['ready'] = 0
+            b['seen'] = set()
             b['launched'] = False
         self._armed = True
         if self.arena.is_cuda:
@@ -140,7 +160,7 @@ class GradReducer:
 
 def sync_buffers(module, group=None):
     """Broadcast floating-point buffers (BN running statistics) from rank 0, coalesced into one message."""
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not dp_active(group):
         return
     bufs = [b for b in module.buffers() if b.dtype.is_floating_point and b.numel() < (1 << 16)]
     if not bufs:

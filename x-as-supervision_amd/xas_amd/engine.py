@@ -18,7 +18,7 @@ from modules.model import Counter3DDisc, Counter3DModel
 from modules.physique_network import PhysiqueMaskGenerator
 
 from . import ops_nn
-from .dp import GradReducer, sync_buffers
+from .dp import GradReducer, dp_active, sync_buffers
 from .optim import FusedAdam
 
 
@@ -84,7 +84,7 @@ class TrainStep:
         opt_det.grad_arena                       # materialise the gradient arenas: conv weight gradients are
         if opt_disc is not None:                 # accumulated straight into them on a side stream
             opt_disc.grad_arena
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dp_active():
             f = opt_det
             f.grad_arena
             self.red_det = GradReducer(f._flat['g'], f._flat['params'], f._flat['offs'], num_buckets)

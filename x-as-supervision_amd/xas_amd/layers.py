@@ -81,8 +81,10 @@ class BatchNorm2d(nn.Module):
 
     def sync_group(self):
         """Process group of the statistic exchange, or None for a rank-local norm."""
-        if self.sync and self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            return dist.group.WORLD
+        if self.sync and self.training:
+            from .dp import dp_active
+            if dp_active():
+                return dist.group.WORLD
         return None
 
     def count_batch(self):

@@ -86,15 +86,17 @@ def track_grad_uses(on=True):
 
 
 def note_use(p):
+    # keyed by storage address: inside autograd.Function.forward the tensor arguments are not the Python objects the
+    # caller passed (their id() differs from the nn.Parameter's), the arena address of a parameter is unique and stable
     if _uses['on'] and p is not None:
-        k = id(p)
+        k = p.data_ptr()
         _uses['pending'][k] = _uses['pending'].get(k, 0) + 1
 
 
 def grad_ready(p):
     if not _uses['on']:
         return
-    k = id(p)
+    k = p.data_ptr()
     left = _uses['pending'].get(k, 0) - 1
     if left > 0:
         _uses['pending'][k] = left
@@ -155,7 +157,10 @@ class _PackCache:
         self.packed = {}
 
     def get(self, w, transposed):
-        key = (w.data_ptr(), w._version, _weights_epoch[0])
+        # the optimizer that owns w bumps ITS epoch box when it rewrites the arena (raw-pointer update: w._version does
+        # not move); weights outside any fused optimizer fall back to the global epoch
+        box = getattr(w, '_xas_epoch', _weights_epoch)
+        key = (w.data_ptr(), w._version, box[0])
         if key != self.key:
             self.key, self.packed = key, {}
         if transposed not in self.packed:
@@ -308,15 +313,22 @@ class _Bottleneck(torch.autograd.Function):
         ins = [x, a1, a2]
         pgrads = {}
 
+        # parameters that actually want a gradient (frozen ones get none)
+        need = {id(p) for p, n in zip(blk._fused_params, ctx.needs_input_grad[2:]) if n}
+
         def bn_b(idx, bn, dy):
-            dx, dg, db, dres = _bn_backward(saved[idx], cfgs[idx], bn.weight, bn.bias, dy, True)
+            dx, dg, db, dres = _bn_backward(saved[idx], cfgs[idx], bn.weight, bn.bias, dy,
+                                            id(bn.weight) in need and id(bn.bias) in need)
             if dg is not None:
-                pgrads[id(bn.weight)], pgrads[id(bn.bias)] = dg, db
+                if id(bn.weight) in need:
+                    pgrads[id(bn.weight)] = dg
+                if id(bn.bias) in need:
+                    pgrads[id(bn.bias)] = db
             return dx, dres
 
         g, dskip = bn_b(o + 2, bns[2], dout)          # dskip: gradient of the skip branch (= dz of the block output)
         for i in (2, 1):
-            g, dw = _conv_backward(ins[i], convs[i].weight, g, shps[o + i], convs[i]._cache, True, True)
+            g, dw = _conv_backward(ins[i], convs[i].weight, g, shps[o + i], convs[i]._cache, True, id(convs[i].weight) in need)
             if dw is not None:
                 pgrads[id(convs[i].weight)] = dw
             g, _ = bn_b(o + i - 1, bns[i - 1], g)
@@ -324,13 +336,13 @@ class _Bottleneck(torch.autograd.Function):
         if ctx.has_ds:
             ds = blk.downsample
             gd, _ = bn_b(0, ds[1], dskip)
-            dx, dw = _conv_backward(x, ds[0].weight, gd, shps[0], ds[0]._cache, need_dx, True)
+            dx, dw = _conv_backward(x, ds[0].weight, gd, shps[0], ds[0]._cache, need_dx, id(ds[0].weight) in need)
             if dw is not None:
                 pgrads[id(ds[0].weight)] = dw
             acc = dx
         else:
             acc = dskip
-        dx, dw = _conv_backward(x, convs[0].weight, g, shps[o], convs[0]._cache, need_dx, True,
+        dx, dw = _conv_backward(x, convs[0].weight, g, shps[o], convs[0]._cache, need_dx, id(convs[0].weight) in need,
                                 acc_into=acc if (need_dx and _can_accumulate(shps[o])) else None)
         if dw is not None:
             pgrads[id(convs[0].weight)] = dw

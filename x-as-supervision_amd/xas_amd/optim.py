@@ -16,8 +16,11 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        if len(self.param_groups) != 1:
+            raise ValueError('FusedAdam updates one flat arena with one set of hyper-parameters: pass a single param group')
         self._flat = None
         self._steps = 0
+        self._epoch = [0]            # bumped whenever this optimizer rewrites its parameters (ops_nn._PackCache key)
 
     # ---- arenas -------------------------------------------------------------------------------------
     def _build(self):
@@ -43,7 +46,9 @@ class FusedAdam(torch.optim.Optimizer):
                     g.copy_(p.grad)
                 p.grad = g
         self._flat = dict(params=ps, offs=offs, n=n, p=arena, g=grads, m=torch.zeros_like(arena), v=torch.zeros_like(arena))
-        ops_nn.bump_weights_epoch()
+        for p in ps:
+            p._xas_epoch = self._epoch
+        self._epoch[0] += 1
 
     @property
     def grad_arena(self):
@@ -65,6 +70,7 @@ class FusedAdam(torch.optim.Optimizer):
                     v = f['p'][o:o + p.numel()].view(p.shape)
                     v.copy_(p.data)
                     p.data = v
+                self._epoch[0] += 1
             if p.grad is None:
                 p.grad = f['g'][o:o + p.numel()].view(p.shape)
             elif p.grad.data_ptr() != f['g'].data_ptr() + 4 * o:
@@ -86,9 +92,11 @@ class FusedAdam(torch.optim.Optimizer):
         b1, b2 = g0['betas']
         call('xas_adam_step', ptr(f['p']), ptr(f['g']), ptr(f['m']), ptr(f['v']), f['n'], float(g0['lr']), float(b1),
              float(b2), float(g0['eps']), self._steps)
-        ops_nn.bump_weights_epoch()
+        self._epoch[0] += 1          # packed weight copies of THIS optimizer's parameters are stale now
 
     def zero_grad(self, set_to_none=False):
+        """One memset of the gradient arena.  `set_to_none` is ignored on purpose: .grad must stay a view of the arena
+        (kernels accumulate into it by pointer)."""
         if self._flat is None:
             self._build()
         ops_nn.join_side_stream()
@@ -120,6 +128,7 @@ class FusedAdam(torch.optim.Optimizer):
             for k in ('lr', 'betas', 'eps', 'initial_lr'):
                 if k in sg:
                     g[k] = sg[k]
+        steps = set()
         with torch.no_grad():
             for i, (p, o) in enumerate(zip(f['params'], f['offs'])):
                 st = sd['state'].get(i, sd['state'].get(str(i)))
@@ -127,4 +136,8 @@ class FusedAdam(torch.optim.Optimizer):
                     continue
                 f['m'][o:o + p.numel()].view(p.shape).copy_(st['exp_avg'])
                 f['v'][o:o + p.numel()].view(p.shape).copy_(st['exp_avg_sq'])
-                self._steps = int(float(st['step']))
+                steps.add(int(float(st['step'])))
+        if len(steps) > 1:
+            raise ValueError('FusedAdam keeps ONE step counter for the arena; the checkpoint has per-parameter steps %s' % sorted(steps))
+        if steps:
+            self._steps = steps.pop()

@@ -1,5 +1,6 @@
 """Per-entry-point device timing with HIP events recorded on the stream the kernels are launched on
-(torch's current stream), plus the algorithmic FLOP count of every convolution launch."""
+(torch's current stream), plus the algorithmic FLOP count of every convolution launch (for the soft-argmax head
+entries the `flops` field carries the algorithmic HBM BYTES instead: logits read once forward, read + written backward)."""
 import torch
 
 from . import _lib
@@ -51,7 +52,14 @@ class KernelTimer:
         sig = None
         if shape is not None:
             sig = (shape.N, shape.Hi, shape.Wi, shape.Cin, shape.Cout, shape.R, shape.stride)
-        self.records.append((name, a, b, conv_flops(shape) if shape is not None else 0.0, mfma, sig))
+        work = conv_flops(shape) if shape is not None else 0.0
+        if name == 'xas_head_softargmax_fwd':          # (logits, B, K, D, ...): the logits are read once
+            B, K, D = args[1], args[2], args[3]
+            work, sig = 4.0 * B * K * D * D * D, (B, K, D)
+        elif name == 'xas_head_softargmax_bwd':        # (logits, stats, z_idx, grad_kps, B, K, D, ...): read + write
+            B, K, D = args[4], args[5], args[6]
+            work, sig = 8.0 * B * K * D * D * D, (B, K, D)
+        self.records.append((name, a, b, work, mfma, sig))
         self.bytes_total += conv_bytes(shape) if (shape is not None and mfma) else 0.0
 
     def summary(self):
