@@ -226,6 +226,32 @@ int xas_nchw_to_nhwc(const float* x, int N, int C, int H, int W, float* y, void*
 int xas_nhwc_to_nchw(const float* x, int N, int C, int H, int W, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * GPU input pipeline: the per-sample work of the reference's CPU loader
+ * (human_utils/dataloader/dataloader.py:17-91,150-191; OpenCV + scikit-fmm) over a batch of decoded 8-bit images in HBM.
+ * ---------------------------------------------------------------------------------- */
+/* cv2.warpAffine(src_b, trans_b, (P, P), flags=INTER_LINEAR) with BORDER_CONSTANT 0 for every image of the batch
+ * (common/imglib/affine.py:112, dataloader.py:58).  src: packed 8-bit images [H_b][W_b][C] at byte offsets src_off[b];
+ * src_hw [B][2] = (H_b, W_b); minv [B][6] doubles = the INVERTED 2x3 transform (patch pixel -> source pixel), inverted on
+ * the host as cv::warpAffine does; dst [B][P][P][C].  OpenCV's fixed-point arithmetic, bit-exact. */
+int xas_warp_affine_u8(const uint8_t* src, const long* src_off, const int* src_hw, const double* minv, int B, int C,
+                       int P, uint8_t* dst, void* stream);
+/* cv2.GaussianBlur(mask, (5,5), 0) then cv2.threshold(127, 255, THRESH_BINARY) (MPI-INF-3DHP masks, dataloader.py:62-65);
+ * mask, out: [B][P][P] 8-bit, out != mask */
+int xas_mask_blur_threshold(const uint8_t* mask, int B, int P, uint8_t* out, void* stream);
+/* convert_cvimg_to_tensor + colour scale / clip + (x - mean) / std + mask / 255 + rm_bg (dataloader.py:56,67-71,185-188):
+ * img_bgr [B][P][P][3], mask [B][P][P] 8-bit -> out_img [B][3][P][P] RGB float, out_mask [B][1][P][P] float.
+ * color_scale: device [B][3] (RGB order) or NULL; mean3 / std3: HOST pointers to 3 floats (RGB order). */
+int xas_patch_finish(const uint8_t* img_bgr, const uint8_t* mask, const float* color_scale, const float* mean3,
+                     const float* std3, int rm_bg, int B, int P, float* out_img, float* out_mask, void* stream);
+/* compute_geodesic_dis (common/utility/geodesic.py:14-54): mask [B][P][P] float (non-zero = foreground);
+ * centers: device [B][2] ints (x, y) or NULL (centroid of the mask, geodesic.py:4-12); params5: HOST pointer to
+ * geodesic_param_list (5 floats, [4] must be 0); out [B][1][P][P]; center_out: device [B][2] ints or NULL.
+ * Grid Eikonal solves by iterating the first-order upwind update to its fixed point (scikit-fmm: fast marching). */
+size_t xas_geodesic_workspace_bytes(int B, int P);
+int xas_geodesic_weight(const float* mask, const int* centers, const float* params5, int B, int P, float* out,
+                        int* center_out, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Mask losses (modules/base_losses/loss_func.py:4-16), fused clip * weight * MSE.
  * mode bit0: use_clip (mask > 0.1), bit1: has weight.
  * out: 3 floats.

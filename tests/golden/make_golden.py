@@ -543,8 +543,42 @@ def g_evalpath():
         save('evalpath_' + tag, **out)
 
 
+
+# ----------------------------------------------------------------- 11. loader helpers (numpy-only pieces)
+def _extract_functions(path, names, ns):
+    src = open(path).read()
+    fns = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(fns) == len(names), (path, [f.name for f in fns])
+    exec(compile(ast.Module(body=fns, type_ignores=[]), os.path.basename(path), 'exec'), ns)
+    return ns
+
+
+def g_input():
+    """human_utils/common/imglib/affine.py and common/utility/geodesic.py import cv2 / skfmm at module level (absent):
+    their numpy-only functions are extracted from the source files and executed unchanged; imglib/format.py imports as is.
+    cv2.getAffineTransform / warpAffine / GaussianBlur and skfmm.distance stay unpinned (oracle/input_pipeline.py)."""
+    aff = _extract_functions(os.path.join(REF, 'human_utils', 'common', 'imglib', 'affine.py'),
+                             ['norm_rot_angle', 'rotate_2d', 'trans_point2d', 'trans_points_3d', 'fliplr_joints'], {'np': np})
+    geo = _extract_functions(os.path.join(REF, 'human_utils', 'common', 'utility', 'geodesic.py'), ['compute_centroid'], {'np': np})
+    from human_utils.common.imglib.format import convert_cvimg_to_tensor
+    rng = np.random.Generator(np.random.PCG64(111))
+    joints = rng.uniform(0, 1000, (18, 3))
+    vis = (rng.random((18, 3)) > 0.2).astype(np.float64)
+    trans = np.array([[0.27, -0.03, 12.5], [0.03, 0.27, -40.25]])
+    pairs = [[1, 4], [2, 5], [3, 6], [14, 11], [15, 12], [16, 13]]
+    fj, fv = aff['fliplr_joints'](joints, vis, 1000, pairs)
+    img = rng.integers(0, 256, (7, 9, 3), dtype=np.uint8)
+    mask = gi.blob_mask(3, 64, seed=112)                          # [3,1,64,64]
+    cents = np.stack([geo['compute_centroid'](np.bool_(m)) for m in mask])
+    save('input_affine', joints=joints, vis=vis, trans=trans, rots=np.array([aff['norm_rot_angle'](r) for r in (-540.0, -180.0, 179.5, 180.0, 181.0, 725.0)]),
+         rot2d=np.stack([aff['rotate_2d'](np.array([3.0, -2.0], dtype=np.float32), a) for a in (0.0, 0.3, -1.2, np.pi)]),
+         pt=aff['trans_point2d'](np.array([123.0, 456.0]), trans),
+         joints_t=aff['trans_points_3d'](joints, trans, 256.0 / 2000.0), flip_joints=fj, flip_vis=fv,
+         img=img, tensor=convert_cvimg_to_tensor(img), centroids=cents)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['head', 'lines', 'geometry', 'losses', 'physique', 'detector', 'smpl', 'model', 'model2', 'configs',
-                             'disc', 'sparse', 'evalpath']
+                             'disc', 'sparse', 'evalpath', 'input']
     for w in which:
         globals()['g_' + w]()

@@ -1,0 +1,117 @@
+"""GPU input pipeline (HIP kernels through the C ABI) against the oracle restatement of the reference's CPU loader:
+byte / integer work bit-exact (affine crop of image and mask, MPI mask binarisation), float post-processing exact up to
+one rounding, geodesic weight maps against the heap fast-marching oracle."""
+import numpy as np
+import pytest
+import torch
+
+import inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+
+def _samples(B, rng, hw=((1002, 1000), (2048, 2048), (480, 640))):
+    frames, masks, samples, aug = [], [], [], []
+    for i in range(B):
+        H, W = hw[i % len(hw)]
+        frames.append(rng.integers(0, 256, (H, W, 3), dtype=np.uint8))
+        m = np.zeros((H, W), dtype=np.uint8)
+        cy, cx = H // 2 + int(rng.integers(-40, 40)), W // 2 + int(rng.integers(-40, 40))
+        yy, xx = np.mgrid[0:H, 0:W]
+        m[((yy - cy) / (0.30 * H)) ** 2 + ((xx - cx) / (0.12 * W)) ** 2 < 1] = 255
+        m[(abs(yy - cy) < 0.05 * H) & (abs(xx - cx) < 0.33 * W)] = 255                        # arms: non-convex shape
+        masks.append(m)
+        samples.append({'center_x': float(cx + rng.uniform(-5, 5)), 'center_y': float(cy + rng.uniform(-5, 5)),
+                        'width': float(0.85 * min(H, W)), 'height': float(0.85 * min(H, W)), 'rot': 0.0,
+                        'joints_3d': rng.uniform(0, min(H, W), (18, 3)), 'joints_3d_vis': np.ones((18, 3)),
+                        'flip_pairs': [[1, 4], [2, 5], [3, 6], [14, 11], [15, 12], [16, 13]]})
+        aug.append((float(1 + 0.2 * rng.uniform(-1, 1)), float(rng.uniform(-40, 40)) if i % 2 else 0.0, bool(i % 3 == 2),
+                    [float(rng.uniform(0.8, 1.2)) for _ in range(3)]))
+    return frames, masks, samples, aug
+
+
+def test_warp_affine_bit_exact():
+    from oracle import input_pipeline as O
+    from human_utils.dataloader.gpu_patch import warp_affine_batch
+    rng = np.random.Generator(np.random.PCG64(1))
+    frames, masks, samples, aug = _samples(6, rng)
+    trans = [O.gen_affine_trans_from_box(s['center_x'], s['center_y'], s['width'], s['height'], 256, 256, a[0], a[1])
+             for s, a in zip(samples, aug)]
+    trans[1] = np.array([[1.0, 0, 3.0], [0, 1.0, -2.0]])                 # integer shift: exercises the zero border
+    trans[2] = np.array([[2.5, 0.3, -100.0], [-0.3, 2.5, 50.0]])         # magnification, partly outside the frame
+    out = warp_affine_batch(frames, trans, 256, torch.device('cuda')).cpu().numpy()
+    for i in range(len(frames)):
+        assert np.array_equal(out[i], O.warp_affine_u8(frames[i], trans[i], 256)), i
+    outm = warp_affine_batch(masks, trans, 256, torch.device('cuda')).cpu().numpy()
+    for i in range(len(masks)):
+        assert np.array_equal(outm[i, ..., 0], O.warp_affine_u8(masks[i], trans[i], 256)[..., 0]), i
+
+
+@pytest.mark.parametrize('mpi', [False, True])
+def test_patch_batch_vs_oracle(mpi):
+    """generate_patch_batch == the per-sample loader of the reference (oracle), flips / rotations / colour scales included."""
+    from oracle import input_pipeline as O
+    from human_utils.dataloader.gpu_patch import generate_patch_batch
+    rng = np.random.Generator(np.random.PCG64(2 + mpi))
+    frames, masks, samples, aug = _samples(5, rng)
+    mean, std = [0.0, 0.0, 0.0], [255.0, 255.0, 255.0]                  # config/*.yaml:10-18
+    out = generate_patch_batch(samples, frames, masks, 256, 256, 2000, mean, std, torch.device('cuda'), aug=aug,
+                               rm_bg=True, mpi_masks=mpi)
+    assert out['img'].shape == (5, 3, 256, 256) and out['mask'].shape == (5, 1, 256, 256)
+    for i, (smp, (scale, rot, flip, cs)) in enumerate(zip(samples, aug)):
+        img, msk, cx = frames[i], masks[i], smp['center_x']
+        if flip:
+            img, msk, cx = img[:, ::-1, :], msk[:, ::-1], img.shape[1] - cx - 1
+        t = O.gen_affine_trans_from_box(cx, smp['center_y'], smp['width'], smp['height'], 256, 256, scale, O.norm_rot_angle(rot))
+        ip = O.warp_affine_u8(img, t, 256)
+        mp = O.warp_affine_u8(msk, t, 256)[..., 0]
+        if mpi:
+            mp = O.mask_blur_threshold(mp)
+        eimg, emask = O.patch_finish(ip, mp, mean, std, cs, rm_bg=True)
+        assert np.array_equal(out['mask'][i].cpu().numpy(), emask), i
+        assert np.abs(out['img'][i].cpu().numpy() - eimg).max() <= 1.2e-7, i
+        if mpi:
+            assert set(np.unique(emask)) <= {0.0, 1.0}
+        j = smp['joints_3d']
+        if flip:
+            j, _ = O.fliplr_joints(j, smp['joints_3d_vis'], img.shape[1], smp['flip_pairs'])
+        ej = O.trans_points_3d(j, t, 1.0 / (2000 * scale) * 256)
+        assert np.abs(out['joints'][i].cpu().numpy() - ej.astype(np.float32)).max() < 1e-3
+        assert np.abs(out['trans_image'][i].cpu().numpy() - t.astype(np.float32)).max() < 1e-6
+
+
+def test_geodesic_weight_vs_fast_marching_oracle():
+    from oracle import input_pipeline as O
+    from human_utils.common.utility.geodesic import compute_geodesic_dis
+    P = 96
+    m = gi.blob_mask(5, P, seed=7).astype(np.float32)                    # [5,1,P,P] body-like blobs
+    m[1, 0, :, :] *= 0.5                                                 # non-binary values: any non-zero is foreground
+    m[3] = 0.0                                                           # centroid on the background of a ring
+    yy, xx = np.mgrid[0:P, 0:P]
+    ring = ((yy - 48) ** 2 + (xx - 48) ** 2 < 40 ** 2) & ((yy - 48) ** 2 + (xx - 48) ** 2 > 25 ** 2)
+    m[3, 0][ring] = 1.0
+    params = [2, 1, 3, 20, 0.0]
+    out, cen = compute_geodesic_dis(torch.from_numpy(m).cuda(), params)
+    out, cen = out.cpu().numpy(), cen.cpu().numpy()
+    for i in range(5):
+        ref, c = O.compute_geodesic_dis(m[i], params)
+        assert cen[i].tolist() == c[0].tolist(), i
+        # the iterative solver converges to the fixed point of the same first-order stencil the heap solver evaluates
+        assert np.abs(out[i] - ref.astype(np.float64)).max() < 2e-4 * np.abs(ref).max(), (i, np.abs(out[i] - ref).max())
+    assert (out[3] == 1.0).all()                                         # geodesic.py:25-27 early-out
+    assert out[0].min() >= 21.9 and out[0].max() <= np.exp(2.0) + 1 + 3 + 20 + 1e-3
+
+
+def test_geodesic_full_size_properties():
+    """256 x 256, B = 32 (one camera of the benchmark batch): finite, bounded, centre value, monotone away from the mask."""
+    from human_utils.common.utility.geodesic import compute_geodesic_dis
+    m = torch.from_numpy(gi.blob_mask(32, 256, seed=9).astype(np.float32)).cuda()
+    out, cen = compute_geodesic_dis(m, [2, 1, 3, 20, 0.0])
+    assert torch.isfinite(out).all()
+    inside = m[torch.arange(32), 0, cen[:, 1].long(), cen[:, 0].long()] != 0
+    for b in range(32):
+        if inside[b]:
+            assert abs(float(out[b, 0, cen[b, 1], cen[b, 0]]) - 22.0) < 1e-5          # exp(0) + 1 + 0 + 20
+            assert float(out[b].max()) <= float(np.exp(2.0)) + 24.0 + 1e-3
+        else:
+            assert (out[b] == 1).all()

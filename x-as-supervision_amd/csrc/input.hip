@@ -1,0 +1,290 @@
+// GPU input pipeline: what the reference's CPU loader does per sample and camera with OpenCV and
+// scikit-fmm (human_utils/dataloader/dataloader.py:17-91,150-191, common/imglib/affine.py:56-114,
+// common/utility/geodesic.py:14-54), as HIP kernels over a whole batch of decoded images resident in HBM:
+//
+//   warp_affine_u8      cv2.warpAffine(img, trans, (P, P), INTER_LINEAR), BORDER_CONSTANT 0, for 8-bit images: OpenCV's
+//                       fixed-point scheme restated exactly (10-bit coordinates, 5-bit sub-pixel position, 15-bit weights,
+//                       round to nearest) - integer arithmetic, bit-exact against the oracle (oracle/input_pipeline.py)
+//   mask_blur_threshold cv2.GaussianBlur(mask, (5,5), 0) + threshold(127) of the MPI-INF-3DHP masks (dataloader.py:62-65)
+//   patch_finish        BGR->RGB, HWC->CHW, colour scale + clip, (x - mean) / std, mask / 255, image * mask (rm_bg)
+//   geodesic_weight     centroid, two grid Eikonal solves (inside the mask from the centroid; outside from the mask),
+//                       normalisation and combination of geodesic.py:42-52
+//
+// HBM-bound byte work except the Eikonal solve, which is latency-bound (one workgroup per image iterating the upwind
+// update to its fixed point).  gfx950.
+#include "common.h"
+
+namespace xas {
+
+constexpr int kInterBits = 5, kInterTab = 1 << kInterBits;           // INTER_BITS, INTER_TAB_SIZE
+constexpr int kAbBits = 10, kAbScale = 1 << kAbBits;                 // AB_BITS, AB_SCALE
+constexpr int kCoefBits = 15;                                        // INTER_REMAP_COEF_BITS
+
+struct WarpGeom { int B, C, P; };
+
+// minv: [B][6] doubles = the INVERTED 2x3 map (dst -> src), computed on the host exactly as cv::warpAffine does.
+__global__ void warp_affine_u8_kernel(const uint8_t* __restrict__ src, const long* __restrict__ src_off,
+                                      const int* __restrict__ src_hw, const double* __restrict__ minv, WarpGeom g,
+                                      uint8_t* __restrict__ dst) {
+  const int b = blockIdx.y;
+  const int H = src_hw[2 * b], W = src_hw[2 * b + 1];
+  const uint8_t* S = src + src_off[b];
+  const double* M = minv + 6 * b;
+  const int round_delta = kAbScale / kInterTab / 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.P * g.P; i += gridDim.x * blockDim.x) {
+    const int y = i / g.P, x = i - y * g.P;
+    // cv::warpAffine: integer coordinates with AB_BITS fractional bits, rounded (half to even) per term
+    const int adelta = __double2int_rn(M[0] * x * kAbScale), bdelta = __double2int_rn(M[3] * x * kAbScale);
+    const int X0 = __double2int_rn((M[1] * y + M[2]) * kAbScale) + round_delta;
+    const int Y0 = __double2int_rn((M[4] * y + M[5]) * kAbScale) + round_delta;
+    const int X = (X0 + adelta) >> (kAbBits - kInterBits), Y = (Y0 + bdelta) >> (kAbBits - kInterBits);
+    int sx = X >> kInterBits, sy = Y >> kInterBits;
+    sx = max(-32768, min(32767, sx)); sy = max(-32768, min(32767, sy));       // saturate_cast<short>
+    const int fx = X & (kInterTab - 1), fy = Y & (kInterTab - 1);
+    // bilinear weights of the 32 x 32 table, scaled by 2^15: (32-fx)(32-fy)*32 ... exact integers summing to 32768
+    const int w00 = (kInterTab - fx) * (kInterTab - fy) * 32, w01 = fx * (kInterTab - fy) * 32;
+    const int w10 = (kInterTab - fx) * fy * 32, w11 = fx * fy * 32;
+    uint8_t* o = dst + ((size_t)b * g.P * g.P + i) * g.C;
+    const bool in00 = (unsigned)sx < (unsigned)W && (unsigned)sy < (unsigned)H;
+    const bool in01 = (unsigned)(sx + 1) < (unsigned)W && (unsigned)sy < (unsigned)H;
+    const bool in10 = (unsigned)sx < (unsigned)W && (unsigned)(sy + 1) < (unsigned)H;
+    const bool in11 = (unsigned)(sx + 1) < (unsigned)W && (unsigned)(sy + 1) < (unsigned)H;
+    const size_t p00 = ((size_t)sy * W + sx) * g.C;
+    for (int c = 0; c < g.C; ++c) {
+      const int v00 = in00 ? S[p00 + c] : 0, v01 = in01 ? S[p00 + g.C + c] : 0;
+      const int v10 = in10 ? S[p00 + (size_t)W * g.C + c] : 0, v11 = in11 ? S[p00 + (size_t)W * g.C + g.C + c] : 0;
+      o[c] = (uint8_t)((v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << (kCoefBits - 1))) >> kCoefBits);
+    }
+  }
+}
+
+// 5x5 Gaussian ([1 4 6 4 1] x [1 4 6 4 1] / 256, BORDER_REFLECT_101, rounded half up as OpenCV's 8-bit fixed-point path)
+// followed by threshold(127) -> {0, 255}
+__global__ void mask_blur_threshold_kernel(const uint8_t* __restrict__ m, int B, int P, uint8_t* __restrict__ out) {
+  const int b = blockIdx.y;
+  const uint8_t* S = m + (size_t)b * P * P;
+  const int wk[5] = {1, 4, 6, 4, 1};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P * P; i += gridDim.x * blockDim.x) {
+    const int y = i / P, x = i - y * P;
+    int s = 0;
+#pragma unroll
+    for (int dy = -2; dy <= 2; ++dy) {
+      int yy = y + dy; yy = yy < 0 ? -yy : (yy >= P ? 2 * P - 2 - yy : yy);
+#pragma unroll
+      for (int dx = -2; dx <= 2; ++dx) {
+        int xx = x + dx; xx = xx < 0 ? -xx : (xx >= P ? 2 * P - 2 - xx : xx);
+        s += wk[dy + 2] * wk[dx + 2] * S[yy * P + xx];
+      }
+    }
+    const int v = (s + 128) >> 8;
+    out[(size_t)b * P * P + i] = v > 127 ? 255 : 0;
+  }
+}
+
+// img_patch [B][P][P][3] BGR u8, mask_patch [B][P][P] u8 -> img [B][3][P][P] RGB float, mask [B][1][P][P] float
+__global__ void patch_finish_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ mask,
+                                    const float* __restrict__ color_scale /*[B][3] RGB order or null*/, float3 mean,
+                                    float3 stdv, int rm_bg, int B, int P, float* __restrict__ out_img,
+                                    float* __restrict__ out_mask) {
+  const int b = blockIdx.y;
+  const size_t plane = (size_t)P * P;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P * P; i += gridDim.x * blockDim.x) {
+    const uint8_t* p = img + ((size_t)b * plane + i) * 3;
+    const float mk = (float)mask[(size_t)b * plane + i] / 255.0f;
+    const float mean3[3] = {mean.x, mean.y, mean.z}, std3[3] = {stdv.x, stdv.y, stdv.z};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {                     // output channel c = RGB index; source is BGR
+      float v = (float)p[2 - c];
+      if (color_scale) v = fminf(fmaxf(v * color_scale[b * 3 + c], 0.f), 255.f);
+      v = (v - mean3[c]) / std3[c];
+      if (rm_bg) v *= mk;
+      out_img[((size_t)b * 3 + c) * plane + i] = v;
+    }
+    out_mask[(size_t)b * plane + i] = mk;
+  }
+}
+
+// ---------------------------------------------------------------- geodesic weight map
+// One workgroup per image.  Phase 1: centroid (geodesic.py:4-12, truncated to integers) or the given centre, early-out
+// flag (centre outside the mask -> map of ones, geodesic.py:25-27).  Phase 2: two first-order upwind Eikonal solves on the
+// pixel grid, iterated to their fixed point (the solution the fast-marching method computes for the same stencil):
+//   d_in : domain = mask pixels, source = centre pixel          (skfmm.distance of the masked array, geodesic.py:29-35)
+//   d_bg : domain = all pixels, sources = mask pixels (value 0) (skfmm.distance(m_bg), geodesic.py:37-39)
+// Phase 3: out = exp(p0 * d_in / max d_in) + p1 + p2 * d_bg / max d_bg + p3 (geodesic.py:45-52).
+constexpr int kGeoThreads = 1024;
+constexpr float kInf = 3.0e38f;
+
+__device__ __forceinline__ float eikonal_update(float a, float b) {     // a, b: smaller neighbour per axis (kInf if none)
+  const float lo = fminf(a, b), hi = fmaxf(a, b);
+  if (lo >= kInf) return kInf;
+  if (hi - lo >= 1.0f) return lo + 1.0f;
+  return 0.5f * (a + b + sqrtf(2.0f - (a - b) * (a - b)));
+}
+
+// u: distances (sources 0, others kInf on entry); dom: 1 = pixel takes part
+__device__ void eikonal_solve(float* __restrict__ u, const uint8_t* __restrict__ dom, int P, int max_sweeps) {
+  const int n = P * P;
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    int changed = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      if (!dom[i]) continue;
+      const float cur = u[i];
+      if (cur == 0.f) continue;
+      const int y = i / P, x = i - y * P;
+      const float l = (x > 0 && dom[i - 1]) ? u[i - 1] : kInf, r = (x < P - 1 && dom[i + 1]) ? u[i + 1] : kInf;
+      const float t = (y > 0 && dom[i - P]) ? u[i - P] : kInf, d = (y < P - 1 && dom[i + P]) ? u[i + P] : kInf;
+      const float nu = eikonal_update(fminf(l, r), fminf(t, d));
+      if (nu < cur) { u[i] = nu; changed = 1; }
+    }
+    if (!__syncthreads_or(changed)) break;            // barrier: this workgroup's global writes are visible to its waves
+  }
+}
+
+__device__ float block_max(float v, float* red) {      // red: >= 33 floats; result valid in every thread
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float r = threadIdx.x < (blockDim.x >> 6) ? red[threadIdx.x] : -kInf;
+    r = wave_max(r);
+    if (threadIdx.x == 0) red[32] = r;
+  }
+  __syncthreads();
+  return red[32];
+}
+
+__global__ __launch_bounds__(kGeoThreads) void geodesic_weight_kernel(const float* __restrict__ mask, const int* __restrict__ centers,
+                                                                      float p0, float p1, float p2, float p3, int P,
+                                                                      float* __restrict__ work /*[B][2][P*P]*/,
+                                                                      uint8_t* __restrict__ dom /*[B][P*P]*/,
+                                                                      float* __restrict__ out, int* __restrict__ center_out) {
+  __shared__ float red[33];
+  __shared__ double sred[3][16];
+  __shared__ int s_c[2];
+  const int b = blockIdx.x, n = P * P;
+  const float* m = mask + (size_t)b * n;
+  float* din = work + (size_t)b * 2 * n;
+  float* dbg = din + n;
+  uint8_t* dm = dom + (size_t)b * n;
+  float* o = out + (size_t)b * n;
+  // centroid of the BOOLEAN mask (np.bool_(img): any non-zero value is foreground), truncated to int16 (geodesic.py:4-12,15)
+  double sx = 0.0, sy = 0.0, sm = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double v = m[i] != 0.f ? 1.0 : 0.0;
+    const int y = i / P, x = i - y * P;
+    sx += (double)x * v; sy += (double)y * v; sm += v;
+    dm[i] = v != 0.0;
+  }
+  for (int off = 32; off > 0; off >>= 1) { sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64); sm += __shfl_xor(sm, off, 64); }
+  if ((threadIdx.x & 63) == 0) { sred[0][threadIdx.x >> 6] = sx; sred[1][threadIdx.x >> 6] = sy; sred[2][threadIdx.x >> 6] = sm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, c = 0, d = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { a += sred[0][k]; c += sred[1][k]; d += sred[2][k]; }
+    int cx, cy;
+    if (centers) { cx = centers[2 * b]; cy = centers[2 * b + 1]; }
+    else { cx = (int)(a / d); cy = (int)(c / d); }                 // astype(np.int16): truncation (NaN for an empty mask -> 0)
+    if (!(d > 0.0) && !centers) { cx = 0; cy = 0; }
+    s_c[0] = cx; s_c[1] = cy;
+    if (center_out) { center_out[2 * b] = cx; center_out[2 * b + 1] = cy; }
+  }
+  __syncthreads();
+  const int cx = s_c[0], cy = s_c[1];
+  const bool inside = (unsigned)cx < (unsigned)P && (unsigned)cy < (unsigned)P && m[cy * P + cx] != 0.f;
+  if (!inside) {                                       // geodesic.py:25-27: centre on the background -> weights of one
+    for (int i = threadIdx.x; i < n; i += blockDim.x) o[i] = 1.0f;
+    return;
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    din[i] = (i == cy * P + cx) ? 0.f : kInf;
+    dbg[i] = dm[i] ? 0.f : kInf;
+  }
+  __syncthreads();
+  eikonal_solve(din, dm, P, 4 * P);
+  // background solve: every pixel is in the domain -> reuse `o` region? no: a second domain array of ones is implied
+  {
+    const int nn = n;
+    for (int sweep = 0; sweep < 4 * P; ++sweep) {
+      int changed = 0;
+      for (int i = threadIdx.x; i < nn; i += blockDim.x) {
+        const float cur = dbg[i];
+        if (cur == 0.f) continue;
+        const int y = i / P, x = i - y * P;
+        const float l = x > 0 ? dbg[i - 1] : kInf, r = x < P - 1 ? dbg[i + 1] : kInf;
+        const float t = y > 0 ? dbg[i - P] : kInf, d = y < P - 1 ? dbg[i + P] : kInf;
+        const float nu = eikonal_update(fminf(l, r), fminf(t, d));
+        if (nu < cur) { dbg[i] = nu; changed = 1; }
+      }
+      if (!__syncthreads_or(changed)) break;
+    }
+  }
+  // maxima (pixels outside the mask count as 0 in d_in, as in the array scikit-fmm returns for masked cells)
+  float mi = 0.f, mb = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float a = (dm[i] && din[i] < kInf) ? din[i] : 0.f;
+    mi = fmaxf(mi, a);
+    mb = fmaxf(mb, dbg[i] < kInf ? dbg[i] : 0.f);
+  }
+  mi = block_max(mi, red);
+  mb = block_max(mb, red);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float a = (dm[i] && din[i] < kInf) ? din[i] : 0.f;
+    const float g = dbg[i] < kInf ? dbg[i] : 0.f;
+    o[i] = __expf(p0 * (a / mi)) + p1 + p2 * (g / mb) + p3;
+  }
+}
+
+}  // namespace xas
+
+using namespace xas;
+
+extern "C" int xas_warp_affine_u8(const uint8_t* src, const long* src_off, const int* src_hw, const double* minv, int B,
+                                  int C, int P, uint8_t* dst, void* stream) {
+  XAS_REQUIRE(src && src_off && src_hw && minv && dst && B > 0 && C >= 1 && C <= 4 && P > 0 && P <= 4096,
+              "warp_affine_u8: bad arguments (B=%d C=%d P=%d)", B, C, P);
+  WarpGeom g{B, C, P};
+  const unsigned bx = (unsigned)cdiv((long)P * P, 256);
+  hipLaunchKernelGGL(warp_affine_u8_kernel, dim3(bx > 256 ? 256 : bx, B), dim3(256), 0, as_stream(stream), src, src_off,
+                     src_hw, minv, g, dst);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int xas_mask_blur_threshold(const uint8_t* mask, int B, int P, uint8_t* out, void* stream) {
+  XAS_REQUIRE(mask && out && mask != out && B > 0 && P >= 3, "mask_blur_threshold: bad arguments");
+  const unsigned bx = (unsigned)cdiv((long)P * P, 256);
+  hipLaunchKernelGGL(mask_blur_threshold_kernel, dim3(bx > 256 ? 256 : bx, B), dim3(256), 0, as_stream(stream), mask, B, P, out);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int xas_patch_finish(const uint8_t* img_bgr, const uint8_t* mask, const float* color_scale, const float* mean3,
+                                const float* std3, int rm_bg, int B, int P, float* out_img, float* out_mask, void* stream) {
+  XAS_REQUIRE(img_bgr && mask && mean3 && std3 && out_img && out_mask && B > 0 && P > 0, "patch_finish: bad arguments");
+  XAS_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "patch_finish: zero std");
+  const unsigned bx = (unsigned)cdiv((long)P * P, 256);
+  hipLaunchKernelGGL(patch_finish_kernel, dim3(bx > 256 ? 256 : bx, B), dim3(256), 0, as_stream(stream), img_bgr, mask,
+                     color_scale, make_float3(mean3[0], mean3[1], mean3[2]), make_float3(std3[0], std3[1], std3[2]), rm_bg,
+                     B, P, out_img, out_mask);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t xas_geodesic_workspace_bytes(int B, int P) {
+  if (B <= 0 || P <= 0) return 0;
+  return (size_t)B * P * P * (2 * sizeof(float) + 1);
+}
+
+extern "C" int xas_geodesic_weight(const float* mask, const int* centers, const float* params5, int B, int P, float* out,
+                                   int* center_out, void* workspace, void* stream) {
+  XAS_REQUIRE(mask && params5 && out && workspace && B > 0 && P >= 2 && P <= 1024, "geodesic_weight: bad arguments");
+  XAS_REQUIRE(params5[4] == 0.f, "geodesic_weight: geodesic_param_list[4] = %g: only the shipped 0.0 (mask = zero level) is built",
+              (double)params5[4]);
+  float* work = reinterpret_cast<float*>(workspace);
+  uint8_t* dom = reinterpret_cast<uint8_t*>(work + (size_t)B * 2 * P * P);
+  hipLaunchKernelGGL(geodesic_weight_kernel, dim3(B), dim3(kGeoThreads), 0, as_stream(stream), mask, centers, params5[0],
+                     params5[1], params5[2], params5[3], P, work, dom, out, center_out);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}

@@ -56,6 +56,11 @@ SIGNATURES = {
     'xas_sigmoid_bwd': ('pplpp', 'i'),
     'xas_nchw_to_nhwc': ('piiiipp', 'i'),
     'xas_nhwc_to_nchw': ('piiiipp', 'i'),
+    'xas_warp_affine_u8': ('ppppiiipp', 'i'),
+    'xas_mask_blur_threshold': ('piipp', 'i'),
+    'xas_patch_finish': ('pppppiiippp', 'i'),
+    'xas_geodesic_workspace_bytes': ('ii', 'z'),
+    'xas_geodesic_weight': ('pppiipppp', 'i'),
     'xas_loss_nblk': ('l', 'i'),
     'xas_mask_loss_fwd': ('pppliPpp'.replace('P', 'p'), 'i'),
     'xas_mask_loss_bwd': ('pppliPppp'.replace('P', 'p'), 'i'),
