@@ -577,8 +577,56 @@ def g_input():
          img=img, tensor=convert_cvimg_to_tensor(img), centroids=cents)
 
 
+
+# ----------------------------------------------------------------- 12. tb_vis tag contract
+class _RecWriter:
+    def __init__(self):
+        self.calls = []
+
+    def add_scalar(self, tag, value, step):
+        self.calls.append(('scalar', tag, int(step)))
+
+    def add_image(self, tag, img, step):
+        self.calls.append(('image', tag, int(step)))
+
+    def add_text(self, tag, text, step):
+        self.calls.append(('text', tag, int(step)))
+
+
+from make_golden_inputs import tbvis_inputs      # noqa: E402
+
+
+def g_tbvis():
+    """train_util.py imports cv2 / easydict / the dataset package at module level: `tb_vis` alone is extracted from the
+    source and executed unchanged with recording stand-ins for the writer and the image helpers; the golden is the list of
+    (kind, tag, step) calls - the logging contract."""
+    import json
+    ns = {'np': np, 'torch': torch}
+    for name in ('img_vis', 'pose_vis', 'pose_vis_3d', 'dis_vis', 'depth_heatmap_vis'):
+        ns[name] = lambda *a, **k: np.zeros((3, 4, 4), dtype=np.uint8)
+    _extract_functions(os.path.join(REF, 'train_util.py'), ['tb_vis'], ns)
+
+    class Sched:
+        def get_last_lr(self):
+            return [2e-4]
+    torch.manual_seed(0)
+    x, out, losses = tbvis_inputs()
+    cfg = {'dataset_params': {'dataiter': {'mean': [0.0, 0.0, 0.0], 'std': [255.0, 255.0, 255.0]}}}
+    rec = {}
+    for step in (50, 51):
+        w = _RecWriter()
+        ns['tb_vis'](w, step, np.array([[1, 4]]), np.arange(18), 1.25, losses, torch.tensor(0.5), out, x, cfg, Sched())
+        rec[str(step)] = w.calls
+    w = _RecWriter()
+    ns['tb_vis'](w, 100, np.array([[1, 4]]), np.arange(18), None, {}, None, out, x, cfg, Sched())
+    rec['100_no_gen'] = w.calls
+    with open(os.path.join(HERE, 'tbvis_tags.json'), 'w') as f:
+        json.dump(rec, f, indent=0)
+    print('wrote tbvis_tags.json', {k: len(v) for k, v in rec.items()})
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['head', 'lines', 'geometry', 'losses', 'physique', 'detector', 'smpl', 'model', 'model2', 'configs',
-                             'disc', 'sparse', 'evalpath', 'input']
+                             'disc', 'sparse', 'evalpath', 'input', 'tbvis']
     for w in which:
         globals()['g_' + w]()

@@ -23,6 +23,7 @@ import yaml
 from torch.distributed import destroy_process_group, init_process_group
 from torch.optim.lr_scheduler import MultiStepLR
 
+from train_util import tb_vis
 from xas_amd import engine
 from xas_amd.synthetic import synthetic_batch
 
@@ -53,6 +54,8 @@ class Trainer:
         self.optimizer_discriminator = optimizer_discriminator
         self.epochs_run = 0
         self.config = config
+        self.tb_parent_ids = np.array(config['model_params']['parent_ids'])      # train.py:91-92
+        self.tb_pair_ids = np.array(config['model_params']['flip_pairs'])
         self.save_dir = save_dir
         if checkpoint_path is not None:
             self._load_checkpoint(checkpoint_path, mode)
@@ -107,14 +110,12 @@ class Trainer:
                 self.train_data.sampler.set_epoch(epoch)
             for it, x in enumerate(self.train_data):
                 x = self.convert_data_to_device(x)
-                loss_disc, loss_kp, total, _ = self.step(x)
-                if self.gpu_id == 0 and tb_logger is not None and total is not None:
+                loss_disc, loss_kp, total, output = self.step(x)
+                if self.gpu_id == 0 and tb_logger is not None and total is not None:      # train.py:192-199
                     cur = epoch * len(self.train_data) + it
-                    tb_logger.add_scalar('training_loss/total', float(total), cur)
-                    for k, v in loss_kp.items():
-                        tb_logger.add_scalar('training_loss/' + k, float(v.mean()), cur)
-                    if loss_disc is not None:
-                        tb_logger.add_scalar('training_loss/disc', float(loss_disc), cur)
+                    x.setdefault('cam_0_img_path', ['synthetic'])
+                    tb_vis(tb_logger, cur, self.tb_pair_ids, self.tb_parent_ids, total.detach().item(), loss_kp, loss_disc,
+                           output, x, self.config, self.scheduler_detector)
             self.scheduler_detector.step()
             if self.scheduler_discriminator is not None:
                 self.scheduler_discriminator.step()
@@ -160,8 +161,9 @@ def create_logger(opt):
         try:
             from torch.utils.tensorboard import SummaryWriter
             tb = SummaryWriter(log_dir=os.path.join(log_dir, 'tensorboard'))
-        except Exception:
-            tb = None
+        except Exception:                      # TensorBoard not installed: same calls, plain files
+            from train_util import JsonlWriter
+            tb = JsonlWriter(os.path.join(log_dir, 'tensorboard'))
     return log_dir, tb
 
 
