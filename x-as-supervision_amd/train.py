@@ -113,7 +113,6 @@ class Trainer:
                 loss_disc, loss_kp, total, output = self.step(x)
                 if self.gpu_id == 0 and tb_logger is not None and total is not None:      # train.py:192-199
                     cur = epoch * len(self.train_data) + it
-                    x.setdefault('cam_0_img_path', ['synthetic'])
                     tb_vis(tb_logger, cur, self.tb_pair_ids, self.tb_parent_ids, total.detach().item(), loss_kp, loss_disc,
                            output, x, self.config, self.scheduler_detector)
             self.scheduler_detector.step()

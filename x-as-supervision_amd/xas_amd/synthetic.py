@@ -38,6 +38,8 @@ def synthetic_batch(B, cam_ids, device, seed=0, S=256, K=18):
         x[key + '_mask'] = mask
         x[key + '_img'] = r(B, 3, S, S) * mask                       # rm_bg: image * mask, /255 normalised
         x[key + '_geodesic_dis'] = 1.0 + 24.0 * r(B, 1, S, S)
+        x[key + '_geodesic_center'] = torch.full((B, 1, 2), S // 2, dtype=torch.int16, device=device)   # geodesic.py:19
+        x[key + '_img_path'] = ['synthetic/%s/%06d.jpg' % (key, seed * 1000 + i) for i in range(B)]        # dataloader.py:168
         j = 40 + 176 * r(B, K, 3)
         j[..., 2] = 80 * r(B, K) - 40
         x[key + '_joints'] = j
@@ -58,6 +60,7 @@ def synthetic_batch(B, cam_ids, device, seed=0, S=256, K=18):
         pj = 1.6 * r(B, K, 3) - 0.8
         pj[..., 2] = 0.8 * r(B, K) - 0.4
         x[key + '_pseudo_joints'] = pj
+    x['act'] = ['act_%02d_subact_01' % (2 + (seed + i) % 15) for i in range(B)]                           # dataloader.py:228
     return x
 
 
