@@ -10,6 +10,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o w --output-format csv
 if [ -x $GRAFT_REPO_ROOT/tools/micro/mfma_peak ]; then
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace -d $OUT/peak -o p --output-format csv -- $GRAFT_REPO_ROOT/tools/micro/mfma_peak > $OUT/peak.log 2>&1
 fi
-find $OUT -name "*.csv" | xargs ls -la
-# keep the merged-back payload small: counter CSVs only
-find $OUT -name "*_agent_info.csv" -delete
+# summarise on the box; the raw counter CSVs (tens of MB) stay there
+python3 $GRAFT_REPO_ROOT/tools/pmc_report.py $OUT $OUT/pmc_summary.md $OUT/conv_traffic.json > /dev/null
+find $OUT -name "*.csv" -delete
+ls -la $OUT

@@ -34,9 +34,17 @@ def union(iv):
 
 
 def main():
-    db = sqlite3.connect(sys.argv[1])
     back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    rows = db.execute('select name, stream_id, start, end from kernels order by start').fetchall()
+    if sys.argv[1].endswith('.csv.gz'):            # compact table written by tools/gpu/slim_trace.py
+        import csv
+        import gzip
+        with gzip.open(sys.argv[1], 'rt') as f:
+            rd = csv.reader(f)
+            next(rd)
+            rows = [(r[0], r[1], int(r[2]), int(r[3])) for r in rd]
+    else:
+        db = sqlite3.connect(sys.argv[1])
+        rows = db.execute('select name, stream_id, start, end from kernels order by start').fetchall()
     adam = [i for i, r in enumerate(rows) if 'adam' in r[0]]
     # a step = [after adam 2k-1] .. [adam 2k+1]; phase A (disc update) ends at the first adam of the pair
     last = len(adam) - 1 - 2 * back              # index of the 2nd adam of the chosen step (skip the trailing serial step)
