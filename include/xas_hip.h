@@ -134,6 +134,12 @@ int xas_conv_dgrad(const float* dy, const float* w_packed_t, float* dx,
 /* Same, but dx += result: the residual-branch gradient is already in dx (one read-modify-write instead of a
  * separate gradient-accumulation kernel per bottleneck).  MFMA path only (Cout % 32 == 0, Cin % 4 == 0, Cin >= 16). */
 int xas_conv_dgrad_acc(const float* dy, const float* w_packed_t, float* dx, const xas_conv_shape* shape, void* stream);
+/* dx = dgrad(dy, W) + relu'(mask) * dprev: the block-input gradient of a bottleneck without a projection, with the skip
+ * gradient formed in the epilogue from the block-OUTPUT gradient dprev [like dx] and the sign bytes xas_bn_apply wrote for
+ * the block output (one byte per float4 of dx): the skip gradient tensor is never materialised.  Same shape limits as
+ * xas_conv_dgrad_acc; dx is written, not read. */
+int xas_conv_dgrad_acc_masked(const float* dy, const float* w_packed_t, float* dx, const xas_conv_shape* s,
+                              const float* dprev, const uint8_t* mask, void* stream);
 /* dw_packed [Cout][R][S][Cin] (+)= sum_n,ho,wo dy * x ; workspace for split-K partials. */
 size_t xas_conv_wgrad_workspace_floats(const xas_conv_shape* s);
 int xas_conv_wgrad(const float* x, const float* dy, float* dw_packed, float* workspace,
@@ -185,10 +191,12 @@ int xas_bn_sync_merge(const float* gathered, int world, int groups, int C, long 
 /* out[c] = sum_m x[m][c]  (bias gradients: deconv_head.py:34, physique_network.py:17, discriminator.py:11);
  * workspace: xas_bn_workspace_floats(M, C, 1) */
 int xas_col_sum(const float* x, long M, int C, float* out, float* workspace, void* stream);
-/* y = act(gamma*(x-mean_g)*rsqrt(var_g+eps)+beta [+ residual]); mean / var_biased: [groups][C] */
+/* y = act(gamma*(x-mean_g)*rsqrt(var_g+eps)+beta [+ residual]); mean / var_biased: [groups][C].
+ * mask_out (may be NULL): [M*C/4] bytes, bit e of byte i = (pre-activation value of element 4i+e > 0): all the backward
+ * needs of y for a layer with a residual, at 1/16 of y's bytes. */
 int xas_bn_apply(const float* x, const float* mean, const float* var_biased, const float* gamma,
                  const float* beta, const float* residual, float eps, int act, long M, int C, int groups,
-                 float* y, void* stream);
+                 float* y, uint8_t* mask_out, void* stream);
 /* running = (1-momentum)*running + momentum*stat_g for g = 0..groups-1; var uses the unbiased estimate n/(n-1). */
 int xas_bn_update_running(const float* mean, const float* var_biased, float* running_mean,
                           float* running_var, float momentum, long count, int C, int groups, void* stream);
@@ -202,13 +210,14 @@ int xas_bn_update_running(const float* mean, const float* var_biased, float* run
 int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy, const float* mean,
                       const float* var_biased, const float* gamma, const float* beta, float eps, int act,
                       long M, int C, int groups, float* sums, float* workspace,
-                      float* dbeta_acc, float* dgamma_acc, void* stream);
+                      float* dbeta_acc, float* dgamma_acc, const uint8_t* mask, void* stream);
+/* mask (may be NULL): the sign bytes xas_bn_apply wrote; when given, y is not read (x required). */
 /* step 2: dx = gamma*invstd_g*(dz - sum_dz_g/cnt - xhat*sum_dz_xhat_g/cnt); dres = dz if != NULL; cnt = rows per
  * group (x world size for SyncBatchNorm).  x may be NULL only for the leaky-ReLU layers (invertible activation). */
 int xas_bn_bwd_apply(const float* x, const float* y, const float* dy, const float* mean,
                      const float* var_biased, const float* gamma, const float* beta, const float* sums,
                      float eps, int act, long M, int C, int groups, double count,
-                     float* dx, float* dresidual, void* stream);
+                     float* dx, float* dresidual, const uint8_t* mask, void* stream);
 
 /* 3x3 stride-2 pad-1 max pool (resnet.py:20), NHWC. idx: int8 argmax tap 0..8 for backward */
 int xas_maxpool3x3s2_fwd(const float* x, int N, int H, int W, int C, float* y, int8_t* idx, void* stream);

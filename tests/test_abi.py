@@ -90,6 +90,6 @@ def test_argument_checks_return_errors_without_a_gpu():
     assert f('xas_projection_matrix')(None, one, one, 2, one, None) == 1
     shp = _lib.ConvShape(2, 8, 8, 3, 64, 3, 3, 1, 1, 8, 8)         # Cin = 3: not on the accumulating MFMA path
     assert f('xas_conv_dgrad_acc')(one, one, one, ctypes.byref(shp), None) == 1 and 'MFMA path' in err()
-    assert f('xas_bn_bwd_reduce')(None, None, one, one, one, None, None, 1e-5, 1, 64, 64, 1, one, one, None, None, None) == 1
-    assert f('xas_bn_bwd_apply')(None, one, one, one, one, one, None, one, 1e-5, 1, 64, 64, 1, 64.0, one, None, None) == 1
+    assert f('xas_bn_bwd_reduce')(None, None, one, one, one, None, None, 1e-5, 1, 64, 64, 1, one, one, None, None, None, None) == 1
+    assert f('xas_bn_bwd_apply')(None, one, one, one, one, one, None, one, 1e-5, 1, 64, 64, 1, 64.0, one, None, None, None) == 1
     assert 'invertible' in err().lower() or 'null buffer' in err()

@@ -138,3 +138,57 @@ def test_thin_one_channel_kernels(n, c, h, w):
         assert rel(xg.grad, xc.grad) < 3e-6, (cin, cout)
         assert rel(m.weight.grad, wc.grad) < tol, (cin, cout)
         assert rel(m.bias.grad, bc.grad) < tol, (cin, cout)
+
+
+@pytest.mark.parametrize('n,cin,h,w,cout,k,stride,pad', ACC_CASES[:4] + [(1, 2048, 4, 4, 512, 1, 1, 0)])
+def test_conv_dgrad_acc_masked(n, cin, h, w, cout, k, stride, pad):
+    """dx = dgrad(dy, W) + relu'(mask) * dprev with the sign bytes xas_bn_apply writes (block-input gradient of a
+    bottleneck without projection; the skip gradient is never materialised)."""
+    from xas_amd import ops_nn as F
+    from xas_amd._lib import call, ptr
+    x, wt, dy, ho, wo = _conv_case(n, cin, h, w, cout, k, stride, pad, seed=3 + cin + cout + k)
+    g = torch.Generator().manual_seed(4)
+    dprev = torch.randn(n, cin, h, w, generator=g)
+    active = torch.rand(n, cin, h, w, generator=g) > 0.4
+    ref = torch.nn.grad.conv2d_input(x.shape, wt, dy, stride, pad) + dprev * active
+    # mask bytes over the NHWC float4 order: bit e of byte i = element 4i+e active
+    a_nhwc = active.permute(0, 2, 3, 1).reshape(-1, 4).to(torch.uint8)
+    mask = (a_nhwc[:, 0] | (a_nhwc[:, 1] << 1) | (a_nhwc[:, 2] << 2) | (a_nhwc[:, 3] << 3)).contiguous().cuda()
+    shp = F._shape(n, h, w, cin, cout, k, k, stride, pad, ho, wo)
+    cache = F._PackCache()
+    wg = wt.cuda()
+    dyg = dy.cuda().contiguous(memory_format=torch.channels_last)
+    dpg = dprev.cuda().contiguous(memory_format=torch.channels_last)
+    out = torch.full_like(dpg, float('nan'))
+    call('xas_conv_dgrad_acc_masked', ptr(dyg), ptr(cache.get(wg, 1)), ptr(out), shp, ptr(dpg), ptr(mask))
+    assert rel(out, ref) < 3e-6
+
+
+@pytest.mark.parametrize('n,c,h,w,G', [(2, 256, 8, 8, 1), (4, 64, 16, 16, 2), (3, 1024, 4, 4, 3)])
+def test_bn_residual_sign_mask_path(n, c, h, w, G, monkeypatch):
+    """Batch norm with residual + ReLU: the sign-mask backward (neither pass reads y) against the y-reading form and
+    against torch."""
+    import torch.nn.functional as TF
+    from xas_amd import layers as L
+    from xas_amd import ops_nn as F
+    g = torch.Generator().manual_seed(c + G)
+    x = torch.randn(n * G, c, h, w, generator=g)
+    r = torch.randn(n * G, c, h, w, generator=g)
+    gy = torch.randn(n * G, c, h, w, generator=g)
+    outs = []
+    for use_mask in ('1', '0'):
+        monkeypatch.setenv('XAS_BN_MASK', use_mask)
+        bn = L.BatchNorm2d(c, act=F.ACT_RELU).cuda().train()
+        xg, rg = x.cuda().requires_grad_(True), r.cuda().requires_grad_(True)
+        with F.bn_groups(G):
+            y = bn(xg, rg)
+        (y * gy.cuda()).sum().backward()
+        outs.append((y.detach(), xg.grad, rg.grad, bn.weight.grad.clone(), bn.bias.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)                          # same arithmetic, different source of the sign
+    # torch reference per group
+    xs, rs = x.requires_grad_(True), r.requires_grad_(True)
+    ys = [torch.relu(TF.batch_norm(xs[i * n:(i + 1) * n], None, None, torch.ones(c), torch.zeros(c), True, 0.1, 1e-5) + rs[i * n:(i + 1) * n])
+          for i in range(G)]
+    (torch.cat(ys) * gy).sum().backward()
+    assert rel(outs[0][0], torch.cat(ys)) < 3e-6 and rel(outs[0][1], xs.grad) < 2e-5 and rel(outs[0][2], rs.grad) < 3e-6

@@ -78,6 +78,7 @@ struct ColArgs {
   float* count_out;            // != null: count_out[g * out_stride] = rows per group (SyncBatchNorm message)
   float* running_mean; float* running_var; float momentum, unbias;
   float* acc1; float* acc2;    // != null: acc1[c] += sum over groups of out1 ... (parameter gradients, in place)
+  const uint8_t* mask;         // MODE 1: != null -> activation sign bits (one byte per float4, bit e = z_e > 0) instead of y
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -170,7 +171,12 @@ __device__ __forceinline__ void col_reduce_body(const ColArgs& a) {
       s2.x = fmaf(a0, a0, s2.x); s2.y = fmaf(b, b, s2.y); s2.z = fmaf(cc, cc, s2.z); s2.w = fmaf(d, d, s2.w);
     } else {
       float4 g4 = *reinterpret_cast<const float4*>(dy + r * C + c);
-      if (act) {
+      if (act && a.mask) {
+        const unsigned mb = a.mask[(r * C + c) >> 2];
+        const float neg = act == 1 ? 0.f : 0.01f;
+        g4.x *= (mb & 1u) ? 1.f : neg; g4.y *= (mb & 2u) ? 1.f : neg;
+        g4.z *= (mb & 4u) ? 1.f : neg; g4.w *= (mb & 8u) ? 1.f : neg;
+      } else if (act) {
         const float4 yv = *reinterpret_cast<const float4*>(y + r * C + c);
         const float neg = act == 1 ? 0.f : 0.01f;
         g4.x *= yv.x > 0.f ? 1.f : neg; g4.y *= yv.y > 0.f ? 1.f : neg;
@@ -369,7 +375,7 @@ __device__ __forceinline__ float act_fwd(float v, int act) {
 __global__ void bn_apply_kernel(const float4* __restrict__ x, const float* __restrict__ mean,
                                 const float* __restrict__ var, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, const float4* __restrict__ res, float eps, int act,
-                                long n4g, int C4, float4* __restrict__ y) {
+                                long n4g, int C4, float4* __restrict__ y, uint8_t* __restrict__ mask_out) {
   const long goff = (long)blockIdx.y * n4g;
   mean += (size_t)blockIdx.y * C4 * 4; var += (size_t)blockIdx.y * C4 * 4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4g; i += (long)gridDim.x * blockDim.x) {
@@ -383,6 +389,8 @@ __global__ void bn_apply_kernel(const float4* __restrict__ x, const float* __res
     o.z = bn_affine(xv.z, m.z, __fmul_rn(rsqrtf(v.z + eps), g.z), b.z);
     o.w = bn_affine(xv.w, m.w, __fmul_rn(rsqrtf(v.w + eps), g.w), b.w);
     if (res) { const float4 r = res[goff + i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+    if (mask_out)          // sign bits of the pre-activation value: what the backward needs of y (1/16 of its bytes)
+      mask_out[goff + i] = (uint8_t)((o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u));
     o.x = act_fwd(o.x, act); o.y = act_fwd(o.y, act); o.z = act_fwd(o.z, act); o.w = act_fwd(o.w, act);
     y[goff + i] = o;
   }
@@ -394,7 +402,8 @@ __global__ void bn_bwd_apply_kernel(const float4* __restrict__ x, const float4* 
                                     const float* __restrict__ var, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const float* __restrict__ sums,
                                     float eps, int act, long n4g, int C4,
-                                    float inv_count, float4* __restrict__ dx, float4* __restrict__ dres) {
+                                    float inv_count, float4* __restrict__ dx, float4* __restrict__ dres,
+                                    const uint8_t* __restrict__ mask) {
   const long goff = (long)blockIdx.y * n4g;
   mean += (size_t)blockIdx.y * C4 * 4; var += (size_t)blockIdx.y * C4 * 4;
   const float* sdz = sums + (size_t)blockIdx.y * C4 * 8;
@@ -407,7 +416,12 @@ __global__ void bn_bwd_apply_kernel(const float4* __restrict__ x, const float4* 
     const float4 a = *reinterpret_cast<const float4*>(sdz + c), b = *reinterpret_cast<const float4*>(sdzx + c);
     float4 dz = dy[i];
     float4 yv = make_float4(0, 0, 0, 0);
-    if (act && y) {
+    if (act && mask) {                                     // sign bits saved by the forward (layers with a residual)
+      const unsigned mb = mask[i];
+      const float neg = act == 1 ? 0.f : 0.01f;
+      dz.x *= (mb & 1u) ? 1.f : neg; dz.y *= (mb & 2u) ? 1.f : neg;
+      dz.z *= (mb & 4u) ? 1.f : neg; dz.w *= (mb & 8u) ? 1.f : neg;
+    } else if (act && y) {
       yv = y[i];
       const float neg = act == 1 ? 0.f : 0.01f;
       dz.x *= yv.x > 0.f ? 1.f : neg; dz.y *= yv.y > 0.f ? 1.f : neg;
@@ -441,6 +455,114 @@ __global__ void bn_bwd_apply_kernel(const float4* __restrict__ x, const float4* 
     o.z = g.z * is.z * (dz.z - a.z * inv_count - xh.z * b.z * inv_count);
     o.w = g.w * is.w * (dz.w - a.w * inv_count - xh.w * b.w * inv_count);
     dx[i] = o;
+  }
+}
+
+// ---- streaming forms of the two apply kernels.  When the number of threads in a grid row is a multiple of C/4 a thread
+// sees ONE channel quadruple for its whole life: the per-channel parameters are read once, the loop body is only the
+// activation stream, compiled per mode (no branches) and unrolled so that several 16-byte loads are in flight per lane -
+// in the backward pass these kernels share the chip with two weight-gradient blocks per CU and get few wave slots.
+template <int ACT, bool RES, bool MASKOUT>
+__global__ __launch_bounds__(256) void bn_apply_stream_kernel(const float4* __restrict__ x, const float* __restrict__ mean,
+                                                             const float* __restrict__ var, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float4* __restrict__ res,
+                                                             float eps, long n4g, int C4, float4* __restrict__ y,
+                                                             uint8_t* __restrict__ mask_out) {
+  const long goff = (long)blockIdx.y * n4g;
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = (int)(i % C4) * 4;
+  const float4 m = *reinterpret_cast<const float4*>(mean + (size_t)blockIdx.y * C4 * 4 + c);
+  const float4 v = *reinterpret_cast<const float4*>(var + (size_t)blockIdx.y * C4 * 4 + c);
+  const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+  const float4 rs = make_float4(__fmul_rn(rsqrtf(v.x + eps), g.x), __fmul_rn(rsqrtf(v.y + eps), g.y),
+                                __fmul_rn(rsqrtf(v.z + eps), g.z), __fmul_rn(rsqrtf(v.w + eps), g.w));
+  auto one = [&](long k, float4 xv, float4 rv) {
+    float4 o;
+    o.x = bn_affine(xv.x, m.x, rs.x, b.x); o.y = bn_affine(xv.y, m.y, rs.y, b.y);
+    o.z = bn_affine(xv.z, m.z, rs.z, b.z); o.w = bn_affine(xv.w, m.w, rs.w, b.w);
+    if (RES) { o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w; }
+    if (MASKOUT)
+      mask_out[goff + k] = (uint8_t)((o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u));
+    o.x = act_fwd(o.x, ACT); o.y = act_fwd(o.y, ACT); o.z = act_fwd(o.z, ACT); o.w = act_fwd(o.w, ACT);
+    y[goff + k] = o;
+  };
+  const float4 z4 = make_float4(0, 0, 0, 0);
+  for (; i + 3 * stride < n4g; i += 4 * stride) {
+    float4 xv[4], rv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { xv[u] = x[goff + i + u * stride]; rv[u] = RES ? res[goff + i + u * stride] : z4; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(i + u * stride, xv[u], rv[u]);
+  }
+  for (; i < n4g; i += stride) one(i, x[goff + i], RES ? res[goff + i] : z4);
+}
+
+// SIGN: where the activation sign comes from: 0 no activation, 1 y, 2 x (re-derived, no residual), 3 mask bytes
+// XH  : normalised input from x (true) or recovered from y (false: leaky ReLU, SIGN == 1)
+template <int ACT, int SIGN, bool XH, bool DRES>
+__global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(
+    const float4* __restrict__ x, const float4* __restrict__ y, const float4* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ sums, float eps, long n4g, int C4, float inv_count, float4* __restrict__ dx,
+    float4* __restrict__ dres, const uint8_t* __restrict__ mask) {
+  const long goff = (long)blockIdx.y * n4g;
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = (int)(i % C4) * 4;
+  const size_t gc = (size_t)blockIdx.y * C4 * 4 + c;
+  const float4 m = *reinterpret_cast<const float4*>(mean + gc), v = *reinterpret_cast<const float4*>(var + gc);
+  const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+  const float4 bt = beta ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0, 0, 0, 0);
+  const float4 a = *reinterpret_cast<const float4*>(sums + (size_t)blockIdx.y * C4 * 8 + c);
+  const float4 b = *reinterpret_cast<const float4*>(sums + (size_t)blockIdx.y * C4 * 8 + (size_t)C4 * 4 + c);
+  const float4 is = make_float4(rsqrtf(v.x + eps), rsqrtf(v.y + eps), rsqrtf(v.z + eps), rsqrtf(v.w + eps));
+  const float4 rs = make_float4(__fmul_rn(is.x, g.x), __fmul_rn(is.y, g.y), __fmul_rn(is.z, g.z), __fmul_rn(is.w, g.w));
+  constexpr float neg = ACT == 1 ? 0.f : 0.01f, up = ACT == 1 ? 0.f : 100.f;
+  auto one = [&](long k, float4 xv, float4 yv, float4 dz, unsigned mb) {
+    if (SIGN == 1) {
+      dz.x *= yv.x > 0.f ? 1.f : neg; dz.y *= yv.y > 0.f ? 1.f : neg; dz.z *= yv.z > 0.f ? 1.f : neg; dz.w *= yv.w > 0.f ? 1.f : neg;
+    } else if (SIGN == 2) {
+      dz.x *= bn_affine(xv.x, m.x, rs.x, bt.x) > 0.f ? 1.f : neg; dz.y *= bn_affine(xv.y, m.y, rs.y, bt.y) > 0.f ? 1.f : neg;
+      dz.z *= bn_affine(xv.z, m.z, rs.z, bt.z) > 0.f ? 1.f : neg; dz.w *= bn_affine(xv.w, m.w, rs.w, bt.w) > 0.f ? 1.f : neg;
+    } else if (SIGN == 3) {
+      dz.x *= (mb & 1u) ? 1.f : neg; dz.y *= (mb & 2u) ? 1.f : neg; dz.z *= (mb & 4u) ? 1.f : neg; dz.w *= (mb & 8u) ? 1.f : neg;
+    }
+    if (DRES) dres[goff + k] = dz;
+    float4 xh;
+    if (XH) xh = make_float4((xv.x - m.x) * is.x, (xv.y - m.y) * is.y, (xv.z - m.z) * is.z, (xv.w - m.w) * is.w);
+    else {
+      xh.x = g.x != 0.f ? ((yv.x > 0.f ? yv.x : yv.x * up) - bt.x) / g.x : 0.f;
+      xh.y = g.y != 0.f ? ((yv.y > 0.f ? yv.y : yv.y * up) - bt.y) / g.y : 0.f;
+      xh.z = g.z != 0.f ? ((yv.z > 0.f ? yv.z : yv.z * up) - bt.z) / g.z : 0.f;
+      xh.w = g.w != 0.f ? ((yv.w > 0.f ? yv.w : yv.w * up) - bt.w) / g.w : 0.f;
+    }
+    float4 o;
+    o.x = g.x * is.x * (dz.x - a.x * inv_count - xh.x * b.x * inv_count);
+    o.y = g.y * is.y * (dz.y - a.y * inv_count - xh.y * b.y * inv_count);
+    o.z = g.z * is.z * (dz.z - a.z * inv_count - xh.z * b.z * inv_count);
+    o.w = g.w * is.w * (dz.w - a.w * inv_count - xh.w * b.w * inv_count);
+    dx[goff + k] = o;
+  };
+  const float4 z4 = make_float4(0, 0, 0, 0);
+  constexpr bool NEEDX = XH || SIGN == 2, NEEDY = SIGN == 1 || !XH;
+  for (; i + 3 * stride < n4g; i += 4 * stride) {
+    float4 xv[4], yv[4], dv[4];
+    unsigned mb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long k = goff + i + u * stride;
+      dv[u] = dy[k];
+      xv[u] = NEEDX ? x[k] : z4;
+      yv[u] = NEEDY ? y[k] : z4;
+      mb[u] = SIGN == 3 ? mask[k] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(i + u * stride, xv[u], yv[u], dv[u], mb[u]);
+  }
+  for (; i < n4g; i += stride) {
+    const long k = goff + i;
+    one(i, NEEDX ? x[k] : z4, NEEDY ? y[k] : z4, dy[k], SIGN == 3 ? mask[k] : 0u);
   }
 }
 
@@ -707,14 +829,36 @@ extern "C" int xas_col_sum(const float* x, long M, int C, float* out, float* wor
 
 extern "C" int xas_bn_apply(const float* x, const float* mean, const float* var_biased, const float* gamma,
                             const float* beta, const float* residual, float eps, int act, long M, int C, int groups,
-                            float* y, void* stream) {
+                            float* y, uint8_t* mask_out, void* stream) {
   XAS_REQUIRE(x && mean && var_biased && gamma && beta && y, "bn_apply: null buffer");
   XAS_REQUIRE(M > 0 && C >= 4 && C % 4 == 0 && act >= 0 && act <= 2 && groups >= 1 && M % groups == 0,
               "bn_apply: bad shape M=%ld C=%d act=%d groups=%d", M, C, act, groups);
   const long n4g = (M / groups) * (C / 4);
+  {
+    // streaming form: every thread keeps one channel quadruple (threads per grid row a multiple of C/4)
+    const int C4 = C / 4;
+    unsigned gx = ew_grid_g(n4g, groups);
+    const bool pow2 = (C4 & (C4 - 1)) == 0;
+    if (pow2 && C4 > 256) gx = (gx + (C4 / 256) - 1) / (C4 / 256) * (C4 / 256);
+    if (pow2 && ((long)gx * 256) % C4 == 0 && !(tune_flags() & (1 << 22))) {
+      const dim3 grid(gx, groups);
+      const float4* x4 = reinterpret_cast<const float4*>(x);
+      const float4* r4 = reinterpret_cast<const float4*>(residual);
+      float4* y4 = reinterpret_cast<float4*>(y);
+#define XAS_BN_FWD(ACT, RES, MK)                                                                                         \
+  hipLaunchKernelGGL((bn_apply_stream_kernel<ACT, RES, MK>), grid, dim3(256), 0, as_stream(stream), x4, mean, var_biased, \
+                     gamma, beta, r4, eps, n4g, C4, y4, mask_out)
+      if (residual && mask_out) { if (act == 1) XAS_BN_FWD(1, true, true); else if (act == 2) XAS_BN_FWD(2, true, true); else XAS_BN_FWD(0, true, true); }
+      else if (residual) { if (act == 1) XAS_BN_FWD(1, true, false); else if (act == 2) XAS_BN_FWD(2, true, false); else XAS_BN_FWD(0, true, false); }
+      else { if (act == 1) XAS_BN_FWD(1, false, false); else if (act == 2) XAS_BN_FWD(2, false, false); else XAS_BN_FWD(0, false, false); }
+#undef XAS_BN_FWD
+      XAS_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid_g(n4g, groups), groups), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float4*>(x), mean, var_biased, gamma, beta,
-                     reinterpret_cast<const float4*>(residual), eps, act, n4g, C / 4, reinterpret_cast<float4*>(y));
+                     reinterpret_cast<const float4*>(residual), eps, act, n4g, C / 4, reinterpret_cast<float4*>(y), mask_out);
   XAS_LAUNCH_CHECK();
   return 0;
 }
@@ -733,10 +877,11 @@ extern "C" int xas_bn_update_running(const float* mean, const float* var_biased,
 extern "C" int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy, const float* mean,
                                  const float* var_biased, const float* gamma, const float* beta, float eps, int act,
                                  long M, int C, int groups, float* sums, float* workspace,
-                                 float* dbeta_acc, float* dgamma_acc, void* stream) {
+                                 float* dbeta_acc, float* dgamma_acc, const uint8_t* mask, void* stream) {
   ColGeom g;
   if (col_geom(M, C, groups, &g)) return 1;
-  XAS_REQUIRE(dy && mean && var_biased && sums && workspace && (act == 0 || y || (x && gamma && beta)),
+  XAS_REQUIRE(!mask || (x && act != 0), "bn_bwd_reduce: the sign-mask form needs x and an activation");
+  XAS_REQUIRE(dy && mean && var_biased && sums && workspace && (act == 0 || y || mask || (x && gamma && beta)),
               "bn_bwd_reduce: null buffer (an activation needs y, or x with gamma and beta)");
   XAS_REQUIRE(x || (act != 0 && y && gamma && beta), "bn_bwd_reduce: without x the layer needs an activation, y, gamma, beta");
   XAS_REQUIRE((dbeta_acc == nullptr) == (dgamma_acc == nullptr), "bn_bwd_reduce: gradient accumulators come in pairs");
@@ -747,6 +892,10 @@ extern "C" int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy
   a.out1 = sums; a.out2 = sums + C; a.out_stride = 2 * (long)C;            // [G][2][C]
   a.acc1 = dbeta_acc; a.acc2 = dgamma_acc;
   const dim3 grid(g.nslab, g.ncb, g.G);
+  if (mask) {                             // sign bits instead of y (layers with a residual: 1/16 of y's bytes)
+    a.x = x; a.y = nullptr; a.mask = mask;
+    hipLaunchKernelGGL(lean ? col_reduce_lean_kernel<1> : col_reduce_kernel<1>, grid, dim3(256), 0, as_stream(stream), a);
+  } else
   if (x && act != 0 && y == nullptr) {   // y-free form: activation mask re-derived from x (layers without a residual)
     a.x = x; a.y = gamma; a.aux = beta;
     hipLaunchKernelGGL(lean ? col_reduce_lean_kernel<4> : col_reduce_kernel<4>, grid, dim3(256), 0, as_stream(stream), a);
@@ -764,19 +913,58 @@ extern "C" int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy
 extern "C" int xas_bn_bwd_apply(const float* x, const float* y, const float* dy, const float* mean,
                                 const float* var_biased, const float* gamma, const float* beta, const float* sums,
                                 float eps, int act, long M, int C, int groups, double count, float* dx,
-                                float* dresidual, void* stream) {
-  XAS_REQUIRE(dy && mean && var_biased && gamma && sums && dx && (act == 0 || y || (x && beta)),
+                                float* dresidual, const uint8_t* mask, void* stream) {
+  XAS_REQUIRE(!mask || x, "bn_bwd_apply: the sign-mask form needs x");
+  XAS_REQUIRE(dy && mean && var_biased && gamma && sums && dx && (act == 0 || y || mask || (x && beta)),
               "bn_bwd_apply: null buffer (an activation needs y, or x with beta)");
-  XAS_REQUIRE(y || !dresidual || act == 0, "bn_bwd_apply: the y-free form is for layers without a residual");
+  XAS_REQUIRE(y || mask || !dresidual || act == 0, "bn_bwd_apply: the y-free form is for layers without a residual");
   XAS_REQUIRE(x || (act == 2 && y && beta),
               "bn_bwd_apply: without x the layer needs an INVERTIBLE activation (leaky ReLU), y and beta: dx needs xhat "
               "of every element, also where ReLU clipped the output");
   XAS_REQUIRE(M > 0 && C >= 4 && C % 4 == 0 && count > 0 && groups >= 1 && M % groups == 0, "bn_bwd_apply: bad shape");
   const long n4g = (M / groups) * (C / 4);
+  {
+    const int C4 = C / 4;
+    unsigned gx = ew_grid_g(n4g, groups);
+    const bool pow2 = (C4 & (C4 - 1)) == 0;
+    if (pow2 && C4 > 256) gx = (gx + (C4 / 256) - 1) / (C4 / 256) * (C4 / 256);
+    // modes of the model: ReLU without residual (sign from x), leaky ReLU without x (physique net), residual layers
+    // (sign from y or from the mask bytes), no activation (projection norms); anything else takes the generic kernel
+    int mode = -1;
+    if (act == 0 && x && !dresidual) mode = 0;
+    else if (act == 1 && x && !y && !mask && !dresidual) mode = 1;
+    else if (act == 2 && !x && y && !dresidual) mode = 2;
+    else if (act == 1 && x && y && !mask) mode = dresidual ? 3 : 4;
+    else if (act == 1 && x && mask) mode = dresidual ? 5 : 6;
+    if (mode >= 0 && pow2 && ((long)gx * 256) % C4 == 0 && !(tune_flags() & (1 << 22))) {
+      const dim3 grid(gx, groups);
+      const float4* x4 = reinterpret_cast<const float4*>(x);
+      const float4* y4 = reinterpret_cast<const float4*>(y);
+      const float4* d4 = reinterpret_cast<const float4*>(dy);
+      float4* o4 = reinterpret_cast<float4*>(dx);
+      float4* r4 = reinterpret_cast<float4*>(dresidual);
+      const float ic = (float)(1.0 / count);
+#define XAS_BN_BWD(ACT, SIGN, XH, DR)                                                                                      \
+  hipLaunchKernelGGL((bn_bwd_apply_stream_kernel<ACT, SIGN, XH, DR>), grid, dim3(256), 0, as_stream(stream), x4, y4, d4, mean, \
+                     var_biased, gamma, beta, sums, eps, n4g, C4, ic, o4, r4, mask)
+      switch (mode) {
+        case 0: XAS_BN_BWD(0, 0, true, false); break;
+        case 1: XAS_BN_BWD(1, 2, true, false); break;
+        case 2: XAS_BN_BWD(2, 1, false, false); break;
+        case 3: XAS_BN_BWD(1, 1, true, true); break;
+        case 4: XAS_BN_BWD(1, 1, true, false); break;
+        case 5: XAS_BN_BWD(1, 3, true, true); break;
+        default: XAS_BN_BWD(1, 3, true, false); break;
+      }
+#undef XAS_BN_BWD
+      XAS_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid_g(n4g, groups), groups), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(y),
                      reinterpret_cast<const float4*>(dy), mean, var_biased, gamma, beta, sums, eps, act, n4g,
-                     C / 4, (float)(1.0 / count), reinterpret_cast<float4*>(dx), reinterpret_cast<float4*>(dresidual));
+                     C / 4, (float)(1.0 / count), reinterpret_cast<float4*>(dx), reinterpret_cast<float4*>(dresidual), mask);
   XAS_LAUNCH_CHECK();
   return 0;
 }

@@ -57,7 +57,11 @@ struct IgemmParams {
   int nMt, nNt, mt_per_xcd;   // tile counts and M-tiles per XCD for the XCD-aware block order
   unsigned long long* dbg;    // diagnostic builds only: per-phase cycle sums (xas_set_debug_buffer)
   long src_elems, wgt_elems;  // sizes of src / wgt (buffer-load kernel: range of the buffer descriptors)
-  int accumulate;             // epilogue: out += result (residual gradient already in the buffer)
+  int accumulate;             // epilogue: 1: out += result (residual gradient already in the buffer);
+                              //           2: out = result + relu'(mask) * acc_src (the skip gradient is formed here from
+                              //              the block-output gradient and the sign bytes of xas_bn_apply: no dres tensor)
+  const float* acc_src;       // accumulate == 2: [rows][Cd] like out
+  const unsigned char* acc_mask;   // accumulate == 2: one byte per float4 of out, bit e = element active
 };
 
 static unsigned long long* g_dbg = nullptr;
@@ -220,13 +224,17 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
     // one load at a time (load, wait, add, store) left the epilogue waiting out a full memory round trip per float4
     // (rocprof: xas_conv_dgrad_acc at 46 TFLOP/s against 104 for the same shapes without the accumulation)
     float4 prev[C::NI][4];
+    unsigned pmask[C::NI][4];
     if (p.accumulate && vec_ok) {
+      const float* prow = p.accumulate == 2 ? p.acc_src + orow * p.Cd : orow_p;
 #pragma unroll
       for (int ni = 0; ni < C::NI; ++ni)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = n0 + wn * C::WN + ni * 32 + 8 * g + csub;
-          prev[ni][g] = *reinterpret_cast<const float4*>(orow_p + (n + 3 < p.Cd ? n : p.Cd - 4));   // clamped: unconditional load
+          const int nc = n + 3 < p.Cd ? n : p.Cd - 4;                                   // clamped: unconditional load
+          prev[ni][g] = *reinterpret_cast<const float4*>(prow + nc);
+          pmask[ni][g] = p.accumulate == 2 ? p.acc_mask[(orow * p.Cd + nc) >> 2] : 15u;
         }
     }
 #pragma unroll
@@ -242,7 +250,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
           }
           if (p.accumulate) {
             const float4 o = prev[ni][g];
-            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            const unsigned mb = pmask[ni][g];
+            v.x += (mb & 1u) ? o.x : 0.f; v.y += (mb & 2u) ? o.y : 0.f;
+            v.z += (mb & 4u) ? o.z : 0.f; v.w += (mb & 8u) ? o.w : 0.f;
           }
           *reinterpret_cast<float4*>(orow_p + n) = v;
         } else {
@@ -1589,7 +1599,7 @@ extern "C" int xas_conv_fwd(const float* x, const float* w_packed, const float* 
 }
 
 static int conv_dgrad_impl(const float* dy, const float* w_packed_t, float* dx, const xas_conv_shape* s, void* stream,
-                           int accumulate);
+                           int accumulate, const float* acc_src = nullptr, const unsigned char* acc_mask = nullptr);
 
 extern "C" int xas_conv_dgrad(const float* dy, const float* w_packed_t, float* dx, const xas_conv_shape* s,
                               void* stream) {
@@ -1601,8 +1611,14 @@ extern "C" int xas_conv_dgrad_acc(const float* dy, const float* w_packed_t, floa
   return conv_dgrad_impl(dy, w_packed_t, dx, s, stream, 1);
 }
 
+extern "C" int xas_conv_dgrad_acc_masked(const float* dy, const float* w_packed_t, float* dx, const xas_conv_shape* s,
+                                         const float* dprev, const uint8_t* mask, void* stream) {
+  XAS_REQUIRE(dprev && mask, "conv_dgrad_acc_masked: null buffer");
+  return conv_dgrad_impl(dy, w_packed_t, dx, s, stream, 2, dprev, mask);
+}
+
 static int conv_dgrad_impl(const float* dy, const float* w_packed_t, float* dx, const xas_conv_shape* s, void* stream,
-                           int accumulate) {
+                           int accumulate, const float* acc_src, const unsigned char* acc_mask) {
   if (check_shape(s, "conv_dgrad")) return 1;
   XAS_REQUIRE(!accumulate || (s->Cout % BK == 0 && s->Cin >= 16 && s->Cin % 4 == 0 && !(s->Cin == 1 || s->Cout == 1)),
               "conv_dgrad_acc: only the MFMA path accumulates (Cout %% 32 == 0, Cin %% 4 == 0, Cin >= 16)");
@@ -1617,7 +1633,8 @@ static int conv_dgrad_impl(const float* dy, const float* w_packed_t, float* dx, 
       for (int n0 = 0; n0 < s->N; n0 += per) {
         xas_conv_shape part = *s;
         part.N = s->N - n0 < per ? s->N - n0 : per;
-        const int rc = conv_dgrad_impl(dy + (size_t)n0 * yi, w_packed_t, dx + (size_t)n0 * xi, &part, stream, accumulate);
+        const int rc = conv_dgrad_impl(dy + (size_t)n0 * yi, w_packed_t, dx + (size_t)n0 * xi, &part, stream, accumulate,
+                                       acc_src ? acc_src + (size_t)n0 * xi : nullptr, acc_mask ? acc_mask + (size_t)n0 * xi / 4 : nullptr);
         if (rc) return rc;
       }
       return 0;
@@ -1650,7 +1667,7 @@ static int conv_dgrad_impl(const float* dy, const float* w_packed_t, float* dx, 
   p.src = dy; p.wgt = w_packed_t; p.bias = nullptr; p.out = dx; p.N = s->N;
   p.Hs = s->Ho; p.Ws = s->Wo; p.Cs = s->Cout; p.Hd = s->Hi; p.Wd = s->Wi; p.Cd = s->Cin;
   p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.tune = g_tune; p.dbg = g_dbg;
-  p.accumulate = accumulate;
+  p.accumulate = accumulate; p.acc_src = acc_src; p.acc_mask = acc_mask;
   const int Hp = (s->Hi + s->stride - 1) / s->stride, Wp = (s->Wi + s->stride - 1) / s->stride;
   p.src_elems = (long)p.N * p.Hs * p.Ws * p.Cs; p.wgt_elems = (long)p.Cd * p.R * p.S * p.Cs;
   return dispatch_igemm<1>(p, s->N * Hp * Wp, s->stride * s->stride, st);

@@ -34,6 +34,7 @@ SIGNATURES = {
     'xas_conv_fwd': ('ppppsp', 'i'),
     'xas_conv_dgrad': ('pppsp', 'i'),
     'xas_conv_dgrad_acc': ('pppsp', 'i'),
+    'xas_conv_dgrad_acc_masked': ('pppsppp', 'i'),
     'xas_conv_wgrad_workspace_floats': ('s', 'z'),
     'xas_conv_wgrad': ('ppppsp', 'i'),
     'xas_conv_wgrad_oihw': ('ppppsp', 'i'),
@@ -44,10 +45,10 @@ SIGNATURES = {
     'xas_bn_stats': ('pliipplppppflp', 'i'),
     'xas_bn_sync_merge': ('piiilppppfp', 'i'),
     'xas_col_sum': ('plippp', 'i'),
-    'xas_bn_apply': ('ppppppfiliipp', 'i'),
+    'xas_bn_apply': ('ppppppfiliippp', 'i'),
     'xas_bn_update_running': ('ppppfliip', 'i'),
-    'xas_bn_bwd_reduce': ('pppppppfiliippppp', 'i'),
-    'xas_bn_bwd_apply': ('ppppppppfiliidppp', 'i'),
+    'xas_bn_bwd_reduce': ('pppppppfiliipppppp', 'i'),
+    'xas_bn_bwd_apply': ('ppppppppfiliidpppp', 'i'),
     'xas_maxpool3x3s2_fwd': ('piiiippp', 'i'),
     'xas_maxpool3x3s2_bwd': ('ppiiiipp', 'i'),
     'xas_upsample2x_fwd': ('piiiipp', 'i'),

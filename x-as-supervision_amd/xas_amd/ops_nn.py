@@ -316,9 +316,9 @@ class _Bottleneck(torch.autograd.Function):
         # parameters that actually want a gradient (frozen ones get none)
         need = {id(p) for p, n in zip(blk._fused_params, ctx.needs_input_grad[2:]) if n}
 
-        def bn_b(idx, bn, dy):
+        def bn_b(idx, bn, dy, want_dres=True):
             dx, dg, db, dres = _bn_backward(saved[idx], cfgs[idx], bn.weight, bn.bias, dy,
-                                            id(bn.weight) in need and id(bn.bias) in need)
+                                            id(bn.weight) in need and id(bn.bias) in need, want_dres)
             if dg is not None:
                 if id(bn.weight) in need:
                     pgrads[id(bn.weight)] = dg
@@ -326,13 +326,24 @@ class _Bottleneck(torch.autograd.Function):
                     pgrads[id(bn.bias)] = db
             return dx, dres
 
-        g, dskip = bn_b(o + 2, bns[2], dout)          # dskip: gradient of the skip branch (= dz of the block output)
+        need_dx = ctx.needs_input_grad[0]
+        # blocks without a projection: the skip gradient (= relu'(block output) * dout) is formed in the epilogue of conv1's
+        # data gradient from dout and the sign bytes bn3's forward saved - it is never written to memory
+        fuse_skip = (not ctx.has_ds and need_dx and cfgs[o + 2][11] and _can_accumulate(shps[o]))
+        dout = to_cl(dout)
+        g, dskip = bn_b(o + 2, bns[2], dout, want_dres=not fuse_skip)          # dskip: gradient of the skip branch
         for i in (2, 1):
             g, dw = _conv_backward(ins[i], convs[i].weight, g, shps[o + i], convs[i]._cache, True, id(convs[i].weight) in need)
             if dw is not None:
                 pgrads[id(convs[i].weight)] = dw
             g, _ = bn_b(o + i - 1, bns[i - 1], g)
-        need_dx = ctx.needs_input_grad[0]
+        if fuse_skip:
+            dx = torch.empty_like(x)
+            call('xas_conv_dgrad_acc_masked', ptr(g), ptr(convs[0]._cache.get(convs[0].weight, 1)), ptr(dx), shps[o],
+                 ptr(dout), ptr(saved[o + 2][1]))
+            if id(convs[0].weight) in need and not _wgrad_into_grad(x, g, shps[o], convs[0].weight):
+                pgrads[id(convs[0].weight)] = _wgrad(x, g, shps[o], convs[0].weight.shape)
+            return (dx, None) + tuple(pgrads.get(id(p)) for p in ctx.blk._fused_params)
         if ctx.has_ds:
             ds = blk.downsample
             gd, _ = bn_b(0, ds[1], dskip)
@@ -525,7 +536,11 @@ def _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, m
         var = running_var.reshape(1, c).expand(G, c).contiguous() if G > 1 else running_var
     res = to_cl(residual) if residual is not None else None
     y = torch.empty_like(x)
-    call('xas_bn_apply', ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(res), float(eps), act, M, c, G, ptr(y))
+    # layers with a residual (block outputs): the backward needs only the SIGN of the pre-activation value, saved as one
+    # byte per float4 (1/16 of y's bytes) - neither backward pass reads y
+    masked = training and residual is not None and act != ACT_NONE and os.environ.get('XAS_BN_MASK', '0') == '1'
+    mask = torch.empty(M * c // 4, device=dev, dtype=torch.uint8) if masked else None
+    call('xas_bn_apply', ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(res), float(eps), act, M, c, G, ptr(y), ptr(mask))
     # Backward traffic: which of x / y the backward passes need
     #   leaky ReLU, no residual : neither pass reads x (xhat recovered from the invertible output y);
     #   ReLU, no residual       : neither pass reads y (the mask is re-derived from x: 2 reads + 1 write in the apply
@@ -533,28 +548,32 @@ def _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, m
     #   otherwise               : both.
     xfree = training and act == ACT_LEAKY and residual is None
     yfree = training and act == ACT_RELU and residual is None and os.environ.get('XAS_BN_YFREE', '1') == '1'
-    saved = (y if xfree else x, x if yfree else y, mean, var)
-    cfg = (M, c, float(eps), act, count, group, training, residual is not None, xfree, yfree, G)
+    saved = (y if xfree else x, mask if masked else (x if yfree else y), mean, var)
+    cfg = (M, c, float(eps), act, count, group, training, residual is not None, xfree, yfree, G, masked)
     return y, saved, cfg
 
 
-def _bn_backward(saved, cfg, gamma, beta, dy, want_param_grads):
+def _bn_backward(saved, cfg, gamma, beta, dy, want_param_grads, want_dres=True):
     """-> (dx, dgamma, dbeta, dres); dgamma / dbeta are None when they were accumulated straight into gamma.grad /
     beta.grad (LOCAL sums: the gradient all-reduce averages them later), which saves two autograd accumulation kernels
-    per layer."""
+    per layer.  want_dres=False (sign-mask layers only): the residual gradient is not materialised - the consumer forms
+    it from (dy, mask) itself (xas_conv_dgrad_acc_masked)."""
     x, y, mean, var = saved
-    M, c, eps, act, count, group, training, has_res, xfree, yfree, G = cfg
+    M, c, eps, act, count, group, training, has_res, xfree, yfree, G, masked = cfg
     if not training:
         raise RuntimeError('batch-norm backward in eval mode is not part of the training path')
     dy = to_cl(dy)
     dev = x.device
+    mask = y if masked else None
     sums = torch.empty(G, 2, c, device=dev, dtype=torch.float32)          # [g][0] = sum dz, [g][1] = sum dz * xhat
     ws = torch.empty(query('xas_bn_workspace_floats', M, c, G), device=dev, dtype=torch.float32)
     gg, gb = gamma.grad, beta.grad
     direct = (want_param_grads and gg is not None and gb is not None and gg.is_contiguous() and gb.is_contiguous()
               and gg.dtype == torch.float32 and gb.dtype == torch.float32)
-    call('xas_bn_bwd_reduce', None if xfree else ptr(x), None if yfree else ptr(y), ptr(dy), ptr(mean), ptr(var), ptr(gamma),
-         ptr(beta), eps, act, M, c, G, ptr(sums), ptr(ws), ptr(gb) if direct else None, ptr(gg) if direct else None)
+    px = None if xfree else ptr(x)
+    py = None if (yfree or masked) else ptr(y)
+    call('xas_bn_bwd_reduce', px, py, ptr(dy), ptr(mean), ptr(var), ptr(gamma),
+         ptr(beta), eps, act, M, c, G, ptr(sums), ptr(ws), ptr(gb) if direct else None, ptr(gg) if direct else None, ptr(mask))
     if direct:
         dgamma = dbeta = None
         grad_ready(gamma)
@@ -563,10 +582,10 @@ def _bn_backward(saved, cfg, gamma, beta, dy, want_param_grads):
         dgamma, dbeta = sums[:, 1].sum(0), sums[:, 0].sum(0)              # local sums (before the exchange)
     if group is not None:
         dist.all_reduce(sums, group=group)                # one coalesced message per layer (all groups)
-    dx = torch.empty_like(y)
-    dres = torch.empty_like(y) if has_res else None
-    call('xas_bn_bwd_apply', None if xfree else ptr(x), None if yfree else ptr(y), ptr(dy), ptr(mean), ptr(var), ptr(gamma),
-         ptr(beta), ptr(sums), eps, act, M, c, G, float(count), ptr(dx), ptr(dres))
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if (has_res and (want_dres or not masked)) else None
+    call('xas_bn_bwd_apply', px, py, ptr(dy), ptr(mean), ptr(var), ptr(gamma),
+         ptr(beta), ptr(sums), eps, act, M, c, G, float(count), ptr(dx), ptr(dres), ptr(mask))
     return dx, dgamma, dbeta, dres
 
 

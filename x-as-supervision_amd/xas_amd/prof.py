@@ -5,8 +5,8 @@ import torch
 
 from . import _lib
 
-CONV_ENTRIES = ('xas_conv_fwd', 'xas_conv_dgrad', 'xas_conv_dgrad_acc', 'xas_conv_wgrad', 'xas_conv_wgrad_oihw',
-                'xas_conv_wgrad_acc')
+CONV_ENTRIES = ('xas_conv_fwd', 'xas_conv_dgrad', 'xas_conv_dgrad_acc', 'xas_conv_dgrad_acc_masked', 'xas_conv_wgrad',
+                'xas_conv_wgrad_oihw', 'xas_conv_wgrad_acc')
 
 
 def conv_flops(shape):
@@ -45,7 +45,7 @@ class KernelTimer:
         if shape is not None:
             if name == 'xas_conv_fwd':
                 mfma = (shape.Cin % 32 == 0 and shape.Cout >= 16) or (shape.Cin == 3 and shape.R == 7 and shape.Cout == 64)
-            elif name in ('xas_conv_dgrad', 'xas_conv_dgrad_acc'):
+            elif name in ('xas_conv_dgrad', 'xas_conv_dgrad_acc', 'xas_conv_dgrad_acc_masked'):
                 mfma = shape.Cout % 32 == 0 and shape.Cin >= 16
             else:
                 mfma = shape.Cout != 1
