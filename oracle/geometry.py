@@ -99,3 +99,17 @@ def line_heatmaps(kps2d, image_size, parents, children, body_width):
 def draw_lines_max(kps2d, image_size, parents, children, body_width):
     """max over lines -> [B,1,S,S]  (modules/model.py:91-96)."""
     return line_heatmaps(kps2d, image_size, parents, children, body_width).max(dim=1, keepdim=True)[0]
+
+
+def random_rotation_3d(kp):
+    """modules/util.py:389-407: rotation about z by an angle in [-pi/4, pi/4] per sample; the angles come from the CPU
+    generator (torch.rand(B, 1)), one draw per call."""
+    B = kp.shape[0]
+    ang = ((torch.rand(B, 1) - 0.5) * 0.5 * torch.pi).squeeze()
+    rot = torch.zeros(B, 3, 3)
+    rot[:, 0, 0] = torch.cos(ang)
+    rot[:, 0, 1] = -torch.sin(ang)
+    rot[:, 1, 0] = torch.sin(ang)
+    rot[:, 1, 1] = torch.cos(ang)
+    rot[:, 2, 2] = 1
+    return torch.bmm(kp.clone(), rot.to(kp.dtype))

@@ -72,7 +72,11 @@ def generator_losses(cfg, regressor, physique, disc, x, return_aux=False):
             pj = world[key]
             pj = (pj - pj[:, [0]]) / 1000          # model.py:124 indexes the HYPOTHESIS axis
             logits = torch.stack([disc(pj[:, h, :, :sup_dim].detach()) for h in range(pj.shape[1])], dim=1)
-            tot = tot + L.disc_loss(logits, None)
+            if not cfg['smpl_disc_params'].get('use_aug', False):
+                tot = tot + L.disc_loss(logits, None)
+            else:           # model.py:132-140: the rotated branch is NOT detached
+                rot = torch.stack([disc(geo.random_rotation_3d(pj[:, h])[..., :sup_dim]) for h in range(pj.shape[1])], dim=1)
+                tot = tot + L.disc_loss(logits, None) * 0.7 + L.disc_loss(rot, None) * 0.3
         out['smpl_gen'] = tot * lc['smpl_gen_loss']['weight']
     if 'smpl_pseudo_img_loss' in lc:
         tot = 0
@@ -103,7 +107,7 @@ def generator_losses(cfg, regressor, physique, disc, x, return_aux=False):
 
 
 def discriminator_loss(cfg, regressor, disc, x):
-    """modules/model.py:218-264 (use_aug False): detector forward (train-mode BN, graph
+    """modules/model.py:218-264: detector forward (train-mode BN, graph
     built, output detached), LSGAN on hypotheses vs pseudo joints in PATCH coordinates."""
     sup_dim = cfg['smpl_disc_params'].get('disc_sup_dim', 3)
     tot = 0
@@ -112,7 +116,14 @@ def discriminator_loss(cfg, regressor, disc, x):
         pred, _ = regressor(x[key + '_img'])
         fake = torch.stack([disc(pred[:, h, :, :sup_dim].detach()) for h in range(pred.shape[1])], dim=1)
         real = disc(x[key + '_pseudo_joints'][..., :sup_dim])
-        tot = tot + L.disc_loss(fake, real)
+        if not cfg['smpl_disc_params'].get('use_aug', False):
+            tot = tot + L.disc_loss(fake, real)
+        else:               # model.py:249-258
+            real_world = geo.patch_to_world(x[key + '_pseudo_joints'], *[x[key + s] for s in
+                                          ('_trans_image', '_k_mat', '_pelvis', '_rot_world', '_trans_world')],
+                                          rect_width=256, mono=True, patch=False)
+            rot = geo.random_rotation_3d(real_world)
+            tot = tot + L.disc_loss(fake, real) * 0.6 + L.disc_loss(disc(rot[..., :sup_dim]), None) * 0.4
     return tot * cfg['loss_config']['smpl_disc_loss']['weight']
 
 

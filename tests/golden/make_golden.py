@@ -306,7 +306,7 @@ class LinearDisc(nn.Module):
         return self.fc(kp.reshape(kp.shape[0], -1))
 
 
-def _wiring_case(tag, yaml_name, cams, edit=None, seed=83, phys_probe=False):
+def _wiring_case(tag, yaml_name, cams, edit=None, seed=83, phys_probe=False, rng_seed=None):
     cfg = yaml.load(open(os.path.join(REF, 'config', yaml_name + '.yaml')), Loader=yaml.FullLoader)
     mp = cfg['model_params']
     mp['cam_id_list'] = cams
@@ -320,6 +320,8 @@ def _wiring_case(tag, yaml_name, cams, edit=None, seed=83, phys_probe=False):
     dis = ref_model.Counter3DDisc(mp, disc, None, None)
     gen.train(), dis.train()
     x = {k: T(v) for k, v in gi.synthetic_batch(2, cams, seed=seed).items()}
+    if rng_seed is not None:
+        torch.manual_seed(rng_seed)            # the use_aug rotations draw from the global CPU generator
     loss_d, _ = dis(x, gen.regressor)
     loss_d.mean().backward()
     gd = disc.fc.weight.grad.clone()
@@ -353,6 +355,15 @@ def _weighted_masks(mp):
 def g_model():
     _wiring_case('HM36_Multi_SurS1', 'HM36_Multi_SurS1', [0, 1])       # two cameras keep the CPU run short
     _wiring_case('HM36_Multi_SurS2', 'HM36_Multi_SurS2', [0, 1])
+
+
+def _with_aug(mp):
+    mp['smpl_disc_params']['use_aug'] = True
+
+
+def g_model3():
+    """use_aug branch (model.py:132-140, 249-258; util.py:389-407): seeded CPU generator, one torch.rand(B, 1) per call."""
+    _wiring_case('HM36_Multi_SurS2_aug', 'HM36_Multi_SurS2', [0, 1], edit=_with_aug, seed=86, rng_seed=1234)
 
 
 def g_model2():
@@ -626,7 +637,7 @@ def g_tbvis():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['head', 'lines', 'geometry', 'losses', 'physique', 'detector', 'smpl', 'model', 'model2', 'configs',
+    which = sys.argv[1:] or ['head', 'lines', 'geometry', 'losses', 'physique', 'detector', 'smpl', 'model', 'model2', 'model3', 'configs',
                              'disc', 'sparse', 'evalpath', 'input', 'tbvis']
     for w in which:
         globals()['g_' + w]()

@@ -274,7 +274,7 @@ def _hip_models(stage, cam_ids):
     return reg.cuda().train(), phys.cuda().train(), ora_reg.train(), ora_phys.train()
 
 
-def _check_wiring(gname, cfg, cams, seed, tol_loss=3e-4):
+def _check_wiring(gname, cfg, cams, seed, tol_loss=3e-4, rng_seed=None):
     """Counter3DDisc + Counter3DModel on the HIP path vs a golden written by the imported reference classes
     (tests/golden/make_golden.py: _wiring_case): every loss value, outputs, selected gradients."""
     from modules.model import Counter3DDisc, Counter3DModel
@@ -284,6 +284,8 @@ def _check_wiring(gname, cfg, cams, seed, tol_loss=3e-4):
     gen = Counter3DModel(cfg, reg, None, None, phys)
     dis = Counter3DDisc(cfg, disc, None, None)
     x = {k: T(v).cuda() for k, v in gi.synthetic_batch(2, list(cams), seed=seed).items()}
+    if rng_seed is not None:
+        torch.manual_seed(rng_seed)
     ld, info = dis(x, gen.regressor)
     assert abs(float(ld) - float(g['loss_disc'])) < 1e-5 + 2e-4 * abs(float(g['loss_disc']))
     ld.mean().backward()
@@ -339,6 +341,14 @@ def test_model_wiring_weighted_mask_losses():
     assert float(T(g['g_phys_dec4_w']).norm()) > 0
     assert rel(phys.encoder[0][0].weight.grad, T(g['g_phys_enc0_w'])) < 3e-2
     assert rel(dict(reg.named_parameters())['net.backbone.layer1.0.conv2.weight'].grad[:8], T(g['g_l1c2'])) < 5e-2
+
+
+def test_model_wiring_use_aug():
+    """use_aug branch (model.py:132-140,249-258): same CPU-generator seed as the golden run -> same rotations."""
+    mp = _yaml_params('HM36_Multi_SurS2', (0, 1))
+    mp['smpl_disc_params']['use_aug'] = True
+    g, _, _ = _check_wiring('model_HM36_Multi_SurS2_aug', mp, (0, 1), 86, rng_seed=1234)
+    assert float(T(g['g_disc_after_gen']).norm()) > 0
 
 
 def test_model_wiring_mpi_five_cameras():

@@ -64,7 +64,7 @@ class LinearDisc(nn.Module):
         return self.fc(kp.reshape(kp.shape[0], -1))
 
 
-def _run_model(stage, gname=None, cfg=None, cams=(0, 1), seed=83):
+def _run_model(stage, gname=None, cfg=None, cams=(0, 1), seed=83, rng_seed=None):
     from oracle.nets import PhysiqueNet
     g = golden(gname or 'model_HM36_Multi_Sur' + stage)
     cfg = cfg or gi.model_params(stage, cam_ids=(0, 1))
@@ -72,6 +72,8 @@ def _run_model(stage, gname=None, cfg=None, cams=(0, 1), seed=83):
     phys = gi.seeded_fill_(PhysiqueNet([32, 64, 128]), seed=81).train()
     disc = gi.seeded_fill_(LinearDisc(), seed=82)
     x = {k: T(v) for k, v in gi.synthetic_batch(2, list(cams), seed=seed).items()}
+    if rng_seed is not None:
+        torch.manual_seed(rng_seed)
     ld = ostep.discriminator_loss(cfg, reg, disc, x)
     close(ld, g['loss_disc'], 1e-5, 1e-4)
     ld.mean().backward()
@@ -125,3 +127,11 @@ def test_model_wiring_synth_s2():
 def test_model_wiring_mpi_five_cameras():
     cams = (0, 2, 4, 7, 8)
     _run_model(None, 'model_MPI_Multi_SurS1', _yaml_params('MPI_Multi_SurS1', cams), cams, seed=84)
+
+
+def test_model_wiring_use_aug():
+    """use_aug: random z-rotations (util.py:389-407) with the CPU generator seeded as in the golden run; the rotated
+    generator branch is not detached (model.py:136), so the detector receives an adversarial gradient here."""
+    mp = _yaml_params('HM36_Multi_SurS2', (0, 1))
+    mp['smpl_disc_params']['use_aug'] = True
+    _run_model(None, 'model_HM36_Multi_SurS2_aug', mp, seed=86, rng_seed=1234)

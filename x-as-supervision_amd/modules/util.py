@@ -83,9 +83,10 @@ def smpl_to_h36m(verts, h36m_regressor):
 
 
 def random_rotation_3D(keypoints):
-    """Random rotation about z in [-pi/4, pi/4] per sample (util.py:389-407; only with use_aug)."""
+    """Random rotation about z in [-pi/4, pi/4] per sample (util.py:389-407; only with use_aug).  The angles are drawn
+    from the CPU generator exactly as the reference does (torch.rand(B, 1)): same seed, same augmentation."""
     B = keypoints.shape[0]
-    ang = (torch.rand(B, device=keypoints.device) - 0.5) * 0.5 * torch.pi
+    ang = ((torch.rand(B, 1) - 0.5) * 0.5 * torch.pi).squeeze(1).to(keypoints.device)
     c, s, z, o = torch.cos(ang), torch.sin(ang), torch.zeros_like(ang), torch.ones_like(ang)
     rot = torch.stack([c, -s, z, s, c, z, z, z, o], dim=1).view(B, 3, 3)
-    return torch.bmm(keypoints, rot)
+    return torch.bmm(keypoints, rot.to(keypoints.dtype))
