@@ -88,6 +88,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo to rehearse ranks on one GPU)')
     ap.add_argument('--tune', type=int, default=0, help='kernel tuning experiment flags (xas_set_tuning)')
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'],
+                    help='f32 (default, the headline: exact fp32 MFMA) or bf16: NOT the headline - forward / data-gradient '
+                         'convolutions on bf16 MFMA (fp32 accumulate, fp32 master weights, fp32 weight gradients); the JSON line '
+                         'carries dtype "bf16" and peak = the bf16 MFMA peak for those launches')
     ap.add_argument('--dedupe', action='store_true',
                     help='NOT the headline: share the real-image detector forward between the discriminator and the '
                          'generator update (engine.TrainStep(dedupe=True)); the JSON line is marked config.dedupe')
@@ -121,6 +125,7 @@ def main():
     from xas_amd.synthetic import model_config, synthetic_batch
     from xas_amd import _lib as _xl
     _xl.query('xas_set_tuning', args.tune)
+    _xl.query('xas_set_precision', 1 if args.precision == 'bf16' else 0)
     cfg = model_config(args.workload)
     torch.manual_seed(1234)
     model, disc, opt_det, opt_disc = engine.prepare_model(cfg)
@@ -197,7 +202,8 @@ def main():
             'metric': 'images/sec %s 256px bs%d (full disc+gen training step)' % (args.workload, args.batch),
             'value': samples * per_sample / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.precision == 'f32' else 'bf16 fwd/dgrad MFMA + f32 wgrad (variant, not the headline)', 'data': 'synthetic',
             'config': {'workload': args.workload, 'batch_per_gpu': args.batch, 'cameras': len(cams),
                        'image': '256x256', 'images_per_sample': per_sample, 'parallelism': 'dp%d' % world,
                        'samples_per_s': samples / dt,

@@ -38,6 +38,10 @@ const char* xas_last_error(void);
  *   262144  86-VGPR build of the backward column sums
  *   8, 16, 4096  K-loop ablations, diagnostic build only (tools/build_diag.py) */
 int xas_set_tuning(int flags);
+/* Compute precision of the MFMA forward / data-gradient convolutions: 0 (default) = exact fp32 MFMA, the
+ * path every parity figure and the headline benchmark use; 1 = bf16 MFMA (operands rounded to bf16 on the way to LDS,
+ * fp32 accumulation, fp32 activations and master weights in HBM; weight gradients stay fp32).  Process-wide. */
+int xas_set_precision(int mode);
 /* diagnostic builds: device buffer of 8 uint64 that the igemm kernels add per-phase cycle sums to (NULL = off) */
 int xas_set_debug_buffer(void* device_ptr);
 int xas_abi_version(void);

@@ -717,6 +717,183 @@ __global__ __launch_bounds__(256) void igemm_buf_kernel(IgemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------
+// bf16-MFMA variant of fwd / dgrad (NOT the headline path: xas_set_precision(1) selects it, results are
+// reported separately).  Same tiling, addressing and epilogue as igemm_buf_kernel; activations and master weights stay
+// fp32 in HBM and are rounded to bf16 (round to nearest even, v_cvt_pk_bf16_f32) on the way to LDS; products are
+// exact, accumulation is fp32 (v_mfma_f32_32x32x16_bf16: 16x the fp32 MFMA rate).  One K-step (32 channels) is two
+// MFMAs per 32x32 tile instead of sixteen, so the loop is bound by staging (global loads, conversion, LDS) rather than
+// by the matrix pipe.  LDS rows: 32 bf16 + 8 pad = 80 bytes (rows r and r+16 share banks: conflict-free for the 16-lane
+// groups of ds_read_b128).
+// ------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr int LDKH = BK + 8;   // bf16 elements per LDS row
+
+__device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
+  const bf16x2_t lo = __builtin_convertvector(f32x2_t{v.x, v.y}, bf16x2_t);
+  const bf16x2_t hi = __builtin_convertvector(f32x2_t{v.z, v.w}, bf16x2_t);
+  return make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+}
+
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmParams p) {
+  using C = TileCfg<BM, BN>;
+  constexpr int APASS = BM / 32, BPASS = BN / 32;
+  extern __shared__ __align__(16) float lds[];
+  unsigned short* As = reinterpret_cast<unsigned short*>(lds);     // [2][BM][LDKH]
+  unsigned short* Bs = As + 2 * BM * LDKH;                          // [2][BN][LDKH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+  const int kq = tid & 7, lrow = tid >> 3;
+
+  int Hrow = p.Hrow, Wrow = p.Wrow;
+  int ph = 0, pw = 0, base_r = 0, base_s = 0, nr = p.R, ns = p.S, off_h = -p.pad, off_w = -p.pad, rstep = 1;
+  int sa = p.stride;
+  if (MODE == 1) {
+    const int st = p.stride;
+    ph = blockIdx.z / st; pw = blockIdx.z % st;
+    Hrow = (p.Hd - ph + st - 1) / st; Wrow = (p.Wd - pw + st - 1) / st;
+    base_r = (ph + p.pad) % st; base_s = (pw + p.pad) % st;
+    nr = base_r < p.R ? (p.R - base_r + st - 1) / st : 0;
+    ns = base_s < p.S ? (p.S - base_s + st - 1) / st : 0;
+    off_h = (ph + p.pad - base_r) / st; off_w = (pw + p.pad - base_s) / st;
+    rstep = st; sa = 1;
+  }
+  const int Mrows = p.N * Hrow * Wrow;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;          // XCD-aware tile order, as igemm_buf_kernel
+  const int mt = xcd * p.mt_per_xcd + q / p.nNt;
+  const int nt = q - (q / p.nNt) * p.nNt;
+  if (mt >= p.nMt) return;
+  const int m0 = mt * BM, n0 = nt * BN;
+  if (m0 >= Mrows) return;
+  const int HW = Hrow * Wrow;
+  const int cchunks = p.Cs / BK;
+  const int nk = nr * ns * cchunks;
+
+  const long dmin = MODE == 0 ? 0l : -((long)(nr - 1) * p.Ws + (ns - 1)) * p.Cs;
+  const long rmin = MODE == 0 ? -((long)p.pad * p.Ws + p.pad) * p.Cs : 0l;
+  const long bias = -(rmin + dmin);
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src) - bias, 0, (int)((bias + p.src_elems) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, (int)(p.wgt_elems * 4), 0x00020000);
+  unsigned voffA[APASS], maskA[APASS], voffB[BPASS];
+#pragma unroll
+  for (int j = 0; j < APASS; ++j) {
+    const int m = m0 + lrow + 32 * j;
+    voffA[j] = kOOB; maskA[j] = 0u;
+    if (m < Mrows) {
+      int n, a, b;
+      if (MODE == 0) { n = p.div_hw.div(m); const int rem = m - n * HW; a = p.div_w.div(rem); b = rem - a * Wrow; }
+      else { n = m / HW; const int rem = m - n * HW; a = rem / Wrow; b = rem - a * Wrow; }
+      const int ra = a * sa + off_h, rb = b * sa + off_w;
+      const long rbase = (((long)n * p.Hs + ra) * p.Ws + rb) * p.Cs;
+      voffA[j] = (unsigned)((rbase + dmin + bias + kq * 4) * 4);
+      unsigned colmask = 0u, msk = 0u;
+      for (int js = 0; js < ns; ++js) {
+        const int ws = rb + (MODE == 0 ? js : -js);
+        colmask |= ((unsigned)ws < (unsigned)p.Ws ? 1u : 0u) << js;
+      }
+      for (int jr = 0; jr < nr; ++jr) {
+        const int hs = ra + (MODE == 0 ? jr : -jr);
+        if ((unsigned)hs < (unsigned)p.Hs) msk |= colmask << (jr * ns);
+      }
+      maskA[j] = msk;
+    }
+  }
+  const unsigned wrow_bytes = (unsigned)(p.R * p.S * p.Cs) * 4u;
+#pragma unroll
+  for (int j = 0; j < BPASS; ++j) {
+    const int n = n0 + lrow + 32 * j;
+    voffB[j] = n < p.Cd ? (unsigned)n * wrow_bytes + (unsigned)kq * 16u : kOOB;
+  }
+
+  f32x16 acc[C::MI][C::NI];
+#pragma unroll
+  for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+  f32x16 acc2;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+
+  int ld_chunk = 0, ld_js = 0, ld_jr = 0, ld_left = nk;
+  float4 ra4_0[APASS], rb4_0[BPASS], ra4_1[APASS], rb4_1[BPASS];
+  auto load_next = [&](float4 (&ra4)[APASS], float4 (&rb4)[BPASS]) {
+    const int tap = ld_jr * ns + ld_js;
+    const int rel = MODE == 0 ? (ld_jr * p.Ws + ld_js) : ((nr - 1 - ld_jr) * p.Ws + (ns - 1 - ld_js));
+    const unsigned soffA = (unsigned)(rel * p.Cs + ld_chunk * BK) * 4u;
+    const int wtap = (base_r + rstep * ld_jr) * p.S + (base_s + rstep * ld_js);
+    const unsigned soffB = (unsigned)(wtap * p.Cs + ld_chunk * BK) * 4u;
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) {
+      const unsigned off = ((maskA[j] >> tap) & 1u) ? voffA[j] : kOOB;
+      ra4[j] = buf_load16(rsrcA, off, soffA);
+    }
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) rb4[j] = buf_load16(rsrcB, voffB[j], soffB);
+    const bool more = ld_left > 1;
+    ld_left -= more ? 1 : 0;
+    int c = ld_chunk + 1, s2 = ld_js, r = ld_jr;
+    if (c == cchunks) { c = 0; ++s2; }
+    if (s2 == ns) { s2 = 0; ++r; }
+    ld_chunk = more ? c : ld_chunk; ld_js = more ? s2 : ld_js; ld_jr = more ? r : ld_jr;
+  };
+  auto store_step = [&](int buf, const float4 (&ra4)[APASS], const float4 (&rb4)[BPASS]) {
+    unsigned short* a = As + buf * BM * LDKH;
+    unsigned short* b = Bs + buf * BN * LDKH;
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) *reinterpret_cast<uint2*>(a + (lrow + 32 * j) * LDKH + kq * 4) = pack_bf16x4(ra4[j]);
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) *reinterpret_cast<uint2*>(b + (lrow + 32 * j) * LDKH + kq * 4) = pack_bf16x4(rb4[j]);
+  };
+  const int i = lane & 31, h = lane >> 5;
+  auto compute = [&](int buf) {
+    const unsigned short* a_s = As + buf * BM * LDKH;
+    const unsigned short* b_s = Bs + buf * BN * LDKH;
+#pragma unroll
+    for (int sl = 0; sl < BK / 16; ++sl) {
+      bf16x8_t fa[C::MI], fb[C::NI];
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi)
+        fa[mi] = *reinterpret_cast<const bf16x8_t*>(a_s + (wm * C::WM + mi * 32 + i) * LDKH + sl * 16 + h * 8);
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni)
+        fb[ni] = *reinterpret_cast<const bf16x8_t*>(b_s + (wn * C::WN + ni * 32 + i) * LDKH + sl * 16 + h * 8);
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+    }
+  };
+  if (nk > 0) {
+    load_next(ra4_0, rb4_0);
+    load_next(ra4_1, rb4_1);
+    int ks = 0;
+    for (; ks + 1 < nk; ks += 2) {
+      store_step(0, ra4_0, rb4_0);
+      __syncthreads();
+      load_next(ra4_0, rb4_0);
+      compute(0);
+      store_step(1, ra4_1, rb4_1);
+      __syncthreads();
+      load_next(ra4_1, rb4_1);
+      compute(1);
+    }
+    if (ks < nk) {
+      store_step(0, ra4_0, rb4_0);
+      __syncthreads();
+      compute(0);
+    }
+  }
+  igemm_epilogue<BM, BN, MODE>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw);
+}
+
+// ------------------------------------------------------------------------------------
 // wgrad: C[co][nn] = sum_m dY[m][co] * Xcol[m][nn],  nn = (r*S+s)*Cin + c
 // LDS tiles are [k = pixel][row] (row-contiguous, as they come from memory); MFMA operands
 // are read with ds_read_b32 (lanes walk rows: conflict free).
@@ -1509,8 +1686,34 @@ static int launch_tile(const IgemmParams& p, int Mrows_max, int phases, hipStrea
   return launch_igemm<BM, BN, MODE, 2, true>(p, Mrows_max, phases, st);
 }
 
+static int g_precision = 0;      // 0: fp32 MFMA (headline, parity bar); 1: bf16 MFMA for fwd / dgrad (reported separately)
+
+template <int BM, int BN, int MODE>
+static int launch_igemm_bf16(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
+  const size_t lds = (size_t)2 * (BM + BN) * LDKH * sizeof(unsigned short);
+  IgemmParams q = p;
+  q.nMt = (int)cdiv(Mrows_max, BM); q.nNt = (int)cdiv(p.Cd, BN); q.mt_per_xcd = (int)cdiv(q.nMt, 8);
+  dim3 grid((unsigned)(8 * q.mt_per_xcd * q.nNt), 1, (unsigned)phases);
+  hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, MODE>), grid, dim3(256), lds, st, q);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int MODE>
 static int dispatch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
+  if (g_precision == 1) {
+    const long bias = ((long)(p.R + p.pad) * p.Ws + p.S + p.pad) * p.Cs;
+    const bool fits = (bias + p.src_elems) * 4 < 0x7fffff00l && p.wgt_elems * 4 < 0x7fffff00l && p.R * p.S <= 32;
+    if (fits) {
+      if (p.Cd >= 96) {
+        const long blocks128 = cdiv(Mrows_max, 128) * cdiv(p.Cd, 128) * phases;
+        if (blocks128 <= 512) return launch_igemm_bf16<64, 64, MODE>(p, Mrows_max, phases, st);
+        return launch_igemm_bf16<128, 128, MODE>(p, Mrows_max, phases, st);
+      }
+      if (p.Cd >= 48) return launch_igemm_bf16<128, 64, MODE>(p, Mrows_max, phases, st);
+      return launch_igemm_bf16<128, 32, MODE>(p, Mrows_max, phases, st);
+    }
+  }
   if (p.Cd >= 96) {
     // small problems (layer3/4 at B=32: M = 8192 / 2048 rows): 128x128 tiles leave most of the 256 CUs idle
     const long blocks128 = cdiv(Mrows_max, 128) * cdiv(p.Cd, 128) * phases;
@@ -1540,6 +1743,11 @@ static int images_per_launch(int N, long elems_per_image_a, long elems_per_image
 }
 
 extern "C" int xas_set_tuning(int flags) { g_tune = flags; return 0; }
+extern "C" int xas_set_precision(int mode) {
+  XAS_REQUIRE(mode == 0 || mode == 1, "set_precision: 0 = fp32 MFMA, 1 = bf16 MFMA for forward / data-gradient convolutions");
+  g_precision = mode;
+  return 0;
+}
 extern "C" int xas_set_debug_buffer(void* p) { g_dbg = reinterpret_cast<unsigned long long*>(p); return 0; }
 
 extern "C" int xas_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,

@@ -22,6 +22,7 @@ class ConvShape(ctypes.Structure):
 SIGNATURES = {
     'xas_abi_version': ('', 'i'),
     'xas_set_tuning': ('i', 'i'),
+    'xas_set_precision': ('i', 'i'),
     'xas_set_debug_buffer': ('p', 'i'),
     'xas_head_workspace_floats': ('iii', 'z'),
     'xas_head_softargmax_fwd': ('piiiiipppippp', 'i'),
