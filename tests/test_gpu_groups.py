@@ -174,8 +174,9 @@ def test_camera_batched_step_equals_per_camera_step(monkeypatch):
     xn = gi.synthetic_batch(2, cams, seed=97)
     x = {k: T(v).cuda() for k, v in xn.items()}
     res = []
-    for batched in (False, True):
+    for batched, joined in ((False, False), (True, True)):         # default: pseudo images joined into the same pass
         monkeypatch.setattr(mm, 'CAM_BATCH', batched)
+        monkeypatch.setattr(mm, 'JOIN_PSEUDO', joined)
         torch.manual_seed(11)
         model, disc, od, odisc = engine.prepare_model(cfg)
         model.cuda().train(), disc.cuda().train()
