@@ -1483,7 +1483,7 @@ __global__ __launch_bounds__(256) void thin_scalar2vec_kernel(const float* __res
 __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict__ S, const float* __restrict__ V,
                                                          float* __restrict__ slabs, ThinParams p, int scalar_at_src,
                                                          int m_per_chunk) {
-  __shared__ float4 red[256];
+  __shared__ float4 red[4 * 16 * 9];
   const int C4 = p.C / 4, lanes = 256 / C4;
   const int cq = threadIdx.x % C4, pl = threadIdx.x / C4;
   const unsigned M = (unsigned)(p.N * p.H * p.W);
@@ -1507,15 +1507,30 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
       acc[tap].z = fmaf(sv, vv.z, acc[tap].z); acc[tap].w = fmaf(sv, vv.w, acc[tap].w);
     }
   }
+  // reduce over the pixel lanes: inside a wave by shuffles (lanes cq, cq + C4, ... hold the same channels), then across
+  // the four waves through LDS with ONE barrier (the first version ran nine barrier pairs and a serial 32-term sum)
   float* o = slabs + (size_t)blockIdx.x * p.C * 9;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
-    __syncthreads();
-    red[threadIdx.x] = acc[tap];
-    __syncthreads();
-    if (pl == 0) {
-      float4 s4 = red[cq];
-      for (int k = 1; k < lanes; ++k) { const float4 r = red[k * C4 + cq]; s4.x += r.x; s4.y += r.y; s4.z += r.z; s4.w += r.w; }
+    float4 a = acc[tap];
+    for (int off = C4; off < 64; off <<= 1) {
+      a.x += __shfl_xor(a.x, off, 64); a.y += __shfl_xor(a.y, off, 64);
+      a.z += __shfl_xor(a.z, off, 64); a.w += __shfl_xor(a.w, off, 64);
+    }
+    acc[tap] = a;
+  }
+  float4* red4 = red;                                  // [4 waves][C4 <= 16][9 taps] float4 <= 576 entries: see below
+  if (lane < C4) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) red4[(wave * C4 + lane) * 9 + tap] = acc[tap];
+  }
+  __syncthreads();
+  if (threadIdx.x < C4) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      float4 s4 = red4[(0 * C4 + cq) * 9 + tap];
+      for (int k = 1; k < 4; ++k) { const float4 r = red4[(k * C4 + cq) * 9 + tap]; s4.x += r.x; s4.y += r.y; s4.z += r.z; s4.w += r.w; }
       o[(cq * 4 + 0) * 9 + tap] = s4.x; o[(cq * 4 + 1) * 9 + tap] = s4.y;
       o[(cq * 4 + 2) * 9 + tap] = s4.z; o[(cq * 4 + 3) * 9 + tap] = s4.w;
     }
@@ -2021,9 +2036,13 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
     const int C = cout1 ? s->Cin : s->Cout;
     const ThinParams tp = thin_params(s->N, s->Hi, s->Wi, C, s->pad, 0);
     const long M = (long)s->N * s->Hi * s->Wi;
-    const int chunks = (int)cdiv(M, kThinChunk);
+    // ~4 blocks per CU at most: long chunks amortise the block-level reduction (the workspace is sized for kThinChunk)
+    int chunks = (int)cdiv(M, kThinChunk);
+    if (chunks > 1024) chunks = 1024;
+    const int per_chunk = (int)(cdiv(cdiv(M, chunks), 256) * 256);
+    chunks = (int)cdiv(M, per_chunk);
     hipLaunchKernelGGL(thin_wgrad_kernel, dim3(chunks), dim3(256), 0, st, cout1 ? dy : x, cout1 ? x : dy, workspace, tp,
-                       cout1 ? 0 : 1, kThinChunk);
+                       cout1 ? 0 : 1, per_chunk);
     XAS_LAUNCH_CHECK();
     const long n = (long)C * 9;
     if (oihw || !cout1) {
