@@ -49,6 +49,7 @@ _side = {'stream': None, 'enabled': True, 'dirty': False}
 
 
 def side_stream():
+    # (measured, round 2: confining this stream to 1/2 or 3/4 of the CUs with hipExtStreamCreateWithCUMask is 7 % slower)
     if _side['stream'] is None:
         _side['stream'] = torch.cuda.Stream()
     return _side['stream']
