@@ -131,6 +131,28 @@ typedef struct {
 
 int xas_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
                  const xas_conv_shape* s, void* stream);
+/* Bias-free convolution followed by training-mode batch norm (resnet.py:17-18 conv1/bn1 and every torchvision Bottleneck
+ * conv/bn pair, resnet.py:2): y = conv(x, w) AND the per-group batch statistics of y in one call - the conv epilogue
+ * emits per-tile column sums, so y is not read again for its statistics (falls back to xas_conv_fwd + xas_bn_stats when
+ * the tile grid does not line up with the groups).  pivot [Cout] or NULL: a value near the channel means (the running
+ * mean) that the sums are taken around.  mean / var_biased / out_stride / count_out / running_* / momentum: as
+ * xas_bn_stats.  workspace: xas_conv_fwd_bnstats_workspace_floats(s, groups). */
+size_t xas_conv_fwd_bnstats_workspace_floats(const xas_conv_shape* s, int groups);
+int xas_conv_fwd_bnstats(const float* x, const float* w_packed, float* y, const xas_conv_shape* s, int groups,
+                         const float* pivot, float* mean, float* var_biased, long out_stride, float* count_out,
+                         float* workspace, float* running_mean, float* running_var, float momentum, void* stream);
+/* Backward of  h = relu(batch_norm(xb)) -> conv(h)  (torchvision Bottleneck conv/bn/relu chains, resnet.py:2) in one call:
+ * data gradient of the convolution `s` (dy: gradient of its output, w_packed_t as xas_conv_dgrad), ReLU mask re-derived
+ * from xb, and the rank-local batch-norm backward (mean / var_biased [groups][Cin], count = rows per group).
+ * Outputs: dx = gradient wrt xb; sums [groups][2][Cin] (sum dz | sum dz * xhat); dbeta_acc / dgamma_acc (both or neither
+ * NULL) += local parameter gradients; dz: scratch of xb's size.  workspace:
+ * xas_conv_dgrad_bn_bwd_workspace_floats(s, groups).  The reductions ride in the data gradient's epilogue when its tile
+ * grid lines up with the groups (stride 1), otherwise the call is xas_conv_dgrad + xas_bn_bwd_reduce + xas_bn_bwd_apply. */
+size_t xas_conv_dgrad_bn_bwd_workspace_floats(const xas_conv_shape* s, int groups);
+int xas_conv_dgrad_bn_bwd(const float* dy, const float* w_packed_t, const xas_conv_shape* s, const float* xb,
+                          const float* mean, const float* var_biased, const float* gamma, const float* beta, float eps,
+                          int groups, double count, float* dz, float* dx, float* sums, float* workspace, float* dbeta_acc,
+                          float* dgamma_acc, void* stream);
 /* dx = conv_transpose(dy, w): also the FORWARD of nn.ConvTranspose2d (deconv_head.py:27-29)
  * with roles swapped.  w_packed_t: [Cin][R][S][Cout] (xas_pack_weight transposed=1). */
 int xas_conv_dgrad(const float* dy, const float* w_packed_t, float* dx,
@@ -186,6 +208,19 @@ size_t xas_bn_workspace_floats(long M, int C, int groups);
 int xas_bn_stats(const float* x, long M, int C, int groups, float* mean, float* var_biased, long out_stride,
                  float* count_out, float* workspace, float* running_mean, float* running_var, float momentum,
                  long count, void* stream);
+/* Statistics from per-tile partial sums: partial is a [rows][C][2] matrix, (sum(v - pivot), sum((v - pivot)^2)) of
+ * rows_per_group / (rows / groups) consecutive activation rows each, the first rows / groups partial rows belonging to
+ * group 0 and so on; pivot [C] or NULL (= 0).  Outputs and running-statistic update as xas_bn_stats.
+ * workspace: xas_bn_workspace_floats(rows, 2 * C, groups). */
+int xas_bn_stats_from_partials(const float* partial, long rows, int C, int groups, long rows_per_group,
+                               const float* pivot, float* mean, float* var_biased, long out_stride, float* count_out,
+                               float* workspace, float* running_mean, float* running_var, float momentum, void* stream);
+/* Batch-norm backward sums from per-tile partial sums: partial [rows][2][C] (sum dz | sum dz * xhat of the activation rows
+ * behind each partial row; the first rows / groups partial rows belong to group 0, ...) -> sums [groups][2][C]; the local
+ * parameter gradients are added into dbeta_acc / dgamma_acc (both or neither).  workspace:
+ * xas_bn_workspace_floats(rows, 2 * C, groups). */
+int xas_bn_bwd_sums_from_partials(const float* partial, long rows, int C, int groups, float* sums, float* workspace,
+                                  float* dbeta_acc, float* dgamma_acc, void* stream);
 /* SyncBatchNorm merge (torch/nn/modules/_functions.py SyncBatchNorm.forward: batch_norm_gather_stats_with_counts):
  * gathered [world][groups][msg_stride] with mean at +0, biased var at +C, count at +2C of each message;
  * count-weighted merge in double -> mean, var_biased [groups][C]; running statistics (may be NULL) updated once per

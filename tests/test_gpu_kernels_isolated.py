@@ -192,3 +192,138 @@ def test_bn_residual_sign_mask_path(n, c, h, w, G, monkeypatch):
           for i in range(G)]
     (torch.cat(ys) * gy).sum().backward()
     assert rel(outs[0][0], torch.cat(ys)) < 3e-6 and rel(outs[0][1], xs.grad) < 2e-5 and rel(outs[0][2], rs.grad) < 3e-6
+
+
+# (n, cin, h, w, cout, k, stride, pad, groups): bottleneck conv/bn pairs.  Covered tiles: 128x128 (Cout >= 96, many rows),
+# 64x64 (few blocks), 128x64, 128x32, and shapes whose tile grid does NOT line up with the groups (fallback: second pass)
+STATS_CASES = [(8, 64, 32, 32, 256, 1, 1, 0, 1), (8, 64, 32, 32, 256, 1, 1, 0, 4), (16, 256, 64, 64, 64, 1, 1, 0, 8),
+               (8, 64, 32, 32, 64, 3, 1, 1, 2), (8, 128, 16, 16, 128, 3, 2, 1, 4), (4, 512, 8, 8, 2048, 1, 1, 0, 2),
+               (8, 64, 32, 32, 32, 1, 1, 0, 2), (128, 64, 64, 64, 256, 1, 1, 0, 8),
+               (2, 256, 4, 4, 1024, 1, 1, 0, 2), (3, 64, 12, 20, 64, 1, 1, 0, 3), (6, 64, 10, 10, 128, 3, 1, 1, 2)]
+
+
+@pytest.mark.parametrize('n,cin,h,w,cout,k,stride,pad,G', STATS_CASES)
+@pytest.mark.parametrize('form', ['local', 'message'])
+def test_conv_fwd_bnstats(n, cin, h, w, cout, k, stride, pad, G, form):
+    """xas_conv_fwd_bnstats = xas_conv_fwd followed by xas_bn_stats: y bit-identical; mean / biased variance / running
+    statistics / SyncBatchNorm message equal to the two-pass kernels (float64 torch statistics of the same y as the judge
+    of both), with and without a pivot, whether or not the statistics come out of the conv epilogue."""
+    from xas_amd import ops_nn as F
+    from xas_amd._lib import call, ptr, query
+    x, wt, _, ho, wo = _conv_case(n, cin, h, w, cout, k, stride, pad, seed=3 + cin + cout + k + G)
+    x = x + 0.7                                                          # channel means well away from zero
+    shp = F._shape(n, h, w, cin, cout, k, k, stride, pad, ho, wo)
+    cache = F._PackCache()
+    wg = wt.cuda()
+    xg = x.cuda().contiguous(memory_format=torch.channels_last)
+    M, Mg = n * ho * wo, n * ho * wo // G
+    y0 = torch.empty(n, cout, ho, wo, device='cuda').contiguous(memory_format=torch.channels_last)
+    call('xas_conv_fwd', ptr(xg), ptr(cache.get(wg, 0)), None, ptr(y0), shp)
+    rows = y0.permute(0, 2, 3, 1).reshape(G, Mg, cout).double()
+    mean64, var64 = rows.mean(1), rows.var(1, unbiased=False)
+
+    gen = torch.Generator().manual_seed(5)
+    rm0 = (0.3 * torch.randn(cout, generator=gen)).cuda()
+    rv0 = (1.0 + torch.rand(cout, generator=gen)).cuda()
+    for pivot in (None, mean64.mean(0).float().contiguous()):
+        y = torch.full_like(y0, float('nan'))
+        ws = torch.empty(query('xas_conv_fwd_bnstats_workspace_floats', shp, G), device='cuda')
+        rm, rv = rm0.clone(), rv0.clone()
+        if form == 'local':
+            mean = torch.empty(G, cout, device='cuda'); var = torch.empty(G, cout, device='cuda')
+            call('xas_conv_fwd_bnstats', ptr(xg), ptr(cache.get(wg, 0)), ptr(y), shp, G, ptr(pivot), ptr(mean), ptr(var),
+                 cout, None, ptr(ws), ptr(rm), ptr(rv), 0.1)
+            rm_ref, rv_ref = rm0.double(), rv0.double()
+            for g in range(G):
+                rm_ref = 0.9 * rm_ref + 0.1 * mean64[g]
+                rv_ref = 0.9 * rv_ref + 0.1 * var64[g] * (Mg / (Mg - 1))
+            assert rel(rm, rm_ref) < 2e-6 and rel(rv, rv_ref) < 2e-6
+        else:
+            stride_m = 2 * cout + 4
+            msg = torch.zeros(G, stride_m, device='cuda')
+            call('xas_conv_fwd_bnstats', ptr(xg), ptr(cache.get(wg, 0)), ptr(y), shp, G, ptr(pivot), ptr(msg),
+                 ptr(msg[:, cout:]), stride_m, ptr(msg[:, 2 * cout:]), ptr(ws), None, None, 0.1)
+            mean, var = msg[:, :cout], msg[:, cout:2 * cout]
+            assert torch.equal(msg[:, 2 * cout].cpu(), torch.full((G,), float(Mg)))
+            assert torch.equal(rm, rm0) and torch.equal(rv, rv0)
+        assert torch.equal(y, y0)
+        assert float((mean.double() - mean64).abs().max()) < 2e-6 * float(mean64.abs().max() + var64.max().sqrt())
+        assert float(((var.double() - var64).abs() / var64).max()) < 2e-5
+
+
+# (n, cin, h, w, cout, k, stride, pad, groups): conv3 / conv2 of a bottleneck seen from their data gradient; the norm in
+# front has `cin` channels.  Last four: tile grid does not line up (odd rows), strided conv, tiny layer -> three-call fallback
+DGRAD_BN_CASES = [(8, 64, 32, 32, 256, 1, 1, 0, 1), (8, 64, 32, 32, 256, 1, 1, 0, 4), (16, 128, 16, 16, 128, 3, 1, 1, 8),
+                  (32, 64, 64, 64, 64, 3, 1, 1, 8), (4, 512, 8, 8, 2048, 1, 1, 0, 2), (8, 256, 16, 16, 1024, 1, 1, 0, 2),
+                  (3, 64, 12, 20, 64, 1, 1, 0, 3), (4, 128, 16, 16, 128, 3, 2, 1, 2), (2, 256, 4, 4, 1024, 1, 1, 0, 2),
+                  (6, 64, 10, 10, 128, 3, 1, 1, 2)]
+
+
+@pytest.mark.parametrize('n,cin,h,w,cout,k,stride,pad,G', DGRAD_BN_CASES)
+def test_conv_dgrad_bn_bwd(n, cin, h, w, cout, k, stride, pad, G):
+    """xas_conv_dgrad_bn_bwd = xas_conv_dgrad -> xas_bn_bwd_reduce (ReLU mask from the norm's input) -> xas_bn_bwd_apply:
+    gradient wrt the norm's input, the [G][2][C] sums and the in-place parameter-gradient accumulation, against the three
+    separate calls and against float64 torch autograd of relu(batch_norm(xb)) -> conv."""
+    from xas_amd import ops_nn as F
+    from xas_amd._lib import call, ptr, query
+    gen = torch.Generator().manual_seed(11 + cin + cout + k + G)
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    xb = torch.randn(n, cin, h, w, generator=gen) * 1.3 + 0.2
+    wt = torch.randn(cout, cin, k, k, generator=gen) / (cin * k * k) ** 0.5
+    dy = torch.randn(n, cout, ho, wo, generator=gen)
+    gamma = 0.5 + torch.rand(cin, generator=gen)
+    beta = 0.3 * torch.randn(cin, generator=gen)
+    eps = 1e-5
+    # float64 reference, group by group
+    dx_ref = torch.empty(n, cin, h, w, dtype=torch.float64)
+    dgam_ref = torch.zeros(cin, dtype=torch.float64); dbet_ref = torch.zeros(cin, dtype=torch.float64)
+    per = n // G
+    for g in range(G):
+        xg = xb[g * per:(g + 1) * per].double().requires_grad_(True)
+        gm, bt = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+        hh = torch.relu(TF.batch_norm(xg, None, None, gm, bt, True, 0.1, eps))
+        out = TF.conv2d(hh, wt.double(), None, stride, pad)
+        (out * dy[g * per:(g + 1) * per].double()).sum().backward()
+        dx_ref[g * per:(g + 1) * per] = xg.grad
+        dgam_ref += gm.grad; dbet_ref += bt.grad
+
+    shp = F._shape(n, h, w, cin, cout, k, k, stride, pad, ho, wo)
+    cache = F._PackCache()
+    wg = wt.cuda()
+    cl = lambda t: t.cuda().contiguous(memory_format=torch.channels_last)
+    xbg, dyg = cl(xb), cl(dy)
+    M, Mg = n * h * w, n * h * w // G
+    rows = xbg.permute(0, 2, 3, 1).reshape(G, Mg, cin)
+    mean = rows.mean(1).contiguous(); var = rows.var(1, unbiased=False).contiguous()
+    gam, bet = gamma.cuda(), beta.cuda()
+
+    # three separate calls
+    dz0 = torch.empty_like(xbg); dx0 = torch.empty_like(xbg)
+    call('xas_conv_dgrad', ptr(dyg), ptr(cache.get(wg, 1)), ptr(dz0), shp)
+    sums0 = torch.empty(G, 2, cin, device='cuda')
+    ws0 = torch.empty(query('xas_bn_workspace_floats', M, cin, G), device='cuda')
+    acc_b0 = torch.full((cin,), 0.25, device='cuda'); acc_g0 = torch.full((cin,), -0.5, device='cuda')
+    call('xas_bn_bwd_reduce', ptr(xbg), None, ptr(dz0), ptr(mean), ptr(var), ptr(gam), ptr(bet), eps, 1, M, cin, G,
+         ptr(sums0), ptr(ws0), ptr(acc_b0), ptr(acc_g0), None)
+    call('xas_bn_bwd_apply', ptr(xbg), None, ptr(dz0), ptr(mean), ptr(var), ptr(gam), ptr(bet), ptr(sums0), eps, 1, M, cin,
+         G, float(Mg), ptr(dx0), None, None)
+
+    # one call
+    dz = torch.full_like(xbg, float('nan')); dx = torch.full_like(xbg, float('nan'))
+    sums = torch.empty(G, 2, cin, device='cuda')
+    ws = torch.empty(query('xas_conv_dgrad_bn_bwd_workspace_floats', shp, G), device='cuda')
+    acc_b = torch.full((cin,), 0.25, device='cuda'); acc_g = torch.full((cin,), -0.5, device='cuda')
+    call('xas_conv_dgrad_bn_bwd', ptr(dyg), ptr(cache.get(wg, 1)), shp, ptr(xbg), ptr(mean), ptr(var), ptr(gam), ptr(bet),
+         eps, G, float(Mg), ptr(dz), ptr(dx), ptr(sums), ptr(ws), ptr(acc_b), ptr(acc_g))
+
+    scale = float(sums0.abs().max())
+    assert float((sums - sums0).abs().max()) < 2e-5 * scale
+    assert rel(dx, dx0) < 2e-6
+    assert rel(dx, dx_ref) < 5e-6
+    assert rel(acc_b - 0.25, dbet_ref) < 2e-5 and rel(acc_g + 0.5, dgam_ref) < 2e-5
+    assert rel(acc_b, acc_b0) < 2e-6 and rel(acc_g, acc_g0) < 2e-6
+    # without accumulators the sums alone are written
+    sums2 = torch.empty_like(sums)
+    call('xas_conv_dgrad_bn_bwd', ptr(dyg), ptr(cache.get(wg, 1)), shp, ptr(xbg), ptr(mean), ptr(var), ptr(gam), ptr(bet),
+         eps, G, float(Mg), ptr(dz), ptr(dx), ptr(sums2), ptr(ws), None, None)
+    assert torch.equal(sums2, sums)

@@ -295,3 +295,21 @@ def test_conv_transpose_random_shapes():
     rng = random.Random(7)
     for _ in range(8):
         test_conv_transpose2d(rng.choice([1, 2]), rng.choice([32, 64, 128]), rng.randint(3, 11), rng.choice([32, 64, 96]))
+
+
+@pytest.mark.parametrize('n,c,h,w', [(1, 4, 1, 1), (2, 32, 7, 9), (3, 8, 2, 130), (2, 32, 64, 64), (1, 260, 5, 3), (2, 16, 1, 40)])
+def test_upsample2x_shapes(n, c, h, w):
+    """x2 bilinear upsampling (physique_network.py:31) and its adjoint against torch on the CPU: rows shorter and longer
+    than one 256-lane block, one-pixel borders, channel counts that are not powers of two."""
+    from xas_amd import ops_nn as F
+    g = torch.Generator().manual_seed(n + c + h + w)
+    x = torch.randn(n, c, h, w, generator=g)
+    xc = x.clone().requires_grad_(True)
+    yc = TF.interpolate(xc, scale_factor=2, mode='bilinear')
+    gy = torch.randn(yc.shape, generator=g)
+    (yc * gy).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    yg = F.upsample2x(xg)
+    (yg * gy.cuda()).sum().backward()
+    assert yg.shape == yc.shape
+    assert maxabs(yg, yc) < 1e-6 and maxabs(xg.grad, xc.grad) < 2e-6

@@ -10,11 +10,6 @@
 
 namespace xas {
 
-// z = (x - mean) * (rstd * gamma) + beta with a FIXED operation order (no compiler-chosen contraction), so the
-// backward kernels that re-derive the ReLU mask from x reproduce the forward decision bit for bit.
-__device__ __forceinline__ float bn_affine(float x, float m, float rs_g, float b) {
-  return __fmaf_rn(__fsub_rn(x, m), rs_g, b);
-}
 
 // ---------------------------------------------------------------- column reductions
 // x is [M][C] = `G` independent groups of Mg = M / G consecutive rows (the camera-batched step sends the images of
@@ -79,6 +74,7 @@ struct ColArgs {
   float* running_mean; float* running_var; float momentum, unbias;
   float* acc1; float* acc2;    // != null: acc1[c] += sum over groups of out1 ... (parameter gradients, in place)
   const uint8_t* mask;         // MODE 1: != null -> activation sign bits (one byte per float4, bit e = z_e > 0) instead of y
+  long rows_real;              // MODE 5: activation rows per group behind the partial rows
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -98,6 +94,10 @@ template <int MODE, int UNR = 4, int FL = 4>   // 0: stats of x around pivot ; 1
                       // 3: bn backward sums WITHOUT x: xhat = (z - beta)/gamma with z recovered from y (act != 0)
                       // 4: bn backward sums WITHOUT y: the activation mask is re-derived from x (`y` carries gamma,
                       //    `aux` carries beta)
+                      // 5: x = per-tile partial sums of a convolution epilogue, [rows][C/2 channels][sum(v-p), sum((v-p)^2)]
+                      //    (C = 2 x channels, `aux` = pivot per channel or null): plain column sums, finalize -> statistics
+                      // 6: x = per-tile partial sums of a data-gradient epilogue, [rows][2][C/2 channels] (sum dz | sum dz xhat):
+                      //    plain column sums -> out1 = sums [G][2][channels]; acc1 / acc2 (dbeta / dgamma) get the two halves
 __device__ __forceinline__ void col_reduce_body(const ColArgs& a) {
   __shared__ __align__(16) float4 red[2][256];         // 8 KB, also the double scratch of the finalize tail
   const ColGeom& g = a.g;
@@ -124,7 +124,7 @@ __device__ __forceinline__ void col_reduce_body(const ColArgs& a) {
   } else if (MODE == 0) {
     p0 = *reinterpret_cast<const float4*>(x + (size_t)grp * g.Mg * C + c);          // pivot = first row of the group
     p1 = p0;
-  } else if (MODE == 2) {
+  } else if (MODE == 2 || MODE == 5 || MODE == 6) {
     p0 = make_float4(0, 0, 0, 0); p1 = p0;
   } else if (MODE == 3) {                                  // `aux` carries beta, `y`-side parameter pointer: see launcher
     p0 = *reinterpret_cast<const float4*>(a.aux + c);                                 // beta
@@ -163,7 +163,7 @@ __device__ __forceinline__ void col_reduce_body(const ColArgs& a) {
       s2.z = fmaf(g4.z, (xv.z - p0.z) * p1.z, s2.z); s2.w = fmaf(g4.w, (xv.w - p0.w) * p1.w, s2.w);
       continue;
     }
-    if (MODE == 2) {
+    if (MODE == 2 || MODE == 5 || MODE == 6) {
       s1.x += xv.x; s1.y += xv.y; s1.z += xv.z; s1.w += xv.w;
     } else if (MODE == 0) {
       const float a0 = xv.x - p0.x, b = xv.y - p0.y, cc = xv.z - p0.z, d = xv.w - p0.w;
@@ -232,6 +232,12 @@ __device__ __forceinline__ void col_reduce_body(const ColArgs& a) {
     rm = *reinterpret_cast<const float4*>(a.running_mean + c);
     rv = *reinterpret_cast<const float4*>(a.running_var + c);
   }
+  const int ch = c >> 1;                                    // MODE 5: this thread's two channels are ch, ch + 1
+  if (MODE == 5 && a.running_mean && ty == 0) {
+    const float2 m2 = *reinterpret_cast<const float2*>(a.running_mean + ch);
+    const float2 v2 = *reinterpret_cast<const float2*>(a.running_var + ch);
+    rm.x = m2.x; rm.y = m2.y; rv.x = v2.x; rv.y = v2.y;
+  }
   for (int gi = 0; gi < g.G; ++gi) {
     double d1[4] = {0, 0, 0, 0}, d2[4] = {0, 0, 0, 0};
     const unsigned base = (unsigned)((((size_t)gi * g.nslab * 2) * C + c) * sizeof(float));
@@ -272,6 +278,24 @@ __device__ __forceinline__ void col_reduce_body(const ColArgs& a) {
       }
     }
     if (ty != 0) continue;
+    if (MODE == 5) {
+      const float2 pv = a.aux ? *reinterpret_cast<const float2*>(a.aux + ch) : make_float2(0.f, 0.f);
+      const double inv = 1.0 / (double)a.rows_real;
+      const double m0 = d1[0] * inv, m1 = d1[2] * inv;
+      double v0 = d1[1] * inv - m0 * m0, v1 = d1[3] * inv - m1 * m1;
+      if (v0 < 0.0) v0 = 0.0;
+      if (v1 < 0.0) v1 = 0.0;
+      const float mf0 = (float)((double)pv.x + m0), mf1 = (float)((double)pv.y + m1), vf0 = (float)v0, vf1 = (float)v1;
+      *reinterpret_cast<float2*>(a.out1 + (size_t)gi * a.out_stride + ch) = make_float2(mf0, mf1);
+      *reinterpret_cast<float2*>(a.out2 + (size_t)gi * a.out_stride + ch) = make_float2(vf0, vf1);
+      if (a.running_mean) {
+        const float mo = a.momentum, ub = a.unbias;
+        rm.x = (1.f - mo) * rm.x + mo * mf0; rm.y = (1.f - mo) * rm.y + mo * mf1;
+        rv.x = (1.f - mo) * rv.x + mo * (vf0 * ub); rv.y = (1.f - mo) * rv.y + mo * (vf1 * ub);
+      }
+      if (a.count_out && blockIdx.y == 0 && tx == 0) a.count_out[(size_t)gi * a.out_stride] = (float)a.rows_real;
+      continue;
+    }
     float* o1 = a.out1 + (size_t)gi * a.out_stride + c;
     float* o2 = a.out2 + (size_t)gi * a.out_stride + c;
     if (MODE == 0) {
@@ -298,7 +322,7 @@ __device__ __forceinline__ void col_reduce_body(const ColArgs& a) {
       const float4 f1 = make_float4((float)d1[0], (float)d1[1], (float)d1[2], (float)d1[3]);
       const float4 f2 = make_float4((float)d2[0], (float)d2[1], (float)d2[2], (float)d2[3]);
       *reinterpret_cast<float4*>(o1) = f1;
-      *reinterpret_cast<float4*>(o2) = f2;
+      if (MODE != 6) *reinterpret_cast<float4*>(o2) = f2;
       accg1.x += f1.x; accg1.y += f1.y; accg1.z += f1.z; accg1.w += f1.w;
       accg2.x += f2.x; accg2.y += f2.y; accg2.z += f2.z; accg2.w += f2.w;
     }
@@ -308,6 +332,23 @@ __device__ __forceinline__ void col_reduce_body(const ColArgs& a) {
   if (MODE == 0 && a.running_mean) {
     *reinterpret_cast<float4*>(a.running_mean + c) = rm;
     *reinterpret_cast<float4*>(a.running_var + c) = rv;
+  }
+  if (MODE == 5) {
+    if (a.running_mean) {
+      *reinterpret_cast<float2*>(a.running_mean + ch) = make_float2(rm.x, rm.y);
+      *reinterpret_cast<float2*>(a.running_var + ch) = make_float2(rv.x, rv.y);
+    }
+    return;
+  }
+  if (MODE == 6) {                                           // columns [0, C/2): dbeta, [C/2, C): dgamma
+    if (a.acc1) {
+      const int half = C >> 1;
+      float* ap = c < half ? a.acc1 + c : a.acc2 + (c - half);
+      float4 t1 = *reinterpret_cast<const float4*>(ap);
+      t1.x += accg1.x; t1.y += accg1.y; t1.z += accg1.z; t1.w += accg1.w;
+      *reinterpret_cast<float4*>(ap) = t1;
+    }
+    return;
   }
   if (MODE != 0 && a.acc1) {                                 // parameter gradients accumulated in place (.grad arena)
     float4 t1 = *reinterpret_cast<const float4*>(a.acc1 + c), t2 = *reinterpret_cast<const float4*>(a.acc2 + c);
@@ -646,93 +687,88 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int8_t* _
 }
 
 // ---------------------------------------------------------------- bilinear x2 (align_corners=False)
-__global__ void upsample2x_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, float* __restrict__ y) {
-  const int C4 = C / 4, Ho = 2 * H, Wo = 2 * W;
-  const long total = (long)N * Ho * Wo * C4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    long t = i / C4;
-    const int wo = t % Wo; t /= Wo;
-    const int ho = t % Ho; const int n = t / Ho;
-    const float sh = fmaxf(0.f, (ho + 0.5f) * 0.5f - 0.5f), sw = fmaxf(0.f, (wo + 0.5f) * 0.5f - 0.5f);
-    const int h0 = (int)sh, w0 = (int)sw;
-    const int h1 = min(h0 + 1, H - 1), w1 = min(w0 + 1, W - 1);
-    const float lh = sh - h0, lw = sw - w0;
-    const float* base = x + (size_t)n * H * W * C + c;
-    const float4 a = *reinterpret_cast<const float4*>(base + ((size_t)h0 * W + w0) * C);
-    const float4 b = *reinterpret_cast<const float4*>(base + ((size_t)h0 * W + w1) * C);
-    const float4 cc = *reinterpret_cast<const float4*>(base + ((size_t)h1 * W + w0) * C);
-    const float4 d = *reinterpret_cast<const float4*>(base + ((size_t)h1 * W + w1) * C);
-    const float h0l = 1.f - lh, w0l = 1.f - lw;
-    float4 o;
-    o.x = h0l * (w0l * a.x + lw * b.x) + lh * (w0l * cc.x + lw * d.x);
-    o.y = h0l * (w0l * a.y + lw * b.y) + lh * (w0l * cc.y + lw * d.y);
-    o.z = h0l * (w0l * a.z + lw * b.z) + lh * (w0l * cc.z + lw * d.z);
-    o.w = h0l * (w0l * a.w + lw * b.w) + lh * (w0l * cc.w + lw * d.w);
-    *reinterpret_cast<float4*>(y + i * 4) = o;
-  }
+// Workgroups are dealt round-robin over the 8 XCDs (private L2 each).  Neighbouring image rows share their source rows:
+// give every XCD a CONTIGUOUS range of the logical block ids, so the shared rows are found in that XCD's L2.
+// Launch with 8 * ceil(nblk / 8) blocks; ids >= nblk are padding.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned b, unsigned nblk) {
+  const unsigned per = (nblk + 7u) >> 3;
+  return (b & 7u) * per + (b >> 3);
 }
 
-// 1-D adjoint taps of the x2 bilinear map: input i receives from outputs {2i-1,2i,2i+1,2i+2}
-__device__ __forceinline__ int up_taps(int i, int H, int* o, float* w) {
-  int n = 0;
-  o[n] = 2 * i; w[n++] = (i == 0) ? 1.f : 0.75f;                 // out 2i: 0.75 (+0.25 clamp at i==0)
-  o[n] = 2 * i + 1; w[n++] = (i == H - 1) ? 1.f : 0.75f;         // out 2i+1: 0.75 (+0.25 clamp at the end)
-  if (i >= 1) { o[n] = 2 * i - 1; w[n++] = 0.25f; }
-  if (i <= H - 2) { o[n] = 2 * i + 2; w[n++] = 0.25f; }
-  return n;
+// One block = 256 consecutive float4 of ONE output row: the row decode is scalar (block-uniform), a lane only splits its
+// element index into (column, channel quad) with 32-bit arithmetic.  (The first version decoded a flat 64-bit index per
+// thread - three emulated 64-bit divisions - and ran at 1.2 TB/s.)
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C,
+                                                             float* __restrict__ y, unsigned segs, unsigned nblk) {
+  const unsigned C4 = (unsigned)C / 4, Ho = 2u * H, Wo = 2u * W;
+  const unsigned bid = xcd_contiguous(blockIdx.x, nblk);
+  if (bid >= nblk) return;
+  const unsigned row = bid / segs, seg = bid - row * segs;                      // row = n * Ho + ho
+  const unsigned n = row / Ho, ho = row - n * Ho;
+  const unsigned e = seg * 256u + threadIdx.x;
+  if (e >= Wo * C4) return;
+  const unsigned wo = e / C4, c = (e - wo * C4) * 4u;
+  const float sh = fmaxf(0.f, (ho + 0.5f) * 0.5f - 0.5f), sw = fmaxf(0.f, (wo + 0.5f) * 0.5f - 0.5f);
+  const int h0 = (int)sh, w0 = (int)sw;
+  const int h1 = min(h0 + 1, H - 1), w1 = min(w0 + 1, W - 1);
+  const float lh = sh - h0, lw = sw - w0;
+  const float* base = x + (size_t)n * H * W * C + c;
+  const float4 a = *reinterpret_cast<const float4*>(base + ((size_t)h0 * W + w0) * C);
+  const float4 b = *reinterpret_cast<const float4*>(base + ((size_t)h0 * W + w1) * C);
+  const float4 cc = *reinterpret_cast<const float4*>(base + ((size_t)h1 * W + w0) * C);
+  const float4 d = *reinterpret_cast<const float4*>(base + ((size_t)h1 * W + w1) * C);
+  const float h0l = 1.f - lh, w0l = 1.f - lw;
+  float4 o;
+  o.x = h0l * (w0l * a.x + lw * b.x) + lh * (w0l * cc.x + lw * d.x);
+  o.y = h0l * (w0l * a.y + lw * b.y) + lh * (w0l * cc.y + lw * d.y);
+  o.z = h0l * (w0l * a.z + lw * b.z) + lh * (w0l * cc.z + lw * d.z);
+  o.w = h0l * (w0l * a.w + lw * b.w) + lh * (w0l * cc.w + lw * d.w);
+  *reinterpret_cast<float4*>(y + ((size_t)row * Wo + wo) * C + c) = o;
 }
 
-// Adjoint of the x2 bilinear map.  A thread owns one input column (and 4 channels) over a strip of kUpStrip input rows:
-// every output row of the strip is combined horizontally ONCE (4 loads) and added to the one or two input rows it
-// belongs to, 9 loads per result instead of the 16 of a thread-per-pixel gather.
-constexpr int kUpStrip = 8;
-
-__global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, int N, int H, int W, int C, float* __restrict__ dx) {
-  const int C4 = C / 4, Ho = 2 * H, Wo = 2 * W;
-  const int strips = (H + kUpStrip - 1) / kUpStrip;
-  const long total = (long)N * strips * W * C4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    long t = i / C4;
-    const int wi = t % W; t /= W;
-    const int sidx = t % strips; const int n = t / strips;
-    const int h0 = sidx * kUpStrip;
-    int ow[4]; float ww[4];
-    const int nw = up_taps(wi, W, ow, ww);
-    float4 acc[kUpStrip];
+// Adjoint of the x2 bilinear map.  Input i receives from outputs 2i-1 (0.25), 2i (0.75; 1 at i == 0), 2i+1 (0.75; 1 at
+// i == last), 2i+2 (0.25): a lane owns one input pixel (4 channels) and gathers its 4 x 4 output taps - sixteen
+// independent 16-byte loads from clamped addresses, taps outside the image carry weight 0.  Same block layout as the
+// forward kernel (one block = 256 float4 of one input row).
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dy, int N, int H, int W, int C,
+                                                             float* __restrict__ dx, unsigned segs, unsigned nblk) {
+  const unsigned C4 = (unsigned)C / 4;
+  const int Ho = 2 * H, Wo = 2 * W;
+  const unsigned bid = xcd_contiguous(blockIdx.x, nblk);
+  if (bid >= nblk) return;
+  const unsigned row = bid / segs, seg = bid - row * segs;                      // row = n * H + hi
+  const unsigned n = row / (unsigned)H;
+  const int hi = (int)(row - n * (unsigned)H);
+  const unsigned e = seg * 256u + threadIdx.x;
+  if (e >= (unsigned)W * C4) return;
+  const int wi = (int)(e / C4);
+  const unsigned c = (e - (unsigned)wi * C4) * 4u;
+  const float wh[4] = {hi >= 1 ? 0.25f : 0.f, hi == 0 ? 1.f : 0.75f, hi == H - 1 ? 1.f : 0.75f, hi <= H - 2 ? 0.25f : 0.f};
+  const float ww[4] = {wi >= 1 ? 0.25f : 0.f, wi == 0 ? 1.f : 0.75f, wi == W - 1 ? 1.f : 0.75f, wi <= W - 2 ? 0.25f : 0.f};
+  const float* base = dy + (size_t)n * Ho * Wo * C + c;
+  float4 g[4][4];
 #pragma unroll
-    for (int k = 0; k < kUpStrip; ++k) acc[k] = make_float4(0, 0, 0, 0);
+  for (int k = 0; k < 4; ++k) {
+    const int r = min(max(2 * hi - 1 + k, 0), Ho - 1);
 #pragma unroll
-    for (int rl = 0; rl < 2 * kUpStrip + 2; ++rl) {               // output rows 2*h0 - 1 ... 2*h0 + 2*kUpStrip
-      const int r = 2 * h0 - 1 + rl;
-      if (r < 0 || r >= Ho) continue;
-      // output row r feeds input row r/2 (weight 0.75, or 1 at the clamped image border) and its neighbour (0.25)
-      const int ia = r >> 1, ib = (r & 1) ? ia + 1 : ia - 1;
-      const int ka = ia - h0, kb = ib - h0;                         // compile-time after unrolling: (rl-1)/2 etc.
-      const bool use_a = ka >= 0 && ka < kUpStrip && ia < H;
-      const bool use_b = kb >= 0 && kb < kUpStrip && ib >= 0 && ib < H;
-      if (!use_a && !use_b) continue;
-      float4 tr = make_float4(0, 0, 0, 0);
-      const float* row = dy + (((size_t)n * Ho + r) * Wo) * C + c;
-      for (int b = 0; b < nw; ++b) {
-        const float4 g = *reinterpret_cast<const float4*>(row + (size_t)ow[b] * C);
-        tr.x = fmaf(ww[b], g.x, tr.x); tr.y = fmaf(ww[b], g.y, tr.y); tr.z = fmaf(ww[b], g.z, tr.z); tr.w = fmaf(ww[b], g.w, tr.w);
-      }
-      if (use_a) {
-        const float wa = ((r & 1) ? (ia == H - 1) : (ia == 0)) ? 1.f : 0.75f;
-        const int k = (rl - 1) >> 1;                                // == ka for rl >= 1; rl == 0 has ka = -1 (unused)
-        if (rl >= 1) { acc[k].x = fmaf(wa, tr.x, acc[k].x); acc[k].y = fmaf(wa, tr.y, acc[k].y); acc[k].z = fmaf(wa, tr.z, acc[k].z); acc[k].w = fmaf(wa, tr.w, acc[k].w); }
-      }
-      if (use_b) {
-        const int k = (rl & 1) ? ((rl - 1) >> 1) - 1 : (rl >> 1);   // == kb: odd rl -> r even -> ia-1 ; even rl -> r odd -> ia+1
-        if (k >= 0 && k < kUpStrip) { acc[k].x = fmaf(0.25f, tr.x, acc[k].x); acc[k].y = fmaf(0.25f, tr.y, acc[k].y); acc[k].z = fmaf(0.25f, tr.z, acc[k].z); acc[k].w = fmaf(0.25f, tr.w, acc[k].w); }
-      }
+    for (int l = 0; l < 4; ++l) {
+      const int q = min(max(2 * wi - 1 + l, 0), Wo - 1);
+      g[k][l] = *reinterpret_cast<const float4*>(base + ((size_t)r * Wo + q) * C);
     }
-#pragma unroll
-    for (int k = 0; k < kUpStrip; ++k)
-      if (h0 + k < H) *reinterpret_cast<float4*>(dx + ((((size_t)n * H + h0 + k) * W + wi) * C4) * 4 + c) = acc[k];
   }
+  float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float4 tr = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      tr.x = fmaf(ww[l], g[k][l].x, tr.x); tr.y = fmaf(ww[l], g[k][l].y, tr.y);
+      tr.z = fmaf(ww[l], g[k][l].z, tr.z); tr.w = fmaf(ww[l], g[k][l].w, tr.w);
+    }
+    acc.x = fmaf(wh[k], tr.x, acc.x); acc.y = fmaf(wh[k], tr.y, acc.y);
+    acc.z = fmaf(wh[k], tr.z, acc.z); acc.w = fmaf(wh[k], tr.w, acc.w);
+  }
+  *reinterpret_cast<float4*>(dx + ((size_t)row * W + wi) * C + c) = acc;
 }
 
 __global__ void sigmoid_fwd_kernel(const float* __restrict__ x, long n, float* __restrict__ y) {
@@ -798,6 +834,50 @@ extern "C" int xas_bn_stats(const float* x, long M, int C, int groups, float* me
   a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum;
   a.unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
   hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(g.nslab, g.ncb, g.G), dim3(256), 0, as_stream(stream), a);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+// Statistics from the per-tile partial sums a convolution epilogue left (xas_conv_fwd_bnstats): partial is
+// [groups * tiles_per_group... rows][C][2] = (sum(v - pivot), sum((v - pivot)^2)) over rows_per_group / (rows / groups)
+// activation rows each.  One launch: column sums of the [rows][2C] matrix + folded finalize.
+extern "C" int xas_bn_stats_from_partials(const float* partial, long rows, int C, int groups, long rows_per_group,
+                                          const float* pivot, float* mean, float* var_biased, long out_stride,
+                                          float* count_out, float* workspace, float* running_mean, float* running_var,
+                                          float momentum, void* stream) {
+  ColGeom g;
+  if (col_geom(rows, 2 * C, groups, &g)) return 1;
+  XAS_REQUIRE(partial && mean && var_biased && workspace && out_stride >= C && rows_per_group > 0,
+              "bn_stats_from_partials: null buffer / bad stride");
+  XAS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_from_partials: running buffers come in pairs");
+  XAS_REQUIRE((((uintptr_t)mean | (uintptr_t)var_biased | (uintptr_t)partial) & 15) == 0 && out_stride % 4 == 0 && C % 4 == 0,
+              "bn_stats_from_partials: buffers must be 16-byte aligned, C and out_stride multiples of 4");
+  ColArgs a{};
+  if (col_args(&a, g, rows, 2 * C, workspace)) return 1;
+  a.x = partial; a.aux = pivot; a.out1 = mean; a.out2 = var_biased; a.out_stride = out_stride; a.count_out = count_out;
+  a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum;
+  a.rows_real = rows_per_group;
+  a.unbias = rows_per_group > 1 ? (float)((double)rows_per_group / (double)(rows_per_group - 1)) : 1.f;
+  hipLaunchKernelGGL(col_reduce_kernel<5>, dim3(g.nslab, g.ncb, g.G), dim3(256), 0, as_stream(stream), a);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+// Batch-norm backward sums from the per-tile partial sums a data-gradient epilogue left (xas_conv_dgrad_bn_bwd):
+// partial [rows][2][C] (sum dz | sum dz * xhat over the activation rows of a tile) -> sums [groups][2][C], and the LOCAL
+// parameter gradients added into dbeta_acc / dgamma_acc (may be NULL).
+extern "C" int xas_bn_bwd_sums_from_partials(const float* partial, long rows, int C, int groups, float* sums,
+                                             float* workspace, float* dbeta_acc, float* dgamma_acc, void* stream) {
+  ColGeom g;
+  if (col_geom(rows, 2 * C, groups, &g)) return 1;
+  XAS_REQUIRE(partial && sums && workspace && C % 4 == 0, "bn_bwd_sums_from_partials: null buffer / C not a multiple of 4");
+  XAS_REQUIRE((dbeta_acc == nullptr) == (dgamma_acc == nullptr), "bn_bwd_sums_from_partials: gradient accumulators come in pairs");
+  ColArgs a{};
+  if (col_args(&a, g, rows, 2 * C, workspace)) return 1;
+  a.x = partial; a.out1 = sums; a.out_stride = 2 * (long)C;
+  a.out2 = nullptr;                                                    // (no second sums in this mode)
+  a.acc1 = dbeta_acc; a.acc2 = dgamma_acc;
+  hipLaunchKernelGGL(col_reduce_kernel<6>, dim3(g.nslab, g.ncb, g.G), dim3(256), 0, as_stream(stream), a);
   XAS_LAUNCH_CHECK();
   return 0;
 }
@@ -990,16 +1070,20 @@ extern "C" int xas_maxpool3x3s2_bwd(const float* dy, const int8_t* idx, int N, i
 
 extern "C" int xas_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, void* stream) {
   XAS_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C % 4 == 0, "upsample2x: bad arguments");
-  hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(ew_grid((long)N * 4 * H * W * (C / 4))), dim3(256), 0,
-                     as_stream(stream), x, N, H, W, C, y);
+  const long segs = cdiv((long)2 * W * (C / 4), 256), blocks = (long)N * 2 * H * segs;
+  XAS_REQUIRE(blocks < 0x7ffffff0l && (long)N * 4 * H * W * C < (1l << 40), "upsample2x: tensor too large");
+  hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3((unsigned)(8 * cdiv(blocks, 8))), dim3(256), 0, as_stream(stream), x, N, H,
+                     W, C, y, (unsigned)segs, (unsigned)blocks);
   XAS_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int xas_upsample2x_bwd(const float* dy, int N, int H, int W, int C, float* dx, void* stream) {
   XAS_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && C % 4 == 0, "upsample2x bwd: bad arguments");
-  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_grid((long)N * ((H + kUpStrip - 1) / kUpStrip) * W * (C / 4))), dim3(256),
-                     0, as_stream(stream), dy, N, H, W, C, dx);
+  const long segs = cdiv((long)W * (C / 4), 256), blocks = (long)N * H * segs;
+  XAS_REQUIRE(blocks < 0x7ffffff0l && (long)N * 4 * H * W * C < (1l << 40), "upsample2x bwd: tensor too large");
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((unsigned)(8 * cdiv(blocks, 8))), dim3(256), 0, as_stream(stream), dy, N,
+                     H, W, C, dx, (unsigned)segs, (unsigned)blocks);
   XAS_LAUNCH_CHECK();
   return 0;
 }

@@ -54,6 +54,12 @@ __device__ __forceinline__ float block_sum(float v, float* smem /* >= 17 floats 
   return r;
 }
 
+// z = (x - mean) * (rstd * gamma) + beta with a FIXED operation order (no compiler-chosen contraction), so the
+// backward kernels that re-derive the ReLU mask from x reproduce the forward decision bit for bit.
+__device__ __forceinline__ float bn_affine(float x, float m, float rs_g, float b) {
+  return __fmaf_rn(__fsub_rn(x, m), rs_g, b);
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 

@@ -62,6 +62,19 @@ struct IgemmParams {
                               //              the block-output gradient and the sign bytes of xas_bn_apply: no dres tensor)
   const float* acc_src;       // accumulate == 2: [rows][Cd] like out
   const unsigned char* acc_mask;   // accumulate == 2: one byte per float4 of out, bit e = element active
+  // fwd only (xas_conv_fwd_bnstats): != null -> every tile also emits, per output channel, sum(v - pivot) and
+  // sum((v - pivot)^2) over its BM rows: stat_partial[tile row][channel][2].  The batch-norm statistics of the result are
+  // then a reduction over (rows / BM) partial rows instead of a second pass over the activation.
+  float* stat_partial;
+  const float* stat_pivot;         // per channel or null (= 0)
+  // dgrad only, stride 1 (xas_conv_dgrad_bn_bwd): the result is the gradient wrt the OUTPUT h = relu(bn(xb)) of a batch
+  // norm; the epilogue applies the ReLU mask (re-derived from xb exactly as bn_bwd_reduce does), writes the masked
+  // gradient dz and emits per tile and channel sum(dz), sum(dz * xhat): bnb_partial[tile][2][Cd].
+  const float* bnb_x;              // != null enables the path; [rows][Cd] like out
+  const float* bnb_mean; const float* bnb_var; const float* bnb_gamma; const float* bnb_beta;   // mean / var: [groups][Cd]
+  float bnb_eps;
+  int bnb_rows_per_group;
+  float* bnb_partial;
 };
 
 static unsigned long long* g_dbg = nullptr;
@@ -194,15 +207,106 @@ __device__ __forceinline__ void sched_mix() {
   if (NMF - USED > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMF - USED, 0);
 }
 
+// dgrad epilogue with the batch-norm backward reduction folded in (see IgemmParams::bnb_x).  Stride 1: output row = m.
+// Per (channel quad) the norm's parameters are loaded and 1/std formed ONCE, then applied to the MI row blocks; the two
+// sums are pre-reduced over the row blocks in registers, so both [WAVES_M * 32][BN] arrays fit the operand LDS together:
+// one staging pass, one barrier, one column pass.
+template <int BM, int BN>
+__device__ __forceinline__ void bnb_epilogue(const IgemmParams& p, f32x16 (&acc)[TileCfg<BM, BN>::MI][TileCfg<BM, BN>::NI],
+                                             int m0, int n0, int wm, int wn, int lane, float* lds) {
+  using C = TileCfg<BM, BN>;
+  constexpr int LDT = BN + 4, TR = C::WAVES_M * 32;               // staged rows per array
+  constexpr int PARTS = 256 / BN;
+  float* T1 = lds;
+  float* T2 = lds + TR * LDT;
+  float* red = lds + 2 * TR * LDT;                                 // [PARTS][BN][2]
+  static_assert((2 * TR * LDT + 2 * 256) <= 2 * (BM + BN) * LDK, "bn-backward staging does not fit the operand LDS");
+  const int pix_l = lane & 31, csub = 4 * (lane >> 5);
+  const int grp = m0 / p.bnb_rows_per_group;                       // tiles never straddle a group (launcher)
+  const float* mean = p.bnb_mean + (size_t)grp * p.Cd;
+  const float* var = p.bnb_var + (size_t)grp * p.Cd;
+  const size_t row0 = (size_t)(m0 + wm * C::WM + pix_l);           // < Mrows: tiles are full (launcher)
+  __syncthreads();                                                 // operand buffers are free
+#pragma unroll
+  for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nl = wn * C::WN + ni * 32 + 8 * g + csub, n = n0 + nl;
+      float4 xv[C::MI];
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi) xv[mi] = *reinterpret_cast<const float4*>(p.bnb_x + (row0 + mi * 32) * p.Cd + n);
+      const float4 mu = *reinterpret_cast<const float4*>(mean + n);
+      const float4 vr = *reinterpret_cast<const float4*>(var + n);
+      const float4 gm = *reinterpret_cast<const float4*>(p.bnb_gamma + n);
+      const float4 bt = *reinterpret_cast<const float4*>(p.bnb_beta + n);
+      const float mu_[4] = {mu.x, mu.y, mu.z, mu.w}, bt_[4] = {bt.x, bt.y, bt.z, bt.w};
+      float rstd[4], rsg[4];
+      rstd[0] = rsqrtf(vr.x + p.bnb_eps); rstd[1] = rsqrtf(vr.y + p.bnb_eps);
+      rstd[2] = rsqrtf(vr.z + p.bnb_eps); rstd[3] = rsqrtf(vr.w + p.bnb_eps);
+      rsg[0] = __fmul_rn(rstd[0], gm.x); rsg[1] = __fmul_rn(rstd[1], gm.y);
+      rsg[2] = __fmul_rn(rstd[2], gm.z); rsg[3] = __fmul_rn(rstd[3], gm.w);
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi) {
+        const float x_[4] = {xv[mi].x, xv[mi].y, xv[mi].z, xv[mi].w};
+        float dz[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dz[e] = bn_affine(x_[e], mu_[e], rsg[e], bt_[e]) > 0.f ? acc[mi][ni][4 * g + e] : 0.f;
+          s1[e] += dz[e];
+          s2[e] = fmaf(dz[e], (x_[e] - mu_[e]) * rstd[e], s2[e]);
+        }
+        *reinterpret_cast<float4*>(p.out + (row0 + mi * 32) * p.Cd + n) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+      }
+      *reinterpret_cast<float4*>(T1 + (wm * 32 + pix_l) * LDT + nl) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+      *reinterpret_cast<float4*>(T2 + (wm * 32 + pix_l) * LDT + nl) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+    }
+  __syncthreads();
+  const int c = threadIdx.x % BN, part = threadIdx.x / BN;
+  float a1 = 0.f, a2 = 0.f;
+#pragma unroll 8
+  for (int r = part; r < TR; r += PARTS) { a1 += T1[r * LDT + c]; a2 += T2[r * LDT + c]; }
+  red[(part * BN + c) * 2] = a1; red[(part * BN + c) * 2 + 1] = a2;
+  __syncthreads();
+  if (part == 0) {
+#pragma unroll
+    for (int k = 1; k < PARTS; ++k) { a1 += red[(k * BN + c) * 2]; a2 += red[(k * BN + c) * 2 + 1]; }
+    float* prow = p.bnb_partial + (size_t)(m0 / BM) * 2 * p.Cd;
+    prow[n0 + c] = a1;
+    prow[p.Cd + n0 + c] = a2;
+  }
+}
+
 // Epilogue shared by the igemm kernels: accumulators -> global memory (+ bias), float4 per four output channels.
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, bool BNB = false>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&acc)[TileCfg<BM, BN>::MI][TileCfg<BM, BN>::NI],
                                                f32x16& acc2, int m0, int n0, int wm, int wn, int lane, int Mrows, int HW,
-                                               int Wrow, int ph, int pw) {
+                                               int Wrow, int ph, int pw, float* lds = nullptr) {
   using C = TileCfg<BM, BN>;
   if (C::MI == 1 && C::NI == 1) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
+  }
+  if constexpr (MODE == 1 && BNB) {                  // own instantiation: the extra live registers of this path would
+    bnb_epilogue<BM, BN>(p, acc, m0, n0, wm, wn, lane, lds);   // otherwise cost the plain kernel its second block per CU
+    return;
+  }
+  // ---- per-channel sums of the tile for the batch norm that follows (forward only).  The accumulators go through the
+  // (now idle) operand LDS as T[pixel][channel]; after the global stores below, thread t sums column t % BN over the rows
+  // t / BN, t / BN + PARTS, ...  Launcher guarantees: every tile is full in M (rows-per-group % BM == 0), lds != null.
+  constexpr int LDT = BN + 4;
+  const bool want_stats = MODE == 0 && p.stat_partial != nullptr;
+  if (MODE == 0 && want_stats) {
+    __syncthreads();                                   // every wave has left the K-loop: the operand buffers are free
+    const int pl = lane & 31, cs = 4 * (lane >> 5);
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(lds + (wm * C::WM + mi * 32 + pl) * LDT + wn * C::WN + ni * 32 + 8 * g + cs) =
+              make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
   }
   // ---- epilogue.  Accumulator layout (operands swapped): column = lane & 31 = pixel row m of the tile,
   // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) = output channel -> registers 4g..4g+3 are four
@@ -262,6 +366,28 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
               orow_p[n + e] = vv[e] + ((MODE == 0 && p.bias) ? p.bias[n + e] : 0.f) + (p.accumulate ? orow_p[n + e] : 0.f);
         }
       }
+    }
+  }
+  if (MODE == 0 && want_stats) {
+    constexpr int PARTS = 256 / BN;
+    const int tid = threadIdx.x;
+    const int c = tid % BN, part = tid / BN;
+    const int n = n0 + c;
+    const float pv = (p.stat_pivot && n < p.Cd) ? p.stat_pivot[n] : 0.f;
+    __syncthreads();                                   // T complete
+    float s = 0.f, q = 0.f;
+#pragma unroll 8
+    for (int r = part; r < BM; r += PARTS) {
+      const float v = lds[r * LDT + c] - pv;
+      s += v; q = fmaf(v, v, q);
+    }
+    float* red = lds + BM * LDT;                       // [PARTS][BN][2]
+    red[(part * BN + c) * 2] = s; red[(part * BN + c) * 2 + 1] = q;
+    __syncthreads();
+    if (part == 0 && n < p.Cd) {
+#pragma unroll
+      for (int k = 1; k < PARTS; ++k) { s += red[(k * BN + c) * 2]; q += red[(k * BN + c) * 2 + 1]; }
+      *reinterpret_cast<float2*>(p.stat_partial + ((size_t)(m0 / BM) * p.Cd + n) * 2) = make_float2(s, q);
     }
   }
 }
@@ -499,7 +625,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   }
 #endif
 
-  igemm_epilogue<BM, BN, MODE>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw);
+  igemm_epilogue<BM, BN, MODE>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
 }
 
 // ------------------------------------------------------------------------------------
@@ -525,8 +651,8 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned 
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int BM, int BN, int MODE, bool PIPE>
-__global__ __launch_bounds__(256) void igemm_buf_kernel(IgemmParams p) {
+template <int BM, int BN, int MODE, bool PIPE, bool BNB = false>
+__global__ __launch_bounds__(256, 2) void igemm_buf_kernel(IgemmParams p) {
   using C = TileCfg<BM, BN>;
   constexpr int APASS = BM / 32, BPASS = BN / 32;
   extern __shared__ __align__(16) float lds[];
@@ -713,7 +839,7 @@ __global__ __launch_bounds__(256) void igemm_buf_kernel(IgemmParams p) {
       }
     }
   }
-  igemm_epilogue<BM, BN, MODE>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw);
+  igemm_epilogue<BM, BN, MODE, BNB>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1669,12 +1795,12 @@ static int launch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStre
   return 0;
 }
 
-template <int BM, int BN, int MODE, bool PIPE>
+template <int BM, int BN, int MODE, bool PIPE, bool BNB = false>
 static int launch_igemm_buf(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
   const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_buf_kernel<BM, BN, MODE, PIPE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_buf_kernel<BM, BN, MODE, PIPE, BNB>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -1682,7 +1808,7 @@ static int launch_igemm_buf(const IgemmParams& p, int Mrows_max, int phases, hip
   q.nMt = (int)cdiv(Mrows_max, BM); q.nNt = (int)cdiv(p.Cd, BN); q.mt_per_xcd = (int)cdiv(q.nMt, 8);
   const unsigned nblk = (q.tune & 4) ? (unsigned)(q.nMt * q.nNt) : (unsigned)(8 * q.mt_per_xcd * q.nNt);
   dim3 grid(nblk, 1, (unsigned)phases);
-  hipLaunchKernelGGL((igemm_buf_kernel<BM, BN, MODE, PIPE>), grid, dim3(256), lds, st, q);
+  hipLaunchKernelGGL((igemm_buf_kernel<BM, BN, MODE, PIPE, BNB>), grid, dim3(256), lds, st, q);
   XAS_LAUNCH_CHECK();
   return 0;
 }
@@ -1693,6 +1819,12 @@ template <int BM, int BN, int MODE>
 static int launch_tile(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
   const long bias = ((long)(p.R + p.pad) * p.Ws + p.S + p.pad) * p.Cs;
   const bool fits = (bias + p.src_elems) * 4 < 0x7fffff00l && p.wgt_elems * 4 < 0x7fffff00l && p.R * p.S <= 32;
+  if constexpr (MODE == 1) {
+    if (p.bnb_x) {                                    // batch-norm backward epilogue: buffer-load pipelined kernel only
+      XAS_REQUIRE(fits, "conv_dgrad_bn_bwd: tensor beyond the 32-bit offset range of the buffer-load kernel");
+      return launch_igemm_buf<BM, BN, 1, true, true>(p, Mrows_max, phases, st);
+    }
+  }
   if (fits && !(p.tune & 64)) {                       // tune bit5 (32): plain K-loop instead of the pipelined one
     if (p.tune & 32) return launch_igemm_buf<BM, BN, MODE, false>(p, Mrows_max, phases, st);
     return launch_igemm_buf<BM, BN, MODE, true>(p, Mrows_max, phases, st);
@@ -1714,6 +1846,17 @@ static int launch_igemm_bf16(const IgemmParams& p, int Mrows_max, int phases, hi
   return 0;
 }
 
+// tile of the fp32 path for a problem (the one rule both the launcher and xas_conv_fwd_bnstats go by)
+static void pick_tile(int Cd, long Mrows_max, int phases, int tune, int* bm, int* bn) {
+  if (Cd >= 96) {
+    // small problems (layer3/4 at B=32: M = 8192 / 2048 rows): 128x128 tiles leave most of the 256 CUs idle
+    const long blocks128 = cdiv(Mrows_max, 128) * cdiv(Cd, 128) * phases;
+    const long thr = (tune >> 20) & 1 ? 256 : ((tune >> 21) & 1 ? 384 : 512);     // experiment: tune bits 20 / 21
+    if (blocks128 <= thr) { *bm = 64; *bn = 64; } else { *bm = 128; *bn = 128; }
+  } else if (Cd >= 48) { *bm = 128; *bn = 64; }
+  else { *bm = 128; *bn = 32; }
+}
+
 template <int MODE>
 static int dispatch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
   if (g_precision == 1) {
@@ -1729,14 +1872,11 @@ static int dispatch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipSt
       return launch_igemm_bf16<128, 32, MODE>(p, Mrows_max, phases, st);
     }
   }
-  if (p.Cd >= 96) {
-    // small problems (layer3/4 at B=32: M = 8192 / 2048 rows): 128x128 tiles leave most of the 256 CUs idle
-    const long blocks128 = cdiv(Mrows_max, 128) * cdiv(p.Cd, 128) * phases;
-    const long thr = (p.tune >> 20) & 1 ? 256 : ((p.tune >> 21) & 1 ? 384 : 512);     // experiment: tune bits 20 / 21
-    if (blocks128 <= thr) return launch_tile<64, 64, MODE>(p, Mrows_max, phases, st);
-    return launch_tile<128, 128, MODE>(p, Mrows_max, phases, st);
-  }
-  if (p.Cd >= 48) return launch_tile<128, 64, MODE>(p, Mrows_max, phases, st);
+  int bm, bn;
+  pick_tile(p.Cd, Mrows_max, phases, p.tune, &bm, &bn);
+  if (bn == 128) return launch_tile<128, 128, MODE>(p, Mrows_max, phases, st);
+  if (bm == 64) return launch_tile<64, 64, MODE>(p, Mrows_max, phases, st);
+  if (bn == 64) return launch_tile<128, 64, MODE>(p, Mrows_max, phases, st);
   return launch_tile<128, 32, MODE>(p, Mrows_max, phases, st);
 }
 
@@ -1765,14 +1905,38 @@ extern "C" int xas_set_precision(int mode) {
 }
 extern "C" int xas_set_debug_buffer(void* p) { g_dbg = reinterpret_cast<unsigned long long*>(p); return 0; }
 
+static int conv_fwd_impl(const float* x, const float* w_packed, const float* bias, float* y, const xas_conv_shape* s,
+                         void* stream, float* stat_partial, const float* stat_pivot);
+
 extern "C" int xas_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
                             const xas_conv_shape* s, void* stream) {
+  return conv_fwd_impl(x, w_packed, bias, y, s, stream, nullptr, nullptr);
+}
+
+// Rows per tile when the forward pass of `s` can emit batch-norm partial sums for `groups` camera groups (MFMA path, one
+// launch, no tile straddles a group), else 0.
+static int fwd_stats_tile_rows(const xas_conv_shape* s, int groups) {
+  if (!s || groups < 1 || g_precision != 0) return 0;
+  if (s->Cin % BK != 0 || s->Cout < 16 || s->Cout % 4 != 0) return 0;
+  if (s->Cin == 3 || (s->Cout == 1 && thin_ok(s, s->Cin)) || (s->Cin == 1 && thin_ok(s, s->Cout))) return 0;
+  if (images_per_launch(s->N, (long)s->Hi * s->Wi * s->Cin, 0) < s->N || s->N % groups) return 0;
+  const long M = (long)s->N * s->Ho * s->Wo, Mg = M / groups;
+  int bm, bn;
+  pick_tile(s->Cout, M, 1, g_tune, &bm, &bn);
+  if (Mg % bm) return 0;
+  if ((M / bm) * 2 * (long)s->Cout * 4 >= 0x7fffff00l) return 0;
+  return bm;
+}
+
+static int conv_fwd_impl(const float* x, const float* w_packed, const float* bias, float* y, const xas_conv_shape* s,
+                         void* stream, float* stat_partial, const float* stat_pivot) {
   if (check_shape(s, "conv_fwd") || check_fwd_dims(s, "conv_fwd")) return 1;
   XAS_REQUIRE(x && w_packed && y, "conv_fwd: null buffer");
   {
     const long xi = (long)s->Hi * s->Wi * s->Cin, yi = (long)s->Ho * s->Wo * s->Cout;
     const int per = images_per_launch(s->N, xi, 0);
     if (per < s->N) {
+      XAS_REQUIRE(!stat_partial, "conv_fwd: the statistics epilogue needs a single launch");
       for (int n0 = 0; n0 < s->N; n0 += per) {
         xas_conv_shape part = *s;
         part.N = s->N - n0 < per ? s->N - n0 : per;
@@ -1818,11 +1982,47 @@ extern "C" int xas_conv_fwd(const float* x, const float* w_packed, const float* 
   p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.Hrow = s->Ho; p.Wrow = s->Wo; p.tune = g_tune; p.dbg = g_dbg;
   p.div_hw.init((unsigned)(s->Ho * s->Wo)); p.div_w.init((unsigned)s->Wo);
   p.src_elems = (long)p.N * p.Hs * p.Ws * p.Cs; p.wgt_elems = (long)p.Cd * p.R * p.S * p.Cs;
+  p.stat_partial = stat_partial; p.stat_pivot = stat_pivot;
   return dispatch_igemm<0>(p, s->N * s->Ho * s->Wo, 1, st);
 }
 
+// Convolution (no bias) + the training-mode batch-norm statistics of its result.  When the tile grid lines up with the
+// camera groups the statistics come out of the convolution's epilogue (per-tile partial sums, reduced by
+// xas_bn_stats_from_partials); otherwise the result is read once more by xas_bn_stats.  Same outputs either way (up to
+// the order of the fp32 partial sums).
+extern "C" size_t xas_conv_fwd_bnstats_workspace_floats(const xas_conv_shape* s, int groups) {
+  if (!s || groups < 1) return 0;
+  const long M = (long)s->N * s->Ho * s->Wo;
+  const int bm = fwd_stats_tile_rows(s, groups);
+  if (!bm) return xas_bn_workspace_floats(M, s->Cout, groups);
+  const long rows = M / bm;
+  return (size_t)rows * 2 * s->Cout + xas_bn_workspace_floats(rows, 2 * s->Cout, groups);
+}
+
+extern "C" int xas_conv_fwd_bnstats(const float* x, const float* w_packed, float* y, const xas_conv_shape* s, int groups,
+                                    const float* pivot, float* mean, float* var_biased, long out_stride, float* count_out,
+                                    float* workspace, float* running_mean, float* running_var, float momentum,
+                                    void* stream) {
+  XAS_REQUIRE(s && groups >= 1 && s->N % groups == 0, "conv_fwd_bnstats: the batch does not split into %d groups", groups);
+  XAS_REQUIRE(workspace && mean && var_biased, "conv_fwd_bnstats: null buffer");
+  const long M = (long)s->N * s->Ho * s->Wo, Mg = M / groups;
+  const int bm = fwd_stats_tile_rows(s, groups);
+  if (!bm) {
+    const int rc = conv_fwd_impl(x, w_packed, nullptr, y, s, stream, nullptr, nullptr);
+    if (rc) return rc;
+    return xas_bn_stats(y, M, s->Cout, groups, mean, var_biased, out_stride, count_out, workspace, running_mean,
+                        running_var, momentum, Mg, stream);
+  }
+  const long rows = M / bm;
+  const int rc = conv_fwd_impl(x, w_packed, nullptr, y, s, stream, workspace, pivot);
+  if (rc) return rc;
+  return xas_bn_stats_from_partials(workspace, rows, s->Cout, groups, Mg, pivot, mean, var_biased, out_stride, count_out,
+                                    workspace + (size_t)rows * 2 * s->Cout, running_mean, running_var, momentum, stream);
+}
+
 static int conv_dgrad_impl(const float* dy, const float* w_packed_t, float* dx, const xas_conv_shape* s, void* stream,
-                           int accumulate, const float* acc_src = nullptr, const unsigned char* acc_mask = nullptr);
+                           int accumulate, const float* acc_src = nullptr, const unsigned char* acc_mask = nullptr,
+                           const IgemmParams* bnb = nullptr);
 
 extern "C" int xas_conv_dgrad(const float* dy, const float* w_packed_t, float* dx, const xas_conv_shape* s,
                               void* stream) {
@@ -1841,7 +2041,7 @@ extern "C" int xas_conv_dgrad_acc_masked(const float* dy, const float* w_packed_
 }
 
 static int conv_dgrad_impl(const float* dy, const float* w_packed_t, float* dx, const xas_conv_shape* s, void* stream,
-                           int accumulate, const float* acc_src, const unsigned char* acc_mask) {
+                           int accumulate, const float* acc_src, const unsigned char* acc_mask, const IgemmParams* bnb) {
   if (check_shape(s, "conv_dgrad")) return 1;
   XAS_REQUIRE(!accumulate || (s->Cout % BK == 0 && s->Cin >= 16 && s->Cin % 4 == 0 && !(s->Cin == 1 || s->Cout == 1)),
               "conv_dgrad_acc: only the MFMA path accumulates (Cout %% 32 == 0, Cin %% 4 == 0, Cin >= 16)");
@@ -1853,6 +2053,7 @@ static int conv_dgrad_impl(const float* dy, const float* w_packed_t, float* dx, 
     const long xi = (long)s->Hi * s->Wi * s->Cin, yi = (long)s->Ho * s->Wo * s->Cout;
     const int per = images_per_launch(s->N, yi, 0);
     if (per < s->N) {
+      XAS_REQUIRE(!bnb, "conv_dgrad: the batch-norm epilogue needs a single launch");
       for (int n0 = 0; n0 < s->N; n0 += per) {
         xas_conv_shape part = *s;
         part.N = s->N - n0 < per ? s->N - n0 : per;
@@ -1893,7 +2094,72 @@ static int conv_dgrad_impl(const float* dy, const float* w_packed_t, float* dx, 
   p.accumulate = accumulate; p.acc_src = acc_src; p.acc_mask = acc_mask;
   const int Hp = (s->Hi + s->stride - 1) / s->stride, Wp = (s->Wi + s->stride - 1) / s->stride;
   p.src_elems = (long)p.N * p.Hs * p.Ws * p.Cs; p.wgt_elems = (long)p.Cd * p.R * p.S * p.Cs;
+  if (bnb) {
+    p.bnb_x = bnb->bnb_x; p.bnb_mean = bnb->bnb_mean; p.bnb_var = bnb->bnb_var; p.bnb_gamma = bnb->bnb_gamma;
+    p.bnb_beta = bnb->bnb_beta; p.bnb_eps = bnb->bnb_eps; p.bnb_rows_per_group = bnb->bnb_rows_per_group;
+    p.bnb_partial = bnb->bnb_partial;
+  }
   return dispatch_igemm<1>(p, s->N * Hp * Wp, s->stride * s->stride, st);
+}
+
+// Rows per tile when the data gradient of `s` can carry the batch-norm backward reduction of the layer in front of the
+// convolution in its epilogue (MFMA path, stride 1, one launch, full tiles that do not straddle a camera group), else 0.
+static int dgrad_bnb_tile_rows(const xas_conv_shape* s, int groups) {
+  if (!s || groups < 1 || g_precision != 0 || s->stride != 1) return 0;
+  if (s->Cout % BK != 0 || s->Cin < 16 || s->Cin % 4 != 0 || s->Cin == 1 || s->Cout == 1) return 0;
+  if (images_per_launch(s->N, (long)s->Ho * s->Wo * s->Cout, 0) < s->N || s->N % groups) return 0;
+  const long M = (long)s->N * s->Hi * s->Wi, Mg = M / groups;
+  int bm, bn;
+  pick_tile(s->Cin, M, 1, g_tune, &bm, &bn);
+  if (Mg % bm || s->Cin % bn) return 0;
+  if ((M / bm) * 2 * (long)s->Cin * 4 >= 0x7fffff00l) return 0;
+  return bm;
+}
+
+// Data gradient of a convolution whose input is h = relu(batch_norm(xb)) (rank-local statistics), followed by that batch
+// norm's backward pass: -> dx = gradient wrt xb, sums [groups][2][Cin], and the local dbeta / dgamma added into the
+// accumulators (may be NULL).  dz is scratch of xb's size (the gradient wrt the norm's pre-activation output).
+// When the tile grid lines up with the groups, the ReLU mask and the two reductions of the norm's backward are done in
+// the convolution's epilogue (dz is never re-read for them); otherwise xas_conv_dgrad + xas_bn_bwd_reduce.
+extern "C" size_t xas_conv_dgrad_bn_bwd_workspace_floats(const xas_conv_shape* s, int groups) {
+  if (!s || groups < 1) return 0;
+  const long M = (long)s->N * s->Hi * s->Wi;
+  const int bm = dgrad_bnb_tile_rows(s, groups);
+  if (!bm) return xas_bn_workspace_floats(M, s->Cin, groups);
+  const long rows = M / bm;
+  return (size_t)rows * 2 * s->Cin + xas_bn_workspace_floats(rows, 2 * s->Cin, groups);
+}
+
+extern "C" int xas_conv_dgrad_bn_bwd(const float* dy, const float* w_packed_t, const xas_conv_shape* s, const float* xb,
+                                     const float* mean, const float* var_biased, const float* gamma, const float* beta,
+                                     float eps, int groups, double count, float* dz, float* dx, float* sums,
+                                     float* workspace, float* dbeta_acc, float* dgamma_acc, void* stream) {
+  XAS_REQUIRE(s && groups >= 1 && s->N % groups == 0, "conv_dgrad_bn_bwd: the batch does not split into %d groups", groups);
+  XAS_REQUIRE(xb && mean && var_biased && gamma && beta && dz && dx && sums && workspace, "conv_dgrad_bn_bwd: null buffer");
+  const long M = (long)s->N * s->Hi * s->Wi;
+  const int C = s->Cin;
+  const int bm = dgrad_bnb_tile_rows(s, groups);
+  if (!bm) {
+    int rc = conv_dgrad_impl(dy, w_packed_t, dz, s, stream, 0);
+    if (rc) return rc;
+    rc = xas_bn_bwd_reduce(xb, nullptr, dz, mean, var_biased, gamma, beta, eps, 1, M, C, groups, sums, workspace, dbeta_acc,
+                           dgamma_acc, nullptr, stream);
+    if (rc) return rc;
+    return xas_bn_bwd_apply(xb, nullptr, dz, mean, var_biased, gamma, beta, sums, eps, 1, M, C, groups, count, dx, nullptr,
+                            nullptr, stream);
+  }
+  const long rows = M / bm;
+  IgemmParams b{};
+  b.bnb_x = xb; b.bnb_mean = mean; b.bnb_var = var_biased; b.bnb_gamma = gamma; b.bnb_beta = beta; b.bnb_eps = eps;
+  b.bnb_rows_per_group = (int)(M / groups); b.bnb_partial = workspace;
+  int rc = conv_dgrad_impl(dy, w_packed_t, dz, s, stream, 0, nullptr, nullptr, &b);
+  if (rc) return rc;
+  rc = xas_bn_bwd_sums_from_partials(workspace, rows, C, groups, sums, workspace + (size_t)rows * 2 * C, dbeta_acc,
+                                     dgamma_acc, stream);
+  if (rc) return rc;
+  // dz is already masked: the apply pass runs without an activation
+  return xas_bn_bwd_apply(xb, nullptr, dz, mean, var_biased, gamma, beta, sums, eps, 0, M, C, groups, count, dx, nullptr,
+                          nullptr, stream);
 }
 
 static inline unsigned slab_threads() { return (g_tune & 16384) ? 1024u : 256u; }   // tune bit14: old 1024-thread blocks

@@ -33,6 +33,10 @@ SIGNATURES = {
     'xas_draw_lines_max_fwd': ('plliippiufipp', 'i'),
     'xas_draw_lines_max_bwd': ('plliippiufipppp', 'i'),
     'xas_conv_fwd': ('ppppsp', 'i'),
+    'xas_conv_fwd_bnstats_workspace_floats': ('si', 'z'),
+    'xas_conv_fwd_bnstats': ('pppsippplppppfp', 'i'),
+    'xas_conv_dgrad_bn_bwd_workspace_floats': ('si', 'z'),
+    'xas_conv_dgrad_bn_bwd': ('ppspppppfidppppppp', 'i'),
     'xas_conv_dgrad': ('pppsp', 'i'),
     'xas_conv_dgrad_acc': ('pppsp', 'i'),
     'xas_conv_dgrad_acc_masked': ('pppsppp', 'i'),
@@ -44,6 +48,8 @@ SIGNATURES = {
     'xas_unpack_weight': ('ppiiiiip', 'i'),
     'xas_bn_workspace_floats': ('lii', 'z'),
     'xas_bn_stats': ('pliipplppppflp', 'i'),
+    'xas_bn_stats_from_partials': ('pliilppplppppfp', 'i'),
+    'xas_bn_bwd_sums_from_partials': ('pliippppp', 'i'),
     'xas_bn_sync_merge': ('piiilppppfp', 'i'),
     'xas_col_sum': ('plippp', 'i'),
     'xas_bn_apply': ('ppppppfiliippp', 'i'),

@@ -49,7 +49,8 @@ _side = {'stream': None, 'enabled': True, 'dirty': False}
 
 
 def side_stream():
-    # (measured, round 2: confining this stream to 1/2 or 3/4 of the CUs with hipExtStreamCreateWithCUMask is 7 % slower)
+    # (measured, round 2: confining this stream to 1/2 or 3/4 of the CUs with hipExtStreamCreateWithCUMask is 7 % slower;
+    # a low- or high-priority stream (hipStreamCreateWithPriority) changes nothing: 224.8 / 225.7 / 226.2 ms per step)
     if _side['stream'] is None:
         _side['stream'] = torch.cuda.Stream()
     return _side['stream']
@@ -246,6 +247,83 @@ def _conv_forward(x, weight, stride, pad, cache):
     return y, shp
 
 
+FUSE_CONV_STATS = os.environ.get('XAS_CONV_STATS', '1') == '1'
+
+
+def _conv_bn_forward(x, conv, bn, residual, group):
+    """conv (no bias) -> batch norm (+ residual, activation): -> (out, saved, cfg, shp).  In training mode the batch
+    statistics come out of the convolution's epilogue (xas_conv_fwd_bnstats): the conv result is not read a second time
+    for them."""
+    weight = conv.weight
+    if not (FUSE_CONV_STATS and bn.training) or streams.forked():
+        y, shp = _conv_forward(x, weight, conv.stride, conv.padding, conv._cache)
+        out, sv, cf = _bn_forward(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, bn.training,
+                                  bn.momentum, bn.eps, bn.act, group)
+        return out, sv, cf, shp
+    n, ci, hi, wi = x.shape
+    co, ci2, r, s = weight.shape
+    if ci != ci2:
+        raise RuntimeError('conv2d: input has %d channels, weight expects %d' % (ci, ci2))
+    stride, pad = conv.stride, conv.padding
+    ho, wo = (hi + 2 * pad - r) // stride + 1, (wi + 2 * pad - s) // stride + 1
+    shp = _shape(n, hi, wi, ci, co, r, s, stride, pad, ho, wo)
+    y = empty_cl(n, co, ho, wo, x)
+    wp = conv._cache.get(weight, 0)
+    G = _groups[0]
+    # sums are taken around 0: a pivot taken from the running mean would make the last bits of the statistics depend on
+    # optimisation state (a detector pass computed once and re-used - TrainStep(dedupe=True) - must equal the recomputed
+    # one bit for bit); per-tile sums run over <= 128 rows in fp32 and are combined in double
+    pivot = None
+
+    def stats(mean_p, var_p, out_stride, count_p, rm_p, rv_p, momentum):
+        ws = torch.empty(query('xas_conv_fwd_bnstats_workspace_floats', shp, G), device=x.device, dtype=torch.float32)
+        call('xas_conv_fwd_bnstats', ptr(x), ptr(wp), ptr(y), shp, G, ptr(pivot), mean_p, var_p, out_stride, count_p,
+             ptr(ws), rm_p, rv_p, float(momentum))
+
+    out, sv, cf = _bn_forward(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, True, bn.momentum,
+                              bn.eps, bn.act, group, stats_fn=stats)
+    return out, sv, cf, shp
+
+
+# Off by default.  Measured (round 2, B = 32 x 4 cameras, interleaved in one process): 222.5 ms/step without, 223.3 ms with.
+# The two reductions it removes (col_reduce_lean_kernel<4>, 7.6 ms/step) run BESIDE the weight gradients of the side
+# stream and are mostly hidden; the extra epilogue work lands in the data-gradient kernels, which are the critical path.
+FUSE_DGRAD_BN = os.environ.get('XAS_DGRAD_BN', '0') == '1'
+
+
+def _bn_bwd_fusable(cfg):
+    """A rank-local training-mode norm with ReLU and no residual whose backward re-derives the mask from its input."""
+    M, c, eps, act, count, group, training, has_res, xfree, yfree, G, masked = cfg
+    return training and group is None and act == ACT_RELU and not has_res and yfree and not masked
+
+
+def _conv_dgrad_bn_bwd(dy, conv, shp, saved, cfg, bn, want_param_grads):
+    """Data gradient of `conv` (its input is relu(bn(xb))) + the backward of that norm: -> (dxb, (dgamma, dbeta) | None).
+    One C call (xas_conv_dgrad_bn_bwd): the norm's two reductions ride in the data gradient's epilogue."""
+    xb, _, mean, var = saved
+    M, c, eps, act, count, group, training, has_res, xfree, yfree, G, masked = cfg
+    dy = to_cl(dy)
+    dev = xb.device
+    gamma, beta = bn.weight, bn.bias
+    sums = torch.empty(G, 2, c, device=dev, dtype=torch.float32)
+    ws = torch.empty(query('xas_conv_dgrad_bn_bwd_workspace_floats', shp, G), device=dev, dtype=torch.float32)
+    gg, gb = gamma.grad, beta.grad
+    direct = (want_param_grads and gg is not None and gb is not None and gg.is_contiguous() and gb.is_contiguous()
+              and gg.dtype == torch.float32 and gb.dtype == torch.float32)
+    dz = torch.empty_like(xb)
+    dx = torch.empty_like(xb)
+    call('xas_conv_dgrad_bn_bwd', ptr(dy), ptr(conv._cache.get(conv.weight, 1)), shp, ptr(xb), ptr(mean), ptr(var),
+         ptr(gamma), ptr(beta), float(eps), G, float(count), ptr(dz), ptr(dx), ptr(sums), ptr(ws),
+         ptr(gb) if direct else None, ptr(gg) if direct else None)
+    if direct:
+        grad_ready(gamma)
+        grad_ready(beta)
+        return dx, None
+    if want_param_grads:
+        return dx, (sums[:, 1].sum(0), sums[:, 0].sum(0))
+    return dx, None
+
+
 def _conv_backward(x, weight, dy, shp, cache, need_dx, need_dw, acc_into=None):
     """-> (dx, dw).  acc_into: a gradient buffer of x's shape that already holds the other branch's gradient; the
     data gradient is added to it in the kernel epilogue.  dw is None when it went straight into weight.grad."""
@@ -281,16 +359,12 @@ class _Bottleneck(torch.autograd.Function):
         saved, cfgs, shps = [], [], []
         skip = x
         if ds is not None:
-            yd, shp_d = _conv_forward(x, ds[0].weight, ds[0].stride, ds[0].padding, ds[0]._cache)
-            skip, sv, cf = _bn_forward(yd, ds[1].weight, ds[1].bias, ds[1].running_mean, ds[1].running_var, None,
-                                       ds[1].training, ds[1].momentum, ds[1].eps, ds[1].act, ds[1].sync_group())
+            skip, sv, cf, shp_d = _conv_bn_forward(x, ds[0], ds[1], None, ds[1].sync_group())
             saved.append(sv); cfgs.append(cf); shps.append(shp_d)
         a = x
         acts = [x]
         for i in range(3):
-            y, shp = _conv_forward(a, convs[i].weight, convs[i].stride, convs[i].padding, convs[i]._cache)
-            a, sv, cf = _bn_forward(y, bns[i].weight, bns[i].bias, bns[i].running_mean, bns[i].running_var,
-                                    skip if i == 2 else None, bns[i].training, bns[i].momentum, bns[i].eps, bns[i].act, None)
+            a, sv, cf, shp = _conv_bn_forward(a, convs[i], bns[i], skip if i == 2 else None, bns[i].sync_group())
             saved.append(sv); cfgs.append(cf); shps.append(shp)
             acts.append(a)
         flat = [t for sv in saved for t in sv]
@@ -334,6 +408,17 @@ class _Bottleneck(torch.autograd.Function):
         dout = to_cl(dout)
         g, dskip = bn_b(o + 2, bns[2], dout, want_dres=not fuse_skip)          # dskip: gradient of the skip branch
         for i in (2, 1):
+            bn, cf = bns[i - 1], cfgs[o + i - 1]
+            want_bn = id(bn.weight) in need and id(bn.bias) in need
+            if FUSE_DGRAD_BN and _bn_bwd_fusable(cf) and (want_bn or (id(bn.weight) not in need and id(bn.bias) not in need)):
+                # conv_i's data gradient with bn_{i-1}'s backward reductions in its epilogue
+                dyc = g
+                g, dgb = _conv_dgrad_bn_bwd(dyc, convs[i], shps[o + i], saved[o + i - 1], cf, bn, want_bn)
+                if id(convs[i].weight) in need and not _wgrad_into_grad(ins[i], dyc, shps[o + i], convs[i].weight):
+                    pgrads[id(convs[i].weight)] = _wgrad(ins[i], dyc, shps[o + i], convs[i].weight.shape)
+                if dgb is not None:
+                    pgrads[id(bn.weight)], pgrads[id(bn.bias)] = dgb
+                continue
             g, dw = _conv_backward(ins[i], convs[i].weight, g, shps[o + i], convs[i]._cache, True, id(convs[i].weight) in need)
             if dw is not None:
                 pgrads[id(convs[i].weight)] = dw
@@ -484,7 +569,7 @@ def _sync_stats(mean, var, count, group):
     return gm.float().contiguous(), gv.float().contiguous()
 
 
-def _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, group):
+def _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, group, stats_fn=None):
     """-> (y, saved tensors (x|y, y|x, mean, var), cfg) - the body of _BatchNorm.forward, also used by _Bottleneck.
     The batch is `current_groups()` independent sub-batches (cameras): statistics are [G, C]."""
     x = to_cl(x)
@@ -497,14 +582,18 @@ def _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, m
     dev = x.device
     count = float(Mg)
     if training:
-        ws = torch.empty(query('xas_bn_workspace_floats', M, c, G), device=dev, dtype=torch.float32)
+        if stats_fn is None:
+            ws = torch.empty(query('xas_bn_workspace_floats', M, c, G), device=dev, dtype=torch.float32)
+
+            def stats_fn(mean_p, var_p, out_stride, count_p, rm_p, rv_p, mom):
+                call('xas_bn_stats', ptr(x), M, c, G, mean_p, var_p, out_stride, count_p, ptr(ws), rm_p, rv_p, float(mom), int(Mg))
+        # (stats_fn given: x is still EMPTY here - the callable runs the producing convolution together with the statistics)
         if group is None:
             mean = torch.empty(G, c, device=dev, dtype=torch.float32)
             var = torch.empty(G, c, device=dev, dtype=torch.float32)
             fuse_running = running_mean is not None and not streams.forked()
-            call('xas_bn_stats', ptr(x), M, c, G, ptr(mean), ptr(var), c, None, ptr(ws),
-                 ptr(running_mean) if fuse_running else None, ptr(running_var) if fuse_running else None,
-                 float(momentum), int(Mg))
+            stats_fn(ptr(mean), ptr(var), c, None, ptr(running_mean) if fuse_running else None,
+                     ptr(running_var) if fuse_running else None, momentum)
             if running_mean is not None and not fuse_running:
                 # order-dependent update: serialised on the bookkeeping stream in host program order
                 book, cur = streams.book_stream(), torch.cuda.current_stream()
@@ -521,8 +610,7 @@ def _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, m
             world = dist.get_world_size(group)
             stride = 2 * c + 4
             msg = torch.empty(G, stride, device=dev, dtype=torch.float32)
-            call('xas_bn_stats', ptr(x), M, c, G, ptr(msg), ptr(msg[:, c:]), stride, ptr(msg[:, 2 * c:]), ptr(ws),
-                 None, None, float(momentum), int(Mg))
+            stats_fn(ptr(msg), ptr(msg[:, c:]), stride, ptr(msg[:, 2 * c:]), None, None, momentum)
             gathered = torch.empty(world * G * stride, device=dev, dtype=torch.float32)     # [world][G][stride]
             dist.all_gather_into_tensor(gathered, msg.view(-1), group=group)
             mean = torch.empty(G, c, device=dev, dtype=torch.float32)
