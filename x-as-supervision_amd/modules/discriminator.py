@@ -69,6 +69,16 @@ class GCNDiscriminator_base(nn.Module):
             self._graph = (a.to(device).contiguous(), a.t().contiguous().to(device))
         return (self._graph[0], self._graph[1], batch_size, self.num_nodes)
 
+    def _bone_index(self, device):
+        """parent / child joint indices as device tensors, uploaded once (a Python-list index is uploaded - with a
+        blocking copy - at every call)."""
+        key = (tuple(self.parent_ids), tuple(self.child_ids), str(device))
+        if getattr(self, '_bone_key', None) != key:
+            self._bone_key = key
+            self._bone_idx = (torch.tensor(list(self.parent_ids), dtype=torch.long, device=device),
+                              torch.tensor(list(self.child_ids), dtype=torch.long, device=device))
+        return self._bone_idx
+
     def forward_groups(self, inputs):
         """Evaluate the discriminator on several independent inputs [B,N,C] in ONE batched pass and return
         the list of logits.  Equivalent to `[self(x) for x in inputs]` (graph-LayerNorm statistics stay per
@@ -130,7 +140,8 @@ class GCNDiscriminatorDecouple(GCNDiscriminator_base):
 
     def _forward(self, keypoints, groups=1):
         B, _, dim = keypoints.shape
-        bone = keypoints[:, self.parent_ids, :] - keypoints[:, self.child_ids, :]
+        pidx, cidx = self._bone_index(keypoints.device)
+        bone = keypoints[:, pidx, :] - keypoints[:, cidx, :]
         bone = torch.cat([keypoints.new_zeros(B, 1, dim), bone], dim=1)       # zero row for the root node
         g = self.graph(B, keypoints.device) + (groups,)
         if self.use_pe:

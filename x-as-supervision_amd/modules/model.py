@@ -118,7 +118,9 @@ class Counter3DModel(torch.nn.Module):
         per_cam = {}
         for cam, key, (kps, depth_map) in zip(cams, keys, dets):
             assert kps.dim() == 4, "use aligned multi-hypothesis settings"
-            out['pose_2d_pred_{}_ori'.format(key)] = kps[[0], 0].detach().clone()
+            # (slices, not the reference's `[[0]]` lists: a list index is an index TENSOR that torch uploads with a blocking
+            # copy - 46 pipeline drains per step; the values are the same)
+            out['pose_2d_pred_{}_ori'.format(key)] = kps[0:1, 0].detach().clone()
             out['depth_map_{}'.format(key)] = depth_map
             world = _to_world(kps, x, key, cam == 'mono')                  # [B, Hy, K, 3], one launch
             out['pose_3d_depth_{}'.format(key)] = world[:, 0].detach().clone()
@@ -130,7 +132,7 @@ class Counter3DModel(torch.nn.Module):
         if 'physique_recons_loss' in lc and self.physique_network is not None:
             use_w = lc['physique_recons_loss']['use_dis_map']
             for key, phys in zip(keys, _grouped(self.physique_network, [per_cam[k]['recon'] for k in keys])):
-                out['mask_physique_{}'.format(key)] = phys[[0]].detach()
+                out['mask_physique_{}'.format(key)] = phys[0:1].detach()
                 per_cam[key]['phys'] = compute_mask_reconstruction_loss(
                     phys, x[key + '_mask'], weight=x[key + '_geodesic_dis'] if use_w else None)
         if 'recons_loss' in lc:
@@ -154,9 +156,9 @@ class Counter3DModel(torch.nn.Module):
             dets = _grouped(self.regressor, [x[k + '_pseudo_img'] for k in keys])
         for key, (pred, _) in zip(keys, dets):
             gt = x[key + '_pseudo_joints']
-            out['pose_2d_pred_{}_pseudo'.format(key)] = pred[[0], 0].detach().clone()
-            out['pose_3d_pred_{}_pseudo'.format(key)] = _to_world(pred[:, 0].detach(), x, key, True)[[0]]
-            out['pose_3d_gt_{}_pseudo'.format(key)] = _to_world(gt, x, key, True)[[0]]
+            out['pose_2d_pred_{}_pseudo'.format(key)] = pred[0:1, 0].detach().clone()
+            out['pose_3d_pred_{}_pseudo'.format(key)] = _to_world(pred[:, 0].detach(), x, key, True)[0:1]
+            out['pose_3d_gt_{}_pseudo'.format(key)] = _to_world(gt, x, key, True)[0:1]
             per_cam[key]['pseudo'] = compute_supervision_min(pred, gt)
 
     def finish(self, x, smpl_discriminator, per_cam, out):
@@ -167,7 +169,7 @@ class Counter3DModel(torch.nn.Module):
         kps = {k: v['kps'] for k, v in per_cam.items()}
         world = {k: v['world'] for k, v in per_cam.items()}
         if 'mono' not in cams:
-            out['kp_gt_world'] = convert_patch_to_world(x['cam_0_joints'], x, 'cam_0', is_norm=False)[[0]]
+            out['kp_gt_world'] = convert_patch_to_world(x['cam_0_joints'], x, 'cam_0', is_norm=False)[0:1]
 
         if 'symmetry_loss' in lc:
             w = lc['symmetry_loss']['weight']
@@ -184,7 +186,7 @@ class Counter3DModel(torch.nn.Module):
             rels = {}
             for cam in cams:
                 key = 'cam_{}'.format(cam)
-                rels[key] = ((world[key] - world[key][:, [0]]) / 1000)[..., :self.DISC_SUP_DIMENSION].detach()
+                rels[key] = ((world[key] - world[key][:, 0:1]) / 1000)[..., :self.DISC_SUP_DIMENSION].detach()
             hy = world['cam_{}'.format(cams[0])].shape[1]
             flat = _disc_many(smpl_discriminator, [rels['cam_{}'.format(c)][:, h] for c in cams for h in range(hy)])
             for ci, cam in enumerate(cams):
@@ -194,7 +196,7 @@ class Counter3DModel(torch.nn.Module):
                 if not self.use_aug:
                     total = total + compute_disc_loss(logits, None)
                 else:
-                    rot = torch.stack([smpl_discriminator(random_rotation_3D((world[key] - world[key][:, [0]])[:, h] / 1000)
+                    rot = torch.stack([smpl_discriminator(random_rotation_3D((world[key] - world[key][:, 0:1])[:, h] / 1000)
                                                           [..., :self.DISC_SUP_DIMENSION]) for h in range(rel.shape[1])], dim=1)
                     total = total + compute_disc_loss(logits, None) * 0.7 + compute_disc_loss(rot, None) * 0.3
             losses['smpl_gen'] = total * lc['smpl_gen_loss']['weight']
@@ -253,15 +255,15 @@ class Counter3DDisc(torch.nn.Module):
             key = 'cam_{}'.format(cam)
             real = reals[key]
             real_world = _to_world(real, x, key, True)
-            out['pose_smpl_2d_{}'.format(key)] = real[[0]]
-            out['pose_smpl_3d_{}'.format(key)] = real_world[[0]].clone()
+            out['pose_smpl_2d_{}'.format(key)] = real[0:1]
+            out['pose_smpl_3d_{}'.format(key)] = real_world[0:1].clone()
             mine = logits[ci * per_cam:(ci + 1) * per_cam]
             fake_logits, real_logits = torch.stack(mine[:-1], dim=1), mine[-1]
-            out['smpl_logits_{}'.format(key)] = real_logits[[0]]
-            out['pred_logits_{}'.format(key)] = fake_logits[[0], 0]
+            out['smpl_logits_{}'.format(key)] = real_logits[0:1]
+            out['pred_logits_{}'.format(key)] = fake_logits[0:1, 0]
             if self.use_aug:
                 rot = random_rotation_3D(real_world)
-                out['pose_smpl_3d_{}_rot'.format(key)] = rot[[0]]
+                out['pose_smpl_3d_{}_rot'.format(key)] = rot[0:1]
                 total = total + compute_disc_loss(fake_logits, real_logits) * 0.6 \
                     + compute_disc_loss(self.smpl_discriminator(rot[..., :d]), None) * 0.4
             else:

@@ -79,7 +79,7 @@ def smpl_to_h36m(verts, h36m_regressor):
     j = torch.einsum('bki,lk->bli', verts, h36m_regressor)
     j = j[:, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 14, 15, 16, 11, 12, 13]]
     j = torch.cat([j, j[:, [11, 14]].mean(dim=1, keepdim=True)], dim=1)
-    return j - j[:, [0]]
+    return j - j[:, 0:1]
 
 
 def random_rotation_3D(keypoints):
