@@ -501,3 +501,31 @@ def test_dedupe_step_is_bit_identical(monkeypatch):
         for k in a[2]:
             assert torch.equal(a[2][k], b[2][k]), k
     assert int(a[2]['net.backbone.bn1.num_batches_tracked']) == 2 * (2 + 2 + 2)   # disc + real + pseudo passes, 2 cams
+
+
+def test_step_switches_are_bit_identical(monkeypatch):
+    """The step-level switches that only change WHERE a value is computed must not change any bit of the result:
+    sign-mask batch-norm backward with the skip gradient formed in conv1's data-gradient epilogue (XAS_BN_MASK, default on)
+    vs the y-reading form with a materialised residual gradient."""
+    from modules.discriminator import GCNDiscriminatorDecouple
+    from modules.model import Counter3DDisc, Counter3DModel
+    from xas_amd.engine import TrainStep
+    from xas_amd.optim import FusedAdam
+    cfg = gi.model_params('S2', cam_ids=(0, 1))
+    full = {'model_params': cfg, 'train_params': {'lr_kp_detector': 1e-4, 'lr_discriminator': 1e-4}}
+    xg = {k: T(v).cuda() for k, v in gi.synthetic_batch(2, [0, 1], seed=94).items()}
+    states = []
+    for mask in ('1', '0'):
+        monkeypatch.setenv('XAS_BN_MASK', mask)
+        reg, phys, _, _ = _hip_models('S2', (0, 1))
+        disc = gi.seeded_fill_(GCNDiscriminatorDecouple(cfg['smpl_disc_params']), seed=9).cuda().train()
+        disc.header.p = 0.0
+        gen, dis = Counter3DModel(cfg, reg, None, None, phys), Counter3DDisc(cfg, disc, None, None)
+        opt_det = FusedAdam(list(reg.parameters()) + list(phys.parameters()), lr=1e-4, betas=(0.5, 0.999))
+        opt_disc = FusedAdam(disc.parameters(), lr=1e-4, betas=(0.5, 0.999))
+        step = TrainStep(full, gen, dis, opt_det, opt_disc)
+        for _ in range(2):
+            step(xg)
+        torch.cuda.synchronize()
+        states.append((opt_det.param_arena.clone(), opt_disc.param_arena.clone()))
+    assert torch.equal(states[0][0], states[1][0]) and torch.equal(states[0][1], states[1][1])

@@ -167,6 +167,10 @@ class _PackCache:
             self.key, self.packed = key, {}
         if transposed not in self.packed:
             co, ci, r, s = w.shape
+            if not transposed and r == 1 and s == 1 and w.is_contiguous() and w.data_ptr() % 16 == 0:
+                # a 1x1 filter in OIHW order IS the packed [Cout][R][S][Cin] layout: no copy (36 of ResNet-50's 53 convs)
+                self.packed[transposed] = w.detach().view(-1)
+                return self.packed[transposed]
             p = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
             call('xas_pack_weight', ptr(w.detach().contiguous()), ptr(p), co, ci, r, s, int(transposed))
             self.packed[transposed] = p
@@ -627,7 +631,7 @@ def _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, m
     y = torch.empty_like(x)
     # layers with a residual (block outputs): the backward needs only the SIGN of the pre-activation value, saved as one
     # byte per float4 (1/16 of y's bytes) - neither backward pass reads y
-    masked = training and residual is not None and act != ACT_NONE and os.environ.get('XAS_BN_MASK', '0') == '1'
+    masked = training and residual is not None and act != ACT_NONE and os.environ.get('XAS_BN_MASK', '1') == '1'
     mask = torch.empty(M * c // 4, device=dev, dtype=torch.uint8) if masked else None
     call('xas_bn_apply', ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(res), float(eps), act, M, c, G, ptr(y), ptr(mask))
     # Backward traffic: which of x / y the backward passes need
