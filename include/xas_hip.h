@@ -230,6 +230,9 @@ int xas_bn_sync_merge(const float* gathered, int world, int groups, int C, long 
 /* out[c] = sum_m x[m][c]  (bias gradients: deconv_head.py:34, physique_network.py:17, discriminator.py:11);
  * workspace: xas_bn_workspace_floats(M, C, 1) */
 int xas_col_sum(const float* x, long M, int C, float* out, float* workspace, void* stream);
+/* acc[c] += column sums (bias gradients accumulated in place: nn.Conv2d / nn.Linear bias, physique_network.py:16,
+ * discriminator.py:23).  workspace as xas_col_sum. */
+int xas_col_sum_acc(const float* x, long M, int C, float* acc, float* workspace, void* stream);
 /* y = act(gamma*(x-mean_g)*rsqrt(var_g+eps)+beta [+ residual]); mean / var_biased: [groups][C].
  * mask_out (may be NULL): [M*C/4] bytes, bit e of byte i = (pre-activation value of element 4i+e > 0): all the backward
  * needs of y for a layer with a residual, at 1/16 of y's bytes. */

@@ -327,3 +327,20 @@ def test_conv_dgrad_bn_bwd(n, cin, h, w, cout, k, stride, pad, G):
     call('xas_conv_dgrad_bn_bwd', ptr(dyg), ptr(cache.get(wg, 1)), shp, ptr(xbg), ptr(mean), ptr(var), ptr(gam), ptr(bet),
          eps, G, float(Mg), ptr(dz), ptr(dx), ptr(sums2), ptr(ws), None, None)
     assert torch.equal(sums2, sums)
+
+
+@pytest.mark.parametrize('M,C', [(1000, 32), (8 * 64 * 64, 64), (77, 4), (300000, 128), (5, 260)])
+def test_col_sum_acc(M, C):
+    """xas_col_sum_acc: acc += column sums (conv bias gradients added into the gradient arena in place)."""
+    from xas_amd._lib import call, ptr, query
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g)
+    acc0 = torch.randn(C, generator=g)
+    xg, acc = x.cuda(), acc0.cuda()
+    ws = torch.empty(query('xas_bn_workspace_floats', M, C, 1), device='cuda')
+    call('xas_col_sum_acc', ptr(xg), M, C, ptr(acc), ptr(ws))
+    ref = acc0.double() + x.double().sum(0)
+    assert float((acc.cpu().double() - ref).abs().max()) < 1e-5 * (1 + float(x.abs().sum(0).max()))
+    call('xas_col_sum_acc', ptr(xg), M, C, ptr(acc), ptr(ws))                 # twice: accumulates again
+    ref = ref + x.double().sum(0)
+    assert float((acc.cpu().double() - ref).abs().max()) < 2e-5 * (1 + float(x.abs().sum(0).max()))

@@ -33,5 +33,36 @@ def main():
         print('upsample2x_bwd  %s  %.3f ms  %.2f TB/s' % ((n, c, h, w), t * 1e3, byts / t / 1e12))
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and 'conv' not in sys.argv[1:]:
     main()
+
+
+def conv_cases():
+    """Short-K 1x1 layers of the bottleneck stack: plain forward vs forward + statistics epilogue."""
+    from xas_amd import ops_nn as F
+    from xas_amd._lib import query
+    dev = 'cuda'
+    for (n, cin, h, cout, k) in [(256, 64, 64, 256, 1), (256, 128, 32, 512, 1), (256, 256, 64, 64, 1), (256, 64, 64, 64, 3)]:
+        x = torch.randn(n, h, h, cin, device=dev)
+        w = torch.randn(cout, k, k, cin, device=dev) * 0.05
+        y = torch.empty(n, h, h, cout, device=dev)
+        shp = F._shape(n, h, h, cin, cout, k, k, 1, k // 2, h, h)
+        fl = 2.0 * n * h * h * cin * cout * k * k
+        byts = (x.numel() + y.numel()) * 4
+        t = timed(lambda: call('xas_conv_fwd', ptr(x), ptr(w), None, ptr(y), shp))
+        print('conv_fwd          %s  %.3f ms  %.1f TF  %.2f TB/s' % ((n, cin, h, cout, k), t * 1e3, fl / t / 1e12, byts / t / 1e12))
+        G = 8
+        mean = torch.empty(G, cout, device=dev); var = torch.empty(G, cout, device=dev)
+        ws = torch.empty(query('xas_conv_fwd_bnstats_workspace_floats', shp, G), device=dev)
+        t = timed(lambda: call('xas_conv_fwd_bnstats', ptr(x), ptr(w), ptr(y), shp, G, None, ptr(mean), ptr(var), cout, None,
+                               ptr(ws), None, None, 0.1))
+        print('conv_fwd_bnstats  %s  %.3f ms  %.1f TF  %.2f TB/s' % ((n, cin, h, cout, k), t * 1e3, fl / t / 1e12, byts / t / 1e12))
+        for tune in (4, 32, 8388608 | 16777216):
+            query('xas_set_tuning', tune)
+            t = timed(lambda: call('xas_conv_fwd', ptr(x), ptr(w), None, ptr(y), shp))
+            print('   tune %-9d      %.3f ms  %.1f TF' % (tune, t * 1e3, fl / t / 1e12))
+        query('xas_set_tuning', 0)
+
+
+if __name__ == '__main__' and 'conv' in sys.argv[1:]:
+    conv_cases()

@@ -954,6 +954,21 @@ extern "C" int xas_bn_update_running(const float* mean, const float* var_biased,
   return 0;
 }
 
+// acc[c] += sum over rows of x[:, c] (bias gradients added straight into the gradient arena, on the weight-gradient stream)
+extern "C" int xas_col_sum_acc(const float* x, long M, int C, float* acc, float* workspace, void* stream) {
+  ColGeom g;
+  if (col_geom(M, C, 1, &g)) return 1;
+  XAS_REQUIRE(x && acc && workspace && (((uintptr_t)acc) & 15) == 0, "col_sum_acc: null / misaligned buffer");
+  ColArgs a{};
+  if (col_args(&a, g, M, C, workspace)) return 1;
+  float* scratch = workspace + (size_t)g.nslab * 2 * C;                 // C floats: plain sums, second sums and their accumulator
+  a.x = x; a.out1 = scratch; a.out2 = scratch; a.out_stride = C;
+  a.acc1 = acc; a.acc2 = scratch;
+  hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(g.nslab, g.ncb, 1), dim3(256), 0, as_stream(stream), a);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy, const float* mean,
                                  const float* var_biased, const float* gamma, const float* beta, float eps, int act,
                                  long M, int C, int groups, float* sums, float* workspace,

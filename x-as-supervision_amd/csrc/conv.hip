@@ -1825,8 +1825,12 @@ static int launch_tile(const IgemmParams& p, int Mrows_max, int phases, hipStrea
       return launch_igemm_buf<BM, BN, 1, true, true>(p, Mrows_max, phases, st);
     }
   }
+  // K loops of one or two steps (1x1 layers with 32 / 64 input channels): the pipelined loop's look-ahead loads have
+  // nothing to look ahead to (they re-load the last step) - the plain loop is 18 % faster there (0.608 -> 0.497 ms for
+  // 64 -> 256 channels at 256 x 64 x 64, tools/bench_ops.py); tune bit25 keeps the pipelined loop everywhere
+  const bool short_k = p.stride == 1 && (long)p.R * p.S * p.Cs <= 2 * BK && !(p.tune & (1 << 25));
   if (fits && !(p.tune & 64)) {                       // tune bit5 (32): plain K-loop instead of the pipelined one
-    if (p.tune & 32) return launch_igemm_buf<BM, BN, MODE, false>(p, Mrows_max, phases, st);
+    if ((p.tune & 32) || short_k) return launch_igemm_buf<BM, BN, MODE, false>(p, Mrows_max, phases, st);
     return launch_igemm_buf<BM, BN, MODE, true>(p, Mrows_max, phases, st);
   }
   if (p.tune & 32) return launch_igemm<BM, BN, MODE, 2, false>(p, Mrows_max, phases, st);
@@ -1847,7 +1851,9 @@ static int launch_igemm_bf16(const IgemmParams& p, int Mrows_max, int phases, hi
 }
 
 // tile of the fp32 path for a problem (the one rule both the launcher and xas_conv_fwd_bnstats go by)
-static void pick_tile(int Cd, long Mrows_max, int phases, int tune, int* bm, int* bn) {
+static void pick_tile(int Cd, long Mrows_max, int phases, int tune, int* bm, int* bn, long Ktot = 1 << 30) {
+  // experiment (tune bits 23 / 24): short K loops (<= 64 / <= 128 deep) are streaming kernels - more, smaller blocks per CU
+  if (Cd >= 64 && (((tune >> 23) & 1 && Ktot <= 64) || ((tune >> 24) & 1 && Ktot <= 128))) { *bm = 64; *bn = 64; return; }
   if (Cd >= 96) {
     // small problems (layer3/4 at B=32: M = 8192 / 2048 rows): 128x128 tiles leave most of the 256 CUs idle
     const long blocks128 = cdiv(Mrows_max, 128) * cdiv(Cd, 128) * phases;
@@ -1873,7 +1879,7 @@ static int dispatch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipSt
     }
   }
   int bm, bn;
-  pick_tile(p.Cd, Mrows_max, phases, p.tune, &bm, &bn);
+  pick_tile(p.Cd, Mrows_max, phases, p.tune, &bm, &bn, (long)p.R * p.S * p.Cs);
   if (bn == 128) return launch_tile<128, 128, MODE>(p, Mrows_max, phases, st);
   if (bm == 64) return launch_tile<64, 64, MODE>(p, Mrows_max, phases, st);
   if (bn == 64) return launch_tile<128, 64, MODE>(p, Mrows_max, phases, st);
@@ -1922,7 +1928,7 @@ static int fwd_stats_tile_rows(const xas_conv_shape* s, int groups) {
   if (images_per_launch(s->N, (long)s->Hi * s->Wi * s->Cin, 0) < s->N || s->N % groups) return 0;
   const long M = (long)s->N * s->Ho * s->Wo, Mg = M / groups;
   int bm, bn;
-  pick_tile(s->Cout, M, 1, g_tune, &bm, &bn);
+  pick_tile(s->Cout, M, 1, g_tune, &bm, &bn, (long)s->R * s->S * s->Cin);
   if (Mg % bm) return 0;
   if ((M / bm) * 2 * (long)s->Cout * 4 >= 0x7fffff00l) return 0;
   return bm;
@@ -2110,7 +2116,7 @@ static int dgrad_bnb_tile_rows(const xas_conv_shape* s, int groups) {
   if (images_per_launch(s->N, (long)s->Ho * s->Wo * s->Cout, 0) < s->N || s->N % groups) return 0;
   const long M = (long)s->N * s->Hi * s->Wi, Mg = M / groups;
   int bm, bn;
-  pick_tile(s->Cin, M, 1, g_tune, &bm, &bn);
+  pick_tile(s->Cin, M, 1, g_tune, &bm, &bn, (long)s->R * s->S * s->Cout);
   if (Mg % bm || s->Cin % bn) return 0;
   if ((M / bm) * 2 * (long)s->Cin * 4 >= 0x7fffff00l) return 0;
   return bm;

@@ -52,6 +52,7 @@ SIGNATURES = {
     'xas_bn_bwd_sums_from_partials': ('pliippppp', 'i'),
     'xas_bn_sync_merge': ('piiilppppfp', 'i'),
     'xas_col_sum': ('plippp', 'i'),
+    'xas_col_sum_acc': ('plippp', 'i'),
     'xas_bn_apply': ('ppppppfiliippp', 'i'),
     'xas_bn_update_running': ('ppppfliip', 'i'),
     'xas_bn_bwd_reduce': ('pppppppfiliipppppp', 'i'),

@@ -5,7 +5,8 @@ import torch
 
 from . import _lib
 
-CONV_ENTRIES = ('xas_conv_fwd', 'xas_conv_dgrad', 'xas_conv_dgrad_acc', 'xas_conv_dgrad_acc_masked', 'xas_conv_wgrad',
+# (xas_conv_fwd_bnstats: the bracket also holds the ~10 us reduction of the per-tile partial sums that follows the convolution)
+CONV_ENTRIES = ('xas_conv_fwd', 'xas_conv_fwd_bnstats', 'xas_conv_dgrad', 'xas_conv_dgrad_acc', 'xas_conv_dgrad_acc_masked', 'xas_conv_wgrad',
                 'xas_conv_wgrad_oihw', 'xas_conv_wgrad_acc')
 
 
@@ -43,7 +44,7 @@ class KernelTimer:
             raise RuntimeError('%s failed (%d): %s' % (name, rc, _lib.load().xas_last_error().decode()))
         mfma = False
         if shape is not None:
-            if name == 'xas_conv_fwd':
+            if name in ('xas_conv_fwd', 'xas_conv_fwd_bnstats'):
                 mfma = (shape.Cin % 32 == 0 and shape.Cout >= 16) or (shape.Cin == 3 and shape.R == 7 and shape.Cout == 64)
             elif name in ('xas_conv_dgrad', 'xas_conv_dgrad_acc', 'xas_conv_dgrad_acc_masked'):
                 mfma = shape.Cout % 32 == 0 and shape.Cin >= 16
