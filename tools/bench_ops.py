@@ -33,7 +33,7 @@ def main():
         print('upsample2x_bwd  %s  %.3f ms  %.2f TB/s' % ((n, c, h, w), t * 1e3, byts / t / 1e12))
 
 
-if __name__ == '__main__' and 'conv' not in sys.argv[1:]:
+if __name__ == '__main__' and len(sys.argv) == 1:
     main()
 
 
@@ -66,3 +66,44 @@ def conv_cases():
 
 if __name__ == '__main__' and 'conv' in sys.argv[1:]:
     conv_cases()
+
+
+def thin_cases():
+    """Weight gradients of the one-channel 3x3 convs of the physique network (1 -> 32 and 32 -> 1 at 256 x 256)."""
+    from xas_amd import ops_nn as F
+    from xas_amd._lib import query
+    dev = 'cuda'
+    n, h, c = 128, 256, 32
+    for cin, cout in ((1, c), (c, 1)):
+        x = torch.randn(n, h, h, cin, device=dev)
+        dy = torch.randn(n, h, h, cout, device=dev)
+        shp = F._shape(n, h, h, cin, cout, 3, 3, 1, 1, h, h)
+        dw = torch.empty(cout, cin, 3, 3, device=dev)
+        ws = torch.empty(max(1, query('xas_conv_wgrad_workspace_floats', shp)), device=dev)
+        t = timed(lambda: call('xas_conv_wgrad_oihw', ptr(x), ptr(dy), ptr(dw), ptr(ws), shp))
+        byts = (x.numel() + dy.numel()) * 4
+        print('thin wgrad %d -> %d  %.3f ms  %.2f TB/s' % (cin, cout, t * 1e3, byts / t / 1e12))
+
+
+if __name__ == '__main__' and 'thin' in sys.argv[1:]:
+    thin_cases()
+
+
+def thin_fwd_cases():
+    from xas_amd import ops_nn as F
+    dev = 'cuda'
+    n, h, c = 128, 256, 32
+    for cin, cout in ((1, c), (c, 1)):
+        x = torch.randn(n, h, h, cin, device=dev)
+        y = torch.empty(n, h, h, cout, device=dev)
+        w = torch.randn(cout * 9 * cin, device=dev)
+        shp = F._shape(n, h, h, cin, cout, 3, 3, 1, 1, h, h)
+        byts = (x.numel() + y.numel()) * 4
+        t = timed(lambda: call('xas_conv_fwd', ptr(x), ptr(w), None, ptr(y), shp))
+        print('thin fwd   %d -> %d  %.3f ms  %.2f TB/s' % (cin, cout, t * 1e3, byts / t / 1e12))
+        t = timed(lambda: call('xas_conv_dgrad', ptr(y), ptr(w), ptr(x), shp))
+        print('thin dgrad %d -> %d  %.3f ms  %.2f TB/s' % (cin, cout, t * 1e3, byts / t / 1e12))
+
+
+if __name__ == '__main__' and 'thin' in sys.argv[1:]:
+    thin_fwd_cases()

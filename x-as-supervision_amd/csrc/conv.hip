@@ -79,6 +79,13 @@ struct IgemmParams {
 
 static unsigned long long* g_dbg = nullptr;
 
+constexpr int kMaxDevices = 16;
+static inline int current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+  return d;
+}
+
 static int g_tune = 0;
 int tune_flags() { return g_tune; }
 
@@ -1559,14 +1566,23 @@ __global__ __launch_bounds__(256) void thin_vec2scalar_kernel(const float* __res
     const bool on = m < M;
     int n, h, w;
     thin_decode(p, on ? m : 0u, &n, &h, &w);
-    float acc = 0.f;
+    // all nine 16-byte loads are issued before the first is used (clamped address, zero weight outside the image): a
+    // `continue` around each load made every tap wait out its own round trip
+    float4 a[9];
+    bool inb[9];
+    const float* Vn = V + (size_t)n * p.H * p.W * p.C + cq * 4;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       int hs, ws;
-      if (!thin_src(p, h, w, tap / 3, tap % 3, &hs, &ws)) continue;
-      const float4 a = *reinterpret_cast<const float4*>(V + (((size_t)n * p.H + hs) * p.W + ws) * p.C + cq * 4);
-      acc = fmaf(a.x, wv[tap].x, acc); acc = fmaf(a.y, wv[tap].y, acc);
-      acc = fmaf(a.z, wv[tap].z, acc); acc = fmaf(a.w, wv[tap].w, acc);
+      inb[tap] = thin_src(p, h, w, tap / 3, tap % 3, &hs, &ws);
+      a[tap] = *reinterpret_cast<const float4*>(Vn + (size_t)(inb[tap] ? hs * p.W + ws : h * p.W + w) * p.C);
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      float t = a[tap].x * wv[tap].x;
+      t = fmaf(a[tap].y, wv[tap].y, t); t = fmaf(a[tap].z, wv[tap].z, t); t = fmaf(a[tap].w, wv[tap].w, t);
+      acc += inb[tap] ? t : 0.f;
     }
     for (int o = C4 >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);     // the C4 lanes of a pixel are adjacent
     if (on && cq == 0) out[m] = acc + b0;
@@ -1592,11 +1608,12 @@ __global__ __launch_bounds__(256) void thin_scalar2vec_kernel(const float* __res
     int n, h, w;
     thin_decode(p, m, &n, &h, &w);
     float4 acc = b4;
+    const float* Sn = S + (size_t)n * p.H * p.W;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       int hs, ws;
-      if (!thin_src(p, h, w, tap / 3, tap % 3, &hs, &ws)) continue;
-      const float sv = S[((size_t)n * p.H + hs) * p.W + ws];
+      const bool inb = thin_src(p, h, w, tap / 3, tap % 3, &hs, &ws);
+      const float sv = inb ? Sn[hs * p.W + ws] : 0.f;
       acc.x = fmaf(sv, wv[tap].x, acc.x); acc.y = fmaf(sv, wv[tap].y, acc.y);
       acc.z = fmaf(sv, wv[tap].z, acc.z); acc.w = fmaf(sv, wv[tap].w, acc.w);
     }
@@ -1607,8 +1624,11 @@ __global__ __launch_bounds__(256) void thin_scalar2vec_kernel(const float* __res
 // slabs[chunk][c][tap];  scalar_at_src = 0: S = dy[m], V = x[src(m,tap)]   (wgrad Cout = 1)
 //                        scalar_at_src = 1: S = x[src(m,tap)], V = dy[m]   (wgrad Cin = 1)
 __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict__ S, const float* __restrict__ V,
-                                                         float* __restrict__ slabs, ThinParams p, int scalar_at_src,
+                                                         float* __restrict__ slabs, ThinParams p, int dir,
                                                          int m_per_chunk) {
+  // dW[c][tap] = sum over pixels m of V[m][c] * S[m + dir * (tap - centre)]: the VECTOR side is walked once (one 16-byte
+  // load per lane and pixel, four pixels in flight), the scalar side is gathered (9 taps, L1 hits).
+  //   Cin == 1 : V = dy at the output pixel, S = x,  dir = +1;   Cout == 1: V = x at the source pixel, S = dy, dir = -1.
   __shared__ float4 red[4 * 16 * 9];
   const int C4 = p.C / 4, lanes = 256 / C4;
   const int cq = threadIdx.x % C4, pl = threadIdx.x / C4;
@@ -1617,20 +1637,30 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
   float4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = make_float4(0, 0, 0, 0);
-  for (unsigned m = mbeg + pl; m < mend; m += lanes) {
-    int n, h, w;
-    thin_decode(p, m, &n, &h, &w);
-    float s0 = 0.f; float4 v0 = make_float4(0, 0, 0, 0);
-    if (!scalar_at_src) s0 = S[m]; else v0 = *reinterpret_cast<const float4*>(V + (size_t)m * p.C + cq * 4);
+  constexpr int U = 4;
+  for (unsigned m = mbeg + pl; m < mend; m += U * lanes) {
+    float4 vv[U];
+    unsigned mu[U];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      int hs, ws;
-      if (!thin_src(p, h, w, tap / 3, tap % 3, &hs, &ws)) continue;
-      const size_t sp = ((size_t)n * p.H + hs) * p.W + ws;
-      const float sv = scalar_at_src ? S[sp] : s0;
-      const float4 vv = scalar_at_src ? v0 : *reinterpret_cast<const float4*>(V + sp * p.C + cq * 4);
-      acc[tap].x = fmaf(sv, vv.x, acc[tap].x); acc[tap].y = fmaf(sv, vv.y, acc[tap].y);
-      acc[tap].z = fmaf(sv, vv.z, acc[tap].z); acc[tap].w = fmaf(sv, vv.w, acc[tap].w);
+    for (int u = 0; u < U; ++u) {
+      mu[u] = m + u * lanes;
+      const bool on = mu[u] < mend;
+      vv[u] = *reinterpret_cast<const float4*>(V + (size_t)(on ? mu[u] : mbeg) * p.C + cq * 4);
+      if (!on) vv[u] = make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int n, h, w;
+      thin_decode(p, mu[u] < mend ? mu[u] : mbeg, &n, &h, &w);
+      const float* Sn = S + (size_t)n * p.H * p.W;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int hs = h + dir * (tap / 3 - p.pad), ws = w + dir * (tap % 3 - p.pad);
+        const bool inb = (unsigned)hs < (unsigned)p.H && (unsigned)ws < (unsigned)p.W;
+        const float sv = inb ? Sn[hs * p.W + ws] : 0.f;
+        acc[tap].x = fmaf(sv, vv[u].x, acc[tap].x); acc[tap].y = fmaf(sv, vv[u].y, acc[tap].y);
+        acc[tap].z = fmaf(sv, vv[u].z, acc[tap].z); acc[tap].w = fmaf(sv, vv[u].w, acc[tap].w);
+      }
     }
   }
   // reduce over the pixel lanes: inside a wave by shuffles (lanes cq, cq + C4, ... hold the same channels), then across
@@ -1780,7 +1810,8 @@ static int check_fwd_dims(const xas_conv_shape* s, const char* who) {
 template <int BM, int BN, int MODE, int NBUF = 2, bool PIPE = false>
 static int launch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
   const size_t lds = (size_t)NBUF * (BM + BN) * LDK * sizeof(float);
-  static bool attr_set = false;
+  static bool attr_set_dev[kMaxDevices] = {};          // per device: the LDS limit is a per-device function attribute
+  bool& attr_set = attr_set_dev[current_device()];
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, NBUF, PIPE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1798,7 +1829,8 @@ static int launch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStre
 template <int BM, int BN, int MODE, bool PIPE, bool BNB = false>
 static int launch_igemm_buf(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
   const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
-  static bool attr_set = false;
+  static bool attr_set_dev[kMaxDevices] = {};          // per device: the LDS limit is a per-device function attribute
+  bool& attr_set = attr_set_dev[current_device()];
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_buf_kernel<BM, BN, MODE, PIPE, BNB>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2211,7 +2243,8 @@ extern "C" size_t xas_conv_wgrad_workspace_floats(const xas_conv_shape* s) {
 template <int BM, int BN, bool VEC>
 static int launch_wgrad(const WgradParams& p, int splits, hipStream_t st) {
   const size_t lds = (size_t)2 * WBK * ((BM + 4) + (BN + 4)) * sizeof(float);
-  static bool attr_set = false;
+  static bool attr_set_dev[kMaxDevices] = {};          // per device: the LDS limit is a per-device function attribute
+  bool& attr_set = attr_set_dev[current_device()];
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<BM, BN, VEC>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2233,7 +2266,8 @@ static int launch_wgrad_buf_t(const WgradParams& p, int splits, hipStream_t st) 
   if (PIPE && (g_tune & 524288)) return launch_wgrad_buf_t<BM, BN, T, false>(p, splits, st);   // tune bit19: plain K-loop
   size_t lds = (size_t)2 * WBK * ((BM + 4) + (BN + 32)) * sizeof(float);
   if ((g_tune & 131072) && lds < 84 * 1024) lds = 84 * 1024;     // experiment (bit17): one block per CU
-  static size_t attr_set = 0;
+  static size_t attr_set_dev[kMaxDevices] = {};
+  size_t& attr_set = attr_set_dev[current_device()];
   if (attr_set < lds) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_buf_kernel<BM, BN, T, PIPE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2314,7 +2348,7 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
     const int per_chunk = (int)(cdiv(cdiv(M, chunks), 256) * 256);
     chunks = (int)cdiv(M, per_chunk);
     hipLaunchKernelGGL(thin_wgrad_kernel, dim3(chunks), dim3(256), 0, st, cout1 ? dy : x, cout1 ? x : dy, workspace, tp,
-                       cout1 ? 0 : 1, per_chunk);
+                       cout1 ? -1 : 1, per_chunk);
     XAS_LAUNCH_CHECK();
     const long n = (long)C * 9;
     if (oihw || !cout1) {
