@@ -368,6 +368,15 @@ int xas_smpl_lbs_fwd(const float* pose /*[B][72]*/, const float* betas /*[B][10]
                      int center_idx, float* verts /*[B][V][3]*/, float* joints /*[B][24][3]*/,
                      float* workspace /* B*(24*3 + 24*16 + 207) floats */, void* stream);
 
+/* Backward of xas_smpl_lbs_fwd (autograd of smpl_layer.py:63-156): d_verts [B][V][3], d_joints [B][24][3] (or NULL)
+ * -> d_pose [B][72], d_betas [B][10].  fwd_workspace: the workspace the forward call filled for the same inputs.
+ * workspace: xas_smpl_lbs_bwd_workspace_floats(B, V).  Deterministic (no atomics). */
+size_t xas_smpl_lbs_bwd_workspace_floats(int B, int V);
+int xas_smpl_lbs_bwd(const float* pose, const float* betas, const float* v_template, const float* shapedirs,
+                     const float* posedirs, const float* j_regressor, const float* weights, const int* parents, int B,
+                     int V, int center_idx, const float* fwd_workspace, const float* d_verts, const float* d_joints,
+                     float* d_pose, float* d_betas, float* workspace, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Fused multi-tensor Adam (train.py:257-264: betas (0.5, 0.999), eps 1e-8, no decay).
  * One launch updates a flat parameter arena: p, g, m, v are arenas of n floats.

@@ -219,6 +219,54 @@ def test_smpl_layer_vs_golden():
     assert 'th_posedirs' in lay.state_dict() and 'th_weights' in lay.state_dict()
 
 
+@pytest.mark.parametrize('center', [0, 5, None])
+def test_smpl_layer_backward_vs_oracle_autograd(center):
+    """d(pose), d(betas) of the SMPL layer (xas_smpl_lbs_bwd) against float64 autograd through the oracle's restatement
+    of smpl_layer.py:63-156 (itself pinned by the reference-import golden above): random output gradients on verts and
+    joints, a near-zero rotation among the joints (the 1e-8 of rodrigues_layer.py:41), deterministic run to run."""
+    from modules.smplpytorch.pytorch.smpl_layer import SMPL_Layer
+    from oracle import smpl as osmpl
+    buf = gi.smpl_buffers(seed=71)
+    gen = torch.Generator().manual_seed(5)
+    B = 3
+    pose = 0.6 * torch.randn(B, 72, generator=gen)
+    pose[0, 9:12] = 0.0                                   # identity rotation: angle = |1e-8|
+    pose[1, 30:33] = torch.tensor([1e-4, -2e-4, 5e-5])
+    betas = torch.randn(B, 10, generator=gen)
+    gv = torch.randn(B, 6890, 3, generator=gen) / 6890 ** 0.5
+    gj = torch.randn(B, 24, 3, generator=gen)
+    pd_, bd = pose.double().requires_grad_(True), betas.double().requires_grad_(True)
+    D = lambda k: T(buf[k]).double()
+    v_ref, j_ref = osmpl.smpl_lbs(pd_, bd, D('v_template'), D('shapedirs'), D('posedirs'), D('J_regressor'), D('weights'),
+                                  center_idx=center)
+    ((v_ref * gv.double()).sum() + (j_ref * gj.double()).sum()).backward()
+
+    lay = SMPL_Layer.from_arrays(buf, center_idx=center).cuda()
+    grads = []
+    for _ in range(2):
+        pg, bg = pose.cuda().requires_grad_(True), betas.cuda().requires_grad_(True)
+        verts, jtr = lay(pg, bg)
+        ((verts * gv.cuda()).sum() + (jtr * gj.cuda()).sum()).backward()
+        grads.append((pg.grad.clone(), bg.grad.clone()))
+    assert maxabs(verts, v_ref.float()) < 3e-5 and maxabs(jtr, j_ref.float()) < 3e-5
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    mask = torch.ones(B, 72, dtype=torch.bool)
+    mask[0, 9:12] = False                                 # d/dtheta at theta = 0 divides by the 1e-8 guard: compare the rest tightly
+    ref_p, got_p = pd_.grad.float(), grads[0][0].cpu()
+    assert float((got_p - ref_p)[mask].abs().max()) < 2e-4 * float(ref_p[mask].abs().max())
+    assert rel(grads[0][1], bd.grad) < 2e-4
+    # only the vertex gradient / only the joint gradient
+    pg, bg = pose.cuda().requires_grad_(True), betas.cuda().requires_grad_(True)
+    verts, jtr = lay(pg, bg)
+    (jtr * gj.cuda()).sum().backward()
+    p2, b2 = pose.double().requires_grad_(True), betas.double().requires_grad_(True)
+    _, j2 = osmpl.smpl_lbs(p2, b2, D('v_template'), D('shapedirs'), D('posedirs'), D('J_regressor'), D('weights'),
+                           center_idx=center)
+    (j2 * gj.double()).sum().backward()
+    assert float((pg.grad.cpu() - p2.grad.float())[mask].abs().max()) < 2e-4 * float(p2.grad[mask].abs().max())
+    assert rel(bg.grad, b2.grad) < 2e-4
+
+
 def test_fused_adam_vs_torch():
     from xas_amd.optim import FusedAdam
     g = torch.Generator().manual_seed(0)

@@ -512,6 +512,242 @@ __global__ void smpl_verts_kernel(const float* __restrict__ betas, const float* 
   for (int r = 0; r < 3; ++r) o[r] = T[r * 4] * p[0] + T[r * 4 + 1] * p[1] + T[r * 4 + 2] * p[2] + T[r * 4 + 3] - cen[r];
 }
 
+// ------------------------------------------------------------------ SMPL LBS backward
+// d(verts), d(joints) -> d(pose), d(betas).  Three launches:
+//   1. vertex pass (same tiling as the forward): recompute v_posed and the blended transform T of each vertex,
+//      dv_posed = T_R^T dV, and reduce over the block's 128 vertices
+//        dG'[j] += w[v][j] * [dV (x) v_posed | dV],  dpose_map += PD[v]^T dv_posed,  dbeta += SD[v]^T dv_posed,  sum dV
+//      into per-block partial records (no atomics: the second pass sums them in block order);
+//   2. per sample: sum the partials, walk the kinematic chain backwards (children before parents), Rodrigues backward;
+//   3. per sample: the joint-regressor term of d(betas).
+constexpr int kSmplP = 24 * 12 + 207 + 10 + 3;   // dG' | dpose_map | dbeta (vertex term) | sum dV
+
+__global__ __launch_bounds__(128) void smpl_bwd_verts_kernel(const float* __restrict__ betas, const float* __restrict__ vt,
+                                                             const float* __restrict__ sd, const float* __restrict__ pd,
+                                                             const float* __restrict__ wts, const float* __restrict__ ws,
+                                                             const float* __restrict__ dverts, int V,
+                                                             float* __restrict__ partial) {
+  __shared__ float g2[24 * 16];
+  __shared__ float pm[207];
+  __shared__ float bt[10];
+  __shared__ float s_dv[128][3], s_p[128][3], s_dvp[128][3];
+  const int b = blockIdx.y, t = threadIdx.x;
+  const float* wsb = ws + (size_t)b * (72 + 24 * 16 + 207);
+  for (int i = t; i < 24 * 16; i += blockDim.x) g2[i] = wsb[72 + i];
+  for (int i = t; i < 207; i += blockDim.x) pm[i] = wsb[72 + 24 * 16 + i];
+  if (t < 10) bt[t] = betas[b * 10 + t];
+  __syncthreads();
+  const int v0 = blockIdx.x * 128, v = v0 + t;
+  const bool on = v < V;
+  float p[3] = {0.f, 0.f, 0.f}, dV[3] = {0.f, 0.f, 0.f}, dvp[3] = {0.f, 0.f, 0.f};
+  if (on) {
+    for (int c = 0; c < 3; ++c) {
+      float a = vt[v * 3 + c];
+      const float* d = sd + ((size_t)v * 3 + c) * 10;
+      for (int k = 0; k < 10; ++k) a = fmaf(d[k], bt[k], a);
+      const float* q = pd + ((size_t)v * 3 + c) * 207;
+      for (int k = 0; k < 207; ++k) a = fmaf(q[k], pm[k], a);
+      p[c] = a;
+    }
+    float T[12];
+    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+    for (int j = 0; j < 24; ++j) {
+      const float w = wts[(size_t)v * 24 + j];
+      if (w == 0.f) continue;
+      for (int e = 0; e < 12; ++e) T[e] = fmaf(w, g2[j * 16 + e], T[e]);
+    }
+    const float* g = dverts + ((size_t)b * V + v) * 3;
+    for (int r = 0; r < 3; ++r) dV[r] = g[r];
+    for (int c = 0; c < 3; ++c) dvp[c] = T[c] * dV[0] + T[4 + c] * dV[1] + T[8 + c] * dV[2];
+  }
+  for (int c = 0; c < 3; ++c) { s_dv[t][c] = dV[c]; s_p[t][c] = p[c]; s_dvp[t][c] = dvp[c]; }
+  __syncthreads();
+  const int nv = min(128, V - v0);
+  float* out = partial + ((size_t)b * gridDim.x + blockIdx.x) * kSmplP;
+  for (int o = t; o < kSmplP; o += blockDim.x) {
+    float a = 0.f;
+    if (o < 288) {
+      const int j = o / 12, e = o % 12, r = e >> 2, c = e & 3;
+      for (int u = 0; u < nv; ++u) {
+        const float w = wts[(size_t)(v0 + u) * 24 + j];
+        a = fmaf(w * s_dv[u][r], c < 3 ? s_p[u][c] : 1.f, a);
+      }
+    } else if (o < 288 + 207) {
+      const int k = o - 288;
+      for (int u = 0; u < nv; ++u) {
+        const float* q = pd + (size_t)(v0 + u) * 3 * 207 + k;
+        a = fmaf(q[0], s_dvp[u][0], a); a = fmaf(q[207], s_dvp[u][1], a); a = fmaf(q[414], s_dvp[u][2], a);
+      }
+    } else if (o < 288 + 207 + 10) {
+      const int k = o - 288 - 207;
+      for (int u = 0; u < nv; ++u) {
+        const float* q = sd + (size_t)(v0 + u) * 3 * 10 + k;
+        a = fmaf(q[0], s_dvp[u][0], a); a = fmaf(q[10], s_dvp[u][1], a); a = fmaf(q[20], s_dvp[u][2], a);
+      }
+    } else {
+      const int r = o - 288 - 207 - 10;
+      for (int u = 0; u < nv; ++u) a += s_dv[u][r];
+    }
+    out[o] = a;
+  }
+}
+
+// one block (64 threads) per sample.  ws2 per sample: dJ0 [72] | dbeta (vertex term) [10]
+__global__ __launch_bounds__(64) void smpl_bwd_chain_kernel(const float* __restrict__ pose, const int* __restrict__ parents,
+                                                            int center_idx, const float* __restrict__ ws,
+                                                            const float* __restrict__ partial, int nblk,
+                                                            const float* __restrict__ djoints, float* __restrict__ d_pose,
+                                                            float* __restrict__ ws2) {
+  __shared__ float acc[kSmplP];
+  __shared__ float R[24][9], Rg[24][9], dR[24][9], dRg[24][9];
+  __shared__ float dtg[24][3], dJ0[24][3];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* j0 = ws + (size_t)b * (72 + 24 * 16 + 207);
+  for (int o = t; o < kSmplP; o += blockDim.x) {
+    float a = 0.f;
+    for (int k = 0; k < nblk; ++k) a += partial[((size_t)b * nblk + k) * kSmplP + o];
+    acc[o] = a;
+  }
+  float qw = 1.f, qx = 0.f, qy = 0.f, qz = 0.f, angle = 1.f, qn = 1.f, sn = 0.f, cs = 1.f;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  if (t < 24) {                                        // Rodrigues, exactly as the forward kernel
+    ax = pose[b * 72 + t * 3]; ay = pose[b * 72 + t * 3 + 1]; az = pose[b * 72 + t * 3 + 2];
+    const float ex = ax + 1e-8f, ey = ay + 1e-8f, ez = az + 1e-8f;
+    angle = sqrtf(ex * ex + ey * ey + ez * ez);
+    const float nx = ax / angle, ny = ay / angle, nz = az / angle;
+    const float half = angle * 0.5f;
+    sn = sinf(half); cs = cosf(half);
+    float w = cs, x = sn * nx, y = sn * ny, z = sn * nz;
+    qn = sqrtf(w * w + x * x + y * y + z * z);
+    w /= qn; x /= qn; y /= qn; z /= qn;
+    qw = w; qx = x; qy = y; qz = z;
+    float* r = R[t];
+    r[0] = w * w + x * x - y * y - z * z; r[1] = 2 * x * y - 2 * w * z; r[2] = 2 * w * y + 2 * x * z;
+    r[3] = 2 * w * z + 2 * x * y; r[4] = w * w - x * x + y * y - z * z; r[5] = 2 * y * z - 2 * w * x;
+    r[6] = 2 * x * z - 2 * w * y; r[7] = 2 * w * x + 2 * y * z; r[8] = w * w - x * x - y * y + z * z;
+    for (int e = 0; e < 9; ++e) { dR[t][e] = 0.f; dRg[t][e] = 0.f; }
+    for (int c = 0; c < 3; ++c) { dtg[t][c] = 0.f; dJ0[t][c] = 0.f; }
+  }
+  __syncthreads();
+  if (t == 0) {
+    // global rotations (the translations are not needed by the backward)
+    for (int i = 0; i < 24; ++i) {
+      const int par = i == 0 ? -1 : parents[i];
+      if (par < 0) { for (int e = 0; e < 9; ++e) Rg[i][e] = R[i][e]; }
+      else {
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c) {
+            float a = 0.f;
+            for (int k = 0; k < 3; ++k) a = fmaf(Rg[par][r * 3 + k], R[i][k * 3 + c], a);
+            Rg[i][r * 3 + c] = a;
+          }
+      }
+    }
+    // outputs: joints_out[i] = tg_i - c, verts = ... - c with c = tg_center
+    float dc[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < 24; ++i)
+      for (int c = 0; c < 3; ++c) {
+        const float g = djoints ? djoints[((size_t)b * 24 + i) * 3 + c] : 0.f;
+        dtg[i][c] += g;
+        dc[c] -= g;
+      }
+    for (int c = 0; c < 3; ++c) dc[c] -= acc[288 + 207 + 10 + c];
+    if (center_idx >= 0) for (int c = 0; c < 3; ++c) dtg[center_idx][c] += dc[c];
+    // G'_j = [Rg_j | tg_j - Rg_j J0_j]
+    for (int j = 0; j < 24; ++j) {
+      const float* a = acc + j * 12;
+      for (int r = 0; r < 3; ++r) {
+        const float gt = a[r * 4 + 3];
+        for (int c = 0; c < 3; ++c) {
+          dRg[j][r * 3 + c] += a[r * 4 + c] - gt * j0[j * 3 + c];
+          dJ0[j][c] -= Rg[j][r * 3 + c] * gt;
+        }
+        dtg[j][r] += gt;
+      }
+    }
+    // pose map: p = R_i - I, i >= 1
+    for (int i = 1; i < 24; ++i)
+      for (int e = 0; e < 9; ++e) dR[i][e] += acc[288 + (i - 1) * 9 + e];
+    // chain, children before parents (parents[i] < i)
+    for (int i = 23; i >= 0; --i) {
+      const int par = i == 0 ? -1 : parents[i];
+      if (par < 0) {
+        for (int e = 0; e < 9; ++e) dR[i][e] += dRg[i][e];
+        for (int c = 0; c < 3; ++c) dJ0[i][c] += dtg[i][c];
+        continue;
+      }
+      float ti[3];
+      for (int c = 0; c < 3; ++c) ti[c] = j0[i * 3 + c] - j0[par * 3 + c];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          float a = dtg[i][r] * ti[c];                                    // d tg_i (x) t_i
+          for (int k = 0; k < 3; ++k) a = fmaf(dRg[i][r * 3 + k], R[i][c * 3 + k], a);   // dRg_i R_i^T
+          dRg[par][r * 3 + c] += a;
+          float d = 0.f;
+          for (int k = 0; k < 3; ++k) d = fmaf(Rg[par][k * 3 + r], dRg[i][k * 3 + c], d);   // Rg_par^T dRg_i
+          dR[i][r * 3 + c] += d;
+        }
+      for (int c = 0; c < 3; ++c) {
+        float dt = 0.f;
+        for (int k = 0; k < 3; ++k) dt = fmaf(Rg[par][k * 3 + c], dtg[i][k], dt);          // Rg_par^T d tg_i
+        dJ0[i][c] += dt;
+        dJ0[par][c] -= dt;
+        dtg[par][c] += dtg[i][c];
+      }
+    }
+  }
+  __syncthreads();
+  float* o2 = ws2 + (size_t)b * 82;
+  if (t < 24) {
+    for (int c = 0; c < 3; ++c) o2[t * 3 + c] = dJ0[t][c];
+    // Rodrigues backward: R(q^), q^ = q / |q|, q = (cos h, sin h * n), h = angle / 2, n = theta / angle, angle = |theta + 1e-8|
+    const float* d = dR[t];
+    const float w = qw, x = qx, y = qy, z = qz;
+    const float dw = 2.f * (w * (d[0] + d[4] + d[8]) - z * d[1] + y * d[2] + z * d[3] - x * d[5] - y * d[6] + x * d[7]);
+    const float dx = 2.f * (x * (d[0] - d[4] - d[8]) + y * d[1] + z * d[2] + y * d[3] - w * d[5] + z * d[6] + w * d[7]);
+    const float dy = 2.f * (y * (-d[0] + d[4] - d[8]) + x * d[1] + w * d[2] + x * d[3] + z * d[5] - w * d[6] + z * d[7]);
+    const float dz = 2.f * (z * (-d[0] - d[4] + d[8]) - w * d[1] + x * d[2] + w * d[3] + y * d[5] + x * d[6] + y * d[7]);
+    const float dot = w * dw + x * dx + y * dy + z * dz;
+    const float gw = (dw - w * dot) / qn, gx = (dx - x * dot) / qn, gy = (dy - y * dot) / qn, gz = (dz - z * dot) / qn;
+    const float nx = ax / angle, ny = ay / angle, nz = az / angle;
+    const float dh = -sn * gw + cs * (nx * gx + ny * gy + nz * gz);
+    const float dnx = sn * gx, dny = sn * gy, dnz = sn * gz;
+    const float dang = 0.5f * dh - (dnx * ax + dny * ay + dnz * az) / (angle * angle);
+    d_pose[b * 72 + t * 3] = dnx / angle + dang * (ax + 1e-8f) / angle;
+    d_pose[b * 72 + t * 3 + 1] = dny / angle + dang * (ay + 1e-8f) / angle;
+    d_pose[b * 72 + t * 3 + 2] = dnz / angle + dang * (az + 1e-8f) / angle;
+  }
+  if (t < 10) o2[72 + t] = acc[288 + 207 + t];
+}
+
+// d(betas) = vertex term + sum_j sum_v J_regressor[j][v] * SD[v]^T dJ0_j   (one block per sample)
+__global__ __launch_bounds__(256) void smpl_bwd_betas_kernel(const float* __restrict__ sd, const float* __restrict__ jr, int V,
+                                                             const float* __restrict__ ws2, float* __restrict__ d_betas) {
+  __shared__ float dj[72];
+  __shared__ float sm[20];
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t < 72) dj[t] = ws2[(size_t)b * 82 + t];
+  __syncthreads();
+  float a[10];
+  for (int k = 0; k < 10; ++k) a[k] = 0.f;
+  for (int v = t; v < V; v += blockDim.x) {
+    float g[3] = {0.f, 0.f, 0.f};                      // sum_j J_regressor[j][v] * dJ0_j
+    for (int j = 0; j < 24; ++j) {
+      const float w = jr[(size_t)j * V + v];
+      if (w == 0.f) continue;
+      g[0] = fmaf(w, dj[j * 3], g[0]); g[1] = fmaf(w, dj[j * 3 + 1], g[1]); g[2] = fmaf(w, dj[j * 3 + 2], g[2]);
+    }
+    for (int c = 0; c < 3; ++c) {
+      const float* d = sd + ((size_t)v * 3 + c) * 10;
+      for (int k = 0; k < 10; ++k) a[k] = fmaf(d[k], g[c], a[k]);
+    }
+  }
+  for (int k = 0; k < 10; ++k) {
+    const float r = block_sum(a[k], sm);
+    if (t == 0) d_betas[b * 10 + k] = r + ws2[(size_t)b * 82 + 72 + k];
+  }
+}
+
 // ------------------------------------------------------------------ Adam
 __global__ void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
                             float4* __restrict__ v, long n4, float b1, float b2, float eps, float step_size,
@@ -629,6 +865,33 @@ extern "C" int xas_smpl_lbs_fwd(const float* pose, const float* betas, const flo
   XAS_LAUNCH_CHECK();
   hipLaunchKernelGGL(smpl_verts_kernel, dim3((unsigned)cdiv(V, 128), B), dim3(128), 0, st, betas, v_template, shapedirs,
                      posedirs, weights, workspace, V, center_idx, verts);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t xas_smpl_lbs_bwd_workspace_floats(int B, int V) {
+  if (B <= 0 || V <= 0) return 0;
+  return (size_t)B * cdiv(V, 128) * kSmplP + (size_t)B * 82;
+}
+
+extern "C" int xas_smpl_lbs_bwd(const float* pose, const float* betas, const float* v_template, const float* shapedirs,
+                                const float* posedirs, const float* j_regressor, const float* weights, const int* parents,
+                                int B, int V, int center_idx, const float* fwd_workspace, const float* d_verts,
+                                const float* d_joints, float* d_pose, float* d_betas, float* workspace, void* stream) {
+  XAS_REQUIRE(pose && betas && v_template && shapedirs && posedirs && j_regressor && weights && parents && fwd_workspace &&
+                  d_verts && d_pose && d_betas && workspace, "smpl_lbs_bwd: null buffer");
+  XAS_REQUIRE(B > 0 && V > 0 && center_idx < 24, "smpl_lbs_bwd: bad shape");
+  hipStream_t st = as_stream(stream);
+  const int nblk = (int)cdiv(V, 128);
+  float* partial = workspace;
+  float* ws2 = workspace + (size_t)B * nblk * kSmplP;
+  hipLaunchKernelGGL(smpl_bwd_verts_kernel, dim3(nblk, B), dim3(128), 0, st, betas, v_template, shapedirs, posedirs, weights,
+                     fwd_workspace, d_verts, V, partial);
+  XAS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(smpl_bwd_chain_kernel, dim3(B), dim3(64), 0, st, pose, parents, center_idx, fwd_workspace, partial, nblk,
+                     d_joints, d_pose, ws2);
+  XAS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(smpl_bwd_betas_kernel, dim3(B), dim3(256), 0, st, shapedirs, j_regressor, V, ws2, d_betas);
   XAS_LAUNCH_CHECK();
   return 0;
 }

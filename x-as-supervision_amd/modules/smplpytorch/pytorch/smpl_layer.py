@@ -3,9 +3,9 @@ modules/smplpytorch/pytorch/smpl_layer.py:13-156, rodrigues_layer.py:13-52, tens
 
 forward(pose [B,72], betas [B,10]) -> (verts [B,6890,3], joints [B,24,3]) in metres, both minus joint
 `center_idx`.  Three launches (joint regression, Rodrigues + kinematic chain in one wave, blend + skin per
-vertex) replace ~100 small ATen kernels.  Forward only: the reference instantiates the layer
-(train.py:230-234) but never calls it on the training path (its only call site,
-util.project_smpl_to_patch_kps, has no caller).
+vertex) replace ~100 small ATen kernels; differentiable in pose and betas (xas_smpl_lbs_bwd: three more
+launches, no atomics).  The reference instantiates the layer (train.py:230-234) but never calls it on the
+training path (its only call site, util.project_smpl_to_patch_kps, has no caller).
 
 The licensed SMPL .pkl needs chumpy to unpickle (smpl_layer.py:38, serialization.py); when that import
 is unavailable the constructor raises, and `SMPL_Layer.from_arrays` builds the layer from plain arrays.

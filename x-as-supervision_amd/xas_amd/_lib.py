@@ -82,6 +82,8 @@ SIGNATURES = {
     'xas_gln_fwd': ('ppppliifpppp', 'i'),
     'xas_gln_bwd': ('pppppliifppppp', 'i'),
     'xas_smpl_lbs_fwd': ('ppppppppiiipppp', 'i'),
+    'xas_smpl_lbs_bwd_workspace_floats': ('ii', 'z'),
+    'xas_smpl_lbs_bwd': ('ppppppppiiippppppp', 'i'),
     'xas_adam_step': ('pppplffffip', 'i'),
     'xas_eval_select': ('pppiiiifippppp', 'i'),
     'xas_projection_matrix': ('pppipp', 'i'),

@@ -94,18 +94,41 @@ def graph_layernorm_relu(x, gamma, beta, residual=None, eps=1e-5, groups=1):
     return _GraphLayerNormRelu.apply(x, gamma, beta, residual, eps, groups)
 
 
+class _SmplLbs(torch.autograd.Function):
+    """SMPL linear blend skinning with its backward (pose and shape gradients; the model arrays are constants)."""
+
+    @staticmethod
+    def forward(ctx, pose, betas, v_template, shapedirs, posedirs, j_regressor, weights, parents, center_idx):
+        B, V = pose.shape[0], v_template.shape[-2]
+        dev = pose.device
+        pose, betas = pose.contiguous(), betas.contiguous()
+        bufs = tuple(t.contiguous() for t in (v_template, shapedirs, posedirs, j_regressor, weights))
+        verts = torch.empty(B, V, 3, device=dev, dtype=torch.float32)
+        joints = torch.empty(B, 24, 3, device=dev, dtype=torch.float32)
+        ws = torch.empty(B * (72 + 24 * 16 + 207), device=dev, dtype=torch.float32)
+        c = -1 if center_idx is None else int(center_idx)
+        call('xas_smpl_lbs_fwd', ptr(pose), ptr(betas), *(ptr(t) for t in bufs), ptr(parents), B, V, c, ptr(verts),
+             ptr(joints), ptr(ws))
+        ctx.save_for_backward(pose, betas, *bufs, parents, ws)
+        ctx.cfg = (B, V, c)
+        return verts, joints
+
+    @staticmethod
+    def backward(ctx, d_verts, d_joints):
+        pose, betas, vt, sd, pd, jr, w, parents, ws = ctx.saved_tensors
+        B, V, c = ctx.cfg
+        d_pose, d_betas = torch.empty_like(pose), torch.empty_like(betas)
+        dv = d_verts.contiguous() if d_verts is not None else torch.zeros(B, V, 3, device=pose.device)
+        dj = d_joints.contiguous() if d_joints is not None else None
+        ws2 = torch.empty(query('xas_smpl_lbs_bwd_workspace_floats', B, V), device=pose.device, dtype=torch.float32)
+        call('xas_smpl_lbs_bwd', ptr(pose), ptr(betas), ptr(vt), ptr(sd), ptr(pd), ptr(jr), ptr(w), ptr(parents), B, V, c,
+             ptr(ws), ptr(dv), ptr(dj), ptr(d_pose), ptr(d_betas), ptr(ws2))
+        return d_pose, d_betas, None, None, None, None, None, None, None
+
+
 def smpl_lbs(pose, betas, v_template, shapedirs, posedirs, j_regressor, weights, parents, center_idx=0):
-    """SMPL forward (smpl_layer.py:63-156): -> verts [B,V,3], joints [B,24,3].  Forward only."""
-    B, V = pose.shape[0], v_template.shape[-2]
-    dev = pose.device
-    verts = torch.empty(B, V, 3, device=dev, dtype=torch.float32)
-    joints = torch.empty(B, 24, 3, device=dev, dtype=torch.float32)
-    ws = torch.empty(B * (72 + 24 * 16 + 207), device=dev, dtype=torch.float32)
-    call('xas_smpl_lbs_fwd', ptr(pose.contiguous()), ptr(betas.contiguous()), ptr(v_template.contiguous()),
-         ptr(shapedirs.contiguous()), ptr(posedirs.contiguous()), ptr(j_regressor.contiguous()),
-         ptr(weights.contiguous()), ptr(parents), B, V, -1 if center_idx is None else int(center_idx), ptr(verts),
-         ptr(joints), ptr(ws))
-    return verts, joints
+    """SMPL layer (smpl_layer.py:63-156): -> verts [B,V,3], joints [B,24,3]; differentiable in pose and betas."""
+    return _SmplLbs.apply(pose, betas, v_template, shapedirs, posedirs, j_regressor, weights, parents, center_idx)
 
 
 class _PoseLoss(torch.autograd.Function):
