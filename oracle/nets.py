@@ -280,3 +280,98 @@ class GCNDecouple(nn.Module):
         for blk in self.bone_gcn:
             b = blk(b, adj)
         return self.header(torch.cat([j, b], -1).reshape(B, -1), drop_mask)
+
+
+# ---------------------------------------------------------------- GCNConv discriminator (no shipped config selects it)
+class _GCNConv(nn.Module):
+    """torch_geometric 2.5.3 GCNConv(in, out, add_self_loops) on an edge list (published algorithm, gcn_conv.py:
+    gcn_norm + propagate): self loops of weight 1 are added to the nodes that have none (existing ones keep their weight),
+    deg_i = sum of the weights of the edges ending in i, norm_e = deg^-1/2[source] * w_e * deg^-1/2[target] (1/sqrt(0) -> 0),
+    out_i = sum over edges (j -> i) of norm_e * (x W)_j, plus the bias (the linear layer itself has none)."""
+
+    def __init__(self, cin, cout, add_self_loops=True):
+        super().__init__()
+        self.lin = _Lin(cin, cout, False)
+        self.bias = nn.Parameter(torch.zeros(cout))
+        self.add_self_loops = add_self_loops
+
+    def forward(self, x, edge_index, edge_weight):
+        n = x.shape[0]
+        row, col, w = edge_index[0], edge_index[1], edge_weight
+        if self.add_self_loops:
+            loop = row == col
+            lw = torch.ones(n, dtype=x.dtype).index_put((row[loop],), w[loop])
+            ar = torch.arange(n)
+            row, col, w = torch.cat([row[~loop], ar]), torch.cat([col[~loop], ar]), torch.cat([w[~loop], lw])
+        deg = torch.zeros(n, dtype=x.dtype).index_add(0, col, w)
+        dis = deg.pow(-0.5)
+        dis = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis)
+        norm = dis[row] * w * dis[col]
+        xw = self.lin(x)
+        return torch.zeros_like(xw).index_add(0, col, norm[:, None] * xw[row]) + self.bias
+
+
+class _GCNSimple(nn.Module):
+    """gcn.py:40-49."""
+
+    def __init__(self, cin, cout, self_loop):
+        super().__init__()
+        self.gc = _GCNConv(cin, cout, self_loop)
+
+    def forward(self, x, ei, ew):
+        return F.relu(self.gc(x, ei, ew))
+
+
+class _GCNResidual(nn.Module):
+    """gcn.py:52-77: gc1 -> (bn) -> relu -> dropout -> gc2 -> (bn) -> relu -> dropout, + input; ONE norm module for both."""
+
+    def __init__(self, c, self_loop, use_bn, p_dropout=0.5):
+        super().__init__()
+        self.gc1 = _GCNConv(c, c, self_loop)
+        self.gc2 = _GCNConv(c, c, self_loop)
+        self.use_bn = use_bn
+        if use_bn:
+            self.bn = nn.BatchNorm1d(c)          # nn.SyncBatchNorm without a process group = plain batch norm
+        self.p = p_dropout
+
+    def forward(self, x, ei, ew):
+        res = x
+        for gc in (self.gc1, self.gc2):
+            x = gc(x, ei, ew)
+            if self.use_bn:
+                x = self.bn(x)
+            x = F.dropout(F.relu(x), self.p, self.training)
+        return x + res
+
+
+class GCNConvDisc(nn.Module):
+    """GCNDiscriminator, discriminator.py:80-139 ('simple_gcn' / 'res_gcn'): edge weights 1 / bone length."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.num_nodes, self.use_self_loop = cfg['num_node'], cfg['use_self_loop']
+        i, h, o, sl = cfg['input_dim'], cfg['hidden_dim'], cfg['output_dim'], cfg['use_self_loop']
+        if cfg['name'] == 'simple_gcn':
+            self.name = 'SimpleGCN'
+            self.gcn = nn.ModuleList([_GCNSimple(i, h, sl), _GCNSimple(i, h, sl)])
+        else:
+            self.name = 'ResGCN'
+            self.gcn = nn.ModuleList([_GCNSimple(i, h, sl)] + [_GCNResidual(h, sl, cfg['use_bn']) for _ in range(cfg['num_layers'])]
+                                     + [_GCNSimple(h, o, sl)])
+        self.input_layer = nn.Linear(cfg['disc_sup_dim'], i)
+        self.header = nn.Linear(o * self.num_nodes, 1)
+        self.parent_ids = self.child_ids = None
+
+    def forward(self, kp):
+        B, N, _ = kp.shape
+        diff = kp[:, self.parent_ids] - kp[:, self.child_ids]
+        inv = 1.0 / torch.sqrt((diff ** 2).sum(-1))
+        w = torch.eye(N, dtype=kp.dtype).repeat(B, 1, 1) if self.use_self_loop else torch.zeros(B, N, N, dtype=kp.dtype)
+        bi = torch.arange(B)[:, None]
+        w = w.index_put((bi, torch.tensor(self.parent_ids)[None], torch.tensor(self.child_ids)[None]), inv)
+        w = w.index_put((bi, torch.tensor(self.child_ids)[None], torch.tensor(self.parent_ids)[None]), inv)
+        ei, ew = batched_dense_to_sparse(w)
+        x = self.input_layer(kp).reshape(B * N, -1)
+        for blk in self.gcn:
+            x = blk(x, ei, ew)
+        return self.header(x.reshape(B, -1))

@@ -423,13 +423,41 @@ class _PygLayerNorm(nn.Module):
         return x / (x.std(unbiased=False) + self.eps) * self.weight + self.bias
 
 
+class _PygGCNConv(nn.Module):
+    """torch_geometric 2.5.3 GCNConv(in, out, add_self_loops=...) restated on edge lists (gcn_conv.py: gcn_norm with
+    add_remaining_self_loops(fill_value=1), flow 'source_to_target', then propagate with aggr='add'): lin has no bias, the
+    bias parameter is added after the aggregation."""
+
+    def __init__(self, in_channels, out_channels, add_self_loops=True):
+        super().__init__()
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        self.add_self_loops = add_self_loops
+
+    def forward(self, x, edge_index, edge_weight=None):
+        n = x.shape[0]
+        row, col = edge_index[0], edge_index[1]
+        w = edge_weight if edge_weight is not None else torch.ones(row.shape[0], dtype=x.dtype)
+        if self.add_self_loops:
+            loop = row == col
+            lw = torch.ones(n, dtype=x.dtype).index_put((row[loop],), w[loop])
+            ar = torch.arange(n)
+            row, col, w = torch.cat([row[~loop], ar]), torch.cat([col[~loop], ar]), torch.cat([w[~loop], lw])
+        deg = torch.zeros(n, dtype=x.dtype).index_add(0, col, w)
+        dis = deg.pow(-0.5)
+        dis = dis.masked_fill(dis == float('inf'), 0.0)
+        norm = dis[row] * w * dis[col]
+        xw = self.lin(x)
+        return torch.zeros_like(xw).index_add(0, col, norm[:, None] * xw[row]) + self.bias
+
+
 def _install_pyg_shims():
     tg = types.ModuleType('torch_geometric')
     tgn = types.ModuleType('torch_geometric.nn')
     norm = types.ModuleType('torch_geometric.nn.norm')
     norm.LayerNorm = _PygLayerNorm
     tgn.SAGEConv, tgn.norm = _PygSAGEConv, norm
-    tgn.GCNConv = type('GCNConv', (nn.Module,), {})        # imported by gcn.py:3, never constructed by the shipped configs
+    tgn.GCNConv = _PygGCNConv                               # constructed only by GCNDiscriminator ('simple_gcn' / 'res_gcn')
     tg.nn = tgn
     sys.modules.update({'torch_geometric': tg, 'torch_geometric.nn': tgn, 'torch_geometric.nn.norm': norm})
 
@@ -474,6 +502,48 @@ def g_disc():
                 else:
                     out[pre + 'g_head_w'] = prm['header.weight'].grad
         save('disc_' + tag, **out)
+
+
+def g_disc_gcn():
+    """GCNDiscriminator (discriminator.py:80-139) imported UNCHANGED with GCNConv restated above: pins the bone-length edge
+    weights, the dense -> sparse conversion, the GCN_simple / GCN_residual wiring (one shared norm per residual block) and
+    the header.  Dropout p is set to 0 for the train-mode cases (its random stream cannot be shared)."""
+    _install_pyg_shims()
+    from modules.discriminator import GCNDiscriminator
+    base = yaml.load(open(os.path.join(REF, 'config', 'HM36_Multi_SurS2.yaml')), Loader=yaml.FullLoader)['model_params']
+    p17, c17 = ref_model.cal_links(base['parent_ids'], base['line_select_ids'], use_root=False, extension=False)
+    rng = np.random.Generator(np.random.PCG64(93))
+    for tag, name, use_bn, self_loop in (('res', 'res_gcn', False, True), ('res_bn', 'res_gcn', True, True),
+                                         ('simple_noloop', 'simple_gcn', False, False)):
+        cfg = dict(base['smpl_disc_params'], name=name, use_bn=use_bn, use_self_loop=self_loop)
+        ref = GCNDiscriminator(cfg)
+        gi.seeded_fill_(ref, seed=94)
+        ref.parent_ids, ref.child_ids = p17, c17
+        for m in ref.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = 0.0
+        out = {'keys': np.array(list(ref.state_dict().keys())),
+               'shapes': np.array([str(list(v.shape)) for v in ref.state_dict().values()])}
+        for B in (2, 5):
+            kp = T((0.4 * rng.standard_normal((B, 18, 3))).astype(np.float32))
+            for mode in ('eval', 'train_p0'):
+                ref.train(mode != 'eval')
+                ref.zero_grad()
+                x = kp.clone().requires_grad_(True)
+                y = ref(x)
+                gw = T(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+                (y * gw).sum().backward()
+                pre = '%s_B%d_' % (mode, B)
+                prm = dict(ref.named_parameters())
+                out.update({pre + 'kp': kp, pre + 'logits': y, pre + 'grad_out': gw, pre + 'grad_kp': x.grad,
+                            pre + 'g_in_w': prm['input_layer.weight'].grad, pre + 'g_gc0_w': prm['gcn.0.gc.lin.weight'].grad,
+                            pre + 'g_gc0_b': prm['gcn.0.gc.bias'].grad, pre + 'g_head_w': prm['header.weight'].grad})
+                if name == 'res_gcn':
+                    out.update({pre + 'g_res_w': prm['gcn.1.gc2.lin.weight'].grad, pre + 'g_last_b': prm['gcn.3.gc.bias'].grad})
+                    if use_bn:
+                        out.update({pre + 'g_bn_w': prm['gcn.2.bn.weight'].grad,
+                                    pre + 'bn_rm': ref.state_dict()['gcn.1.bn.running_mean'].clone()})
+        save('disc_gcn_' + tag, **out)
 
 
 # ----------------------------------------------------------------- 9. dense -> sparse known answer
@@ -638,6 +708,6 @@ def g_tbvis():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['head', 'lines', 'geometry', 'losses', 'physique', 'detector', 'smpl', 'model', 'model2', 'model3', 'configs',
-                             'disc', 'sparse', 'evalpath', 'input', 'tbvis']
+                             'disc', 'disc_gcn', 'sparse', 'evalpath', 'input', 'tbvis']
     for w in which:
         globals()['g_' + w]()

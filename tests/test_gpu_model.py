@@ -577,3 +577,23 @@ def test_step_switches_are_bit_identical(monkeypatch):
         torch.cuda.synchronize()
         states.append((opt_det.param_arena.clone(), opt_disc.param_arena.clone()))
     assert torch.equal(states[0][0], states[1][0]) and torch.equal(states[0][1], states[1][1])
+
+
+@pytest.mark.parametrize('tag,name,use_bn,self_loop', [('res', 'res_gcn', False, True), ('res_bn', 'res_gcn', True, True),
+                                                       ('simple_noloop', 'simple_gcn', False, False)])
+def test_gcnconv_discriminator_vs_reference_golden(tag, name, use_bn, self_loop):
+    """modules.discriminator.GCNDiscriminator (GCNConv, 1 / bone-length edge weights: discriminator.py:80-139) on the GPU
+    against goldens of the reference class imported unchanged (make_golden.py: g_disc_gcn): logits, gradient wrt the
+    keypoints (through the edge weights), parameter gradients, running mean of the shared norm."""
+    from modules.discriminator import GCNDiscriminator
+    from oracle.geometry import skeleton_links
+    from test_oracle_disc import _load, check_gcn_disc_sequence
+    g = golden('disc_gcn_' + tag)
+    cfg = dict(gi.model_params('S2')['smpl_disc_params'], name=name, use_bn=use_bn, use_self_loop=self_loop)
+    net = GCNDiscriminator(cfg)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    net = _load(net, g, seed=94).cuda()
+    net.parent_ids, net.child_ids = skeleton_links(gi.HM36_PARENTS, gi.LINE_SELECT, False, False)
+    check_gcn_disc_sequence(net, g, tol_logit=5e-5, tol_grad=2e-4, dev='cuda')

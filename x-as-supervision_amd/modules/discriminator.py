@@ -1,15 +1,16 @@
 """GCN pose discriminators (reference: modules/discriminator.py:8-238).
 
-Only `GCNDiscriminatorDecouple` (config name 'res_sage_gcn_decouple', every shipped YAML) and
-`GCNSAGEDiscriminator` are built on the HIP kernels; `GCNDiscriminator` (GCNConv with bone-length edge
-weights, unused by the shipped configs) raises NotImplementedError when constructed.
+`GCNDiscriminatorDecouple` (config name 'res_sage_gcn_decouple', every shipped YAML) and `GCNSAGEDiscriminator`
+run on the fused graph kernels; `GCNDiscriminator` (GCNConv with bone-length edge weights, unused by the shipped
+configs) keeps its per-sample graph as a dense [B,18,18] matrix: HIP linear layers, tiny batched torch ops for
+the normalisation and aggregation (autograd through the edge weights).
 """
 import math
 
 import torch
 import torch.nn as nn
 
-from modules.gcn import GCN_SAGE_residual
+from modules.gcn import GCN_SAGE_residual, GCN_residual, GCN_simple
 from xas_amd import layers as L
 
 
@@ -97,9 +98,50 @@ class GCNDiscriminator_base(nn.Module):
 
 
 class GCNDiscriminator(GCNDiscriminator_base):
+    """GCNConv discriminator with 1 / bone-length edge weights (discriminator.py:80-139; config names 'simple_gcn' /
+    'res_gcn', not selected by any shipped YAML).  The per-sample graph is a dense [B, 18, 18] matrix (modules/gcn.py)."""
+
     def __init__(self, cfg):
-        raise NotImplementedError('GCNConv discriminators (simple_gcn / res_gcn) are not used by any shipped '
-                                  'config and are not built on the MI355X path')
+        super().__init__(cfg)
+        sl = self.use_self_loop
+        if cfg['name'] == 'simple_gcn':
+            self.name = 'SimpleGCN'
+            self.gcn = nn.Sequential(GCN_simple(self.input_dim, self.hidden_dim, self_loop=sl),
+                                     GCN_simple(self.input_dim, self.hidden_dim, self_loop=sl))
+        elif cfg['name'] == 'res_gcn':
+            self.name = 'ResGCN'
+            self.num_layers = cfg['num_layers']
+            self.gcn = nn.Sequential(
+                GCN_simple(self.input_dim, self.hidden_dim, self_loop=sl),
+                *[GCN_residual(self.hidden_dim, self.hidden_dim, self.hidden_dim, self_loop=sl, use_bn=cfg['use_bn'])
+                  for _ in range(self.num_layers)],
+                GCN_simple(self.hidden_dim, self.output_dim, self_loop=sl))
+        else:
+            raise NotImplementedError
+        self.input_layer = L.Linear(self.disc_sup_dim, self.input_dim)
+
+    def compute_graph_matrix(self, keypoints):
+        """[B, N, N] weights: identity (use_self_loop) and 1 / bone length on both directions of every skeleton edge
+        (discriminator.py:108-127; the reference converts this matrix to an edge list, the dense form is kept here)."""
+        B = keypoints.shape[0]
+        pidx, cidx = self._bone_index(keypoints.device)
+        diff = keypoints[:, pidx, :] - keypoints[:, cidx, :]
+        inv = 1.0 / torch.sqrt(torch.sum(diff ** 2, dim=-1))                     # [B, E]
+        n = self.num_nodes
+        w = torch.eye(n, device=keypoints.device).repeat(B, 1, 1) if self.use_self_loop else \
+            torch.zeros(B, n, n, device=keypoints.device)
+        w = w.index_put((torch.arange(B, device=keypoints.device)[:, None], pidx[None, :], cidx[None, :]), inv)
+        w = w.index_put((torch.arange(B, device=keypoints.device)[:, None], cidx[None, :], pidx[None, :]), inv)
+        return w
+
+    def forward(self, keypoints):
+        B = keypoints.shape[0]
+        adj = self.compute_graph_matrix(keypoints)
+        x = self.input_layer(keypoints.reshape(B * self.num_nodes, -1))
+        return self.header_forward(self.gcn((x, adj))[0], B)
+
+    def forward_groups(self, inputs):
+        return [self(x) for x in inputs]
 
 
 def _stream(hidden, out, num_layers):

@@ -74,3 +74,71 @@ class GCN_SAGE_residual(nn.Module):
             return (y, graph)
         y = ops_misc.graph_layernorm_relu(self.gc2(y, graph), self.ln2.weight, self.ln2.bias, x, self.ln2.eps, groups)
         return (y, graph)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GCNConv variant (reference: modules/gcn.py:40-77, used by modules/discriminator.py:80-139 `GCNDiscriminator`; no shipped
+# config selects it).  The edge weights are 1 / bone length - a function of the INPUT, per sample - so the graph is a
+# dense per-sample [B, N, N] matrix (N = 18) and the normalisation / aggregation are a few tiny batched torch ops with
+# autograd through the edge weights; the feature transforms are the HIP linear layers.
+# ---------------------------------------------------------------------------------------------------------------------
+class GCNConv(nn.Module):
+    """PyG GCNConv(in, out, add_self_loops): out = D^-1/2 (A [+ I]) D^-1/2 applied along source -> target, times x W, plus b.
+    `lin` has no bias; `bias` is added after the aggregation (parameter names as in PyG).  A node that already has a
+    self loop keeps its weight (add_remaining_self_loops); degrees are sums of incoming weights; 1/sqrt(0) -> 0."""
+
+    def __init__(self, cin, cout, add_self_loops=True):
+        super().__init__()
+        self.lin = L.Linear(cin, cout, bias=False)
+        self.bias = nn.Parameter(torch.zeros(cout))
+        self.add_self_loops = add_self_loops
+
+    def norm(self, adj):
+        """adj [B, N, N], adj[b, i, j] = weight of the edge i -> j (0 = no edge) -> normalised weights, same layout."""
+        if self.add_self_loops:
+            diag = adj.diagonal(dim1=1, dim2=2)
+            adj = adj + torch.diag_embed((diag == 0).to(adj.dtype))        # weight 1 only where no self loop exists
+        deg = adj.sum(dim=1)                                   # incoming weight per target node
+        dis = deg.pow(-0.5)
+        dis = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis)
+        return dis.unsqueeze(2) * adj * dis.unsqueeze(1)
+
+    def forward(self, x, adj):
+        B, N = adj.shape[:2]
+        xw = self.lin(x).view(B, N, -1)
+        out = torch.bmm(self.norm(adj).transpose(1, 2), xw)   # out[b, j] = sum_i norm[b, i, j] * xw[b, i]
+        return out.reshape(B * N, -1) + self.bias
+
+
+class GCN_simple(nn.Module):
+    def __init__(self, input_dim, output_dim, self_loop=False):
+        super().__init__()
+        self.gc = GCNConv(input_dim, output_dim, add_self_loops=self_loop)
+
+    def forward(self, input):
+        x, adj = input
+        return (torch.relu(self.gc(x, adj)), adj)
+
+
+class GCN_residual(nn.Module):
+    def __init__(self, input_dim, hidden_dim, output_dim, self_loop=False, use_bn=False, p_dropout=0.5):
+        super().__init__()
+        self.gc1 = GCNConv(input_dim, hidden_dim, add_self_loops=self_loop)
+        self.gc2 = GCNConv(hidden_dim, output_dim, add_self_loops=self_loop)
+        self.use_bn = use_bn
+        if use_bn:
+            self.bn = L.BatchNorm2d(output_dim, sync=True)      # nn.SyncBatchNorm on [B*N, C] node features (gcn.py:62)
+        self.dropout = nn.Dropout(p=p_dropout)
+
+    def _bn(self, x):
+        return self.bn(x.reshape(x.shape[0], x.shape[1], 1, 1)).reshape(x.shape[0], x.shape[1])
+
+    def forward(self, input):
+        x, adj = input
+        res = x
+        for gc in (self.gc1, self.gc2):
+            x = gc(x, adj)
+            if self.use_bn:
+                x = self._bn(x)
+            x = self.dropout(torch.relu(x))
+        return (x + res, adj)

@@ -680,7 +680,23 @@ def _bn_backward(saved, cfg, gamma, beta, dy, want_param_grads, want_dres=True):
     x, y, mean, var = saved
     M, c, eps, act, count, group, training, has_res, xfree, yfree, G, masked = cfg
     if not training:
-        raise RuntimeError('batch-norm backward in eval mode is not part of the training path')
+        # eval-mode norm inside a graph that is differentiated (frozen statistics: an affine map per channel).  Off the
+        # training path - a handful of torch ops instead of kernels of its own.
+        dy = to_cl(dy)
+        n = dy.shape[0]
+        shp = (G, 1, c, 1, 1)
+        grp = lambda t: t.reshape(G, n // G, c, *t.shape[2:])
+        gz = grp(dy)
+        if act != ACT_NONE:
+            pos = grp(y) > 0
+            gz = torch.where(pos, gz, gz * (0.01 if act == ACT_LEAKY else 0.0))
+        rstd = torch.rsqrt(var.reshape(G, c) + eps).reshape(shp)
+        xhat = (grp(x) - mean.reshape(shp)) * rstd
+        dx = (gz * (gamma.reshape(1, 1, c, 1, 1) * rstd)).reshape(dy.shape).contiguous(memory_format=CL)
+        dgamma = (gz * xhat).sum(dim=(0, 1, 3, 4)) if want_param_grads else None
+        dbeta = gz.sum(dim=(0, 1, 3, 4)) if want_param_grads else None
+        dres = gz.reshape(dy.shape).contiguous(memory_format=CL) if has_res else None
+        return dx, dgamma, dbeta, dres
     dy = to_cl(dy)
     dev = x.device
     mask = y if masked else None
