@@ -88,7 +88,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo to rehearse ranks on one GPU)')
     ap.add_argument('--tune', type=int, default=0, help='kernel tuning experiment flags (xas_set_tuning)')
-    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'],
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16', 'bf16x6'],
                     help='f32 (default, the headline: exact fp32 MFMA) or bf16: NOT the headline - forward / data-gradient '
                          'convolutions on bf16 MFMA (fp32 accumulate, fp32 master weights, fp32 weight gradients); the JSON line '
                          'carries dtype "bf16" and peak = the bf16 MFMA peak for those launches')
@@ -125,7 +125,7 @@ def main():
     from xas_amd.synthetic import model_config, synthetic_batch
     from xas_amd import _lib as _xl
     _xl.query('xas_set_tuning', args.tune)
-    _xl.query('xas_set_precision', 1 if args.precision == 'bf16' else 0)
+    _xl.query('xas_set_precision', {'f32': 0, 'bf16': 1, 'bf16x6': 2}[args.precision])
     cfg = model_config(args.workload)
     torch.manual_seed(1234)
     model, disc, opt_det, opt_disc = engine.prepare_model(cfg)
@@ -203,7 +203,9 @@ def main():
             'value': samples * per_sample / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.precision == 'f32' else 'bf16 fwd/dgrad MFMA + f32 wgrad (variant, not the headline)', 'data': 'synthetic',
+            'dtype': {'f32': 'f32', 'bf16': 'bf16 fwd/dgrad MFMA + f32 wgrad (variant, not the headline)',
+                      'bf16x6': 'f32 products from 6 bf16 MFMA partial products in fwd/dgrad + f32 wgrad (variant, not the headline)'}[args.precision],
+            'data': 'synthetic',
             'config': {'workload': args.workload, 'batch_per_gpu': args.batch, 'cameras': len(cams),
                        'image': '256x256', 'images_per_sample': per_sample, 'parallelism': 'dp%d' % world,
                        'samples_per_s': samples / dt,

@@ -40,7 +40,9 @@ const char* xas_last_error(void);
 int xas_set_tuning(int flags);
 /* Compute precision of the MFMA forward / data-gradient convolutions: 0 (default) = exact fp32 MFMA, the
  * path every parity figure and the headline benchmark use; 1 = bf16 MFMA (operands rounded to bf16 on the way to LDS,
- * fp32 accumulation, fp32 activations and master weights in HBM; weight gradients stay fp32).  Process-wide. */
+ * fp32 accumulation, fp32 activations and master weights in HBM; weight gradients stay fp32); 2 = bf16x6: every fp32 operand
+ * split exactly into three bf16 pieces, six exact partial products accumulated in fp32 - fp32-accurate results (per-product
+ * error below one fp32 rounding) at 2.67x the fp32-MFMA math rate; weight gradients stay fp32.  Process-wide. */
 int xas_set_precision(int mode);
 /* diagnostic builds: device buffer of 8 uint64 that the igemm kernels add per-phase cycle sums to (NULL = off) */
 int xas_set_debug_buffer(void* device_ptr);

@@ -86,3 +86,66 @@ def test_detector_bf16_close_to_fp32(bf16_mode):
     d = float((kb - kf).abs().max())
     print('bf16 vs fp32 detector, max |kps diff| = %.3e (normalised patch units)' % d)
     assert d < 5e-2
+
+
+# ---- bf16x6: fp32-accurate products from six bf16 MFMA partial products (xas_set_precision(2)) -------------------------
+@pytest.fixture
+def bf16x6_mode():
+    from xas_amd import _lib
+    assert _lib.query('xas_set_precision', 2) == 0
+    yield
+    _lib.query('xas_set_precision', 0)
+
+
+@pytest.mark.parametrize('n,cin,h,w,cout,k,stride,pad', CASES + [(2, 64, 9, 11, 48, 3, 1, 1), (2, 2048, 4, 4, 512, 1, 1, 0)])
+def test_conv_bf16x6_is_fp32_accurate(bf16x6_mode, n, cin, h, w, cout, k, stride, pad):
+    """Every operand is split exactly into three bf16 pieces and six exact partial products are accumulated in fp32: the
+    forward and data-gradient results must meet the SAME bar as the fp32-MFMA path (3e-6 relative against a float64
+    convolution of the unrounded operands) - three orders of magnitude tighter than the plain bf16 variant."""
+    from xas_amd import layers as L
+    g = torch.Generator().manual_seed(cin + cout + k + n)
+    x = torch.randn(n, cin, h, w, generator=g) * 3.0 + 0.5
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    m = L.Conv2d(cin, cout, k, stride, pad, bias=False).cuda()
+    with torch.no_grad():
+        m.weight.copy_(wt)
+    xg = x.cuda().requires_grad_(True)
+    y = m(xg)
+    exact = TF.conv2d(x.double(), wt.double(), None, stride, pad)
+    assert rel(y, exact) < 3e-6, rel(y, exact)
+    gy = torch.randn(exact.shape, generator=g)
+    (y * gy.cuda()).sum().backward()
+    dref = torch.nn.grad.conv2d_input(x.shape, wt.double(), gy.double(), stride, pad)
+    assert rel(xg.grad, dref) < 3e-6, rel(xg.grad, dref)
+    # the fp32-MFMA path on the same inputs, for the record: the two agree to fp32 rounding
+    from xas_amd import _lib
+    _lib.query('xas_set_precision', 0)
+    y32 = m(x.cuda())
+    _lib.query('xas_set_precision', 2)
+    assert rel(y, y32) < 2e-6
+
+
+def test_detector_bf16x6_matches_fp32_path(bf16x6_mode):
+    """End to end through 56 conv layers and the soft-argmax head: joints of the bf16x6 mode against the fp32-MFMA path on
+    the same weights and images - within the fp32 path's own distance to the reference golden (2e-6), far inside the 1e-4 bar."""
+    import numpy as np
+    import inputs as gi
+    from modules.keypoint_detector_integral_multi import KPDetector3DMulti
+    from oracle import step as ostep
+    from xas_amd import _lib
+    ora = gi.seeded_fill_(ostep.Regressor('resnet_multi', 18, 64, 3, 15), seed=61)
+    with torch.no_grad():
+        ora.net.head.features[9].bias.copy_(torch.from_numpy(gi.planted_depth_bias(18, 64, seed=62)))
+    det = KPDetector3DMulti('resnet_multi', 18, 64, 3, 15)
+    det.load_state_dict(ora.state_dict())
+    det.cuda().train()
+    img = torch.from_numpy(gi.synthetic_batch(2, [0], seed=5)['cam_0_img']).cuda()
+    with torch.no_grad():
+        k6, _ = det(img)
+        _lib.query('xas_set_precision', 0)
+        det.load_state_dict(ora.state_dict())          # same running statistics for the second pass
+        k32, _ = det(img)
+        _lib.query('xas_set_precision', 2)
+    d = float((k6 - k32).abs().max())
+    print('bf16x6 vs fp32 MFMA, max |d joint| =', d)
+    assert d < 1e-5

@@ -869,13 +869,27 @@ __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
   return make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
 }
 
-template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmParams p) {
+// v - float(q) for the four bf16 values packed in q (exact: q is the leading part of v)
+__device__ __forceinline__ float4 sub_bf16x4(float4 v, uint2 q) {
+  return make_float4(v.x - __uint_as_float(q.x << 16), v.y - __uint_as_float(q.x & 0xffff0000u),
+                     v.z - __uint_as_float(q.y << 16), v.w - __uint_as_float(q.y & 0xffff0000u));
+}
+
+
+// PIECES = 3 ("bf16x6", xas_set_precision(2)): fp32-ACCURATE products on the bf16 matrix pipe.  Every fp32 operand is split
+// exactly into three bf16 pieces x = x1 + x2 + x3 (8 significant bits each: x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2));
+// the six partial products x1y1, x1y2, x2y1, x2y2, x1y3, x3y1 are each EXACT in fp32 and are accumulated in fp32 by the MFMA;
+// the three dropped ones are below 2^-25 |xy| - under the rounding error of one fp32 product.  6 x 32 cycles per K = 16 against
+// 8 x 64 cycles of v_mfma_f32_32x32x2_f32.  One LDS buffer (three planes per operand) and two barriers per K-step keep two
+// blocks per CU.
+template <int BM, int BN, int MODE, int PIECES = 1>
+__global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmParams p) {
   using C = TileCfg<BM, BN>;
   constexpr int APASS = BM / 32, BPASS = BN / 32;
+  constexpr int NBUF = PIECES == 1 ? 2 : 1;
   extern __shared__ __align__(16) float lds[];
-  unsigned short* As = reinterpret_cast<unsigned short*>(lds);     // [2][BM][LDKH]
-  unsigned short* Bs = As + 2 * BM * LDKH;                          // [2][BN][LDKH]
+  unsigned short* As = reinterpret_cast<unsigned short*>(lds);     // [NBUF][PIECES][BM][LDKH]
+  unsigned short* Bs = As + NBUF * PIECES * BM * LDKH;              // [NBUF][PIECES][BN][LDKH]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
   const int kq = tid & 7, lrow = tid >> 3;
@@ -976,51 +990,95 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmParams p) {
     ld_chunk = more ? c : ld_chunk; ld_js = more ? s2 : ld_js; ld_jr = more ? r : ld_jr;
   };
   auto store_step = [&](int buf, const float4 (&ra4)[APASS], const float4 (&rb4)[BPASS]) {
-    unsigned short* a = As + buf * BM * LDKH;
-    unsigned short* b = Bs + buf * BN * LDKH;
+    unsigned short* a = As + buf * PIECES * BM * LDKH;
+    unsigned short* b = Bs + buf * PIECES * BN * LDKH;
 #pragma unroll
-    for (int j = 0; j < APASS; ++j) *reinterpret_cast<uint2*>(a + (lrow + 32 * j) * LDKH + kq * 4) = pack_bf16x4(ra4[j]);
+    for (int j = 0; j < APASS; ++j) {
+      float4 r = ra4[j];
 #pragma unroll
-    for (int j = 0; j < BPASS; ++j) *reinterpret_cast<uint2*>(b + (lrow + 32 * j) * LDKH + kq * 4) = pack_bf16x4(rb4[j]);
+      for (int pc = 0; pc < PIECES; ++pc) {
+        const uint2 q = pack_bf16x4(r);
+        *reinterpret_cast<uint2*>(a + (pc * BM + lrow + 32 * j) * LDKH + kq * 4) = q;
+        if (pc + 1 < PIECES) r = sub_bf16x4(r, q);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) {
+      float4 r = rb4[j];
+#pragma unroll
+      for (int pc = 0; pc < PIECES; ++pc) {
+        const uint2 q = pack_bf16x4(r);
+        *reinterpret_cast<uint2*>(b + (pc * BN + lrow + 32 * j) * LDKH + kq * 4) = q;
+        if (pc + 1 < PIECES) r = sub_bf16x4(r, q);
+      }
+    }
   };
   const int i = lane & 31, h = lane >> 5;
   auto compute = [&](int buf) {
-    const unsigned short* a_s = As + buf * BM * LDKH;
-    const unsigned short* b_s = Bs + buf * BN * LDKH;
+    const unsigned short* a_s = As + buf * PIECES * BM * LDKH;
+    const unsigned short* b_s = Bs + buf * PIECES * BN * LDKH;
 #pragma unroll
     for (int sl = 0; sl < BK / 16; ++sl) {
-      bf16x8_t fa[C::MI], fb[C::NI];
+      bf16x8_t fa[PIECES][C::MI], fb[PIECES][C::NI];
 #pragma unroll
-      for (int mi = 0; mi < C::MI; ++mi)
-        fa[mi] = *reinterpret_cast<const bf16x8_t*>(a_s + (wm * C::WM + mi * 32 + i) * LDKH + sl * 16 + h * 8);
+      for (int pc = 0; pc < PIECES; ++pc) {
 #pragma unroll
-      for (int ni = 0; ni < C::NI; ++ni)
-        fb[ni] = *reinterpret_cast<const bf16x8_t*>(b_s + (wn * C::WN + ni * 32 + i) * LDKH + sl * 16 + h * 8);
-#pragma unroll
-      for (int mi = 0; mi < C::MI; ++mi)
+        for (int mi = 0; mi < C::MI; ++mi)
+          fa[pc][mi] = *reinterpret_cast<const bf16x8_t*>(a_s + (pc * BM + wm * C::WM + mi * 32 + i) * LDKH + sl * 16 + h * 8);
 #pragma unroll
         for (int ni = 0; ni < C::NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+          fb[pc][ni] = *reinterpret_cast<const bf16x8_t*>(b_s + (pc * BN + wn * C::WN + ni * 32 + i) * LDKH + sl * 16 + h * 8);
+      }
+      // smallest partial products first: (a3 b1), (a1 b3), (a2 b2), (a2 b1), (a1 b2), (a1 b1)
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t = (PIECES == 1 ? 5 : 0); t < 6; ++t)
+#pragma unroll
+        for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < C::NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PIECES == 1 ? 0 : PB[t]][ni], fa[PIECES == 1 ? 0 : PA[t]][mi],
+                                                                  acc[mi][ni], 0, 0, 0);
     }
   };
   if (nk > 0) {
     load_next(ra4_0, rb4_0);
     load_next(ra4_1, rb4_1);
     int ks = 0;
-    for (; ks + 1 < nk; ks += 2) {
-      store_step(0, ra4_0, rb4_0);
-      __syncthreads();
-      load_next(ra4_0, rb4_0);
-      compute(0);
-      store_step(1, ra4_1, rb4_1);
-      __syncthreads();
-      load_next(ra4_1, rb4_1);
-      compute(1);
-    }
-    if (ks < nk) {
-      store_step(0, ra4_0, rb4_0);
-      __syncthreads();
-      compute(0);
+    if constexpr (PIECES == 1) {
+      for (; ks + 1 < nk; ks += 2) {
+        store_step(0, ra4_0, rb4_0);
+        __syncthreads();
+        load_next(ra4_0, rb4_0);
+        compute(0);
+        store_step(1, ra4_1, rb4_1);
+        __syncthreads();
+        load_next(ra4_1, rb4_1);
+        compute(1);
+      }
+      if (ks < nk) {
+        store_step(0, ra4_0, rb4_0);
+        __syncthreads();
+        compute(0);
+      }
+    } else {                                           // one LDS buffer: write, barrier, compute, barrier
+      for (; ks + 1 < nk; ks += 2) {
+        store_step(0, ra4_0, rb4_0);
+        __syncthreads();
+        load_next(ra4_0, rb4_0);
+        compute(0);
+        __syncthreads();
+        store_step(0, ra4_1, rb4_1);
+        __syncthreads();
+        load_next(ra4_1, rb4_1);
+        compute(0);
+        __syncthreads();
+      }
+      if (ks < nk) {
+        store_step(0, ra4_0, rb4_0);
+        __syncthreads();
+        compute(0);
+      }
     }
   }
   igemm_epilogue<BM, BN, MODE>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw);
@@ -1869,17 +1927,31 @@ static int launch_tile(const IgemmParams& p, int Mrows_max, int phases, hipStrea
   return launch_igemm<BM, BN, MODE, 2, true>(p, Mrows_max, phases, st);
 }
 
-static int g_precision = 0;      // 0: fp32 MFMA (headline, parity bar); 1: bf16 MFMA for fwd / dgrad (reported separately)
+static int g_precision = 0;      // 0: fp32 MFMA (headline, parity bar); 1: bf16 MFMA for fwd / dgrad; 2: bf16x6 (fp32-accurate
+                                 // products from six bf16 MFMA products) for fwd / dgrad - both reported separately
 
-template <int BM, int BN, int MODE>
-static int launch_igemm_bf16(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
-  const size_t lds = (size_t)2 * (BM + BN) * LDKH * sizeof(unsigned short);
+template <int BM, int BN, int MODE, int PIECES = 1>
+static int launch_igemm_bf16_p(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
+  const size_t lds = (size_t)(PIECES == 1 ? 2 : 1) * PIECES * (BM + BN) * LDKH * sizeof(unsigned short);
+  static bool attr_set_dev[kMaxDevices] = {};
+  bool& attr_set = attr_set_dev[current_device()];
+  if (!attr_set && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_kernel<BM, BN, MODE, PIECES>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
   IgemmParams q = p;
   q.nMt = (int)cdiv(Mrows_max, BM); q.nNt = (int)cdiv(p.Cd, BN); q.mt_per_xcd = (int)cdiv(q.nMt, 8);
   dim3 grid((unsigned)(8 * q.mt_per_xcd * q.nNt), 1, (unsigned)phases);
-  hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, MODE>), grid, dim3(256), lds, st, q);
+  hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, MODE, PIECES>), grid, dim3(256), lds, st, q);
   XAS_LAUNCH_CHECK();
   return 0;
+}
+
+template <int BM, int BN, int MODE>
+static int launch_igemm_bf16(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
+  if (g_precision == 2) return launch_igemm_bf16_p<BM, BN, MODE, 3>(p, Mrows_max, phases, st);
+  return launch_igemm_bf16_p<BM, BN, MODE, 1>(p, Mrows_max, phases, st);
 }
 
 // tile of the fp32 path for a problem (the one rule both the launcher and xas_conv_fwd_bnstats go by)
@@ -1897,7 +1969,7 @@ static void pick_tile(int Cd, long Mrows_max, int phases, int tune, int* bm, int
 
 template <int MODE>
 static int dispatch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
-  if (g_precision == 1) {
+  if (g_precision != 0) {
     const long bias = ((long)(p.R + p.pad) * p.Ws + p.S + p.pad) * p.Cs;
     const bool fits = (bias + p.src_elems) * 4 < 0x7fffff00l && p.wgt_elems * 4 < 0x7fffff00l && p.R * p.S <= 32;
     if (fits) {
@@ -1937,7 +2009,7 @@ static int images_per_launch(int N, long elems_per_image_a, long elems_per_image
 
 extern "C" int xas_set_tuning(int flags) { g_tune = flags; return 0; }
 extern "C" int xas_set_precision(int mode) {
-  XAS_REQUIRE(mode == 0 || mode == 1, "set_precision: 0 = fp32 MFMA, 1 = bf16 MFMA for forward / data-gradient convolutions");
+  XAS_REQUIRE(mode >= 0 && mode <= 2, "set_precision: 0 = fp32 MFMA, 1 = bf16 MFMA, 2 = bf16x6 (fp32-accurate) for forward / data-gradient convolutions");
   g_precision = mode;
   return 0;
 }

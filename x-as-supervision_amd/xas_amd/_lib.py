@@ -104,6 +104,12 @@ def load():
     lib.xas_last_error.restype = ctypes.c_char_p
     lib.xas_last_error.argtypes = []
     _lib = lib
+    mode = os.environ.get('XAS_PRECISION', '')          # '' / '0' = fp32 MFMA (default); '1' = bf16; '2' = bf16x6 (see xas_hip.h)
+    if mode not in ('', '0'):
+        lib.xas_set_precision.argtypes = [ctypes.c_int]
+        lib.xas_set_precision.restype = ctypes.c_int
+        if lib.xas_set_precision(int(mode)) != 0:
+            raise RuntimeError('XAS_PRECISION=%s: %s' % (mode, lib.xas_last_error().decode()))
     return lib
 
 
