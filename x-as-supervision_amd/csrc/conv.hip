@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmParams p) {
       }
     }
   }
-  igemm_epilogue<BM, BN, MODE>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw);
+  igemm_epilogue<BM, BN, MODE>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1932,7 +1932,9 @@ static int g_precision = 0;      // 0: fp32 MFMA (headline, parity bar); 1: bf16
 
 template <int BM, int BN, int MODE, int PIECES = 1>
 static int launch_igemm_bf16_p(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
-  const size_t lds = (size_t)(PIECES == 1 ? 2 : 1) * PIECES * (BM + BN) * LDKH * sizeof(unsigned short);
+  size_t lds = (size_t)(PIECES == 1 ? 2 : 1) * PIECES * (BM + BN) * LDKH * sizeof(unsigned short);
+  const size_t lds_stats = ((size_t)BM * (BN + 4) + 2 * 256) * sizeof(float);      // T[BM][BN+4] + the partial-combine area
+  if (lds < lds_stats) lds = lds_stats;                                            // (always: one LDS size per instantiation)
   static bool attr_set_dev[kMaxDevices] = {};
   bool& attr_set = attr_set_dev[current_device()];
   if (!attr_set && lds > 64 * 1024) {
@@ -1973,14 +1975,14 @@ static int dispatch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipSt
     const long bias = ((long)(p.R + p.pad) * p.Ws + p.S + p.pad) * p.Cs;
     const bool fits = (bias + p.src_elems) * 4 < 0x7fffff00l && p.wgt_elems * 4 < 0x7fffff00l && p.R * p.S <= 32;
     if (fits) {
-      if (p.Cd >= 96) {
-        const long blocks128 = cdiv(Mrows_max, 128) * cdiv(p.Cd, 128) * phases;
-        if (blocks128 <= 512) return launch_igemm_bf16<64, 64, MODE>(p, Mrows_max, phases, st);
-        return launch_igemm_bf16<128, 128, MODE>(p, Mrows_max, phases, st);
-      }
-      if (p.Cd >= 48) return launch_igemm_bf16<128, 64, MODE>(p, Mrows_max, phases, st);
+      int bm, bn;
+      pick_tile(p.Cd, Mrows_max, phases, p.tune, &bm, &bn, (long)p.R * p.S * p.Cs);     // same tile rule as the fp32 path
+      if (bn == 128) return launch_igemm_bf16<128, 128, MODE>(p, Mrows_max, phases, st);
+      if (bm == 64) return launch_igemm_bf16<64, 64, MODE>(p, Mrows_max, phases, st);
+      if (bn == 64) return launch_igemm_bf16<128, 64, MODE>(p, Mrows_max, phases, st);
       return launch_igemm_bf16<128, 32, MODE>(p, Mrows_max, phases, st);
     }
+    XAS_REQUIRE(!p.stat_partial && !p.bnb_x, "conv: the statistics epilogues need the buffer-load kernels (tensor too large)");
   }
   int bm, bn;
   pick_tile(p.Cd, Mrows_max, phases, p.tune, &bm, &bn, (long)p.R * p.S * p.Cs);
@@ -2026,7 +2028,7 @@ extern "C" int xas_conv_fwd(const float* x, const float* w_packed, const float* 
 // Rows per tile when the forward pass of `s` can emit batch-norm partial sums for `groups` camera groups (MFMA path, one
 // launch, no tile straddles a group), else 0.
 static int fwd_stats_tile_rows(const xas_conv_shape* s, int groups) {
-  if (!s || groups < 1 || g_precision != 0) return 0;
+  if (!s || groups < 1) return 0;
   if (s->Cin % BK != 0 || s->Cout < 16 || s->Cout % 4 != 0) return 0;
   if (s->Cin == 3 || (s->Cout == 1 && thin_ok(s, s->Cin)) || (s->Cin == 1 && thin_ok(s, s->Cout))) return 0;
   if (images_per_launch(s->N, (long)s->Hi * s->Wi * s->Cin, 0) < s->N || s->N % groups) return 0;
