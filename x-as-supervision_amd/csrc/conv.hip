@@ -1977,6 +1977,8 @@ static int dispatch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipSt
     if (fits) {
       int bm, bn;
       pick_tile(p.Cd, Mrows_max, phases, p.tune, &bm, &bn, (long)p.R * p.S * p.Cs);     // same tile rule as the fp32 path
+      if (bn == 128 && (p.tune & (1 << 26)) && !p.stat_partial)                          // experiment: 3 blocks per CU
+        return launch_igemm_bf16<128, 64, MODE>(p, Mrows_max, phases, st);
       if (bn == 128) return launch_igemm_bf16<128, 128, MODE>(p, Mrows_max, phases, st);
       if (bm == 64) return launch_igemm_bf16<64, 64, MODE>(p, Mrows_max, phases, st);
       if (bn == 64) return launch_igemm_bf16<128, 64, MODE>(p, Mrows_max, phases, st);
