@@ -597,3 +597,47 @@ def test_gcnconv_discriminator_vs_reference_golden(tag, name, use_bn, self_loop)
     net = _load(net, g, seed=94).cuda()
     net.parent_ids, net.child_ids = skeleton_links(gi.HM36_PARENTS, gi.LINE_SELECT, False, False)
     check_gcn_disc_sequence(net, g, tol_logit=5e-5, tol_grad=2e-4, dev='cuda')
+
+
+def test_optional_step_switches_agree(monkeypatch):
+    """Switches that are OFF by default (measured not to pay) still have to compute the same step: batch-norm backward
+    reductions in the data-gradient epilogue (ops_nn.FUSE_DGRAD_BN), bias gradients on the side stream
+    (ops_nn.BIAS_ON_SIDE), and the two-pass statistics (FUSE_CONV_STATS off).  Different summation orders: parameters after
+    one step agree to 2e-5 of the update size scale (lr = 1e-4)."""
+    from modules.discriminator import GCNDiscriminatorDecouple
+    from modules.model import Counter3DDisc, Counter3DModel
+    from xas_amd import ops_nn
+    from xas_amd.engine import TrainStep
+    from xas_amd.optim import FusedAdam
+    cfg = gi.model_params('S2', cam_ids=(0, 1))
+    full = {'model_params': cfg, 'train_params': {'lr_kp_detector': 1e-4, 'lr_discriminator': 1e-4}}
+    xg = {k: T(v).cuda() for k, v in gi.synthetic_batch(2, [0, 1], seed=95).items()}
+
+    def run(**flags):
+        for k, v in flags.items():
+            monkeypatch.setattr(ops_nn, k, v)
+        reg, phys, _, _ = _hip_models('S2', (0, 1))
+        disc = gi.seeded_fill_(GCNDiscriminatorDecouple(cfg['smpl_disc_params']), seed=9).cuda().train()
+        disc.header.p = 0.0
+        gen, dis = Counter3DModel(cfg, reg, None, None, phys), Counter3DDisc(cfg, disc, None, None)
+        opt_det = FusedAdam(list(reg.parameters()) + list(phys.parameters()), lr=1e-4, betas=(0.5, 0.999))
+        opt_disc = FusedAdam(disc.parameters(), lr=1e-4, betas=(0.5, 0.999))
+        p0 = opt_det.param_arena.clone()
+        step = TrainStep(full, gen, dis, opt_det, opt_disc)
+        _, _, total, _ = step(xg)
+        torch.cuda.synchronize()
+        grads_seen = (opt_det.param_arena - p0)
+        return float(total.detach()), opt_det.param_arena.clone(), grads_seen
+
+    base = run(FUSE_DGRAD_BN=False, BIAS_ON_SIDE=False, FUSE_CONV_STATS=True)
+    for flags in (dict(FUSE_DGRAD_BN=True, BIAS_ON_SIDE=False, FUSE_CONV_STATS=True),
+                  dict(FUSE_DGRAD_BN=False, BIAS_ON_SIDE=True, FUSE_CONV_STATS=True),
+                  dict(FUSE_DGRAD_BN=False, BIAS_ON_SIDE=False, FUSE_CONV_STATS=False)):
+        other = run(**flags)
+        assert abs(other[0] - base[0]) < 1e-5 * abs(base[0]), flags
+        # Adam's first step moves every weight by ~lr * sign(g): compare where the gradient is not at noise level
+        upd = base[2].abs()
+        big = upd > 0.5e-4
+        assert float(big.float().mean()) > 0.5
+        diff = (other[1] - base[1]).abs()[big]
+        assert float((diff > 1e-5).float().mean()) < 2e-3, (flags, float(diff.max()))
