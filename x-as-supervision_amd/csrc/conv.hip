@@ -307,8 +307,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
   // to memory whole rows at a time - a wave stores 1 KiB of contiguous channels per instruction, old values / sign bytes
   // of the accumulating forms are read the same way - instead of 64 scattered 16-byte pieces per instruction straight
   // from the MFMA register layout (64 -> 256 channels at 256 x 64 x 64: 0.671 -> 0.547 ms; tune bit27 = old way).
+  // Plain (non-accumulating) data gradients keep the register epilogue: their long K loops gain nothing and pay the extra
+  // barrier (215.3 vs 215.9 ms/step; tune bit28 stages them too).
   const bool rows_from_lds = lds != nullptr && !(p.tune & (1 << 27)) && (p.Cd & 3) == 0 && m0 + BM <= Mrows &&
-                             n0 + BN <= p.Cd;
+                             n0 + BN <= p.Cd && !(MODE == 1 && !p.accumulate && !(p.tune & (1 << 28)));
   if (want_stats || rows_from_lds) {
     __syncthreads();                                   // every wave has left the K-loop: the operand buffers are free
     const int pl = lane & 31, cs = 4 * (lane >> 5);
