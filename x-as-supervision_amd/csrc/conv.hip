@@ -885,6 +885,88 @@ __global__ __launch_bounds__(256, 2) void igemm_buf_kernel(IgemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------
+// Short-K 1x1 layers (32 / 64 input channels, stride 1: one or two K-steps per tile): PERSISTENT blocks.  Such a tile is
+// 3.4 us of MFMA between a 2-3 us wait for its operands and a 64-128 KB epilogue - with one tile per block the two phases
+// of the (at most two) resident blocks barely overlap and the layer runs at half of both its MFMA and its HBM bound.  Here a
+// block walks its share of the tiles and requests tile t+1's operands right after tile t's have gone to LDS: they arrive
+// during t's MFMAs and epilogue.  Same tile order (XCD-contiguous M ranges), same epilogue.
+// ------------------------------------------------------------------------------------
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(256, 2) void igemm_shortk_kernel(IgemmParams p) {
+  using C = TileCfg<BM, BN>;
+  constexpr int APASS = BM / 32, BPASS = BN / 32;
+  extern __shared__ __align__(16) float lds[];
+  float* As = lds;                       // [2][BM][LDK]: K-step 0 and K-step 1
+  float* Bs = lds + 2 * BM * LDK;        // [2][BN][LDK]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+  const int kq = tid & 7, lrow = tid >> 3;
+  const int Hrow = MODE == 0 ? p.Hrow : p.Hd, Wrow = MODE == 0 ? p.Wrow : p.Wd;     // 1x1, stride 1: row grid = image
+  const int Mrows = p.N * Hrow * Wrow, HW = Hrow * Wrow;
+  const int nk = p.Cs / BK;                                                           // 1 or 2 (launcher)
+  const __amdgpu_buffer_rsrc_t rsrcA =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, (int)(p.src_elems * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, (int)(p.wgt_elems * 4), 0x00020000);
+  const unsigned row_bytes = (unsigned)p.Cs * 4u;
+  const int total_q = 8 * p.mt_per_xcd * p.nNt;
+  float4 ra4_0[APASS], rb4_0[BPASS], ra4_1[APASS], rb4_1[BPASS];
+  auto issue = [&](int mt, int nt) {
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) {
+      const int m = mt * BM + lrow + 32 * j;
+      const unsigned off = m < Mrows ? (unsigned)m * row_bytes + (unsigned)kq * 16u : kOOB;
+      ra4_0[j] = buf_load16(rsrcA, off, 0u);
+      if (nk > 1) ra4_1[j] = buf_load16(rsrcA, off, (unsigned)BK * 4u);
+    }
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) {
+      const int n = nt * BN + lrow + 32 * j;
+      const unsigned off = n < p.Cd ? (unsigned)n * row_bytes + (unsigned)kq * 16u : kOOB;
+      rb4_0[j] = buf_load16(rsrcB, off, 0u);
+      if (nk > 1) rb4_1[j] = buf_load16(rsrcB, off, (unsigned)BK * 4u);
+    }
+  };
+  // tiles of this block: q = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8: the XCD of a q is the block's)
+  int q = blockIdx.x;
+  int mt = (q & 7) * p.mt_per_xcd + (q >> 3) / p.nNt, nt = (q >> 3) % p.nNt;
+  bool valid = q < total_q && mt < p.nMt && mt * BM < Mrows;
+  if (valid) issue(mt, nt);
+  while (valid) {
+    const int qn = q + (int)gridDim.x;
+    const int mtn = (qn & 7) * p.mt_per_xcd + (qn >> 3) / p.nNt, ntn = (qn >> 3) % p.nNt;
+    const bool vn = qn < total_q && mtn < p.nMt && mtn * BM < Mrows;
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) *reinterpret_cast<float4*>(As + (lrow + 32 * j) * LDK + kq * 4) = ra4_0[j];
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) *reinterpret_cast<float4*>(Bs + (lrow + 32 * j) * LDK + kq * 4) = rb4_0[j];
+    if (nk > 1) {
+#pragma unroll
+      for (int j = 0; j < APASS; ++j) *reinterpret_cast<float4*>(As + BM * LDK + (lrow + 32 * j) * LDK + kq * 4) = ra4_1[j];
+#pragma unroll
+      for (int j = 0; j < BPASS; ++j) *reinterpret_cast<float4*>(Bs + BN * LDK + (lrow + 32 * j) * LDK + kq * 4) = rb4_1[j];
+    }
+    __syncthreads();
+    if (vn) issue(mtn, ntn);                           // in flight during this tile's MFMAs and epilogue
+    f32x16 acc[C::MI][C::NI];
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+    f32x16 acc2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+    mfma_tile<BM, BN>(As, Bs, acc, acc2, wm, wn, lane, 0);
+    if (nk > 1) mfma_tile<BM, BN>(As + BM * LDK, Bs + BN * LDK, acc, acc2, wm, wn, lane, 0);
+    igemm_epilogue<BM, BN, MODE>(p, acc, acc2, mt * BM, nt * BN, wm, wn, lane, Mrows, HW, Wrow, 0, 0, lds);
+    __syncthreads();                                   // the LDS image of this tile is consumed
+    q = qn; mt = mtn; nt = ntn; valid = vn;
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // bf16-MFMA variant of fwd / dgrad (NOT the headline path: xas_set_precision(1) selects it, results are
 // reported separately).  Same tiling, addressing and epilogue as igemm_buf_kernel; activations and master weights stay
 // fp32 in HBM and are rounded to bf16 (round to nearest even, v_cvt_pk_bf16_f32) on the way to LDS; products are
@@ -1938,6 +2020,25 @@ static int launch_igemm_buf(const IgemmParams& p, int Mrows_max, int phases, hip
   return 0;
 }
 
+template <int BM, int BN, int MODE>
+static int launch_shortk(const IgemmParams& p, int Mrows_max, hipStream_t st) {
+  const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+  static bool attr_set_dev[kMaxDevices] = {};
+  bool& attr_set = attr_set_dev[current_device()];
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_shortk_kernel<BM, BN, MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  IgemmParams q = p;
+  q.nMt = (int)cdiv(Mrows_max, BM); q.nNt = (int)cdiv(p.Cd, BN); q.mt_per_xcd = (int)cdiv(q.nMt, 8);
+  const long total = 8l * q.mt_per_xcd * q.nNt;
+  const unsigned grid = (unsigned)(total < 512 ? total : 512);          // two resident blocks per CU, a multiple of 8
+  hipLaunchKernelGGL((igemm_shortk_kernel<BM, BN, MODE>), dim3(grid), dim3(256), lds, st, q);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
 // Buffer-load kernel unless its 32-bit offset scheme cannot address the tensor (>= 2 GiB incl. the bias region, or a
 // tap window of more than 32 taps) or an experiment flag asks for the old kernel (tune bit6 = 64).
 template <int BM, int BN, int MODE>
@@ -1954,6 +2055,13 @@ static int launch_tile(const IgemmParams& p, int Mrows_max, int phases, hipStrea
   // nothing to look ahead to (they re-load the last step) - the plain loop is 18 % faster there (0.608 -> 0.497 ms for
   // 64 -> 256 channels at 256 x 64 x 64, tools/bench_ops.py); tune bit25 keeps the pipelined loop everywhere
   const bool short_k = p.stride == 1 && (long)p.R * p.S * p.Cs <= 2 * BK && !(p.tune & (1 << 25));
+  // persistent variant (igemm_shortk_kernel): measured equal to one tile per block (215.1 vs 215.1 ms/step) - these layers
+  // are 80 % output writes and sit at ~2.6 of the ~3.4 TB/s that write-dominated kernels reach on this part, not on
+  // operand latency; kept behind tune bit29
+  if (short_k && fits && p.R == 1 && p.S == 1 && p.pad == 0 && phases == 1 && (p.tune & (1 << 29))) {
+    if constexpr (MODE == 0) return launch_shortk<BM, BN, 0>(p, Mrows_max, st);
+    else if (!p.bnb_x) return launch_shortk<BM, BN, 1>(p, Mrows_max, st);
+  }
   if (fits && !(p.tune & 64)) {                       // tune bit5 (32): plain K-loop instead of the pipelined one
     if ((p.tune & 32) || short_k) return launch_igemm_buf<BM, BN, MODE, false>(p, Mrows_max, phases, st);
     return launch_igemm_buf<BM, BN, MODE, true>(p, Mrows_max, phases, st);
