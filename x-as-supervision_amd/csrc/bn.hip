@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void bn_apply_stream_kernel(const float4* __re
     if (MASKOUT)
       mask_out[goff + k] = (uint8_t)((o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u));
     o.x = act_fwd(o.x, ACT); o.y = act_fwd(o.y, ACT); o.z = act_fwd(o.z, ACT); o.w = act_fwd(o.w, ACT);
-    y[goff + k] = o;
+    stream_store(y + goff + k, o);
   };
   const float4 z4 = make_float4(0, 0, 0, 0);
   for (; i + 3 * stride < n4g; i += 4 * stride) {
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(
     } else if (SIGN == 3) {
       dz.x *= (mb & 1u) ? 1.f : neg; dz.y *= (mb & 2u) ? 1.f : neg; dz.z *= (mb & 4u) ? 1.f : neg; dz.w *= (mb & 8u) ? 1.f : neg;
     }
-    if (DRES) dres[goff + k] = dz;
+    if (DRES) stream_store(dres + goff + k, dz);
     float4 xh;
     if (XH) xh = make_float4((xv.x - m.x) * is.x, (xv.y - m.y) * is.y, (xv.z - m.z) * is.z, (xv.w - m.w) * is.w);
     else {
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(
     o.y = g.y * is.y * (dz.y - a.y * inv_count - xh.y * b.y * inv_count);
     o.z = g.z * is.z * (dz.z - a.z * inv_count - xh.z * b.z * inv_count);
     o.w = g.w * is.w * (dz.w - a.w * inv_count - xh.w * b.w * inv_count);
-    dx[goff + k] = o;
+    stream_store(dx + goff + k, o);
   };
   const float4 z4 = make_float4(0, 0, 0, 0);
   constexpr bool NEEDX = XH || SIGN == 2, NEEDY = SIGN == 1 || !XH;
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __rest
   o.y = h0l * (w0l * a.y + lw * b.y) + lh * (w0l * cc.y + lw * d.y);
   o.z = h0l * (w0l * a.z + lw * b.z) + lh * (w0l * cc.z + lw * d.z);
   o.w = h0l * (w0l * a.w + lw * b.w) + lh * (w0l * cc.w + lw * d.w);
-  *reinterpret_cast<float4*>(y + ((size_t)row * Wo + wo) * C + c) = o;
+  stream_store(reinterpret_cast<float4*>(y + ((size_t)row * Wo + wo) * C + c), o);
 }
 
 // Adjoint of the x2 bilinear map.  Input i receives from outputs 2i-1 (0.25), 2i (0.75; 1 at i == 0), 2i+1 (0.75; 1 at
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
     acc.x = fmaf(wh[k], tr.x, acc.x); acc.y = fmaf(wh[k], tr.y, acc.y);
     acc.z = fmaf(wh[k], tr.z, acc.z); acc.w = fmaf(wh[k], tr.w, acc.w);
   }
-  *reinterpret_cast<float4*>(dx + ((size_t)row * W + wi) * C + c) = acc;
+  stream_store(reinterpret_cast<float4*>(dx + ((size_t)row * W + wi) * C + c), acc);
 }
 
 __global__ void sigmoid_fwd_kernel(const float* __restrict__ x, long n, float* __restrict__ y) {

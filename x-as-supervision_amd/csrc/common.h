@@ -60,6 +60,17 @@ __device__ __forceinline__ float bn_affine(float x, float m, float rs_g, float b
   return __fmaf_rn(__fsub_rn(x, m), rs_g, b);
 }
 
+// Store of a large result that is streamed out once: non-temporal (global_store ... nt).  Measured (build A/B on one box,
+// XAS_HIPCC_DEFS=-DXAS_NO_NT_STORES): x2 upsample forward 3.28 -> 4.70 TB/s, step 213.5 -> 213.0 ms.
+__device__ __forceinline__ void stream_store(float4* p, float4 v) {
+#ifndef XAS_NO_NT_STORES
+  typedef float f32x4_nt_t __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(f32x4_nt_t{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_nt_t*>(p));
+#else
+  *p = v;
+#endif
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 

@@ -408,7 +408,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
         v.x += (mb & 1u) ? o.x : 0.f; v.y += (mb & 2u) ? o.y : 0.f;
         v.z += (mb & 4u) ? o.z : 0.f; v.w += (mb & 8u) ? o.w : 0.f;
       }
-      *reinterpret_cast<float4*>(op) = v;
+      stream_store(reinterpret_cast<float4*>(op), v);
     }
   }
   if (MODE == 0 && want_stats) {
