@@ -139,8 +139,8 @@ __device__ __forceinline__ void col_reduce_body(const ColArgs& a) {
 #pragma unroll UNR
   for (long r = r0 + ty; r < r1; r += g.TY) {
     if (MODE == 3) {
-      float4 g4 = *reinterpret_cast<const float4*>(dy + r * C + c);
-      const float4 yv = *reinterpret_cast<const float4*>(y + r * C + c);
+      float4 g4 = stream_load(reinterpret_cast<const float4*>(dy + r * C + c));
+      const float4 yv = stream_load(reinterpret_cast<const float4*>(y + r * C + c));
       const float neg = act == 1 ? 0.f : 0.01f, up = act == 1 ? 0.f : 100.f;
       float4 z;                                            // pre-activation value
       z.x = yv.x > 0.f ? yv.x : yv.x * up; z.y = yv.y > 0.f ? yv.y : yv.y * up;
@@ -152,9 +152,9 @@ __device__ __forceinline__ void col_reduce_body(const ColArgs& a) {
       s2.z = fmaf(g4.z, (z.z - p0.z) * p1.z, s2.z); s2.w = fmaf(g4.w, (z.w - p0.w) * p1.w, s2.w);
       continue;
     }
-    const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c);
+    const float4 xv = stream_load(reinterpret_cast<const float4*>(x + r * C + c));
     if (MODE == 4) {
-      float4 g4 = *reinterpret_cast<const float4*>(dy + r * C + c);
+      float4 g4 = stream_load(reinterpret_cast<const float4*>(dy + r * C + c));
       const float neg = act == 1 ? 0.f : 0.01f;
       g4.x *= bn_affine(xv.x, p0.x, rsg.x, bt.x) > 0.f ? 1.f : neg; g4.y *= bn_affine(xv.y, p0.y, rsg.y, bt.y) > 0.f ? 1.f : neg;
       g4.z *= bn_affine(xv.z, p0.z, rsg.z, bt.z) > 0.f ? 1.f : neg; g4.w *= bn_affine(xv.w, p0.w, rsg.w, bt.w) > 0.f ? 1.f : neg;
@@ -170,14 +170,14 @@ __device__ __forceinline__ void col_reduce_body(const ColArgs& a) {
       s1.x += a0; s1.y += b; s1.z += cc; s1.w += d;
       s2.x = fmaf(a0, a0, s2.x); s2.y = fmaf(b, b, s2.y); s2.z = fmaf(cc, cc, s2.z); s2.w = fmaf(d, d, s2.w);
     } else {
-      float4 g4 = *reinterpret_cast<const float4*>(dy + r * C + c);
+      float4 g4 = stream_load(reinterpret_cast<const float4*>(dy + r * C + c));
       if (act && a.mask) {
         const unsigned mb = a.mask[(r * C + c) >> 2];
         const float neg = act == 1 ? 0.f : 0.01f;
         g4.x *= (mb & 1u) ? 1.f : neg; g4.y *= (mb & 2u) ? 1.f : neg;
         g4.z *= (mb & 4u) ? 1.f : neg; g4.w *= (mb & 8u) ? 1.f : neg;
       } else if (act) {
-        const float4 yv = *reinterpret_cast<const float4*>(y + r * C + c);
+        const float4 yv = stream_load(reinterpret_cast<const float4*>(y + r * C + c));
         const float neg = act == 1 ? 0.f : 0.01f;
         g4.x *= yv.x > 0.f ? 1.f : neg; g4.y *= yv.y > 0.f ? 1.f : neg;
         g4.z *= yv.z > 0.f ? 1.f : neg; g4.w *= yv.w > 0.f ? 1.f : neg;
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void bn_apply_stream_kernel(const float4* __re
   for (; i + 3 * stride < n4g; i += 4 * stride) {
     float4 xv[4], rv[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { xv[u] = x[goff + i + u * stride]; rv[u] = RES ? res[goff + i + u * stride] : z4; }
+    for (int u = 0; u < 4; ++u) { xv[u] = stream_load(x + goff + i + u * stride); rv[u] = RES ? stream_load(res + goff + i + u * stride) : z4; }
 #pragma unroll
     for (int u = 0; u < 4; ++u) one(i + u * stride, xv[u], rv[u]);
   }
@@ -593,9 +593,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const long k = goff + i + u * stride;
-      dv[u] = dy[k];
-      xv[u] = NEEDX ? x[k] : z4;
-      yv[u] = NEEDY ? y[k] : z4;
+      dv[u] = stream_load(dy + k);
+      xv[u] = NEEDX ? stream_load(x + k) : z4;
+      yv[u] = NEEDY ? stream_load(y + k) : z4;
       mb[u] = SIGN == 3 ? mask[k] : 0u;
     }
 #pragma unroll

@@ -403,7 +403,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
       v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
       float* op = p.out + orow * p.Cd + nn;
       if (p.accumulate) {
-        const float4 o = *reinterpret_cast<const float4*>((p.accumulate == 2 ? p.acc_src + orow * p.Cd + nn : op));
+        const float4 o = stream_load(reinterpret_cast<const float4*>(p.accumulate == 2 ? p.acc_src + orow * p.Cd + nn : op));
         const unsigned mb = p.accumulate == 2 ? p.acc_mask[(orow * p.Cd + nn) >> 2] : 15u;
         v.x += (mb & 1u) ? o.x : 0.f; v.y += (mb & 2u) ? o.y : 0.f;
         v.z += (mb & 4u) ? o.z : 0.f; v.w += (mb & 8u) ? o.w : 0.f;

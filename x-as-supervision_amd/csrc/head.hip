@@ -61,7 +61,7 @@ __global__ void head_partial_kernel(const float4* __restrict__ logits, float* __
   for (; p + 3 * g.R < pend; p += 4 * g.R) {
     float4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = base[(size_t)(p + u * g.R) * g.C4];
+    for (int u = 0; u < 4; ++u) v[u] = stream_load(base + (size_t)(p + u * g.R) * g.C4);
     float mn = m;
 #pragma unroll
     for (int u = 0; u < 4; ++u) mn = fmaxf(mn, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
@@ -223,7 +223,7 @@ __global__ void head_bwd_kernel(const float4* __restrict__ logits, const float* 
   const size_t off = ((size_t)b * g.HW + pix0) * g.C4 + c4;
 #pragma unroll 4
   for (int p = slot; p < pend; p += g.R) {
-    const float4 v = logits[off + (size_t)p * g.C4];
+    const float4 v = stream_load(logits + off + (size_t)p * g.C4);
     const int pix = pix0 + p;
     const float lin = cx * (float)(pix & (g.W - 1)) + cy * (float)(pix >> g.wshift) + c0;
     float4 o;
@@ -231,7 +231,7 @@ __global__ void head_bwd_kernel(const float4* __restrict__ logits, const float* 
     o.y = __expf(v.y - lse) * (lin + gz.y);
     o.z = __expf(v.z - lse) * (lin + gz.z);
     o.w = __expf(v.w - lse) * (lin + gz.w);
-    grad[off + (size_t)p * g.C4] = o;
+    stream_store(grad + off + (size_t)p * g.C4, o);
   }
 }
 
