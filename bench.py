@@ -171,6 +171,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     log('timed %d steps: %.1f ms/step' % (args.steps, dt / args.steps * 1e3))
+    log('memory: peak allocated %.1f GB, reserved %.1f GB' % (torch.cuda.max_memory_allocated() / 2**30, torch.cuda.memory_reserved() / 2**30))
 
     # one extra, UNTIMED step with the side stream disabled: the same kernels measured without concurrent
     # neighbours (kernel quality), beside the overlapped figures of the timed region (step throughput)

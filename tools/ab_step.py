@@ -6,7 +6,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, 'x-as-supervision_amd')]
 import torch
 from xas_amd import engine, ops_nn, streams, _lib
 from xas_amd.synthetic import model_config, synthetic_batch
-cfg = model_config('HM36_Multi_SurS1')
+cfg = model_config(os.environ.get('WORKLOAD', 'HM36_Multi_SurS1'))
 torch.manual_seed(0)
 model, disc, od, odisc = engine.prepare_model(cfg)
 model.cuda().train(); disc.cuda().train()
@@ -26,7 +26,7 @@ def select(sel):
         _lib.query('xas_set_tuning', sel[1])
     else:
         _lib.query('xas_set_tuning', 0)
-        setattr(ops_nn, sel[1], bool(sel[2]))
+        setattr(ops_nn, sel[1], sel[2] if sel[1].startswith('_') else bool(sel[2]))      # _NAME=int, NAME=0/1
 
 
 variants = [parse(a) for a in (sys.argv[1:] or ['0', '8192'])]

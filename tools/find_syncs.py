@@ -7,7 +7,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, 'x-as-supervision_amd')]
 import torch
 from xas_amd import engine
 from xas_amd.synthetic import model_config, synthetic_batch
-cfg = model_config('HM36_Multi_SurS1')
+cfg = model_config(os.environ.get('WORKLOAD', 'HM36_Multi_SurS1'))
 torch.manual_seed(0)
 model, disc, od, odisc = engine.prepare_model(cfg)
 model.cuda().train(); disc.cuda().train()

@@ -56,11 +56,32 @@ def side_stream():
     return _side['stream']
 
 
+# Lifetime of the tensors a side-stream kernel reads.  `tensor.record_stream(side)` is correct but defers the re-use of the block
+# until the HOST sees the side-stream work complete - and the host runs one to two steps ahead of the GPU, so every activation
+# and gradient of those steps stayed reserved: 132 GB reserved for a 46 GB working set, and gigabytes of hipMalloc inside the
+# timed steps (seconds when the memory had just been released by another process).  Instead the tensors are kept alive in a
+# short FIFO; when an entry leaves it the MAIN stream is made to wait for that entry's side-stream event (long past on the
+# GPU by then), so whatever re-uses the memory is ordered after its last reader on the device, and nothing is deferred.
+_KEEP_DEPTH = 8
+
+
+def _keep_for_side(*tensors):
+    ev = torch.cuda.Event()
+    ev.record(_side['stream'])
+    q = _side.setdefault('keep', [])
+    q.append((ev, tensors))
+    if len(q) > _KEEP_DEPTH:
+        old_ev, _ = q.pop(0)
+        torch.cuda.current_stream().wait_event(old_ev)
+
+
 def join_side_stream():
     """Make the current stream wait for every weight gradient launched on the side stream."""
     if _side['dirty'] and _side['stream'] is not None:
         torch.cuda.current_stream().wait_stream(_side['stream'])
         _side['dirty'] = False
+    if _side.get('keep'):
+        _side['keep'] = []
 
 
 def side_stream_event():
@@ -118,8 +139,7 @@ def _wgrad_into_grad(x, dy, shp, weight):
     with torch.cuda.stream(side):
         ws = torch.empty(max(1, query('xas_conv_wgrad_workspace_floats', shp)), device=x.device, dtype=torch.float32)
         call('xas_conv_wgrad_acc', ptr(x), ptr(dy), ptr(g), ptr(ws), shp)
-    x.record_stream(side)
-    dy.record_stream(side)
+    _keep_for_side(x, dy)
     _side['dirty'] = True
     grad_ready(weight)
     return True
@@ -141,7 +161,7 @@ def _bias_into_grad(dy, M, C, bias):
     with torch.cuda.stream(side):
         ws = torch.empty(query('xas_bn_workspace_floats', M, C, 1), device=dy.device, dtype=torch.float32)
         call('xas_col_sum_acc', ptr(dy), M, C, ptr(g), ptr(ws))
-    dy.record_stream(side)
+    _keep_for_side(dy)
     _side['dirty'] = True
     grad_ready(bias)
     return True
