@@ -199,7 +199,8 @@ def test_bn_residual_sign_mask_path(n, c, h, w, G, monkeypatch):
 STATS_CASES = [(8, 64, 32, 32, 256, 1, 1, 0, 1), (8, 64, 32, 32, 256, 1, 1, 0, 4), (16, 256, 64, 64, 64, 1, 1, 0, 8),
                (8, 64, 32, 32, 64, 3, 1, 1, 2), (8, 128, 16, 16, 128, 3, 2, 1, 4), (4, 512, 8, 8, 2048, 1, 1, 0, 2),
                (8, 64, 32, 32, 32, 1, 1, 0, 2), (128, 64, 64, 64, 256, 1, 1, 0, 8),
-               (2, 256, 4, 4, 1024, 1, 1, 0, 2), (3, 64, 12, 20, 64, 1, 1, 0, 3), (6, 64, 10, 10, 128, 3, 1, 1, 2)]
+               (2, 256, 4, 4, 1024, 1, 1, 0, 2), (3, 64, 12, 20, 64, 1, 1, 0, 3), (6, 64, 10, 10, 128, 3, 1, 1, 2),
+               (8, 64, 16, 16, 96, 1, 1, 0, 2), (8, 32, 32, 32, 160, 3, 1, 1, 4), (4, 64, 16, 16, 20, 1, 1, 0, 2)]     # ragged column tiles
 
 
 @pytest.mark.parametrize('n,cin,h,w,cout,k,stride,pad,G', STATS_CASES)
