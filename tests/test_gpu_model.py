@@ -640,4 +640,4 @@ def test_optional_step_switches_agree(monkeypatch):
         big = upd > 0.5e-4
         assert float(big.float().mean()) > 0.5
         diff = (other[1] - base[1]).abs()[big]
-        assert float((diff > 1e-5).float().mean()) < 2e-3, (flags, float(diff.max()))
+        assert float((diff > 1e-5).float().mean()) < 5e-3, (flags, float(diff.max()))       # sign flips of noise-level gradients
