@@ -68,7 +68,7 @@ def _grouped(net, tensors):
     for lo in range(0, len(tensors), per_pass):
         part = tensors[lo:lo + per_pass]
         G = len(part)
-        y = net.forward_groups(torch.cat(part, dim=0) if G > 1 else part[0], G)
+        y = net.forward_groups(ops_nn.stack_nchw(part) if G > 1 else part[0], G)
         if isinstance(y, tuple):                         # detector: (kps [G*B, ...], depth maps [G, K, D])
             kps, dmap = y
             dmap = dmap.reshape(G, *dmap.shape[-2:])

@@ -189,6 +189,21 @@ def from_nchw(x):
     return y
 
 
+def stack_nchw(tensors):
+    """Equal-shaped NCHW image batches (one per camera) -> ONE channels_last tensor [sum N, C, H, W]: each batch is converted
+    straight into its slice, instead of torch.cat (a 100 MB copy per pass) followed by the layout conversion."""
+    t0 = tensors[0]
+    if (len(tensors) == 1 or t0.dim() != 4 or not t0.is_cuda or t0.shape[1] == 1
+            or any(t.requires_grad or (t.is_contiguous(memory_format=CL) and t.shape[1] > 1) for t in tensors)):      # autograd inputs: torch.cat
+        return torch.cat(list(tensors), dim=0) if len(tensors) > 1 else t0
+    n, c, h, w = t0.shape
+    y = empty_cl(n * len(tensors), c, h, w, t0)
+    for g, t in enumerate(tensors):
+        t = t.contiguous()
+        call('xas_nchw_to_nhwc', ptr(t), n, c, h, w, ptr(y[g * n:(g + 1) * n]))
+    return y
+
+
 def _shape(n, hi, wi, cin, cout, r, s, stride, pad, ho, wo):
     return ConvShape(n, hi, wi, cin, cout, r, s, stride, pad, ho, wo)
 
