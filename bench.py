@@ -199,6 +199,21 @@ def main():
             with open(tpath) as tf:
                 pmc = json.load(tf)
                 traffic = pmc.get('bytes_per_launch')   # PMC passes of this same command (see file)
+        variant_check = None
+        if args.precision != 'f32':
+            # the variant's distance to the fp32-MFMA path, measured here (untimed): joints of one detector pass on 8 images
+            reg = model.regressor
+            was = reg.training
+            reg.eval()                                  # running statistics: both passes see the same normalisation
+            img = x['cam_%s_img' % cams[0]][:8]
+            with torch.no_grad():
+                kv = reg(img)[0].clone()
+                _xl.query('xas_set_precision', 0)
+                k32 = reg(img)[0]
+                _xl.query('xas_set_precision', {'bf16': 1, 'bf16x6': 2}[args.precision])
+            reg.train(was)
+            variant_check = {'max_abs_joint_diff_vs_f32_path': float((kv - k32).abs().max()),
+                             'what': 'detector forward (eval-mode norms) on 8 images, this precision mode vs the fp32-MFMA path; parity bar 1e-4'}
         line = {
             'metric': 'images/sec %s 256px bs%d (full disc+gen training step)' % (args.workload, args.batch),
             'value': samples * per_sample / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
@@ -211,7 +226,7 @@ def main():
                        'image': '256x256', 'images_per_sample': per_sample, 'parallelism': 'dp%d' % world,
                        'samples_per_s': samples / dt,
                        'detector_forwards_per_s': samples * (2 if args.dedupe else 3) * len(cams) / dt,
-                       'dedupe': bool(args.dedupe)},
+                       'dedupe': bool(args.dedupe), **({'variant_check': variant_check} if variant_check else {})},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': timer.bytes_total / max(1, n_launch),
