@@ -16,6 +16,6 @@ with gzip.open(os.path.join(out, 'kernels.csv.gz'), 'wt', newline='') as f:
         w.writerow(r)
 with open(os.path.join(out, 'kernel_stats.csv'), 'w', newline='') as f:
     w = csv.writer(f)
-    w.writerow(['name', 'calls', 'total_ns', 'avg_ns', 'pct'])
+    w.writerow(['name', 'calls', 'total_us', 'avg_us', 'pct'])          # rocpd top_kernels reports microseconds
     for r in db.execute('select name, total_calls, total_duration, average, percentage from top_kernels'):
         w.writerow(r)
