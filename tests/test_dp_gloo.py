@@ -130,3 +130,39 @@ def test_reducer_disabled_without_process_group():
     assert not red.enabled
     red.arm()
     red.finish()
+
+
+def test_use_counts_are_per_reducer():
+    """r02 ADVICE (medium): under TrainStep(dedupe=True) the detector's real-image forward is counted BEFORE the
+    discriminator step; the discriminator reducer's finish() must not wipe those counts, and a parameter without a
+    counted use must never be reported early (its bucket is left to finish())."""
+    sys.path.insert(0, os.path.join(ROOT, 'x-as-supervision_amd'))
+    from xas_amd import ops_nn
+    det = [torch.nn.Parameter(torch.zeros(4)) for _ in range(2)]
+    disc = [torch.nn.Parameter(torch.zeros(4))]
+    fired = []
+    ops_nn.track_grad_uses(True)
+    try:
+        ops_nn._uses['hook'] = lambda p: fired.append(p.data_ptr())
+        for p in det:                       # real-image detector pass, counted first (dedupe)
+            ops_nn.note_use(p)
+        ops_nn.note_use(disc[0])            # discriminator step
+        ops_nn.grad_ready(disc[0])
+        assert fired == [disc[0].data_ptr()]
+        ops_nn.forget_uses([disc[0].data_ptr()])          # what red_disc.finish() does now
+        assert all(p.data_ptr() in ops_nn._uses['pending'] for p in det)
+        for p in det:                       # pseudo-image pass: second use of every detector parameter
+            ops_nn.note_use(p)
+        fired.clear()
+        ops_nn.grad_ready(det[0])           # first of two contributions: not complete
+        assert fired == []
+        ops_nn.grad_ready(det[0])           # second: complete
+        assert fired == [det[0].data_ptr()]
+        ops_nn.grad_ready(det[0])           # a contribution nobody counted: never reported
+        assert fired == [det[0].data_ptr()]
+        stranger = torch.nn.Parameter(torch.zeros(4))
+        ops_nn.grad_ready(stranger)
+        assert fired == [det[0].data_ptr()]
+    finally:
+        ops_nn._uses['hook'] = None
+        ops_nn.track_grad_uses(False)

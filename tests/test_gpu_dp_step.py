@@ -14,9 +14,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, opts=None):
+    opts = opts or {}
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK='0')
+                      LOCAL_RANK='0', XAS_DP_NOTIFY=str(opts.get('notify', 1)), XAS_CAM_BATCH=str(opts.get('cam_batch', 1)))
     for p in (ROOT, os.path.join(ROOT, 'x-as-supervision_amd')):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -26,14 +27,17 @@ def _worker(rank, world, port, ret):
         from xas_amd import engine
         from xas_amd.synthetic import model_config, synthetic_batch
         cfg = model_config('HM36_Multi_SurS2')
-        cfg['model_params']['cam_id_list'] = [0]
+        cfg['model_params']['cam_id_list'] = opts.get('cams', [0])
         torch.manual_seed(100 + rank)                         # different init per rank: the broadcast must fix it
         model, disc, od, odisc = engine.prepare_model(cfg)
         model.cuda().train(), disc.cuda().train()
         disc.smpl_discriminator.header.p = 0.0
-        step = engine.TrainStep(cfg, model, disc, od, odisc, num_buckets=3)
+        step = engine.TrainStep(cfg, model, disc, od, odisc, num_buckets=3, dedupe=bool(opts.get('dedupe', False)))
         assert step.red_det is not None and len(step.red_det.buckets) >= 2
-        x = synthetic_batch(2, [0], torch.device('cuda'), seed=10 + rank)   # different data per rank
+        early = []
+        orig_launch = step.red_det._launch
+        step.red_det._launch = lambda b: (early.append(step.red_det._armed), orig_launch(b))[1]
+        x = synthetic_batch(2, opts.get('cams', [0]), torch.device('cuda'), seed=10 + rank)   # different data per rank
         ld, lk, tot, _ = step(x)
         torch.cuda.synchronize()
         p = od.param_arena
@@ -41,27 +45,46 @@ def _worker(rank, world, port, ret):
         ret[rank] = (float(p.double().sum()), float(p.double().abs().sum()), float(odisc.param_arena.double().sum()),
                      float(sd['regressor.net.backbone.bn1.running_mean'].double().sum()),
                      float(sd['regressor.net.backbone.layer1.0.bn1.running_mean'].double().sum()),
-                     bool(torch.isfinite(tot)))
+                     bool(torch.isfinite(tot)), int(sum(early)))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_step_keeps_replicas_identical():
+def _run2(opts=None):
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context('spawn')
     ret = ctx.Manager().dict()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret, opts)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(600)
         assert p.exitcode == 0
-    a, b = ret[0], ret[1]
+    return ret[0], ret[1]
+
+
+def test_two_rank_step_keeps_replicas_identical():
+    a, b = _run2()
     assert a[5] and b[5]
     assert a[0] == b[0] and a[1] == b[1]          # generator parameters bit-identical after the averaged step
     assert a[2] == b[2]                           # discriminator parameters too
     assert a[3] == b[3]                           # SyncBatchNorm (stem) running mean is global
     assert a[4] != b[4]                           # in-block BatchNorm2d stays rank-local (different data)
+
+
+@pytest.mark.parametrize('dedupe,cam_batch', [(False, 1), (True, 1), (True, 0)])
+def test_early_bucket_launch_equals_launch_at_finish(dedupe, cam_batch):
+    """Buckets launched from the readiness reports during backward (XAS_DP_NOTIFY=1) must carry COMPLETE gradients: the
+    step must be bit-identical to the one whose buckets are all launched by finish() (XAS_DP_NOTIFY=0), with two ranks
+    (the all-reduce is not the identity), with and without TrainStep(dedupe=True) - whose real-image detector forward is
+    counted before the discriminator step (r02 ADVICE: those counts were wiped and buckets left early, incomplete) - and
+    with one detector call per camera (XAS_CAM_BATCH=0: several uses per parameter and pass)."""
+    opts = dict(dedupe=dedupe, cam_batch=cam_batch, cams=[0, 1])
+    a1, b1 = _run2(dict(opts, notify=1))
+    a0, b0 = _run2(dict(opts, notify=0))
+    assert a1[5] and a0[5]
+    assert a1[:3] == b1[:3] and a0[:3] == b0[:3]               # replicas agree within each mode
+    assert a1[:3] == a0[:3], (a1, a0)                          # and early launches change nothing

@@ -60,8 +60,8 @@ def test_patch_batch_vs_oracle(mpi):
     assert out['img'].shape == (5, 3, 256, 256) and out['mask'].shape == (5, 1, 256, 256)
     for i, (smp, (scale, rot, flip, cs)) in enumerate(zip(samples, aug)):
         img, msk, cx = frames[i], masks[i], smp['center_x']
-        if flip:
-            img, msk, cx = img[:, ::-1, :], msk[:, ::-1], img.shape[1] - cx - 1
+        if flip:                                   # only the image is flipped; the mask is warped un-flipped with the flipped
+            img, cx = img[:, ::-1, :], img.shape[1] - cx - 1     # image's transform (reference dataloader.py:57-59, affine.py:107-110)
         t = O.gen_affine_trans_from_box(cx, smp['center_y'], smp['width'], smp['height'], 256, 256, scale, O.norm_rot_angle(rot))
         ip = O.warp_affine_u8(img, t, 256)
         mp = O.warp_affine_u8(msk, t, 256)[..., 0]
@@ -82,7 +82,7 @@ def test_patch_batch_vs_oracle(mpi):
 
 def test_geodesic_weight_vs_fast_marching_oracle():
     from oracle import input_pipeline as O
-    from human_utils.common.utility.geodesic import compute_geodesic_dis
+    from human_utils.common.utility.geodesic import compute_geodesic_dis_batch as compute_geodesic_dis
     P = 96
     m = gi.blob_mask(5, P, seed=7).astype(np.float32)                    # [5,1,P,P] body-like blobs
     m[1, 0, :, :] *= 0.5                                                 # non-binary values: any non-zero is foreground
@@ -104,7 +104,7 @@ def test_geodesic_weight_vs_fast_marching_oracle():
 
 def test_geodesic_full_size_properties():
     """256 x 256, B = 32 (one camera of the benchmark batch): finite, bounded, centre value, monotone away from the mask."""
-    from human_utils.common.utility.geodesic import compute_geodesic_dis
+    from human_utils.common.utility.geodesic import compute_geodesic_dis_batch as compute_geodesic_dis
     m = torch.from_numpy(gi.blob_mask(32, 256, seed=9).astype(np.float32)).cuda()
     out, cen = compute_geodesic_dis(m, [2, 1, 3, 20, 0.0])
     assert torch.isfinite(out).all()

@@ -90,3 +90,9 @@ def trans_coords_from_patch_to_org_3d(coords_in_patch, c_x, c_y, bb_width, bb_he
                                                       patch_height)
     coords_in_org[:, 2] = coords_in_patch[:, 2] * depth_scale
     return coords_in_org
+
+
+# names this mirror does not replace resolve, lazily, to the reference module behind it on sys.path
+from xas_amd._next import fallthrough as _fallthrough  # noqa: E402
+
+__getattr__ = _fallthrough(__name__, __file__)

@@ -1,17 +1,26 @@
 """Geodesic weight maps on the GPU (reference: human_utils/common/utility/geodesic.py:14-54, scikit-fmm on the CPU,
-two fast-marching solves per sample and camera).  One HIP launch produces the maps of a whole batch."""
+two fast-marching solves per sample and camera).
+
+`compute_geodesic_dis_batch` is the product path: one HIP launch produces the maps of a whole batch of device masks
+(called by human_utils/dataloader/gpu_patch.py).  `compute_geodesic_dis` keeps the REFERENCE's positional signature
+(`img [1,H,W]` numpy, `img_path`, parameter list, optional centres, `is_norm`) and return types, so that the reference's
+own loader (`human_utils/dataloader/dataloader.py:13,80`) keeps working with the mirror in front of it on PYTHONPATH: it
+runs the batch kernel on a batch of one.  `is_norm=False` (raw distances; no shipped config) and anything else this
+module does not define fall through to the reference module.
+"""
 import ctypes
 
+import numpy as np
 import torch
 
 from xas_amd._lib import call, ptr, query
 
 
-def compute_geodesic_dis(mask, geodesic_param_list, centers=None):
+def compute_geodesic_dis_batch(mask, geodesic_param_list, centers=None):
     """mask [B,1,P,P] float device tensor (non-zero = foreground) -> (weights [B,1,P,P] float32, centres [B,2] int32 (x, y)).
     centers: optional [B,2] integer tensor of source pixels (geodesic_pt_list joints); default: mask centroid."""
     if mask.dim() != 4 or mask.shape[1] != 1 or mask.shape[2] != mask.shape[3]:
-        raise RuntimeError('compute_geodesic_dis expects a [B,1,P,P] mask batch')
+        raise RuntimeError('compute_geodesic_dis_batch expects a [B,1,P,P] mask batch')
     mask = mask.contiguous().float()
     B, _, P, _ = mask.shape
     out = torch.empty_like(mask)
@@ -21,3 +30,26 @@ def compute_geodesic_dis(mask, geodesic_param_list, centers=None):
     c = centers.to(device=mask.device, dtype=torch.int32).contiguous() if centers is not None else None
     call('xas_geodesic_weight', ptr(mask), ptr(c), ctypes.cast(params, ctypes.c_void_p), B, P, ptr(out), ptr(cen), ptr(ws))
     return out, cen
+
+
+def compute_centroid(mask):
+    """[1,H,W] boolean mask -> int16 (x, y) centroid (geodesic.py:4-12)."""
+    _, h, w = mask.shape
+    grid = np.mgrid[0:h, 0:w]
+    return np.array([np.sum(grid[1] * mask) / np.sum(mask), np.sum(grid[0] * mask) / np.sum(mask)]).astype(np.int16)
+
+
+def compute_geodesic_dis(img, img_path, geodesic_param_list, centers=None, is_norm=True):
+    """Reference signature (geodesic.py:14): img [1,H,W] numpy mask -> (weight map [1,H,W], centres [n,2] int16)."""
+    if not is_norm or img.shape[-1] != img.shape[-2] or (centers is not None and len(centers) != 1):
+        return __getattr__('compute_geodesic_dis')(img, img_path, geodesic_param_list, centers, is_norm)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    m = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32)).to(dev)[None]
+    c = None if centers is None else torch.as_tensor(np.asarray(centers, dtype=np.int32).reshape(1, 2))
+    out, cen = compute_geodesic_dis_batch(m, geodesic_param_list, c)
+    return out[0].cpu().numpy(), cen.cpu().numpy().astype(np.int16).reshape(-1, 2)
+
+
+from xas_amd._next import fallthrough as _fallthrough  # noqa: E402
+
+__getattr__ = _fallthrough(__name__, __file__)

@@ -13,7 +13,7 @@ import torch
 
 from human_utils.common.imglib.affine import (fliplr_joints, gen_affine_trans_from_box_cv, invert_for_warp, norm_rot_angle,
                                                trans_points_3d)
-from human_utils.common.utility.geodesic import compute_geodesic_dis
+from human_utils.common.utility.geodesic import compute_geodesic_dis_batch
 from xas_amd._lib import call, ptr
 
 
@@ -57,9 +57,9 @@ def generate_patch_batch(samples, frames, masks, patch_width, patch_height, rect
         scale, rot, do_flip, color_scale = aug[i] if aug is not None else (1.0, 0, False, [1.0, 1.0, 1.0])
         rot = norm_rot_angle(rot - smp['rot'] if do_flip else rot + smp['rot'])
         img, msk, c_x = frames[i], masks[i], smp['center_x']
-        if do_flip:                                            # affine.py:107-110
-            img, msk = img[:, ::-1, :], msk[:, ::-1]
-            c_x = img.shape[1] - c_x - 1
+        if do_flip:                                            # affine.py:107-110: only the IMAGE is flipped; the mask is
+            img = img[:, ::-1, :]                              # warped un-flipped with the same transform, as the reference
+            c_x = img.shape[1] - c_x - 1                       # does (dataloader.py:57-59) - reproduced, not "fixed"
         t = gen_affine_trans_from_box_cv(c_x, smp['center_y'], smp['width'], smp['height'], P, P, scale, rot, False)
         if do_flip:
             j, _ = fliplr_joints(smp['joints_3d'], smp['joints_3d_vis'], img.shape[1], smp['flip_pairs'])
@@ -87,6 +87,6 @@ def generate_patch_batch(samples, frames, masks, patch_width, patch_height, rect
     centers = None
     if geodesic_pts is not None and len(geodesic_pts):
         raise NotImplementedError('geodesic_pt_list with several source joints (shipped configs use the centroid)')
-    geo, cen = compute_geodesic_dis(out_mask, geodesic_param_list, centers)
+    geo, cen = compute_geodesic_dis_batch(out_mask, geodesic_param_list, centers)
     return {'img': out_img, 'mask': out_mask, 'geodesic_dis': geo, 'geodesic_center': cen, 'joints': joints,
             'trans_image': torch.tensor(np.stack(trans), dtype=torch.float32, device=device)}

@@ -71,3 +71,9 @@ def keypoint_pckh(pred, gt, head_size, PCKh_thred=0.5):
     """PCKh per sample (metrics.py:247-253)."""
     error = torch.linalg.norm(pred - gt, ord=2, dim=-1) / head_size.unsqueeze(-1)
     return (error < PCKh_thred).float().mean(dim=-1) * 100
+
+
+# names this mirror does not replace resolve, lazily, to the reference module behind it on sys.path
+from xas_amd._next import fallthrough as _fallthrough  # noqa: E402
+
+__getattr__ = _fallthrough(__name__, __file__)

@@ -67,3 +67,9 @@ def compute_symmetry_min(world, w_bone, w_kp, kps=None, w_kp2d=None):
     """min over hypotheses of w_bone*bone_sym + w_kp*kp_sym [+ 100*w_kp2d*kp_sym_2d]: one fused kernel
     (model.py:104-114)."""
     return ops_misc.symmetry_min(world, w_bone, w_kp, kps if w_kp2d is not None else None, w_kp2d or 0.0)
+
+
+# names this mirror does not replace resolve, lazily, to the reference module behind it on sys.path
+from xas_amd._next import fallthrough as _fallthrough  # noqa: E402
+
+__getattr__ = _fallthrough(__name__, __file__)

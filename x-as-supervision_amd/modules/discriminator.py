@@ -193,3 +193,9 @@ class GCNDiscriminatorDecouple(GCNDiscriminator_base):
         j = self.joint_gcn((self.joint_input_layer(keypoints.reshape(B * self.num_nodes, -1)), g))[0]
         b = self.bone_gcn((self.bone_input_layer(bone.reshape(B * self.num_nodes, -1)), g))[0]
         return self.header_forward(torch.cat([j, b], dim=-1), B)
+
+
+# names this mirror does not replace resolve, lazily, to the reference module behind it on sys.path
+from xas_amd._next import fallthrough as _fallthrough  # noqa: E402
+
+__getattr__ = _fallthrough(__name__, __file__)

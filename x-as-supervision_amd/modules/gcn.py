@@ -142,3 +142,9 @@ class GCN_residual(nn.Module):
                 x = self._bn(x)
             x = self.dropout(torch.relu(x))
         return (x + res, adj)
+
+
+# names this mirror does not replace resolve, lazily, to the reference module behind it on sys.path
+from xas_amd._next import fallthrough as _fallthrough  # noqa: E402
+
+__getattr__ = _fallthrough(__name__, __file__)

@@ -60,3 +60,9 @@ def get_pose_net(cfg, num_joints):
     head = DeconvHead(channels[-1], cfg.num_deconv_layers, cfg.num_deconv_filters, cfg.num_deconv_kernel,
                       cfg.final_conv_kernel, num_joints, cfg.depth_dim)
     return init_pose_net(ResPoseNet(backbone, head), cfg)
+
+
+# names this mirror does not replace resolve, lazily, to the reference module behind it on sys.path
+from xas_amd._next import fallthrough as _fallthrough  # noqa: E402
+
+__getattr__ = _fallthrough(__name__, __file__)

@@ -90,3 +90,9 @@ def random_rotation_3D(keypoints):
     c, s, z, o = torch.cos(ang), torch.sin(ang), torch.zeros_like(ang), torch.ones_like(ang)
     rot = torch.stack([c, -s, z, s, c, z, z, z, o], dim=1).view(B, 3, 3)
     return torch.bmm(keypoints, rot.to(keypoints.dtype))
+
+
+# names this mirror does not replace resolve, lazily, to the reference module behind it on sys.path
+from xas_amd._next import fallthrough as _fallthrough  # noqa: E402
+
+__getattr__ = _fallthrough(__name__, __file__)

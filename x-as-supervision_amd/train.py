@@ -111,10 +111,11 @@ class Trainer:
             for it, x in enumerate(self.train_data):
                 x = self.convert_data_to_device(x)
                 loss_disc, loss_kp, total, output = self.step(x)
-                if self.gpu_id == 0 and tb_logger is not None and total is not None:      # train.py:192-199
-                    cur = epoch * len(self.train_data) + it
-                    tb_vis(tb_logger, cur, self.tb_pair_ids, self.tb_parent_ids, total.detach().item(), loss_kp, loss_disc,
-                           output, x, self.config, self.scheduler_detector)
+                if self.gpu_id == 0 and tb_logger is not None:      # train.py:192-199: every step, total = None on steps
+                    cur = epoch * len(self.train_data) + it          # where only the discriminator was updated
+                    tb_vis(tb_logger, cur, self.tb_pair_ids, self.tb_parent_ids,
+                           total.detach().item() if total is not None else None, loss_kp, loss_disc, output, x, self.config,
+                           self.scheduler_detector)
             self.scheduler_detector.step()
             if self.scheduler_discriminator is not None:
                 self.scheduler_discriminator.step()

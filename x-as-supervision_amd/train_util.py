@@ -238,3 +238,9 @@ def tb_vis(tb_log, cur_step, tb_pair_ids, tb_parent_ids, total_loss, loss_kp, lo
     if 'kp_gt_world' in output.keys():
         _image(tb_log, 'training_pose_3d/src_gt_pose_3d', pose_vis_3d(_np(output['kp_gt_world'][0]), tb_pair_ids, tb_parent_ids),
                cur_step)
+
+
+# names this mirror does not replace resolve, lazily, to the reference module behind it on sys.path
+from xas_amd._next import fallthrough as _fallthrough  # noqa: E402
+
+__getattr__ = _fallthrough(__name__, __file__)

@@ -5,9 +5,9 @@ MI355X-first design: gradients already live in ONE contiguous arena per optimize
 out in parameter-registration order.  Backward produces gradients roughly in reverse order, so the arena is
 cut into a few large buckets from the tail.  A bucket's all-reduce is launched on a side HIP stream as soon as
 every member's gradient of this step is complete:
-  * every parameter reports through a post-accumulate-grad hook (torch runs the leaf's AccumulateGrad node, and its
-    hooks, once all backward nodes that use the parameter have run - also when those nodes returned no gradient
-    because the kernels added it to the arena themselves);
+  * every parameter that receives its gradient from autograd reports through a post-accumulate-grad hook (it fires when
+    the leaf's AccumulateGrad node has run; for a leaf whose backward nodes return no gradient - the kernels added it to
+    the arena themselves - torch may or may not run the hook: nothing here depends on it, members are kept as a set);
   * conv weights (weight-gradient side stream) and batch-norm parameters (reduce kernel) are ALSO reported by ops_nn,
     which counts their forward uses and reports a parameter when its last backward contribution of the step has been
     launched (ops_nn.grad_ready): this does not rely on the hook behaviour for gradient-less returns.
@@ -145,7 +145,8 @@ class GradReducer:
         if self.arena.is_cuda:
             from . import ops_nn
             ops_nn._uses['hook'] = None
-            ops_nn._uses['pending'].clear()
+            ops_nn.forget_uses(self._index.keys())       # only this reducer's parameters (r02 ADVICE: a global clear dropped
+                                                         # the detector's counts taken before the discriminator step)
             ops_nn.join_side_stream()          # weight gradients still in flight on the side stream
         for b in self.buckets:
             if not b.get('launched'):

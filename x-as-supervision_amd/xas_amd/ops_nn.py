@@ -120,13 +120,25 @@ def grad_ready(p):
     if not _uses['on']:
         return
     k = p.data_ptr()
-    left = _uses['pending'].get(k, 0) - 1
+    if k not in _uses['pending']:
+        # no counted forward use (the count was taken before tracking started, or belongs to a cleared epoch): never
+        # report - the parameter's bucket is then launched by GradReducer.finish(), after ALL contributions
+        return
+    left = _uses['pending'][k] - 1
     if left > 0:
         _uses['pending'][k] = left
         return
-    _uses['pending'].pop(k, None)
+    del _uses['pending'][k]
     if _uses['hook'] is not None:
         _uses['hook'](p)
+
+
+def forget_uses(keys):
+    """Drop the counts of the given parameter addresses (a reducer clears ITS parameters after its backward; counts
+    of another reducer's parameters - e.g. detector forwards taken before the discriminator step under
+    TrainStep(dedupe=True) - stay)."""
+    for k in keys:
+        _uses['pending'].pop(k, None)
 
 
 def _wgrad_into_grad(x, dy, shp, weight):
