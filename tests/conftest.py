@@ -22,3 +22,27 @@ def golden(name):
 @pytest.fixture(scope='session')
 def load_golden():
     return golden
+
+
+def check_all_grads(named_grads, g, floor, factor, what=''):
+    """Every parameter gradient against golden `detector_allgrads` (norms + strided samples of the reference's fp32 run,
+    and `dev` = the reference's own fp32-vs-fp64 distance per tensor).  Per-tensor tolerance = max(floor, factor * dev).
+    -> worst (error / tolerance) over the tensors, for reporting."""
+    import torch
+    names = g['names'].tolist()
+    assert [n for n, _ in named_grads] == names
+    worst = 0.0
+    for i, (n, grad) in enumerate(named_grads):
+        grad = grad.detach().double().cpu()
+        tol = max(floor, factor * float(g['dev'][i]))
+        ref_norm = float(g['norms'][i])
+        e_norm = abs(float(grad.norm()) / ref_norm - 1)
+        flat = grad.reshape(-1)
+        step = max(1, flat.numel() // 32)
+        s = flat[::step][:32]
+        ref = torch.from_numpy(g['samples'][i]).double()[:s.numel()]
+        rms = ref_norm / max(1, flat.numel()) ** 0.5
+        e_samp = float((s - ref).norm()) / (float(ref.norm()) + rms * s.numel() ** 0.5)
+        assert e_norm < tol and e_samp < tol, '%s %s: norm error %.2e, sample error %.2e, tolerance %.2e' % (what, n, e_norm, e_samp, tol)
+        worst = max(worst, e_norm / tol, e_samp / tol)
+    return worst

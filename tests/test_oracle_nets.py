@@ -135,3 +135,26 @@ def test_model_wiring_use_aug():
     mp = _yaml_params('HM36_Multi_SurS2', (0, 1))
     mp['smpl_disc_params']['use_aug'] = True
     _run_model(None, 'model_HM36_Multi_SurS2_aug', mp, seed=86, rng_seed=1234)
+
+
+def test_model_wiring_s1_four_cameras():
+    """HM36_Multi_SurS1 with the YAML's four cameras and the mask losses switched on (golden: model4)."""
+    cams = (0, 1, 2, 3)
+    mp = _yaml_params('HM36_Multi_SurS1', cams)
+    mp['loss_config']['recons_loss']['weight'] = 0.02
+    mp['loss_config']['physique_recons_loss']['weight'] = 0.02
+    _run_model(None, 'model_HM36_Multi_SurS1_4cam', mp, cams, seed=87)
+
+
+def test_detector_all_parameter_gradients():
+    """Every one of the detector's 170 parameter gradients (norm + strided sample) against the imported reference, on the
+    smooth single-hypothesis head without the planted depth bias (golden: detector_allgrads)."""
+    g = golden('detector_allgrads')
+    reg = gi.seeded_fill_(ostep.Regressor('resnet', 18, 64), seed=61).train()
+    x = T(gi.synthetic_batch(2, [0], seed=63)['cam_0_img'])
+    kps, _ = reg(x)
+    close(kps, g['kps'], 1e-5)
+    gw = T(np.random.Generator(np.random.PCG64(64)).standard_normal(kps.shape).astype(np.float32))
+    (kps * gw).sum().backward()
+    from conftest import check_all_grads
+    check_all_grads([(n, p.grad) for n, p in reg.named_parameters()], g, 2e-3, 2.0, 'oracle')
