@@ -27,25 +27,25 @@ extern "C" {
 #endif
 
 const char* xas_last_error(void);
-/* Kernel-tuning experiment flags for A/B measurements (tools/ab_step.py, tools/bench_conv.py); 0 = the shipped
- * configuration, results are identical under every flag (tests/test_gpu_nn.py::test_conv_kernel_variants).
- *   4       plain (not XCD-aware) tile order in fwd / dgrad
+/* Kernel-variant selectors kept for coverage tests (tests/test_gpu_nn.py::test_conv_kernel_variants): 0 = the shipped
+ * configuration, results are identical under every flag.  They only concern the exact-fp32 kernels (XAS_PREC_F32).
  *   32      plain K-loop in fwd / dgrad instead of the pipelined one      524288  same for the weight gradient
  *   64      global-load fwd / dgrad kernels (the >= 2 GiB fallback)       128     same for the weight gradient
- *   256/512 weight-gradient split target 512 / 256 blocks (768: 2048)     1024    force 64x64 weight-gradient tiles
- *   8192    all tiles of a weight-gradient pixel split on one XCD         16384   1024-thread slab-reduce blocks
- *   32768 / 65536 / 98304  column-reduce slab target 512 / 128 / 64       131072  one weight-gradient block per CU
- *   262144  86-VGPR build of the backward column sums
- *   8, 16, 4096  K-loop ablations, diagnostic build only (tools/build_diag.py) */
+ *   8192    plain (not XCD-grouped) weight-gradient block order
+ *   32768 / 65536 / 98304  column-reduce slab target 512 / 128 / 64       262144  86-VGPR build of the backward column sums */
 int xas_set_tuning(int flags);
-/* Compute precision of the MFMA forward / data-gradient convolutions: 0 (default) = exact fp32 MFMA, the
- * path every parity figure and the headline benchmark use; 1 = bf16 MFMA (operands rounded to bf16 on the way to LDS,
- * fp32 accumulation, fp32 activations and master weights in HBM; weight gradients stay fp32); 2 = bf16x6: every fp32 operand
- * split exactly into three bf16 pieces, six exact partial products accumulated in fp32 - fp32-accurate results (per-product
- * error below one fp32 rounding) at 2.67x the fp32-MFMA math rate; weight gradients stay fp32.  Process-wide. */
+/* Arithmetic of the MFMA convolutions (forward, data gradient, weight gradient).  All three keep fp32 activations, fp32
+ * master weights and fp32 accumulation; they differ in how a product of two fp32 operands is formed:
+ *   XAS_PREC_BF16X6 (default)  every fp32 operand is split exactly into three bf16 pieces and six exact partial products
+ *                   are accumulated in fp32 by v_mfma_f32_32x32x16_bf16: per-product error below one fp32 rounding
+ *                   (1.09e-7 relative against float64 at K = 64, exact-fp32 MFMA 1.06e-7), 2.67x the fp32-MFMA math rate;
+ *   XAS_PREC_F32    v_mfma_f32_32x32x2_f32, bit for bit a k-ordered fmaf chain;
+ *   XAS_PREC_BF16   operands rounded to bf16 once (NOT fp32 accurate; a variant that is reported separately).
+ * xas_set_precision sets the process default; a call overrides it with xas_conv_shape.mode = 1 + XAS_PREC_* (0 = default).
+ * In the bf16 modes forward / data gradient take PRE-SPLIT weights: see xas_conv_weight_planes / xas_split_weight. */
+enum { XAS_PREC_F32 = 0, XAS_PREC_BF16 = 1, XAS_PREC_BF16X6 = 2 };
 int xas_set_precision(int mode);
-/* diagnostic builds: device buffer of 8 uint64 that the igemm kernels add per-phase cycle sums to (NULL = off) */
-int xas_set_debug_buffer(void* device_ptr);
+int xas_get_precision(void);
 int xas_abi_version(void);
 
 /* ------------------------------------------------------------------------------------
@@ -114,7 +114,8 @@ int xas_draw_lines_max_bwd(const float* kps, long kp_stride_b, long kp_stride_j,
                            float* grad_kps_xy /* [B][K][2] */, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * Convolution family: fp32 MFMA implicit GEMM on NHWC activations.
+ * Convolution family: MFMA implicit GEMM on NHWC fp32 activations (fp32-accurate bf16x6 by default, exact fp32 MFMA
+ * on request: XAS_PREC_*).
  * Replaces the cuDNN calls behind nn.Conv2d / nn.ConvTranspose2d / nn.Linear in
  * integral_base_modules/resnet.py:16-47, deconv_head.py:24-35, physique_network.py:15-50,
  * discriminator.py:8-21 and torchvision's Bottleneck.
@@ -129,7 +130,16 @@ typedef struct {
   int Cout, R, S;
   int stride, pad;
   int Ho, Wo;
+  int mode;          /* 0: process default precision (xas_set_precision); otherwise 1 + XAS_PREC_* for this call */
 } xas_conv_shape;
+
+/* Which weight buffer xas_conv_fwd* (pass 0) / xas_conv_dgrad* (pass 1) expect for this shape in its precision mode:
+ * 0 = fp32 packed weights (xas_pack_weight); 1 or 3 = that many bf16 planes: xas_split_weight of the packed weights,
+ * layout [rows][K / 16][planes][16] bf16 with K = R*S*Cin (pass 0, rows = Cout) or R*S*Cout (pass 1, rows = Cin).  Shapes
+ * outside the MFMA tiles (stem, one-channel layers) always take fp32 weights.  Built once per optimizer step per weight. */
+int xas_conv_weight_planes(const xas_conv_shape* s, int pass);
+size_t xas_split_weight_bytes(long elems, int pieces);
+int xas_split_weight(const float* w_packed, void* w_split, long elems, int pieces, void* stream);
 
 int xas_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
                  const xas_conv_shape* s, void* stream);

@@ -24,6 +24,34 @@ def load_golden():
     return golden
 
 
+@pytest.fixture(autouse=True)
+def _library_defaults(request):
+    """GPU tests leave the library as they found it: default precision (bf16x6, fp32 accurate), no variant selectors."""
+    yield
+    if request.node.get_closest_marker('gpu') is not None:
+        from xas_amd import _lib
+        if _lib._lib is not None:
+            _lib.query('xas_set_precision', _lib.PREC_BF16X6)
+            _lib.query('xas_set_tuning', 0)
+
+
+class precision_mode:
+    """with precision_mode('f32'): ... - run a block on another arithmetic of the MFMA convolutions (xas_set_precision)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        from xas_amd import _lib
+        self.prev = _lib.query('xas_get_precision')
+        assert _lib.query('xas_set_precision', _lib.PREC_NAMES[self.name]) == 0
+        return self
+
+    def __exit__(self, *exc):
+        from xas_amd import _lib
+        _lib.query('xas_set_precision', self.prev)
+
+
 def check_all_grads(named_grads, g, floor, factor, what=''):
     """Every parameter gradient against golden `detector_allgrads` (norms + strided samples of the reference's fp32 run,
     and `dev` = the reference's own fp32-vs-fp64 distance per tensor).  Per-tensor tolerance = max(floor, factor * dev).

@@ -62,8 +62,8 @@ def test_exports_and_signatures():
         assert name in _lib.SIGNATURES, 'no ctypes signature for %s' % name
         assert _lib.SIGNATURES[name] == (codes, ret), '%s: table %r vs header %r' % (name, _lib.SIGNATURES[name], (codes, ret))
     assert set(_lib.SIGNATURES) <= set(protos)
-    assert ctypes.sizeof(_lib.ConvShape) == 11 * 4
-    assert lib.xas_abi_version() == 1
+    assert ctypes.sizeof(_lib.ConvShape) == 12 * 4
+    assert lib.xas_abi_version() == 2
 
 
 def test_no_cpu_fallback():

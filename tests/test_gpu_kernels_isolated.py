@@ -89,11 +89,11 @@ def test_conv_dgrad_acc(n, cin, h, w, cout, k, stride, pad):
     wg = wt.cuda()
     buf = skip.cuda().contiguous(memory_format=torch.channels_last)
     dyg = dy.cuda().contiguous(memory_format=torch.channels_last)
-    call('xas_conv_dgrad_acc', ptr(dyg), ptr(cache.get(wg, 1)), ptr(buf), shp)
+    call('xas_conv_dgrad_acc', ptr(dyg), ptr(cache.get(wg, 1, shp)), ptr(buf), shp)
     assert rel(buf, ref) < 3e-6
     # and the plain form writes exactly the difference
     out = torch.empty_like(buf)
-    call('xas_conv_dgrad', ptr(dyg), ptr(cache.get(wg, 1)), ptr(out), shp)
+    call('xas_conv_dgrad', ptr(dyg), ptr(cache.get(wg, 1, shp)), ptr(out), shp)
     assert rel(out, ref - skip) < 3e-6
 
 
@@ -137,7 +137,8 @@ def test_thin_one_channel_kernels(n, c, h, w):
         assert rel(yg, yc) < 3e-6, (cin, cout)
         assert rel(xg.grad, xc.grad) < 3e-6, (cin, cout)
         assert rel(m.weight.grad, wc.grad) < tol, (cin, cout)
-        assert rel(m.bias.grad, bc.grad) < tol, (cin, cout)
+        # (bias gradient: against the float64 sum - the CPU's own fp32 sum of 2 M terms is 1e-5 off, depending on its thread count)
+        assert rel(m.bias.grad, gy.double().sum(dim=(0, 2, 3))) < tol, (cin, cout)
 
 
 @pytest.mark.parametrize('n,cin,h,w,cout,k,stride,pad', ACC_CASES[:4] + [(1, 2048, 4, 4, 512, 1, 1, 0)])
@@ -160,7 +161,7 @@ def test_conv_dgrad_acc_masked(n, cin, h, w, cout, k, stride, pad):
     dyg = dy.cuda().contiguous(memory_format=torch.channels_last)
     dpg = dprev.cuda().contiguous(memory_format=torch.channels_last)
     out = torch.full_like(dpg, float('nan'))
-    call('xas_conv_dgrad_acc_masked', ptr(dyg), ptr(cache.get(wg, 1)), ptr(out), shp, ptr(dpg), ptr(mask))
+    call('xas_conv_dgrad_acc_masked', ptr(dyg), ptr(cache.get(wg, 1, shp)), ptr(out), shp, ptr(dpg), ptr(mask))
     assert rel(out, ref) < 3e-6
 
 
@@ -219,7 +220,7 @@ def test_conv_fwd_bnstats(n, cin, h, w, cout, k, stride, pad, G, form):
     xg = x.cuda().contiguous(memory_format=torch.channels_last)
     M, Mg = n * ho * wo, n * ho * wo // G
     y0 = torch.empty(n, cout, ho, wo, device='cuda').contiguous(memory_format=torch.channels_last)
-    call('xas_conv_fwd', ptr(xg), ptr(cache.get(wg, 0)), None, ptr(y0), shp)
+    call('xas_conv_fwd', ptr(xg), ptr(cache.get(wg, 0, shp)), None, ptr(y0), shp)
     rows = y0.permute(0, 2, 3, 1).reshape(G, Mg, cout).double()
     mean64, var64 = rows.mean(1), rows.var(1, unbiased=False)
 
@@ -232,7 +233,7 @@ def test_conv_fwd_bnstats(n, cin, h, w, cout, k, stride, pad, G, form):
         rm, rv = rm0.clone(), rv0.clone()
         if form == 'local':
             mean = torch.empty(G, cout, device='cuda'); var = torch.empty(G, cout, device='cuda')
-            call('xas_conv_fwd_bnstats', ptr(xg), ptr(cache.get(wg, 0)), ptr(y), shp, G, ptr(pivot), ptr(mean), ptr(var),
+            call('xas_conv_fwd_bnstats', ptr(xg), ptr(cache.get(wg, 0, shp)), ptr(y), shp, G, ptr(pivot), ptr(mean), ptr(var),
                  cout, None, ptr(ws), ptr(rm), ptr(rv), 0.1)
             rm_ref, rv_ref = rm0.double(), rv0.double()
             for g in range(G):
@@ -242,7 +243,7 @@ def test_conv_fwd_bnstats(n, cin, h, w, cout, k, stride, pad, G, form):
         else:
             stride_m = 2 * cout + 4
             msg = torch.zeros(G, stride_m, device='cuda')
-            call('xas_conv_fwd_bnstats', ptr(xg), ptr(cache.get(wg, 0)), ptr(y), shp, G, ptr(pivot), ptr(msg),
+            call('xas_conv_fwd_bnstats', ptr(xg), ptr(cache.get(wg, 0, shp)), ptr(y), shp, G, ptr(pivot), ptr(msg),
                  ptr(msg[:, cout:]), stride_m, ptr(msg[:, 2 * cout:]), ptr(ws), None, None, 0.1)
             mean, var = msg[:, :cout], msg[:, cout:2 * cout]
             assert torch.equal(msg[:, 2 * cout].cpu(), torch.full((G,), float(Mg)))
@@ -300,7 +301,7 @@ def test_conv_dgrad_bn_bwd(n, cin, h, w, cout, k, stride, pad, G):
 
     # three separate calls
     dz0 = torch.empty_like(xbg); dx0 = torch.empty_like(xbg)
-    call('xas_conv_dgrad', ptr(dyg), ptr(cache.get(wg, 1)), ptr(dz0), shp)
+    call('xas_conv_dgrad', ptr(dyg), ptr(cache.get(wg, 1, shp)), ptr(dz0), shp)
     sums0 = torch.empty(G, 2, cin, device='cuda')
     ws0 = torch.empty(query('xas_bn_workspace_floats', M, cin, G), device='cuda')
     acc_b0 = torch.full((cin,), 0.25, device='cuda'); acc_g0 = torch.full((cin,), -0.5, device='cuda')
@@ -314,7 +315,7 @@ def test_conv_dgrad_bn_bwd(n, cin, h, w, cout, k, stride, pad, G):
     sums = torch.empty(G, 2, cin, device='cuda')
     ws = torch.empty(query('xas_conv_dgrad_bn_bwd_workspace_floats', shp, G), device='cuda')
     acc_b = torch.full((cin,), 0.25, device='cuda'); acc_g = torch.full((cin,), -0.5, device='cuda')
-    call('xas_conv_dgrad_bn_bwd', ptr(dyg), ptr(cache.get(wg, 1)), shp, ptr(xbg), ptr(mean), ptr(var), ptr(gam), ptr(bet),
+    call('xas_conv_dgrad_bn_bwd', ptr(dyg), ptr(cache.get(wg, 1, shp)), shp, ptr(xbg), ptr(mean), ptr(var), ptr(gam), ptr(bet),
          eps, G, float(Mg), ptr(dz), ptr(dx), ptr(sums), ptr(ws), ptr(acc_b), ptr(acc_g))
 
     scale = float(sums0.abs().max())
@@ -325,7 +326,7 @@ def test_conv_dgrad_bn_bwd(n, cin, h, w, cout, k, stride, pad, G):
     assert rel(acc_b, acc_b0) < 2e-6 and rel(acc_g, acc_g0) < 2e-6
     # without accumulators the sums alone are written
     sums2 = torch.empty_like(sums)
-    call('xas_conv_dgrad_bn_bwd', ptr(dyg), ptr(cache.get(wg, 1)), shp, ptr(xbg), ptr(mean), ptr(var), ptr(gam), ptr(bet),
+    call('xas_conv_dgrad_bn_bwd', ptr(dyg), ptr(cache.get(wg, 1, shp)), shp, ptr(xbg), ptr(mean), ptr(var), ptr(gam), ptr(bet),
          eps, G, float(Mg), ptr(dz), ptr(dx), ptr(sums2), ptr(ws), None, None)
     assert torch.equal(sums2, sums)
 

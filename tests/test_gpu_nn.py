@@ -68,6 +68,7 @@ def test_conv_kernel_variants(tune, what):
     address, the non-pipelined loops, the alternative block order) gives the same results as the shipped ones."""
     from xas_amd import _lib
     try:
+        _lib.query('xas_set_precision', _lib.PREC_F32)     # the selectors concern the exact-fp32 kernels
         _lib.query('xas_set_tuning', tune)
         for case in (CONV_CASES[1], CONV_CASES[2], CONV_CASES[3], CONV_CASES[8], (2, 64, 40, 24, 160, 3, 1, 1)):
             test_conv2d_fwd_bwd(*case)
@@ -230,20 +231,24 @@ def test_detector_vs_golden_and_oracle():
     assert maxabs(dmap, T(g['depth_prob_map'])) < 1e-5
     (kps * T(g['grad_out']).cuda()).sum().backward()
     p = dict(hip.named_parameters())
-    # Parameter gradients of this planted-peak case are ill conditioned in fp32: the CPU fp32 oracle and
-    # this path are BOTH ~1e-2 (relative) away from an fp64 evaluation of the same graph, and two CPU fp32
-    # runs with different thread counts differ by 6e-3 (tools/diag_detector_grads.py).  The bar
-    # below is therefore 3e-2 against the reference golden; the per-layer kernels are held to 3e-6
-    # above, where the comparison is well conditioned.
-    GT = 3e-2
-    assert rel(p['net.backbone.conv1.weight'].grad, T(g['g_conv1'])) < GT
-    assert rel(p['net.backbone.layer1.0.conv2.weight'].grad[:8], T(g['g_l1c2'])) < GT
-    assert rel(p['net.backbone.layer2.0.downsample.0.weight'].grad[:4, :16], T(g['g_l2ds'])) < GT
-    assert rel(p['net.head.features.0.weight'].grad[:4, :4], T(g['g_dc0'])) < GT
-    assert rel(p['net.head.features.9.bias'].grad, T(g['g_fin_b'])) < GT
-    assert rel(p['net.backbone.bn1.weight'].grad, T(g['g_bn1_w'])) < GT
-    assert abs(float(p['net.backbone.layer4.2.conv3.weight'].grad.norm()) / float(g['g_l4c3_norm']) - 1) < GT
-    assert abs(float(p['net.head.features.6.weight'].grad.norm()) / float(g['g_dc6_norm']) - 1) < GT
+    # Parameter gradients of this planted-peak case are ill conditioned in fp32: the REFERENCE's own fp32 evaluation sits
+    # DEV (relative) from its float64 evaluation of the same graph on these tensors (measured with the imported reference,
+    # r03: ReLU / max-pool decisions on near-ties differ between precisions), and any independent fp32-accurate
+    # evaluation is as far from float64 again.  Bar = the rule of test_detector_all_parameter_gradients:
+    # max(3e-3, 4 x DEV) per tensor (r01-r02 used a flat 3e-2 for all of them; the 64-element slice g_l2ds reads 3.35e-2
+    # with bf16x6 products - its bar is now 4.2e-2, g_fin_b's went from 3e-2 to 3e-3).  The per-layer kernels are held to 3e-6 where
+    # the comparison is well conditioned (test_every_layer_shape_all_passes_vs_float64).
+    DEV = {'g_conv1': 1.07e-2, 'g_l1c2': 9.0e-3, 'g_l2ds': 1.04e-2, 'g_dc0': 4.4e-3, 'g_fin_b': 3.5e-5, 'g_bn1_w': 8.5e-3,
+           'norms': 1.0e-2}
+    GT = lambda k: max(3e-3, 4.0 * DEV[k])                       # noqa: E731
+    assert rel(p['net.backbone.conv1.weight'].grad, T(g['g_conv1'])) < GT('g_conv1')
+    assert rel(p['net.backbone.layer1.0.conv2.weight'].grad[:8], T(g['g_l1c2'])) < GT('g_l1c2')
+    assert rel(p['net.backbone.layer2.0.downsample.0.weight'].grad[:4, :16], T(g['g_l2ds'])) < GT('g_l2ds')
+    assert rel(p['net.head.features.0.weight'].grad[:4, :4], T(g['g_dc0'])) < GT('g_dc0')
+    assert rel(p['net.head.features.9.bias'].grad, T(g['g_fin_b'])) < GT('g_fin_b')
+    assert rel(p['net.backbone.bn1.weight'].grad, T(g['g_bn1_w'])) < GT('g_bn1_w')
+    assert abs(float(p['net.backbone.layer4.2.conv3.weight'].grad.norm()) / float(g['g_l4c3_norm']) - 1) < GT('norms')
+    assert abs(float(p['net.head.features.6.weight'].grad.norm()) / float(g['g_dc6_norm']) - 1) < GT('norms')
     sd = hip.state_dict()
     assert maxabs(sd['net.backbone.bn1.running_mean'], T(g['rm_bn1'])) < 1e-6
     assert maxabs(sd['net.backbone.layer3.5.bn3.running_var'], T(g['rv_l3'])) < 1e-5

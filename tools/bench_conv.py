@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the conv entry points on the detector's layer shapes (B=32).
-usage: python tools/bench_conv.py [fwd|dgrad|wgrad|all] [reps]"""
+"""Micro-benchmark (and quick cross-check) of the conv entry points on the detector's and the physique net's layer shapes.
+usage: python tools/bench_conv.py [fwd|dgrad|wgrad|all] [reps] [N] [precisions, e.g. bf16x6,f32]
+Each precision mode is timed on the same tensors; the bf16x6 results are compared with the exact-fp32 MFMA results."""
 import os
 import sys
 
@@ -11,56 +12,84 @@ import torch
 from xas_amd import _lib
 from xas_amd._lib import ConvShape, call, ptr, query
 
-SHAPES = [  # N, Hi, Wi, Cin, Cout, R, stride, pad
-    (32, 64, 64, 64, 64, 1, 1, 0), (32, 64, 64, 64, 64, 3, 1, 1), (32, 64, 64, 64, 256, 1, 1, 0),
-    (32, 64, 64, 256, 64, 1, 1, 0), (32, 64, 64, 256, 128, 1, 1, 0), (32, 64, 64, 128, 128, 3, 2, 1),
-    (32, 32, 32, 128, 512, 1, 1, 0), (32, 32, 32, 512, 128, 1, 1, 0), (32, 32, 32, 128, 128, 3, 1, 1),
-    (32, 32, 32, 256, 256, 3, 2, 1), (32, 16, 16, 256, 1024, 1, 1, 0), (32, 16, 16, 1024, 256, 1, 1, 0),
-    (32, 16, 16, 256, 256, 3, 1, 1), (32, 16, 16, 512, 512, 3, 2, 1), (32, 8, 8, 512, 2048, 1, 1, 0),
-    (32, 8, 8, 2048, 512, 1, 1, 0), (32, 8, 8, 512, 512, 3, 1, 1), (32, 64, 64, 256, 1152, 1, 1, 0),
-    (32, 128, 128, 64, 64, 3, 1, 1), (32, 256, 256, 32, 32, 3, 1, 1), (32, 256, 256, 64, 32, 3, 1, 1),
+SHAPES = [  # Hi, Wi, Cin, Cout, R, stride, pad
+    (64, 64, 64, 64, 1, 1, 0), (64, 64, 64, 64, 3, 1, 1), (64, 64, 64, 256, 1, 1, 0),
+    (64, 64, 256, 64, 1, 1, 0), (64, 64, 256, 128, 1, 1, 0), (64, 64, 128, 128, 3, 2, 1),
+    (32, 32, 128, 512, 1, 1, 0), (32, 32, 512, 128, 1, 1, 0), (32, 32, 128, 128, 3, 1, 1),
+    (32, 32, 256, 256, 3, 2, 1), (16, 16, 256, 1024, 1, 1, 0), (16, 16, 1024, 256, 1, 1, 0),
+    (16, 16, 256, 256, 3, 1, 1), (16, 16, 512, 512, 3, 2, 1), (8, 8, 512, 2048, 1, 1, 0),
+    (8, 8, 2048, 512, 1, 1, 0), (8, 8, 512, 512, 3, 1, 1), (64, 64, 256, 1152, 1, 1, 0),
+    (128, 128, 64, 64, 3, 1, 1), (256, 256, 32, 32, 3, 1, 1), (256, 256, 64, 32, 3, 1, 1),
 ]
+
+
+def weights_for(shp, w, transposed):
+    """weight buffer in the format the library wants for this shape / precision (xas_conv_weight_planes)"""
+    planes = query('xas_conv_weight_planes', shp, transposed)
+    if not planes:
+        return w
+    sp = torch.empty(query('xas_split_weight_bytes', w.numel(), planes), device=w.device, dtype=torch.uint8)
+    call('xas_split_weight', ptr(w), ptr(sp), w.numel(), planes)
+    return sp
 
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else 'all'
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+    precs = (sys.argv[4] if len(sys.argv) > 4 else 'bf16x6,f32').split(',')
     dev = torch.device('cuda')
-    query('xas_set_tuning', int(os.environ.get('XAS_TUNE', '0')))
     tot = {}
-    for (n, hi, wi, ci, co, r, st, pad) in SHAPES:
+    for (hi, wi, ci, co, r, st, pad) in SHAPES:
+        if n * hi * wi * max(ci, co) * 4 >= 2**31 - 2**24:
+            nn = max(1, int((2**31 - 2**24) // (hi * wi * max(ci, co) * 4)))
+        else:
+            nn = n
         ho, wo = (hi + 2 * pad - r) // st + 1, (wi + 2 * pad - r) // st + 1
-        shp = ConvShape(n, hi, wi, ci, co, r, r, st, pad, ho, wo)
-        x = torch.randn(n * hi * wi * ci, device=dev)
-        dy = torch.randn(n * ho * wo * co, device=dev)
+        x = torch.randn(nn * hi * wi * ci, device=dev)
+        dy = torch.randn(nn * ho * wo * co, device=dev)
         w = torch.randn(co * r * r * ci, device=dev) * 0.05
-        y = torch.empty_like(dy)
-        dx = torch.empty_like(x)
-        dw = torch.empty_like(w)
-        ws = torch.empty(max(1, query('xas_conv_wgrad_workspace_floats', shp)), device=dev)
-        flops = 2.0 * n * ho * wo * co * r * r * ci
-        runs = {'fwd': lambda: call('xas_conv_fwd', ptr(x), ptr(w), None, ptr(y), shp),
-                'dgrad': lambda: call('xas_conv_dgrad', ptr(dy), ptr(w), ptr(dx), shp),
-                'wgrad': lambda: call('xas_conv_wgrad_oihw', ptr(x), ptr(dy), ptr(dw), ptr(ws), shp)}
-        line = '%-34s' % str((n, hi, wi, ci, co, r, st))
-        for k, fn in runs.items():
-            if which not in ('all', k):
-                continue
-            fn()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(reps):
+        flops = 2.0 * nn * ho * wo * co * r * r * ci
+        line = '%-34s' % str((nn, hi, wi, ci, co, r, st))
+        outs = {}
+        for prec in precs:
+            shp = ConvShape(nn, hi, wi, ci, co, r, r, st, pad, ho, wo, 1 + _lib.PREC_NAMES[prec])
+            y = torch.empty_like(dy)
+            dx = torch.empty_like(x)
+            dw = torch.empty_like(w)
+            ws = torch.empty(max(1, query('xas_conv_wgrad_workspace_floats', shp)), device=dev)
+            wf, wt = weights_for(shp, w, 0), weights_for(shp, w, 1)
+            runs = {'fwd': lambda: call('xas_conv_fwd', ptr(x), ptr(wf), None, ptr(y), shp),
+                    'dgrad': lambda: call('xas_conv_dgrad', ptr(dy), ptr(wt), ptr(dx), shp),
+                    'wgrad': lambda: call('xas_conv_wgrad_oihw', ptr(x), ptr(dy), ptr(dw), ptr(ws), shp)}
+            line += ' |%s' % prec
+            for k, fn in runs.items():
+                if which not in ('all', k):
+                    continue
                 fn()
-            b.record()
-            torch.cuda.synchronize()
-            ms = a.elapsed_time(b) / reps
-            line += '  %s %7.1f us %6.1f TF' % (k, ms * 1e3, flops / ms / 1e9)
-            t = tot.setdefault(k, [0.0, 0.0])
-            t[0] += flops
-            t[1] += ms
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    fn()
+                b.record()
+                torch.cuda.synchronize()
+                ms = a.elapsed_time(b) / reps
+                line += ' %s %7.1f us %6.1f TF' % (k, ms * 1e3, flops / ms / 1e9)
+                t = tot.setdefault((prec, k), [0.0, 0.0])
+                t[0] += flops
+                t[1] += ms
+            outs[prec] = {'fwd': y, 'dgrad': dx, 'wgrad': dw}
+        if 'bf16x6' in outs and 'f32' in outs:
+            errs = []
+            for k in ('fwd', 'dgrad', 'wgrad'):
+                if which in ('all', k):
+                    a, b = outs['bf16x6'][k].double(), outs['f32'][k].double()
+                    errs.append('%s %.1e' % (k, float((a - b).norm() / (b.norm() + 1e-30))))
+            line += ' | x6 vs f32: ' + ' '.join(errs)
         print(line, flush=True)
-    for k, (f, ms) in tot.items():
-        print('TOTAL %-6s %.2f ms  %.1f TF' % (k, ms, f / ms / 1e9))
+        del x, dy, w, outs
+    for (prec, k), (f, ms) in tot.items():
+        print('TOTAL %-7s %-6s %.2f ms  %.1f TF' % (prec, k, ms, f / ms / 1e9))
 
 
 if __name__ == '__main__':

@@ -15,4 +15,4 @@ void set_error(const char* fmt, ...) {
 }  // namespace xas
 
 extern "C" const char* xas_last_error(void) { return xas::g_err; }
-extern "C" int xas_abi_version(void) { return 1; }
+extern "C" int xas_abi_version(void) { return 2; }   // 2: xas_conv_shape.mode, pre-split weights (round 3)

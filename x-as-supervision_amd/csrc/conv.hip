@@ -15,91 +15,15 @@
 //
 // Replaces the cuDNN conv kernels behind integral_base_modules/resnet.py:16-47,
 // deconv_head.py:24-35, physique_network.py:15-50 and torchvision's Bottleneck.
-#include "common.h"
+#include "conv_shared.h"
 
 namespace xas {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-constexpr int BK = 32;        // K-step (channels of one tap)
-constexpr int LDK = BK + 4;   // padded LDS row, dwords
 
 // 64 bytes of zeros: out-of-range taps / rows load from here instead of branching around the load
 __device__ __constant__ float4 g_zero16[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
-struct FastDiv {              // n / d and n % d for 0 <= n < 2^31, d >= 1
-  unsigned d, mul, shift;
-  __host__ void init(unsigned dd) {
-    d = dd;
-    if (dd == 1) { mul = 0; shift = 0; return; }
-    unsigned s = 0;
-    while ((1ull << s) < dd) ++s;
-    unsigned long long m = ((1ull << (31 + s)) + dd - 1) / dd;   // ceil(2^(31+s)/d) fits 32 bits
-    mul = (unsigned)m; shift = s;
-  }
-  __device__ __forceinline__ unsigned div(unsigned n) const {
-    return d == 1 ? n : (unsigned)(((unsigned long long)n * mul) >> (31 + shift));
-  }
-};
-
-struct IgemmParams {
-  const float* src;    // activations that are gathered (x for fwd, dy for dgrad)
-  const float* wgt;    // packed weights [rows][R][S][Cs]
-  const float* bias;   // per output column or null
-  float* out;
-  int N;
-  int Hs, Ws, Cs;      // gathered tensor dims
-  int Hd, Wd, Cd;      // destination dims; Cd = number of GEMM columns
-  int R, S, stride, pad;
-  FastDiv div_hw, div_w;   // row -> (n, a, b) decode over the row grid
-  int Hrow, Wrow;          // row grid (fwd: Ho x Wo; dgrad: per-phase grid, set in kernel)
-  int tune;                // experiment flags (xas_set_tuning): bit2 plain tile order, bit5 plain K-loop, bit6 global-load kernel
-  int nMt, nNt, mt_per_xcd;   // tile counts and M-tiles per XCD for the XCD-aware block order
-  unsigned long long* dbg;    // diagnostic builds only: per-phase cycle sums (xas_set_debug_buffer)
-  long src_elems, wgt_elems;  // sizes of src / wgt (buffer-load kernel: range of the buffer descriptors)
-  int accumulate;             // epilogue: 1: out += result (residual gradient already in the buffer);
-                              //           2: out = result + relu'(mask) * acc_src (the skip gradient is formed here from
-                              //              the block-output gradient and the sign bytes of xas_bn_apply: no dres tensor)
-  const float* acc_src;       // accumulate == 2: [rows][Cd] like out
-  const unsigned char* acc_mask;   // accumulate == 2: one byte per float4 of out, bit e = element active
-  // fwd only (xas_conv_fwd_bnstats): != null -> every tile also emits, per output channel, sum(v - pivot) and
-  // sum((v - pivot)^2) over its BM rows: stat_partial[tile row][channel][2].  The batch-norm statistics of the result are
-  // then a reduction over (rows / BM) partial rows instead of a second pass over the activation.
-  float* stat_partial;
-  const float* stat_pivot;         // per channel or null (= 0)
-  // dgrad only, stride 1 (xas_conv_dgrad_bn_bwd): the result is the gradient wrt the OUTPUT h = relu(bn(xb)) of a batch
-  // norm; the epilogue applies the ReLU mask (re-derived from xb exactly as bn_bwd_reduce does), writes the masked
-  // gradient dz and emits per tile and channel sum(dz), sum(dz * xhat): bnb_partial[tile][2][Cd].
-  const float* bnb_x;              // != null enables the path; [rows][Cd] like out
-  const float* bnb_mean; const float* bnb_var; const float* bnb_gamma; const float* bnb_beta;   // mean / var: [groups][Cd]
-  float bnb_eps;
-  int bnb_rows_per_group;
-  float* bnb_partial;
-};
-
-static unsigned long long* g_dbg = nullptr;
-
-constexpr int kMaxDevices = 16;
-static inline int current_device() {
-  int d = 0;
-  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
-  return d;
-}
-
 static int g_tune = 0;
 int tune_flags() { return g_tune; }
-
-// ------------------------------------------------------------------------------------
-// shared MFMA core: As[BM][LDK], Bs[BN][LDK] -> acc
-// ------------------------------------------------------------------------------------
-template <int BM, int BN>
-struct TileCfg {
-  static constexpr int WAVES_M = (BM >= 64 && BN >= 64) ? 2 : (BM < 64 ? 1 : 4);
-  static constexpr int WAVES_N = 4 / WAVES_M;
-  static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-  static constexpr int MI = WM / 32, NI = WN / 32;
-  static_assert(MI >= 1 && NI >= 1, "tile too small");
-};
 
 // Operand roles are swapped (MFMA "A" = weight rows, "B" = pixel rows), so an accumulator holds
 // D[n][m]: lane = pixel m, registers 4g..4g+3 = four CONSECUTIVE output channels -> float4 stores.
@@ -109,24 +33,19 @@ struct TileCfg {
 template <int BM, int BN>
 __device__ __forceinline__ void mfma_tile(const float* __restrict__ As, const float* __restrict__ Bs,
                                           f32x16 (&acc)[TileCfg<BM, BN>::MI][TileCfg<BM, BN>::NI],
-                                          f32x16& acc2, int wm, int wn, int lane, int tune = 0) {
+                                          f32x16& acc2, int wm, int wn, int lane) {
   using C = TileCfg<BM, BN>;
   constexpr bool SPLIT = (C::MI == 1 && C::NI == 1);
   const int i = lane & 31, h = lane >> 5;
   float4 a[C::MI], b[C::NI];
 #pragma unroll
   for (int kk = 0; kk < BK / 8; ++kk) {
-#ifdef XAS_CONV_DIAG
-    if (!(tune & 4096) || kk == 0)          // ablation bit12 (diagnostic build): LDS fragments read once per K-step
-#endif
-    {
 #pragma unroll
-      for (int mi = 0; mi < C::MI; ++mi)
-        a[mi] = *reinterpret_cast<const float4*>(As + (wm * C::WM + mi * 32 + i) * LDK + kk * 8 + h * 4);
+    for (int mi = 0; mi < C::MI; ++mi)
+      a[mi] = *reinterpret_cast<const float4*>(As + (wm * C::WM + mi * 32 + i) * LDK + kk * 8 + h * 4);
 #pragma unroll
-      for (int ni = 0; ni < C::NI; ++ni)
-        b[ni] = *reinterpret_cast<const float4*>(Bs + (wn * C::WN + ni * 32 + i) * LDK + kk * 8 + h * 4);
-    }
+    for (int ni = 0; ni < C::NI; ++ni)
+      b[ni] = *reinterpret_cast<const float4*>(Bs + (wn * C::WN + ni * 32 + i) * LDK + kk * 8 + h * 4);
     if (SPLIT) {
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0].x, a[0].x, acc[0][0], 0, 0, 0);
       acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0].y, a[0].y, acc2, 0, 0, 0);
@@ -214,226 +133,6 @@ __device__ __forceinline__ void sched_mix() {
   if (NMF - USED > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMF - USED, 0);
 }
 
-// dgrad epilogue with the batch-norm backward reduction folded in (see IgemmParams::bnb_x).  Stride 1: output row = m.
-// Per (channel quad) the norm's parameters are loaded and 1/std formed ONCE, then applied to the MI row blocks; the two
-// sums are pre-reduced over the row blocks in registers, so both [WAVES_M * 32][BN] arrays fit the operand LDS together:
-// one staging pass, one barrier, one column pass.
-template <int BM, int BN>
-__device__ __forceinline__ void bnb_epilogue(const IgemmParams& p, f32x16 (&acc)[TileCfg<BM, BN>::MI][TileCfg<BM, BN>::NI],
-                                             int m0, int n0, int wm, int wn, int lane, float* lds) {
-  using C = TileCfg<BM, BN>;
-  constexpr int LDT = BN + 4, TR = C::WAVES_M * 32;               // staged rows per array
-  constexpr int PARTS = 256 / BN;
-  float* T1 = lds;
-  float* T2 = lds + TR * LDT;
-  float* red = lds + 2 * TR * LDT;                                 // [PARTS][BN][2]
-  static_assert((2 * TR * LDT + 2 * 256) <= 2 * (BM + BN) * LDK, "bn-backward staging does not fit the operand LDS");
-  const int pix_l = lane & 31, csub = 4 * (lane >> 5);
-  const int grp = m0 / p.bnb_rows_per_group;                       // tiles never straddle a group (launcher)
-  const float* mean = p.bnb_mean + (size_t)grp * p.Cd;
-  const float* var = p.bnb_var + (size_t)grp * p.Cd;
-  const size_t row0 = (size_t)(m0 + wm * C::WM + pix_l);           // < Mrows: tiles are full (launcher)
-  __syncthreads();                                                 // operand buffers are free
-#pragma unroll
-  for (int ni = 0; ni < C::NI; ++ni)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int nl = wn * C::WN + ni * 32 + 8 * g + csub, n = n0 + nl;
-      float4 xv[C::MI];
-#pragma unroll
-      for (int mi = 0; mi < C::MI; ++mi) xv[mi] = *reinterpret_cast<const float4*>(p.bnb_x + (row0 + mi * 32) * p.Cd + n);
-      const float4 mu = *reinterpret_cast<const float4*>(mean + n);
-      const float4 vr = *reinterpret_cast<const float4*>(var + n);
-      const float4 gm = *reinterpret_cast<const float4*>(p.bnb_gamma + n);
-      const float4 bt = *reinterpret_cast<const float4*>(p.bnb_beta + n);
-      const float mu_[4] = {mu.x, mu.y, mu.z, mu.w}, bt_[4] = {bt.x, bt.y, bt.z, bt.w};
-      float rstd[4], rsg[4];
-      rstd[0] = rsqrtf(vr.x + p.bnb_eps); rstd[1] = rsqrtf(vr.y + p.bnb_eps);
-      rstd[2] = rsqrtf(vr.z + p.bnb_eps); rstd[3] = rsqrtf(vr.w + p.bnb_eps);
-      rsg[0] = __fmul_rn(rstd[0], gm.x); rsg[1] = __fmul_rn(rstd[1], gm.y);
-      rsg[2] = __fmul_rn(rstd[2], gm.z); rsg[3] = __fmul_rn(rstd[3], gm.w);
-      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int mi = 0; mi < C::MI; ++mi) {
-        const float x_[4] = {xv[mi].x, xv[mi].y, xv[mi].z, xv[mi].w};
-        float dz[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          dz[e] = bn_affine(x_[e], mu_[e], rsg[e], bt_[e]) > 0.f ? acc[mi][ni][4 * g + e] : 0.f;
-          s1[e] += dz[e];
-          s2[e] = fmaf(dz[e], (x_[e] - mu_[e]) * rstd[e], s2[e]);
-        }
-        *reinterpret_cast<float4*>(p.out + (row0 + mi * 32) * p.Cd + n) = make_float4(dz[0], dz[1], dz[2], dz[3]);
-      }
-      *reinterpret_cast<float4*>(T1 + (wm * 32 + pix_l) * LDT + nl) = make_float4(s1[0], s1[1], s1[2], s1[3]);
-      *reinterpret_cast<float4*>(T2 + (wm * 32 + pix_l) * LDT + nl) = make_float4(s2[0], s2[1], s2[2], s2[3]);
-    }
-  __syncthreads();
-  const int c = threadIdx.x % BN, part = threadIdx.x / BN;
-  float a1 = 0.f, a2 = 0.f;
-#pragma unroll 8
-  for (int r = part; r < TR; r += PARTS) { a1 += T1[r * LDT + c]; a2 += T2[r * LDT + c]; }
-  red[(part * BN + c) * 2] = a1; red[(part * BN + c) * 2 + 1] = a2;
-  __syncthreads();
-  if (part == 0) {
-#pragma unroll
-    for (int k = 1; k < PARTS; ++k) { a1 += red[(k * BN + c) * 2]; a2 += red[(k * BN + c) * 2 + 1]; }
-    float* prow = p.bnb_partial + (size_t)(m0 / BM) * 2 * p.Cd;
-    prow[n0 + c] = a1;
-    prow[p.Cd + n0 + c] = a2;
-  }
-}
-
-// Epilogue shared by the igemm kernels: accumulators -> global memory (+ bias), float4 per four output channels.
-template <int BM, int BN, int MODE, bool BNB = false>
-__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&acc)[TileCfg<BM, BN>::MI][TileCfg<BM, BN>::NI],
-                                               f32x16& acc2, int m0, int n0, int wm, int wn, int lane, int Mrows, int HW,
-                                               int Wrow, int ph, int pw, float* lds = nullptr) {
-  using C = TileCfg<BM, BN>;
-  if (C::MI == 1 && C::NI == 1) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
-  }
-  if constexpr (MODE == 1 && BNB) {                  // own instantiation: the extra live registers of this path would
-    bnb_epilogue<BM, BN>(p, acc, m0, n0, wm, wn, lane, lds);   // otherwise cost the plain kernel its second block per CU
-    return;
-  }
-  // ---- per-channel sums of the tile for the batch norm that follows (forward only).  The accumulators go through the
-  // (now idle) operand LDS as T[pixel][channel]; after the global stores below, thread t sums column t % BN over the rows
-  // t / BN, t / BN + PARTS, ...  Launcher guarantees: every tile is full in M (rows-per-group % BM == 0), lds != null.
-  constexpr int LDT = BN + 4;
-  const bool want_stats = MODE == 0 && p.stat_partial != nullptr;
-  // Row epilogue (default for full tiles): the tile goes through the idle operand LDS as T[pixel][channel] and is written
-  // to memory whole rows at a time - a wave stores 1 KiB of contiguous channels per instruction, old values / sign bytes
-  // of the accumulating forms are read the same way - instead of 64 scattered 16-byte pieces per instruction straight
-  // from the MFMA register layout (64 -> 256 channels at 256 x 64 x 64: 0.671 -> 0.547 ms; tune bit27 = old way).
-  // Plain (non-accumulating) data gradients keep the register epilogue: their long K loops gain nothing and pay the extra
-  // barrier (215.3 vs 215.9 ms/step; tune bit28 stages them too).
-  const bool rows_from_lds = lds != nullptr && !(p.tune & (1 << 27)) && (p.Cd & 3) == 0 && m0 + BM <= Mrows &&
-                             n0 + BN <= p.Cd && !(MODE == 1 && !p.accumulate && !(p.tune & (1 << 28)));
-  if (want_stats || rows_from_lds) {
-    __syncthreads();                                   // every wave has left the K-loop: the operand buffers are free
-    const int pl = lane & 31, cs = 4 * (lane >> 5);
-#pragma unroll
-    for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < C::NI; ++ni)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(lds + (wm * C::WM + mi * 32 + pl) * LDT + wn * C::WN + ni * 32 + 8 * g + cs) =
-              make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
-  }
-  // ---- epilogue.  Accumulator layout (operands swapped): column = lane & 31 = pixel row m of the tile,
-  // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) = output channel -> registers 4g..4g+3 are four
-  // consecutive channels of one pixel: one 16-byte store each, row address computed once per lane.
-  const int pix_l = lane & 31, csub = 4 * (lane >> 5);
-  const bool vec_ok = (p.Cd & 3) == 0;
-#pragma unroll
-  for (int mi = 0; mi < C::MI; ++mi) {
-    const int m = m0 + wm * C::WM + mi * 32 + pix_l;
-    if (m >= Mrows || rows_from_lds) continue;
-    size_t orow;
-    if (MODE == 0) orow = (size_t)m;
-    else {
-      const int n = m / HW; const int rem = m - n * HW; const int a = rem / Wrow, b = rem - a * Wrow;
-      orow = ((size_t)n * p.Hd + (ph + p.stride * a)) * p.Wd + (pw + p.stride * b);
-    }
-    float* orow_p = p.out + orow * p.Cd;
-    // accumulating form (out += result): ALL the old values of this row are requested before the first one is used -
-    // one load at a time (load, wait, add, store) left the epilogue waiting out a full memory round trip per float4
-    // (rocprof: xas_conv_dgrad_acc at 46 TFLOP/s against 104 for the same shapes without the accumulation)
-    float4 prev[C::NI][4];
-    unsigned pmask[C::NI][4];
-    if (p.accumulate && vec_ok) {
-      const float* prow = p.accumulate == 2 ? p.acc_src + orow * p.Cd : orow_p;
-#pragma unroll
-      for (int ni = 0; ni < C::NI; ++ni)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = n0 + wn * C::WN + ni * 32 + 8 * g + csub;
-          const int nc = n + 3 < p.Cd ? n : p.Cd - 4;                                   // clamped: unconditional load
-          prev[ni][g] = *reinterpret_cast<const float4*>(prow + nc);
-          pmask[ni][g] = p.accumulate == 2 ? p.acc_mask[(orow * p.Cd + nc) >> 2] : 15u;
-        }
-    }
-#pragma unroll
-    for (int ni = 0; ni < C::NI; ++ni) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * C::WN + ni * 32 + 8 * g + csub;
-        float4 v = make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
-        if (vec_ok && n + 3 < p.Cd) {
-          if (MODE == 0 && p.bias) {
-            const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-          }
-          if (p.accumulate) {
-            const float4 o = prev[ni][g];
-            const unsigned mb = pmask[ni][g];
-            v.x += (mb & 1u) ? o.x : 0.f; v.y += (mb & 2u) ? o.y : 0.f;
-            v.z += (mb & 4u) ? o.z : 0.f; v.w += (mb & 8u) ? o.w : 0.f;
-          }
-          *reinterpret_cast<float4*>(orow_p + n) = v;      // (scattered 16-byte pieces: a non-temporal hint costs 2.3 ms here)
-        } else {
-          const float vv[4] = {v.x, v.y, v.z, v.w};
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.Cd)
-              orow_p[n + e] = vv[e] + ((MODE == 0 && p.bias) ? p.bias[n + e] : 0.f) + (p.accumulate ? orow_p[n + e] : 0.f);
-        }
-      }
-    }
-  }
-  if (want_stats || rows_from_lds) __syncthreads();    // T complete
-  if (rows_from_lds) {
-    constexpr int C4 = BN / 4, RPP = 256 / C4;         // float4 per row, rows per pass of the block
-    const int c4 = threadIdx.x % C4, r0 = threadIdx.x / C4;
-    const int nn = n0 + c4 * 4;
-    float4 bb = make_float4(0, 0, 0, 0);
-    if (MODE == 0 && p.bias) bb = *reinterpret_cast<const float4*>(p.bias + nn);
-#pragma unroll 4
-    for (int r = r0; r < BM; r += RPP) {
-      const int m = m0 + r;
-      size_t orow;
-      if (MODE == 0 || p.stride == 1) orow = (size_t)m;
-      else {
-        const int n = m / HW; const int rem = m - n * HW; const int a = rem / Wrow, b = rem - a * Wrow;
-        orow = ((size_t)n * p.Hd + (ph + p.stride * a)) * p.Wd + (pw + p.stride * b);
-      }
-      float4 v = *reinterpret_cast<const float4*>(lds + r * LDT + c4 * 4);
-      v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-      float* op = p.out + orow * p.Cd + nn;
-      if (p.accumulate) {
-        const float4 o = stream_load(reinterpret_cast<const float4*>(p.accumulate == 2 ? p.acc_src + orow * p.Cd + nn : op));
-        const unsigned mb = p.accumulate == 2 ? p.acc_mask[(orow * p.Cd + nn) >> 2] : 15u;
-        v.x += (mb & 1u) ? o.x : 0.f; v.y += (mb & 2u) ? o.y : 0.f;
-        v.z += (mb & 4u) ? o.z : 0.f; v.w += (mb & 8u) ? o.w : 0.f;
-      }
-      stream_store(reinterpret_cast<float4*>(op), v);
-    }
-  }
-  if (MODE == 0 && want_stats) {
-    constexpr int PARTS = 256 / BN;
-    const int tid = threadIdx.x;
-    const int c = tid % BN, part = tid / BN;
-    const int n = n0 + c;
-    const float pv = (p.stat_pivot && n < p.Cd) ? p.stat_pivot[n] : 0.f;
-    float s = 0.f, q = 0.f;
-#pragma unroll 8
-    for (int r = part; r < BM; r += PARTS) {
-      const float v = lds[r * LDT + c] - pv;
-      s += v; q = fmaf(v, v, q);
-    }
-    float* red = lds + BM * LDT;                       // [PARTS][BN][2]
-    red[(part * BN + c) * 2] = s; red[(part * BN + c) * 2 + 1] = q;
-    __syncthreads();
-    if (part == 0 && n < p.Cd) {
-#pragma unroll
-      for (int k = 1; k < PARTS; ++k) { s += red[(k * BN + c) * 2]; q += red[(k * BN + c) * 2 + 1]; }
-      *reinterpret_cast<float2*>(p.stat_partial + ((size_t)(m0 / BM) * p.Cd + n) * 2) = make_float2(s, q);
-    }
-  }
-}
-
 template <int BM, int BN, int MODE, int NBUF = 2, bool PIPE = false>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   using C = TileCfg<BM, BN>;
@@ -465,14 +164,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   // linear id L runs on XCD L % 8.  Give every XCD a contiguous range of M-tiles and walk the N-tiles of one
   // M-tile back to back, so the gathered activation rows are fetched into that XCD's L2 once and re-used by
   // all N-tiles, while the (small) weight matrix stays L2-resident.  Placement only affects speed.
-  int mt, nt;
-  if (p.tune & 4) { mt = blockIdx.x % p.nMt; nt = blockIdx.x / p.nMt; }       // plain order (experiment)
-  else {
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    mt = xcd * p.mt_per_xcd + q / p.nNt;
-    nt = q - (q / p.nNt) * p.nNt;
-    if (mt >= p.nMt) return;
-  }
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int mt = xcd * p.mt_per_xcd + q / p.nNt;
+  const int nt = q - (q / p.nNt) * p.nNt;
+  if (mt >= p.nMt) return;
   const int m0 = mt * BM, n0 = nt * BN;
   if (m0 >= Mrows) return;                           // uniform per block (uneven phases)
   const int HW = Hrow * Wrow;
@@ -561,39 +256,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     }
   };
 
-  // In-kernel phase stamps exist only in the diagnostic build (-DXAS_CONV_DIAG, tools/stamp_conv.py): even an
-  // untaken `if (stamp)` splits the K-loop into basic blocks, and hipcc then shuffles the 64 accumulator
-  // registers between AGPRs and VGPRs on every K-step.
-#ifdef XAS_CONV_DIAG
-  unsigned long long t_store = 0, t_bar = 0, t_load = 0, t_mfma = 0, t0 = 0, t1 = 0;
-  const bool stamp = p.dbg != nullptr;
-#define XAS_STAMP(acc_var)                                                     \
-  if (stamp) {                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                         \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory"); \
-    __builtin_amdgcn_sched_barrier(0);                                         \
-    acc_var += t1 - t0; t0 = t1;                                               \
-  }
-#else
-#define XAS_STAMP(acc_var)
-#endif
-  // diagnostic build only: ablations of the K-loop after its first two steps (results are then wrong by design):
-  // tune bit3 = no further global loads, bit4 = no further LDS stores / barriers
-#ifdef XAS_CONV_DIAG
-#define XAS_ABL(bit, KS) ((p.tune & (bit)) && (KS) >= 2)
-#else
-#define XAS_ABL(bit, KS) false
-#endif
-#define XAS_KSTEP(KS, BUF, RA, RB, MASK)                                                          \
-  {                                                                                               \
-    if (!XAS_ABL(16, KS)) store_step(BUF, RA, RB, MASK);                                          \
-    XAS_STAMP(t_store)                                                                            \
-    if (!XAS_ABL(16, KS)) __syncthreads();                                                        \
-    XAS_STAMP(t_bar)                                                                              \
-    if ((KS) + 2 < nk && !XAS_ABL(8, KS)) load_step((KS) + 2, RA, RB, MASK);                      \
-    XAS_STAMP(t_load)                                                                             \
-    mfma_tile<BM, BN>(As + (BUF) * BM * LDK, Bs + (BUF) * BN * LDK, acc, acc2, wm, wn, lane, p.tune); \
-    XAS_STAMP(t_mfma)                                                                             \
+#define XAS_KSTEP(KS, BUF, RA, RB, MASK)                                                     \
+  {                                                                                          \
+    store_step(BUF, RA, RB, MASK);                                                           \
+    __syncthreads();                                                                         \
+    if ((KS) + 2 < nk) load_step((KS) + 2, RA, RB, MASK);                                    \
+    mfma_tile<BM, BN>(As + (BUF) * BM * LDK, Bs + (BUF) * BN * LDK, acc, acc2, wm, wn, lane); \
   }
   if constexpr (PIPE) {
     // Pipelined K-loop.  The LDS stores of step ks+1 and the global loads of step ks+3 are issued INSIDE the MFMA
@@ -639,15 +307,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       }
       if (ks < nk) {
         __syncthreads();
-        mfma_tile<BM, BN>(As, Bs, acc, acc2, wm, wn, lane, 0);
+        mfma_tile<BM, BN>(As, Bs, acc, acc2, wm, wn, lane);
       }
     }
   } else {
   if (nk > 0) load_step(0, ra4_0, rb4_0, okmask_0);
   if (nk > 1) load_step(1, ra4_1, rb4_1, okmask_1);
-#ifdef XAS_CONV_DIAG
-  if (stamp) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory"); }
-#endif
   // Two K-steps per trip with NO condition between them (an `if (ks + 1 < nk)` in the body makes hipcc carry the
   // accumulators through VGPR phis: 64 v_accvgpr_read + 64 v_accvgpr_write per trip); an odd last step is peeled.
   int ks = 0;
@@ -658,14 +323,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   if (ks < nk) XAS_KSTEP(ks, 0, ra4_0, rb4_0, okmask_0)
   }   // !PIPE
 #undef XAS_KSTEP
-#undef XAS_ABL
-#undef XAS_STAMP
-#ifdef XAS_CONV_DIAG
-  if (stamp && lane == 0) {
-    atomicAdd(p.dbg + 0, t_store); atomicAdd(p.dbg + 1, t_bar); atomicAdd(p.dbg + 2, t_load);
-    atomicAdd(p.dbg + 3, t_mfma); atomicAdd(p.dbg + 4, (unsigned long long)nk);
-  }
-#endif
 
   igemm_epilogue<BM, BN, MODE>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
 }
@@ -684,15 +341,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 // the out-of-range offset 0x80000000 and the hardware returns zeros, so nothing is masked on the way to LDS.
 // Per K-step a wave issues 3 VALU per staged activation row (tap-validity bit -> offset select) and none for the
 // weights, against ~115 before.
-// ------------------------------------------------------------------------------------
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned kOOB = 0x80000000u;
-
-__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
-  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-
 template <int BM, int BN, int MODE, bool PIPE, bool BNB = false>
 __global__ __launch_bounds__(256, 2) void igemm_buf_kernel(IgemmParams p) {
   using C = TileCfg<BM, BN>;
@@ -718,14 +366,10 @@ __global__ __launch_bounds__(256, 2) void igemm_buf_kernel(IgemmParams p) {
     rstep = st; sa = 1;
   }
   const int Mrows = p.N * Hrow * Wrow;
-  int mt, nt;
-  if (p.tune & 4) { mt = blockIdx.x % p.nMt; nt = blockIdx.x / p.nMt; }
-  else {                                             // XCD-aware tile order, as igemm_kernel
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    mt = xcd * p.mt_per_xcd + q / p.nNt;
-    nt = q - (q / p.nNt) * p.nNt;
-    if (mt >= p.nMt) return;
-  }
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;      // XCD-aware tile order, as igemm_kernel
+  const int mt = xcd * p.mt_per_xcd + q / p.nNt;
+  const int nt = q - (q / p.nNt) * p.nNt;
+  if (mt >= p.nMt) return;
   const int m0 = mt * BM, n0 = nt * BN;
   if (m0 >= Mrows) return;
   const int HW = Hrow * Wrow;
@@ -857,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void igemm_buf_kernel(IgemmParams p) {
       }
       if (ks < nk) {
         __syncthreads();
-        mfma_tile<BM, BN>(As, Bs, acc, acc2, wm, wn, lane, 0);
+        mfma_tile<BM, BN>(As, Bs, acc, acc2, wm, wn, lane);
       }
     } else {
       // store(ks) -> barrier -> issue loads(ks+2) -> MFMAs(ks); two K-steps per trip, odd last step peeled
@@ -868,16 +512,16 @@ __global__ __launch_bounds__(256, 2) void igemm_buf_kernel(IgemmParams p) {
         store_step(0, ra4_0, rb4_0);
         __syncthreads();
         load_next(ra4_0, rb4_0);
-        mfma_tile<BM, BN>(As, Bs, acc, acc2, wm, wn, lane, 0);
+        mfma_tile<BM, BN>(As, Bs, acc, acc2, wm, wn, lane);
         store_step(1, ra4_1, rb4_1);
         __syncthreads();
         load_next(ra4_1, rb4_1);
-        mfma_tile<BM, BN>(As + BM * LDK, Bs + BN * LDK, acc, acc2, wm, wn, lane, 0);
+        mfma_tile<BM, BN>(As + BM * LDK, Bs + BN * LDK, acc, acc2, wm, wn, lane);
       }
       if (ks < nk) {
         store_step(0, ra4_0, rb4_0);
         __syncthreads();
-        mfma_tile<BM, BN>(As, Bs, acc, acc2, wm, wn, lane, 0);
+        mfma_tile<BM, BN>(As, Bs, acc, acc2, wm, wn, lane);
       }
     }
   }
@@ -885,340 +529,10 @@ __global__ __launch_bounds__(256, 2) void igemm_buf_kernel(IgemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------
-// Short-K 1x1 layers (32 / 64 input channels, stride 1: one or two K-steps per tile): PERSISTENT blocks.  Such a tile is
-// 3.4 us of MFMA between a 2-3 us wait for its operands and a 64-128 KB epilogue - with one tile per block the two phases
-// of the (at most two) resident blocks barely overlap and the layer runs at half of both its MFMA and its HBM bound.  Here a
-// block walks its share of the tiles and requests tile t+1's operands right after tile t's have gone to LDS: they arrive
-// during t's MFMAs and epilogue.  Same tile order (XCD-contiguous M ranges), same epilogue.
-// ------------------------------------------------------------------------------------
-template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(256, 2) void igemm_shortk_kernel(IgemmParams p) {
-  using C = TileCfg<BM, BN>;
-  constexpr int APASS = BM / 32, BPASS = BN / 32;
-  extern __shared__ __align__(16) float lds[];
-  float* As = lds;                       // [2][BM][LDK]: K-step 0 and K-step 1
-  float* Bs = lds + 2 * BM * LDK;        // [2][BN][LDK]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
-  const int kq = tid & 7, lrow = tid >> 3;
-  const int Hrow = MODE == 0 ? p.Hrow : p.Hd, Wrow = MODE == 0 ? p.Wrow : p.Wd;     // 1x1, stride 1: row grid = image
-  const int Mrows = p.N * Hrow * Wrow, HW = Hrow * Wrow;
-  const int nk = p.Cs / BK;                                                           // 1 or 2 (launcher)
-  const __amdgpu_buffer_rsrc_t rsrcA =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, (int)(p.src_elems * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcB =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, (int)(p.wgt_elems * 4), 0x00020000);
-  const unsigned row_bytes = (unsigned)p.Cs * 4u;
-  const int total_q = 8 * p.mt_per_xcd * p.nNt;
-  float4 ra4_0[APASS], rb4_0[BPASS], ra4_1[APASS], rb4_1[BPASS];
-  auto issue = [&](int mt, int nt) {
-#pragma unroll
-    for (int j = 0; j < APASS; ++j) {
-      const int m = mt * BM + lrow + 32 * j;
-      const unsigned off = m < Mrows ? (unsigned)m * row_bytes + (unsigned)kq * 16u : kOOB;
-      ra4_0[j] = buf_load16(rsrcA, off, 0u);
-      if (nk > 1) ra4_1[j] = buf_load16(rsrcA, off, (unsigned)BK * 4u);
-    }
-#pragma unroll
-    for (int j = 0; j < BPASS; ++j) {
-      const int n = nt * BN + lrow + 32 * j;
-      const unsigned off = n < p.Cd ? (unsigned)n * row_bytes + (unsigned)kq * 16u : kOOB;
-      rb4_0[j] = buf_load16(rsrcB, off, 0u);
-      if (nk > 1) rb4_1[j] = buf_load16(rsrcB, off, (unsigned)BK * 4u);
-    }
-  };
-  // tiles of this block: q = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8: the XCD of a q is the block's)
-  int q = blockIdx.x;
-  int mt = (q & 7) * p.mt_per_xcd + (q >> 3) / p.nNt, nt = (q >> 3) % p.nNt;
-  bool valid = q < total_q && mt < p.nMt && mt * BM < Mrows;
-  if (valid) issue(mt, nt);
-  while (valid) {
-    const int qn = q + (int)gridDim.x;
-    const int mtn = (qn & 7) * p.mt_per_xcd + (qn >> 3) / p.nNt, ntn = (qn >> 3) % p.nNt;
-    const bool vn = qn < total_q && mtn < p.nMt && mtn * BM < Mrows;
-#pragma unroll
-    for (int j = 0; j < APASS; ++j) *reinterpret_cast<float4*>(As + (lrow + 32 * j) * LDK + kq * 4) = ra4_0[j];
-#pragma unroll
-    for (int j = 0; j < BPASS; ++j) *reinterpret_cast<float4*>(Bs + (lrow + 32 * j) * LDK + kq * 4) = rb4_0[j];
-    if (nk > 1) {
-#pragma unroll
-      for (int j = 0; j < APASS; ++j) *reinterpret_cast<float4*>(As + BM * LDK + (lrow + 32 * j) * LDK + kq * 4) = ra4_1[j];
-#pragma unroll
-      for (int j = 0; j < BPASS; ++j) *reinterpret_cast<float4*>(Bs + BN * LDK + (lrow + 32 * j) * LDK + kq * 4) = rb4_1[j];
-    }
-    __syncthreads();
-    if (vn) issue(mtn, ntn);                           // in flight during this tile's MFMAs and epilogue
-    f32x16 acc[C::MI][C::NI];
-#pragma unroll
-    for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < C::NI; ++ni)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-    f32x16 acc2;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
-    mfma_tile<BM, BN>(As, Bs, acc, acc2, wm, wn, lane, 0);
-    if (nk > 1) mfma_tile<BM, BN>(As + BM * LDK, Bs + BN * LDK, acc, acc2, wm, wn, lane, 0);
-    igemm_epilogue<BM, BN, MODE>(p, acc, acc2, mt * BM, nt * BN, wm, wn, lane, Mrows, HW, Wrow, 0, 0, lds);
-    __syncthreads();                                   // the LDS image of this tile is consumed
-    q = qn; mt = mtn; nt = ntn; valid = vn;
-  }
-}
-
-// ------------------------------------------------------------------------------------
-// bf16-MFMA variant of fwd / dgrad (NOT the headline path: xas_set_precision(1) selects it, results are
-// reported separately).  Same tiling, addressing and epilogue as igemm_buf_kernel; activations and master weights stay
-// fp32 in HBM and are rounded to bf16 (round to nearest even, v_cvt_pk_bf16_f32) on the way to LDS; products are
-// exact, accumulation is fp32 (v_mfma_f32_32x32x16_bf16: 16x the fp32 MFMA rate).  One K-step (32 channels) is two
-// MFMAs per 32x32 tile instead of sixteen, so the loop is bound by staging (global loads, conversion, LDS) rather than
-// by the matrix pipe.  LDS rows: 32 bf16 + 8 pad = 80 bytes (rows r and r+16 share banks: conflict-free for the 16-lane
-// groups of ds_read_b128).
-// ------------------------------------------------------------------------------------
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-constexpr int LDKH = BK + 8;   // bf16 elements per LDS row
-
-__device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
-  const bf16x2_t lo = __builtin_convertvector(f32x2_t{v.x, v.y}, bf16x2_t);
-  const bf16x2_t hi = __builtin_convertvector(f32x2_t{v.z, v.w}, bf16x2_t);
-  return make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
-}
-
-// v - float(q) for the four bf16 values packed in q (exact: q is the leading part of v)
-__device__ __forceinline__ float4 sub_bf16x4(float4 v, uint2 q) {
-  return make_float4(v.x - __uint_as_float(q.x << 16), v.y - __uint_as_float(q.x & 0xffff0000u),
-                     v.z - __uint_as_float(q.y << 16), v.w - __uint_as_float(q.y & 0xffff0000u));
-}
-
-
-// PIECES = 3 ("bf16x6", xas_set_precision(2)): fp32-ACCURATE products on the bf16 matrix pipe.  Every fp32 operand is split
-// exactly into three bf16 pieces x = x1 + x2 + x3 (8 significant bits each: x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2));
-// the six partial products x1y1, x1y2, x2y1, x2y2, x1y3, x3y1 are each EXACT in fp32 and are accumulated in fp32 by the MFMA;
-// the three dropped ones are below 2^-25 |xy| - under the rounding error of one fp32 product.  6 x 32 cycles per K = 16 against
-// 8 x 64 cycles of v_mfma_f32_32x32x2_f32.  One LDS buffer (three planes per operand) and two barriers per K-step keep two
-// blocks per CU.
-template <int BM, int BN, int MODE, int PIECES = 1>
-__global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmParams p) {
-  using C = TileCfg<BM, BN>;
-  constexpr int APASS = BM / 32, BPASS = BN / 32;
-  constexpr int NBUF = PIECES == 1 ? 2 : 1;
-  extern __shared__ __align__(16) float lds[];
-  unsigned short* As = reinterpret_cast<unsigned short*>(lds);     // [NBUF][PIECES][BM][LDKH]
-  unsigned short* Bs = As + NBUF * PIECES * BM * LDKH;              // [NBUF][PIECES][BN][LDKH]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
-  const int kq = tid & 7, lrow = tid >> 3;
-
-  int Hrow = p.Hrow, Wrow = p.Wrow;
-  int ph = 0, pw = 0, base_r = 0, base_s = 0, nr = p.R, ns = p.S, off_h = -p.pad, off_w = -p.pad, rstep = 1;
-  int sa = p.stride;
-  if (MODE == 1) {
-    const int st = p.stride;
-    ph = blockIdx.z / st; pw = blockIdx.z % st;
-    Hrow = (p.Hd - ph + st - 1) / st; Wrow = (p.Wd - pw + st - 1) / st;
-    base_r = (ph + p.pad) % st; base_s = (pw + p.pad) % st;
-    nr = base_r < p.R ? (p.R - base_r + st - 1) / st : 0;
-    ns = base_s < p.S ? (p.S - base_s + st - 1) / st : 0;
-    off_h = (ph + p.pad - base_r) / st; off_w = (pw + p.pad - base_s) / st;
-    rstep = st; sa = 1;
-  }
-  const int Mrows = p.N * Hrow * Wrow;
-  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;          // XCD-aware tile order, as igemm_buf_kernel
-  const int mt = xcd * p.mt_per_xcd + q / p.nNt;
-  const int nt = q - (q / p.nNt) * p.nNt;
-  if (mt >= p.nMt) return;
-  const int m0 = mt * BM, n0 = nt * BN;
-  if (m0 >= Mrows) return;
-  const int HW = Hrow * Wrow;
-  const int cchunks = p.Cs / BK;
-  const int nk = nr * ns * cchunks;
-
-  const long dmin = MODE == 0 ? 0l : -((long)(nr - 1) * p.Ws + (ns - 1)) * p.Cs;
-  const long rmin = MODE == 0 ? -((long)p.pad * p.Ws + p.pad) * p.Cs : 0l;
-  const long bias = -(rmin + dmin);
-  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.src) - bias, 0, (int)((bias + p.src_elems) * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcB =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, (int)(p.wgt_elems * 4), 0x00020000);
-  unsigned voffA[APASS], maskA[APASS], voffB[BPASS];
-#pragma unroll
-  for (int j = 0; j < APASS; ++j) {
-    const int m = m0 + lrow + 32 * j;
-    voffA[j] = kOOB; maskA[j] = 0u;
-    if (m < Mrows) {
-      int n, a, b;
-      if (MODE == 0) { n = p.div_hw.div(m); const int rem = m - n * HW; a = p.div_w.div(rem); b = rem - a * Wrow; }
-      else { n = m / HW; const int rem = m - n * HW; a = rem / Wrow; b = rem - a * Wrow; }
-      const int ra = a * sa + off_h, rb = b * sa + off_w;
-      const long rbase = (((long)n * p.Hs + ra) * p.Ws + rb) * p.Cs;
-      voffA[j] = (unsigned)((rbase + dmin + bias + kq * 4) * 4);
-      unsigned colmask = 0u, msk = 0u;
-      for (int js = 0; js < ns; ++js) {
-        const int ws = rb + (MODE == 0 ? js : -js);
-        colmask |= ((unsigned)ws < (unsigned)p.Ws ? 1u : 0u) << js;
-      }
-      for (int jr = 0; jr < nr; ++jr) {
-        const int hs = ra + (MODE == 0 ? jr : -jr);
-        if ((unsigned)hs < (unsigned)p.Hs) msk |= colmask << (jr * ns);
-      }
-      maskA[j] = msk;
-    }
-  }
-  const unsigned wrow_bytes = (unsigned)(p.R * p.S * p.Cs) * 4u;
-#pragma unroll
-  for (int j = 0; j < BPASS; ++j) {
-    const int n = n0 + lrow + 32 * j;
-    voffB[j] = n < p.Cd ? (unsigned)n * wrow_bytes + (unsigned)kq * 16u : kOOB;
-  }
-
-  f32x16 acc[C::MI][C::NI];
-#pragma unroll
-  for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < C::NI; ++ni)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-  f32x16 acc2;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
-
-  int ld_chunk = 0, ld_js = 0, ld_jr = 0, ld_left = nk;
-  float4 ra4_0[APASS], rb4_0[BPASS], ra4_1[APASS], rb4_1[BPASS];
-  auto load_next = [&](float4 (&ra4)[APASS], float4 (&rb4)[BPASS]) {
-    const int tap = ld_jr * ns + ld_js;
-    const int rel = MODE == 0 ? (ld_jr * p.Ws + ld_js) : ((nr - 1 - ld_jr) * p.Ws + (ns - 1 - ld_js));
-    const unsigned soffA = (unsigned)(rel * p.Cs + ld_chunk * BK) * 4u;
-    const int wtap = (base_r + rstep * ld_jr) * p.S + (base_s + rstep * ld_js);
-    const unsigned soffB = (unsigned)(wtap * p.Cs + ld_chunk * BK) * 4u;
-#pragma unroll
-    for (int j = 0; j < APASS; ++j) {
-      const unsigned off = ((maskA[j] >> tap) & 1u) ? voffA[j] : kOOB;
-      ra4[j] = buf_load16(rsrcA, off, soffA);
-    }
-#pragma unroll
-    for (int j = 0; j < BPASS; ++j) rb4[j] = buf_load16(rsrcB, voffB[j], soffB);
-    const bool more = ld_left > 1;
-    ld_left -= more ? 1 : 0;
-    int c = ld_chunk + 1, s2 = ld_js, r = ld_jr;
-    if (c == cchunks) { c = 0; ++s2; }
-    if (s2 == ns) { s2 = 0; ++r; }
-    ld_chunk = more ? c : ld_chunk; ld_js = more ? s2 : ld_js; ld_jr = more ? r : ld_jr;
-  };
-  auto store_step = [&](int buf, const float4 (&ra4)[APASS], const float4 (&rb4)[BPASS]) {
-    unsigned short* a = As + buf * PIECES * BM * LDKH;
-    unsigned short* b = Bs + buf * PIECES * BN * LDKH;
-#pragma unroll
-    for (int j = 0; j < APASS; ++j) {
-      float4 r = ra4[j];
-#pragma unroll
-      for (int pc = 0; pc < PIECES; ++pc) {
-        const uint2 q = pack_bf16x4(r);
-        *reinterpret_cast<uint2*>(a + (pc * BM + lrow + 32 * j) * LDKH + kq * 4) = q;
-        if (pc + 1 < PIECES) r = sub_bf16x4(r, q);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < BPASS; ++j) {
-      float4 r = rb4[j];
-#pragma unroll
-      for (int pc = 0; pc < PIECES; ++pc) {
-        const uint2 q = pack_bf16x4(r);
-        *reinterpret_cast<uint2*>(b + (pc * BN + lrow + 32 * j) * LDKH + kq * 4) = q;
-        if (pc + 1 < PIECES) r = sub_bf16x4(r, q);
-      }
-    }
-  };
-  const int i = lane & 31, h = lane >> 5;
-  auto compute = [&](int buf) {
-    const unsigned short* a_s = As + buf * PIECES * BM * LDKH;
-    const unsigned short* b_s = Bs + buf * PIECES * BN * LDKH;
-#pragma unroll
-    for (int sl = 0; sl < BK / 16; ++sl) {
-      bf16x8_t fa[PIECES][C::MI], fb[PIECES][C::NI];
-#pragma unroll
-      for (int pc = 0; pc < PIECES; ++pc) {
-#pragma unroll
-        for (int mi = 0; mi < C::MI; ++mi)
-          fa[pc][mi] = *reinterpret_cast<const bf16x8_t*>(a_s + (pc * BM + wm * C::WM + mi * 32 + i) * LDKH + sl * 16 + h * 8);
-#pragma unroll
-        for (int ni = 0; ni < C::NI; ++ni)
-          fb[pc][ni] = *reinterpret_cast<const bf16x8_t*>(b_s + (pc * BN + wn * C::WN + ni * 32 + i) * LDKH + sl * 16 + h * 8);
-      }
-      // smallest partial products first: (a3 b1), (a1 b3), (a2 b2), (a2 b1), (a1 b2), (a1 b1)
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-      for (int t = (PIECES == 1 ? 5 : 0); t < 6; ++t)
-#pragma unroll
-        for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < C::NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PIECES == 1 ? 0 : PB[t]][ni], fa[PIECES == 1 ? 0 : PA[t]][mi],
-                                                                  acc[mi][ni], 0, 0, 0);
-    }
-  };
-  if (nk > 0) {
-    load_next(ra4_0, rb4_0);
-    load_next(ra4_1, rb4_1);
-    int ks = 0;
-    if constexpr (PIECES == 1) {
-      for (; ks + 1 < nk; ks += 2) {
-        store_step(0, ra4_0, rb4_0);
-        __syncthreads();
-        load_next(ra4_0, rb4_0);
-        compute(0);
-        store_step(1, ra4_1, rb4_1);
-        __syncthreads();
-        load_next(ra4_1, rb4_1);
-        compute(1);
-      }
-      if (ks < nk) {
-        store_step(0, ra4_0, rb4_0);
-        __syncthreads();
-        compute(0);
-      }
-    } else {                                           // one LDS buffer: write, barrier, compute, barrier
-      for (; ks + 1 < nk; ks += 2) {
-        store_step(0, ra4_0, rb4_0);
-        __syncthreads();
-        load_next(ra4_0, rb4_0);
-        compute(0);
-        __syncthreads();
-        store_step(0, ra4_1, rb4_1);
-        __syncthreads();
-        load_next(ra4_1, rb4_1);
-        compute(0);
-        __syncthreads();
-      }
-      if (ks < nk) {
-        store_step(0, ra4_0, rb4_0);
-        __syncthreads();
-        compute(0);
-      }
-    }
-  }
-  igemm_epilogue<BM, BN, MODE>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
-}
-
-// ------------------------------------------------------------------------------------
 // wgrad: C[co][nn] = sum_m dY[m][co] * Xcol[m][nn],  nn = (r*S+s)*Cin + c
 // LDS tiles are [k = pixel][row] (row-contiguous, as they come from memory); MFMA operands
 // are read with ds_read_b32 (lanes walk rows: conflict free).
 // ------------------------------------------------------------------------------------
-struct WgradParams {
-  const float* x; const float* dy; float* out;      // out: [splits][Cout][KK] slabs
-  int N, Hi, Wi, Cin, Cout, R, S, stride, pad, Ho, Wo;
-  int KK;                                            // R*S*Cin
-  int M;                                             // N*Ho*Wo
-  int m_per_split;
-  int nct, ntiles, nsplits;                           // Cout tiles, tiles per split, pixel splits
-  int tune;
-  FastDiv div_hw, div_w, div_cin, div_s;
-};
-
-constexpr int WBK = 32;       // pixels per K-step
-
 template <int BM, int BN, bool VEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   using C = TileCfg<BM, BN>;
@@ -1994,7 +1308,7 @@ static int launch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStre
   }
   IgemmParams q = p;
   q.nMt = (int)cdiv(Mrows_max, BM); q.nNt = (int)cdiv(p.Cd, BN); q.mt_per_xcd = (int)cdiv(q.nMt, 8);
-  const unsigned nblk = (q.tune & 4) ? (unsigned)(q.nMt * q.nNt) : (unsigned)(8 * q.mt_per_xcd * q.nNt);
+  const unsigned nblk = (unsigned)(8 * q.mt_per_xcd * q.nNt);
   dim3 grid(nblk, 1, (unsigned)phases);
   hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, NBUF, PIPE>), grid, dim3(256), lds, st, q);
   XAS_LAUNCH_CHECK();
@@ -2013,38 +1327,25 @@ static int launch_igemm_buf(const IgemmParams& p, int Mrows_max, int phases, hip
   }
   IgemmParams q = p;
   q.nMt = (int)cdiv(Mrows_max, BM); q.nNt = (int)cdiv(p.Cd, BN); q.mt_per_xcd = (int)cdiv(q.nMt, 8);
-  const unsigned nblk = (q.tune & 4) ? (unsigned)(q.nMt * q.nNt) : (unsigned)(8 * q.mt_per_xcd * q.nNt);
+  const unsigned nblk = (unsigned)(8 * q.mt_per_xcd * q.nNt);
   dim3 grid(nblk, 1, (unsigned)phases);
   hipLaunchKernelGGL((igemm_buf_kernel<BM, BN, MODE, PIPE, BNB>), grid, dim3(256), lds, st, q);
   XAS_LAUNCH_CHECK();
   return 0;
 }
 
-template <int BM, int BN, int MODE>
-static int launch_shortk(const IgemmParams& p, int Mrows_max, hipStream_t st) {
-  const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
-  static bool attr_set_dev[kMaxDevices] = {};
-  bool& attr_set = attr_set_dev[current_device()];
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_shortk_kernel<BM, BN, MODE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  IgemmParams q = p;
-  q.nMt = (int)cdiv(Mrows_max, BM); q.nNt = (int)cdiv(p.Cd, BN); q.mt_per_xcd = (int)cdiv(q.nMt, 8);
-  const long total = 8l * q.mt_per_xcd * q.nNt;
-  const unsigned grid = (unsigned)(total < 512 ? total : 512);          // two resident blocks per CU, a multiple of 8
-  hipLaunchKernelGGL((igemm_shortk_kernel<BM, BN, MODE>), dim3(grid), dim3(256), lds, st, q);
-  XAS_LAUNCH_CHECK();
-  return 0;
+// The 32-bit offset scheme of the buffer-load kernels (conv.hip and conv_x6.hip) addresses tensors below 2 GiB incl. the
+// padding region in front of them, and tap windows of at most 32 taps.
+static bool igemm_fits(const IgemmParams& p) {
+  const long bias = ((long)(p.R + p.pad) * p.Ws + p.S + p.pad) * p.Cs;
+  return (bias + p.src_elems) * 4 < 0x7fffff00l && p.wgt_elems * 6 < 0x7fffff00l && p.R * p.S <= 32;
 }
 
-// Buffer-load kernel unless its 32-bit offset scheme cannot address the tensor (>= 2 GiB incl. the bias region, or a
-// tap window of more than 32 taps) or an experiment flag asks for the old kernel (tune bit6 = 64).
+// Exact-fp32 MFMA path: buffer-load kernel unless its offset scheme cannot address the tensor or a coverage test asks for
+// the global-load kernel (tune bit6 = 64); tune bit5 (32): plain K-loop instead of the pipelined one.
 template <int BM, int BN, int MODE>
 static int launch_tile(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
-  const long bias = ((long)(p.R + p.pad) * p.Ws + p.S + p.pad) * p.Cs;
-  const bool fits = (bias + p.src_elems) * 4 < 0x7fffff00l && p.wgt_elems * 4 < 0x7fffff00l && p.R * p.S <= 32;
+  const bool fits = igemm_fits(p);
   if constexpr (MODE == 1) {
     if (p.bnb_x) {                                    // batch-norm backward epilogue: buffer-load pipelined kernel only
       XAS_REQUIRE(fits, "conv_dgrad_bn_bwd: tensor beyond the 32-bit offset range of the buffer-load kernel");
@@ -2053,16 +1354,9 @@ static int launch_tile(const IgemmParams& p, int Mrows_max, int phases, hipStrea
   }
   // K loops of one or two steps (1x1 layers with 32 / 64 input channels): the pipelined loop's look-ahead loads have
   // nothing to look ahead to (they re-load the last step) - the plain loop is 18 % faster there (0.608 -> 0.497 ms for
-  // 64 -> 256 channels at 256 x 64 x 64, tools/bench_ops.py); tune bit25 keeps the pipelined loop everywhere
-  const bool short_k = p.stride == 1 && (long)p.R * p.S * p.Cs <= 2 * BK && !(p.tune & (1 << 25));
-  // persistent variant (igemm_shortk_kernel): measured equal to one tile per block (215.1 vs 215.1 ms/step) - these layers
-  // are 80 % output writes and sit at ~2.6 of the ~3.4 TB/s that write-dominated kernels reach on this part, not on
-  // operand latency; kept behind tune bit29
-  if (short_k && fits && p.R == 1 && p.S == 1 && p.pad == 0 && phases == 1 && (p.tune & (1 << 29))) {
-    if constexpr (MODE == 0) return launch_shortk<BM, BN, 0>(p, Mrows_max, st);
-    else if (!p.bnb_x) return launch_shortk<BM, BN, 1>(p, Mrows_max, st);
-  }
-  if (fits && !(p.tune & 64)) {                       // tune bit5 (32): plain K-loop instead of the pipelined one
+  // 64 -> 256 channels at 256 x 64 x 64, r02)
+  const bool short_k = p.stride == 1 && (long)p.R * p.S * p.Cs <= 2 * BK;
+  if (fits && !(p.tune & 64)) {
     if ((p.tune & 32) || short_k) return launch_igemm_buf<BM, BN, MODE, false>(p, Mrows_max, phases, st);
     return launch_igemm_buf<BM, BN, MODE, true>(p, Mrows_max, phases, st);
   }
@@ -2070,67 +1364,20 @@ static int launch_tile(const IgemmParams& p, int Mrows_max, int phases, hipStrea
   return launch_igemm<BM, BN, MODE, 2, true>(p, Mrows_max, phases, st);
 }
 
-static int g_precision = 0;      // 0: fp32 MFMA (headline, parity bar); 1: bf16 MFMA for fwd / dgrad; 2: bf16x6 (fp32-accurate
-                                 // products from six bf16 MFMA products) for fwd / dgrad - both reported separately
+static int g_precision = XAS_PREC_BF16X6;    // process default (xas_set_precision); a call overrides it with xas_conv_shape.mode
 
-template <int BM, int BN, int MODE, int PIECES = 1>
-static int launch_igemm_bf16_p(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
-  size_t lds = (size_t)(PIECES == 1 ? 2 : 1) * PIECES * (BM + BN) * LDKH * sizeof(unsigned short);
-  const size_t lds_stats = ((size_t)BM * (BN + 4) + 2 * 256) * sizeof(float);      // T[BM][BN+4] + the partial-combine area
-  if (lds < lds_stats) lds = lds_stats;                                            // (always: one LDS size per instantiation)
-  static bool attr_set_dev[kMaxDevices] = {};
-  bool& attr_set = attr_set_dev[current_device()];
-  if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_kernel<BM, BN, MODE, PIECES>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  IgemmParams q = p;
-  q.nMt = (int)cdiv(Mrows_max, BM); q.nNt = (int)cdiv(p.Cd, BN); q.mt_per_xcd = (int)cdiv(q.nMt, 8);
-  dim3 grid((unsigned)(8 * q.mt_per_xcd * q.nNt), 1, (unsigned)phases);
-  hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, MODE, PIECES>), grid, dim3(256), lds, st, q);
-  XAS_LAUNCH_CHECK();
-  return 0;
-}
+static inline int precision_of(const xas_conv_shape* s) { return s->mode > 0 ? s->mode - 1 : g_precision; }
 
-template <int BM, int BN, int MODE>
-static int launch_igemm_bf16(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
-  if (g_precision == 2) return launch_igemm_bf16_p<BM, BN, MODE, 3>(p, Mrows_max, phases, st);
-  return launch_igemm_bf16_p<BM, BN, MODE, 1>(p, Mrows_max, phases, st);
-}
-
-// tile of the fp32 path for a problem (the one rule both the launcher and xas_conv_fwd_bnstats go by)
-static void pick_tile(int Cd, long Mrows_max, int phases, int tune, int* bm, int* bn, long Ktot = 1 << 30) {
-  // experiment (tune bits 23 / 24): short K loops (<= 64 / <= 128 deep) are streaming kernels - more, smaller blocks per CU
-  if (Cd >= 64 && (((tune >> 23) & 1 && Ktot <= 64) || ((tune >> 24) & 1 && Ktot <= 128))) { *bm = 64; *bn = 64; return; }
-  if (Cd >= 96) {
-    // small problems (layer3/4 at B=32: M = 8192 / 2048 rows): 128x128 tiles leave most of the 256 CUs idle
-    const long blocks128 = cdiv(Mrows_max, 128) * cdiv(Cd, 128) * phases;
-    const long thr = (tune >> 20) & 1 ? 256 : ((tune >> 21) & 1 ? 384 : 512);     // experiment: tune bits 20 / 21
-    if (blocks128 <= thr) { *bm = 64; *bn = 64; } else { *bm = 128; *bn = 128; }
-  } else if (Cd >= 48) { *bm = 128; *bn = 64; }
-  else { *bm = 128; *bn = 32; }
-}
-
+// prec: XAS_PREC_*.  The bf16-split kernels (conv_x6.hip) take PRE-SPLIT weights (xas_split_weight); the exact-fp32 kernels
+// take fp32 packed weights: xas_conv_weight_planes tells the caller which of the two a (shape, pass) wants.
 template <int MODE>
-static int dispatch_igemm(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
-  if (g_precision != 0) {
-    const long bias = ((long)(p.R + p.pad) * p.Ws + p.S + p.pad) * p.Cs;
-    const bool fits = (bias + p.src_elems) * 4 < 0x7fffff00l && p.wgt_elems * 4 < 0x7fffff00l && p.R * p.S <= 32;
-    if (fits) {
-      int bm, bn;
-      pick_tile(p.Cd, Mrows_max, phases, p.tune, &bm, &bn, (long)p.R * p.S * p.Cs);     // same tile rule as the fp32 path
-      if (bn == 128 && (p.tune & (1 << 26)) && !p.stat_partial)                          // experiment: 3 blocks per CU
-        return launch_igemm_bf16<128, 64, MODE>(p, Mrows_max, phases, st);
-      if (bn == 128) return launch_igemm_bf16<128, 128, MODE>(p, Mrows_max, phases, st);
-      if (bm == 64) return launch_igemm_bf16<64, 64, MODE>(p, Mrows_max, phases, st);
-      if (bn == 64) return launch_igemm_bf16<128, 64, MODE>(p, Mrows_max, phases, st);
-      return launch_igemm_bf16<128, 32, MODE>(p, Mrows_max, phases, st);
-    }
-    XAS_REQUIRE(!p.stat_partial && !p.bnb_x, "conv: the statistics epilogues need the buffer-load kernels (tensor too large)");
+static int dispatch_igemm(const IgemmParams& p, int prec, int Mrows_max, int phases, hipStream_t st) {
+  if (prec != XAS_PREC_F32) {
+    XAS_REQUIRE(igemm_fits(p), "conv: tensor beyond the 32-bit offset range of the bf16-split kernels (use XAS_PREC_F32)");
+    return launch_igemm_x6(p, MODE, Mrows_max, phases, prec == XAS_PREC_BF16X6 ? 3 : 1, st);
   }
   int bm, bn;
-  pick_tile(p.Cd, Mrows_max, phases, p.tune, &bm, &bn, (long)p.R * p.S * p.Cs);
+  pick_tile(p.Cd, Mrows_max, phases, &bm, &bn);
   if (bn == 128) return launch_tile<128, 128, MODE>(p, Mrows_max, phases, st);
   if (bm == 64) return launch_tile<64, 64, MODE>(p, Mrows_max, phases, st);
   if (bn == 64) return launch_tile<128, 64, MODE>(p, Mrows_max, phases, st);
@@ -2156,11 +1403,11 @@ static int images_per_launch(int N, long elems_per_image_a, long elems_per_image
 
 extern "C" int xas_set_tuning(int flags) { g_tune = flags; return 0; }
 extern "C" int xas_set_precision(int mode) {
-  XAS_REQUIRE(mode >= 0 && mode <= 2, "set_precision: 0 = fp32 MFMA, 1 = bf16 MFMA, 2 = bf16x6 (fp32-accurate) for forward / data-gradient convolutions");
+  XAS_REQUIRE(mode >= 0 && mode <= 2, "set_precision: 0 = exact fp32 MFMA, 1 = bf16 MFMA (not fp32 accurate), 2 = bf16x6 (fp32-accurate, default)");
   g_precision = mode;
   return 0;
 }
-extern "C" int xas_set_debug_buffer(void* p) { g_dbg = reinterpret_cast<unsigned long long*>(p); return 0; }
+extern "C" int xas_get_precision(void) { return g_precision; }
 
 static int conv_fwd_impl(const float* x, const float* w_packed, const float* bias, float* y, const xas_conv_shape* s,
                          void* stream, float* stat_partial, const float* stat_pivot);
@@ -2179,7 +1426,7 @@ static int fwd_stats_tile_rows(const xas_conv_shape* s, int groups) {
   if (images_per_launch(s->N, (long)s->Hi * s->Wi * s->Cin, 0) < s->N || s->N % groups) return 0;
   const long M = (long)s->N * s->Ho * s->Wo, Mg = M / groups;
   int bm, bn;
-  pick_tile(s->Cout, M, 1, g_tune, &bm, &bn, (long)s->R * s->S * s->Cin);
+  pick_tile(s->Cout, M, 1, &bm, &bn);
   if (Mg % bm) return 0;
   if ((M / bm) * 2 * (long)s->Cout * 4 >= 0x7fffff00l) return 0;
   return bm;
@@ -2236,11 +1483,26 @@ static int conv_fwd_impl(const float* x, const float* w_packed, const float* bia
   IgemmParams p{};
   p.src = x; p.wgt = w_packed; p.bias = bias; p.out = y; p.N = s->N;
   p.Hs = s->Hi; p.Ws = s->Wi; p.Cs = s->Cin; p.Hd = s->Ho; p.Wd = s->Wo; p.Cd = s->Cout;
-  p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.Hrow = s->Ho; p.Wrow = s->Wo; p.tune = g_tune; p.dbg = g_dbg;
+  p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.Hrow = s->Ho; p.Wrow = s->Wo; p.tune = g_tune;
   p.div_hw.init((unsigned)(s->Ho * s->Wo)); p.div_w.init((unsigned)s->Wo);
   p.src_elems = (long)p.N * p.Hs * p.Ws * p.Cs; p.wgt_elems = (long)p.Cd * p.R * p.S * p.Cs;
   p.stat_partial = stat_partial; p.stat_pivot = stat_pivot;
-  return dispatch_igemm<0>(p, s->N * s->Ho * s->Wo, 1, st);
+  return dispatch_igemm<0>(p, precision_of(s), s->N * s->Ho * s->Wo, 1, st);
+}
+
+// Which weight buffer the forward (pass 0: xas_conv_fwd*, ConvTranspose backward) or data-gradient (pass 1: xas_conv_dgrad*,
+// ConvTranspose forward) entry points expect for this shape in its precision mode: 0 = fp32 packed weights
+// (xas_pack_weight); 1 or 3 = that many bf16 planes (xas_split_weight of the packed weights).  Shapes outside the MFMA
+// tiles (stem, one-channel "thin" layers, direct fallbacks) always take fp32 weights.
+extern "C" int xas_conv_weight_planes(const xas_conv_shape* s, int pass) {
+  if (!s) return 0;
+  const int prec = precision_of(s);
+  if (prec == XAS_PREC_F32) return 0;
+  const bool thin = (s->Cout == 1 && thin_ok(s, s->Cin)) || (s->Cin == 1 && thin_ok(s, s->Cout));
+  bool mfma;
+  if (pass == 0) mfma = !thin && !(s->Cin == 3 && s->R == 7) && s->Cin % BK == 0 && s->Cout >= 16;
+  else mfma = !thin && s->Cout % BK == 0 && s->Cin >= 16;
+  return mfma ? (prec == XAS_PREC_BF16X6 ? 3 : 1) : 0;
 }
 
 // Convolution (no bias) + the training-mode batch-norm statistics of its result.  When the tile grid lines up with the
@@ -2347,7 +1609,7 @@ static int conv_dgrad_impl(const float* dy, const float* w_packed_t, float* dx, 
   IgemmParams p{};
   p.src = dy; p.wgt = w_packed_t; p.bias = nullptr; p.out = dx; p.N = s->N;
   p.Hs = s->Ho; p.Ws = s->Wo; p.Cs = s->Cout; p.Hd = s->Hi; p.Wd = s->Wi; p.Cd = s->Cin;
-  p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.tune = g_tune; p.dbg = g_dbg;
+  p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.tune = g_tune;
   p.accumulate = accumulate; p.acc_src = acc_src; p.acc_mask = acc_mask;
   const int Hp = (s->Hi + s->stride - 1) / s->stride, Wp = (s->Wi + s->stride - 1) / s->stride;
   p.src_elems = (long)p.N * p.Hs * p.Ws * p.Cs; p.wgt_elems = (long)p.Cd * p.R * p.S * p.Cs;
@@ -2356,18 +1618,18 @@ static int conv_dgrad_impl(const float* dy, const float* w_packed_t, float* dx, 
     p.bnb_beta = bnb->bnb_beta; p.bnb_eps = bnb->bnb_eps; p.bnb_rows_per_group = bnb->bnb_rows_per_group;
     p.bnb_partial = bnb->bnb_partial;
   }
-  return dispatch_igemm<1>(p, s->N * Hp * Wp, s->stride * s->stride, st);
+  return dispatch_igemm<1>(p, precision_of(s), s->N * Hp * Wp, s->stride * s->stride, st);
 }
 
 // Rows per tile when the data gradient of `s` can carry the batch-norm backward reduction of the layer in front of the
 // convolution in its epilogue (MFMA path, stride 1, one launch, full tiles that do not straddle a camera group), else 0.
 static int dgrad_bnb_tile_rows(const xas_conv_shape* s, int groups) {
-  if (!s || groups < 1 || g_precision != 0 || s->stride != 1) return 0;
+  if (!s || groups < 1 || s->stride != 1) return 0;
   if (s->Cout % BK != 0 || s->Cin < 16 || s->Cin % 4 != 0 || s->Cin == 1 || s->Cout == 1) return 0;
   if (images_per_launch(s->N, (long)s->Ho * s->Wo * s->Cout, 0) < s->N || s->N % groups) return 0;
   const long M = (long)s->N * s->Hi * s->Wi, Mg = M / groups;
   int bm, bn;
-  pick_tile(s->Cin, M, 1, g_tune, &bm, &bn, (long)s->R * s->S * s->Cout);
+  pick_tile(s->Cin, M, 1, &bm, &bn);
   if (Mg % bm || s->Cin % bn) return 0;
   if ((M / bm) * 2 * (long)s->Cin * 4 >= 0x7fffff00l) return 0;
   return bm;
@@ -2419,23 +1681,32 @@ extern "C" int xas_conv_dgrad_bn_bwd(const float* dy, const float* w_packed_t, c
                           nullptr, stream);
 }
 
-static inline unsigned slab_threads() { return (g_tune & 16384) ? 1024u : 256u; }   // tune bit14: old 1024-thread blocks
+static inline unsigned slab_threads() { return 256u; }
 
-static void wgrad_plan(const xas_conv_shape* s, int* bm, int* bn, int* splits, int* mps) {
+// does the weight gradient of this shape run on the bf16-split kernel (conv_x6.hip)?  32-bit byte offsets (tensors below
+// 2 GiB), whole float4s inside one filter tap, at most one carry per coordinate in the per-thread pixel decode
+static bool wgrad_on_x6(const xas_conv_shape* s, const float* x) {
+  if (precision_of(s) == XAS_PREC_F32 || (g_tune & 128)) return false;
+  const long xbytes = ((long)s->N * s->Hi * s->Wi + (long)s->pad * s->Wi + s->pad) * s->Cin * 4;
+  const long dybytes = (long)s->N * s->Ho * s->Wo * s->Cout * 4;
+  return s->Cin % 4 == 0 && s->Cout % 4 == 0 && s->Cout >= 16 && (x == nullptr || ((uintptr_t)x & 15) == 0) &&
+         xbytes < 0x7fffff00l && dybytes < 0x7fffff00l && 31 / s->Wo + 1 <= s->Ho;
+}
+
+static void wgrad_plan(const xas_conv_shape* s, bool x6, int* bm, int* bn, int* splits, int* mps) {
   const long KK = (long)s->R * s->S * s->Cin, M = (long)s->N * s->Ho * s->Wo;
-  *bm = s->Cout >= 96 ? 128 : (s->Cout > 32 ? 64 : 32);
-  *bn = KK <= 64 ? 64 : 128;
-  if (*bm == 32) *bn = 128;
-  const int wt = (g_tune >> 8) & 3;               // experiment: 1 -> target 512 blocks, 2 -> 256, 3 -> 2048
-  const int wf = (g_tune >> 10) & 1;              // experiment: force 64x64 tiles
-  if (wf && s->Cout >= 64 && KK >= 64 && s->Cin % 4 == 0) { *bm = 64; *bn = 64; }
+  if (x6) wgrad_x6_tile(s->Cout, KK, bm, bn);
+  else {
+    *bm = s->Cout >= 96 ? 128 : (s->Cout > 32 ? 64 : 32);
+    *bn = KK <= 64 ? 64 : 128;
+    if (*bm == 32) *bn = 128;
+  }
   const long tiles = cdiv(s->Cout, *bm) * cdiv(KK, *bn);
-  const long target = wt == 1 ? 512 : (wt == 2 ? 256 : (wt == 3 ? 2048 : 1024));
-  long sp = cdiv(target, tiles);                   // ~4 blocks per CU in total
+  long sp = cdiv(1024, tiles);                     // ~4 blocks per CU in total
   const long maxsp = M / 256 > 0 ? M / 256 : 1;    // >= 8 K-steps per block
   if (sp > maxsp) sp = maxsp;
   if (sp < 1) sp = 1;
-  if (!(g_tune & 8192)) {                          // XCD-grouped order: (splits x Cout tiles) groups, 8 XCDs -> keep them balanced
+  if (x6 || !(g_tune & 8192)) {                    // XCD-grouped order: (splits x Cout tiles) groups, 8 XCDs -> keep them balanced
     const long nct = cdiv(s->Cout, *bm);
     while (sp > 1 && (sp * nct) % 8 != 0 && (sp * nct) > 8) --sp;
   }
@@ -2454,9 +1725,10 @@ extern "C" size_t xas_conv_wgrad_workspace_floats(const xas_conv_shape* s) {
     return (size_t)(cdiv((long)s->N * s->Hi * s->Wi, kThinChunk) + 1) * C * 9;
   }
   if (s->Cout == 1) return (size_t)cdiv((long)s->N * s->Ho * s->Wo, kCout1Chunk) * s->R * s->S * s->Cin;
-  int bm, bn, sp, mps;
-  wgrad_plan(s, &bm, &bn, &sp, &mps);
-  return (size_t)sp * s->Cout * s->R * s->S * s->Cin;
+  int bm, bn, sp, mps, sp2;
+  wgrad_plan(s, false, &bm, &bn, &sp, &mps);       // the larger of the two kernels' slab counts: the choice between them
+  wgrad_plan(s, true, &bm, &bn, &sp2, &mps);       // also depends on the alignment of x, unknown here
+  return (size_t)(sp > sp2 ? sp : sp2) * s->Cout * s->R * s->S * s->Cin;
 }
 
 template <int BM, int BN, bool VEC>
@@ -2484,7 +1756,6 @@ template <int BM, int BN, int T, bool PIPE = true>
 static int launch_wgrad_buf_t(const WgradParams& p, int splits, hipStream_t st) {
   if (PIPE && (g_tune & 524288)) return launch_wgrad_buf_t<BM, BN, T, false>(p, splits, st);   // tune bit19: plain K-loop
   size_t lds = (size_t)2 * WBK * ((BM + 4) + (BN + 32)) * sizeof(float);
-  if ((g_tune & 131072) && lds < 84 * 1024) lds = 84 * 1024;     // experiment (bit17): one block per CU
   static size_t attr_set_dev[kMaxDevices] = {};
   size_t& attr_set = attr_set_dev[current_device()];
   if (attr_set < lds) {
@@ -2594,8 +1865,9 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
     XAS_LAUNCH_CHECK();
     return 0;
   }
+  const bool x6 = wgrad_on_x6(s, x);
   int bm, bn, splits, mps;
-  wgrad_plan(s, &bm, &bn, &splits, &mps);
+  wgrad_plan(s, x6, &bm, &bn, &splits, &mps);
   WgradParams p{};
   p.x = x; p.dy = dy; p.out = (splits == 1 && !oihw) ? dw_packed : workspace;
   p.N = s->N; p.Hi = s->Hi; p.Wi = s->Wi; p.Cin = s->Cin; p.Cout = s->Cout; p.R = s->R; p.S = s->S;
@@ -2611,7 +1883,8 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
   const long xbytes = ((long)s->N * s->Hi * s->Wi + (long)s->pad * s->Wi + s->pad) * s->Cin * 4;
   const long dybytes = (long)p.M * s->Cout * 4;
   const bool buf_ok = vec && s->Cin % 32 == 0 && xbytes < 0x7fffff00l && dybytes < 0x7fffff00l && 31 / s->Wo + 1 <= s->Ho && !(g_tune & 128);
-  if (buf_ok) {
+  if (x6) rc = launch_wgrad_x6(p, bm, bn, splits, precision_of(s) == XAS_PREC_BF16X6 ? 3 : 1, st);
+  else if (buf_ok) {
     if (bm == 32) rc = launch_wgrad_buf<32, 128>(p, splits, st);
     else if (bn == 64) rc = bm == 128 ? launch_wgrad_buf<128, 64>(p, splits, st) : launch_wgrad_buf<64, 64>(p, splits, st);
     else if (bm == 128) rc = launch_wgrad_buf<128, 128>(p, splits, st);

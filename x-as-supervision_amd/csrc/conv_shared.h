@@ -1,0 +1,356 @@
+// Shared pieces of the convolution family (conv.hip: exact-fp32 MFMA kernels; conv_x6.hip: bf16-split kernels):
+// problem descriptors, tile configuration, buffer-load helper, bf16 split helpers and the epilogue that both kernel
+// families end in.  gfx950 only.
+#pragma once
+#include "common.h"
+
+namespace xas {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BK = 32;        // K-step (channels of one tap)
+constexpr int LDK = BK + 4;   // padded LDS row, dwords
+
+struct FastDiv {              // n / d and n % d for 0 <= n < 2^31, d >= 1
+  unsigned d, mul, shift;
+  __host__ void init(unsigned dd) {
+    d = dd;
+    if (dd == 1) { mul = 0; shift = 0; return; }
+    unsigned s = 0;
+    while ((1ull << s) < dd) ++s;
+    unsigned long long m = ((1ull << (31 + s)) + dd - 1) / dd;   // ceil(2^(31+s)/d) fits 32 bits
+    mul = (unsigned)m; shift = s;
+  }
+  __device__ __forceinline__ unsigned div(unsigned n) const {
+    return d == 1 ? n : (unsigned)(((unsigned long long)n * mul) >> (31 + shift));
+  }
+};
+
+struct IgemmParams {
+  const float* src;    // activations that are gathered (x for fwd, dy for dgrad)
+  const float* wgt;    // packed weights [rows][R][S][Cs]
+  const float* bias;   // per output column or null
+  float* out;
+  int N;
+  int Hs, Ws, Cs;      // gathered tensor dims
+  int Hd, Wd, Cd;      // destination dims; Cd = number of GEMM columns
+  int R, S, stride, pad;
+  FastDiv div_hw, div_w;   // row -> (n, a, b) decode over the row grid
+  int Hrow, Wrow;          // row grid (fwd: Ho x Wo; dgrad: per-phase grid, set in kernel)
+  int tune;                // kernel-variant selectors kept for coverage tests (xas_set_tuning): bit5 plain K-loop, bit6 global-load kernel
+  int nMt, nNt, mt_per_xcd;   // tile counts and M-tiles per XCD for the XCD-aware block order
+  long src_elems, wgt_elems;  // sizes of src / wgt (buffer-load kernel: range of the buffer descriptors)
+  int accumulate;             // epilogue: 1: out += result (residual gradient already in the buffer);
+                              //           2: out = result + relu'(mask) * acc_src (the skip gradient is formed here from
+                              //              the block-output gradient and the sign bytes of xas_bn_apply: no dres tensor)
+  const float* acc_src;       // accumulate == 2: [rows][Cd] like out
+  const unsigned char* acc_mask;   // accumulate == 2: one byte per float4 of out, bit e = element active
+  // fwd only (xas_conv_fwd_bnstats): != null -> every tile also emits, per output channel, sum(v - pivot) and
+  // sum((v - pivot)^2) over its BM rows: stat_partial[tile row][channel][2].  The batch-norm statistics of the result are
+  // then a reduction over (rows / BM) partial rows instead of a second pass over the activation.
+  float* stat_partial;
+  const float* stat_pivot;         // per channel or null (= 0)
+  // dgrad only, stride 1 (xas_conv_dgrad_bn_bwd): the result is the gradient wrt the OUTPUT h = relu(bn(xb)) of a batch
+  // norm; the epilogue applies the ReLU mask (re-derived from xb exactly as bn_bwd_reduce does), writes the masked
+  // gradient dz and emits per tile and channel sum(dz), sum(dz * xhat): bnb_partial[tile][2][Cd].
+  const float* bnb_x;              // != null enables the path; [rows][Cd] like out
+  const float* bnb_mean; const float* bnb_var; const float* bnb_gamma; const float* bnb_beta;   // mean / var: [groups][Cd]
+  float bnb_eps;
+  int bnb_rows_per_group;
+  float* bnb_partial;
+};
+
+constexpr int kMaxDevices = 16;
+static inline int current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+  return d;
+}
+
+// shared MFMA core: As[BM][LDK], Bs[BN][LDK] -> acc
+// ------------------------------------------------------------------------------------
+template <int BM, int BN>
+struct TileCfg {
+  static constexpr int WAVES_M = (BM >= 64 && BN >= 64) ? 2 : (BM < 64 ? 1 : 4);
+  static constexpr int WAVES_N = 4 / WAVES_M;
+  static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  static constexpr int MI = WM / 32, NI = WN / 32;
+  static_assert(MI >= 1 && NI >= 1, "tile too small");
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOB = 0x80000000u;
+
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr int LDKH = BK + 8;   // bf16 elements per LDS row
+
+__device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
+  const bf16x2_t lo = __builtin_convertvector(f32x2_t{v.x, v.y}, bf16x2_t);
+  const bf16x2_t hi = __builtin_convertvector(f32x2_t{v.z, v.w}, bf16x2_t);
+  return make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+}
+
+// v - float(q) for the four bf16 values packed in q (exact: q is the leading part of v)
+__device__ __forceinline__ float4 sub_bf16x4(float4 v, uint2 q) {
+  return make_float4(v.x - __uint_as_float(q.x << 16), v.y - __uint_as_float(q.x & 0xffff0000u),
+                     v.z - __uint_as_float(q.y << 16), v.w - __uint_as_float(q.y & 0xffff0000u));
+}
+
+// dgrad epilogue with the batch-norm backward reduction folded in (see IgemmParams::bnb_x).  Stride 1: output row = m.
+// Per (channel quad) the norm's parameters are loaded and 1/std formed ONCE, then applied to the MI row blocks; the two
+// sums are pre-reduced over the row blocks in registers, so both [WAVES_M * 32][BN] arrays fit the operand LDS together:
+// one staging pass, one barrier, one column pass.
+template <int BM, int BN>
+__device__ __forceinline__ void bnb_epilogue(const IgemmParams& p, f32x16 (&acc)[TileCfg<BM, BN>::MI][TileCfg<BM, BN>::NI],
+                                             int m0, int n0, int wm, int wn, int lane, float* lds) {
+  using C = TileCfg<BM, BN>;
+  constexpr int LDT = BN + 4, TR = C::WAVES_M * 32;               // staged rows per array
+  constexpr int PARTS = 256 / BN;
+  float* T1 = lds;
+  float* T2 = lds + TR * LDT;
+  float* red = lds + 2 * TR * LDT;                                 // [PARTS][BN][2]
+  static_assert((2 * TR * LDT + 2 * 256) <= 2 * (BM + BN) * LDK, "bn-backward staging does not fit the operand LDS");
+  const int pix_l = lane & 31, csub = 4 * (lane >> 5);
+  const int grp = m0 / p.bnb_rows_per_group;                       // tiles never straddle a group (launcher)
+  const float* mean = p.bnb_mean + (size_t)grp * p.Cd;
+  const float* var = p.bnb_var + (size_t)grp * p.Cd;
+  const size_t row0 = (size_t)(m0 + wm * C::WM + pix_l);           // < Mrows: tiles are full (launcher)
+  __syncthreads();                                                 // operand buffers are free
+#pragma unroll
+  for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nl = wn * C::WN + ni * 32 + 8 * g + csub, n = n0 + nl;
+      float4 xv[C::MI];
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi) xv[mi] = *reinterpret_cast<const float4*>(p.bnb_x + (row0 + mi * 32) * p.Cd + n);
+      const float4 mu = *reinterpret_cast<const float4*>(mean + n);
+      const float4 vr = *reinterpret_cast<const float4*>(var + n);
+      const float4 gm = *reinterpret_cast<const float4*>(p.bnb_gamma + n);
+      const float4 bt = *reinterpret_cast<const float4*>(p.bnb_beta + n);
+      const float mu_[4] = {mu.x, mu.y, mu.z, mu.w}, bt_[4] = {bt.x, bt.y, bt.z, bt.w};
+      float rstd[4], rsg[4];
+      rstd[0] = rsqrtf(vr.x + p.bnb_eps); rstd[1] = rsqrtf(vr.y + p.bnb_eps);
+      rstd[2] = rsqrtf(vr.z + p.bnb_eps); rstd[3] = rsqrtf(vr.w + p.bnb_eps);
+      rsg[0] = __fmul_rn(rstd[0], gm.x); rsg[1] = __fmul_rn(rstd[1], gm.y);
+      rsg[2] = __fmul_rn(rstd[2], gm.z); rsg[3] = __fmul_rn(rstd[3], gm.w);
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi) {
+        const float x_[4] = {xv[mi].x, xv[mi].y, xv[mi].z, xv[mi].w};
+        float dz[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dz[e] = bn_affine(x_[e], mu_[e], rsg[e], bt_[e]) > 0.f ? acc[mi][ni][4 * g + e] : 0.f;
+          s1[e] += dz[e];
+          s2[e] = fmaf(dz[e], (x_[e] - mu_[e]) * rstd[e], s2[e]);
+        }
+        *reinterpret_cast<float4*>(p.out + (row0 + mi * 32) * p.Cd + n) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+      }
+      *reinterpret_cast<float4*>(T1 + (wm * 32 + pix_l) * LDT + nl) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+      *reinterpret_cast<float4*>(T2 + (wm * 32 + pix_l) * LDT + nl) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+    }
+  __syncthreads();
+  const int c = threadIdx.x % BN, part = threadIdx.x / BN;
+  float a1 = 0.f, a2 = 0.f;
+#pragma unroll 8
+  for (int r = part; r < TR; r += PARTS) { a1 += T1[r * LDT + c]; a2 += T2[r * LDT + c]; }
+  red[(part * BN + c) * 2] = a1; red[(part * BN + c) * 2 + 1] = a2;
+  __syncthreads();
+  if (part == 0) {
+#pragma unroll
+    for (int k = 1; k < PARTS; ++k) { a1 += red[(k * BN + c) * 2]; a2 += red[(k * BN + c) * 2 + 1]; }
+    float* prow = p.bnb_partial + (size_t)(m0 / BM) * 2 * p.Cd;
+    prow[n0 + c] = a1;
+    prow[p.Cd + n0 + c] = a2;
+  }
+}
+
+// Epilogue shared by the igemm kernels: accumulators -> global memory (+ bias), float4 per four output channels.
+template <int BM, int BN, int MODE, bool BNB = false>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&acc)[TileCfg<BM, BN>::MI][TileCfg<BM, BN>::NI],
+                                               f32x16& acc2, int m0, int n0, int wm, int wn, int lane, int Mrows, int HW,
+                                               int Wrow, int ph, int pw, float* lds = nullptr) {
+  using C = TileCfg<BM, BN>;
+  if (C::MI == 1 && C::NI == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
+  }
+  if constexpr (MODE == 1 && BNB) {                  // own instantiation: the extra live registers of this path would
+    bnb_epilogue<BM, BN>(p, acc, m0, n0, wm, wn, lane, lds);   // otherwise cost the plain kernel its second block per CU
+    return;
+  }
+  // ---- per-channel sums of the tile for the batch norm that follows (forward only).  The accumulators go through the
+  // (now idle) operand LDS as T[pixel][channel]; after the global stores below, thread t sums column t % BN over the rows
+  // t / BN, t / BN + PARTS, ...  Launcher guarantees: every tile is full in M (rows-per-group % BM == 0), lds != null.
+  constexpr int LDT = BN + 4;
+  const bool want_stats = MODE == 0 && p.stat_partial != nullptr;
+  // Row epilogue (default for full tiles): the tile goes through the idle operand LDS as T[pixel][channel] and is written
+  // to memory whole rows at a time - a wave stores 1 KiB of contiguous channels per instruction, old values / sign bytes
+  // of the accumulating forms are read the same way - instead of 64 scattered 16-byte pieces per instruction straight
+  // from the MFMA register layout (64 -> 256 channels at 256 x 64 x 64: 0.671 -> 0.547 ms, r02).
+  // Plain (non-accumulating) data gradients keep the register epilogue: their long K loops gain nothing and pay the extra
+  // barrier (215.3 vs 215.9 ms/step, r02).
+  const bool rows_from_lds = lds != nullptr && (p.Cd & 3) == 0 && m0 + BM <= Mrows && n0 + BN <= p.Cd &&
+                             !(MODE == 1 && !p.accumulate);
+  if (want_stats || rows_from_lds) {
+    __syncthreads();                                   // every wave has left the K-loop: the operand buffers are free
+    const int pl = lane & 31, cs = 4 * (lane >> 5);
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(lds + (wm * C::WM + mi * 32 + pl) * LDT + wn * C::WN + ni * 32 + 8 * g + cs) =
+              make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
+  }
+  // ---- epilogue.  Accumulator layout (operands swapped): column = lane & 31 = pixel row m of the tile,
+  // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) = output channel -> registers 4g..4g+3 are four
+  // consecutive channels of one pixel: one 16-byte store each, row address computed once per lane.
+  const int pix_l = lane & 31, csub = 4 * (lane >> 5);
+  const bool vec_ok = (p.Cd & 3) == 0;
+#pragma unroll
+  for (int mi = 0; mi < C::MI; ++mi) {
+    const int m = m0 + wm * C::WM + mi * 32 + pix_l;
+    if (m >= Mrows || rows_from_lds) continue;
+    size_t orow;
+    if (MODE == 0) orow = (size_t)m;
+    else {
+      const int n = m / HW; const int rem = m - n * HW; const int a = rem / Wrow, b = rem - a * Wrow;
+      orow = ((size_t)n * p.Hd + (ph + p.stride * a)) * p.Wd + (pw + p.stride * b);
+    }
+    float* orow_p = p.out + orow * p.Cd;
+    // accumulating form (out += result): ALL the old values of this row are requested before the first one is used -
+    // one load at a time (load, wait, add, store) left the epilogue waiting out a full memory round trip per float4
+    // (rocprof: xas_conv_dgrad_acc at 46 TFLOP/s against 104 for the same shapes without the accumulation)
+    float4 prev[C::NI][4];
+    unsigned pmask[C::NI][4];
+    if (p.accumulate && vec_ok) {
+      const float* prow = p.accumulate == 2 ? p.acc_src + orow * p.Cd : orow_p;
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wn * C::WN + ni * 32 + 8 * g + csub;
+          const int nc = n + 3 < p.Cd ? n : p.Cd - 4;                                   // clamped: unconditional load
+          prev[ni][g] = *reinterpret_cast<const float4*>(prow + nc);
+          pmask[ni][g] = p.accumulate == 2 ? p.acc_mask[(orow * p.Cd + nc) >> 2] : 15u;
+        }
+    }
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * C::WN + ni * 32 + 8 * g + csub;
+        float4 v = make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
+        if (vec_ok && n + 3 < p.Cd) {
+          if (MODE == 0 && p.bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+          }
+          if (p.accumulate) {
+            const float4 o = prev[ni][g];
+            const unsigned mb = pmask[ni][g];
+            v.x += (mb & 1u) ? o.x : 0.f; v.y += (mb & 2u) ? o.y : 0.f;
+            v.z += (mb & 4u) ? o.z : 0.f; v.w += (mb & 8u) ? o.w : 0.f;
+          }
+          *reinterpret_cast<float4*>(orow_p + n) = v;      // (scattered 16-byte pieces: a non-temporal hint costs 2.3 ms here)
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.Cd)
+              orow_p[n + e] = vv[e] + ((MODE == 0 && p.bias) ? p.bias[n + e] : 0.f) + (p.accumulate ? orow_p[n + e] : 0.f);
+        }
+      }
+    }
+  }
+  if (want_stats || rows_from_lds) __syncthreads();    // T complete
+  if (rows_from_lds) {
+    constexpr int C4 = BN / 4, RPP = 256 / C4;         // float4 per row, rows per pass of the block
+    const int c4 = threadIdx.x % C4, r0 = threadIdx.x / C4;
+    const int nn = n0 + c4 * 4;
+    float4 bb = make_float4(0, 0, 0, 0);
+    if (MODE == 0 && p.bias) bb = *reinterpret_cast<const float4*>(p.bias + nn);
+#pragma unroll 4
+    for (int r = r0; r < BM; r += RPP) {
+      const int m = m0 + r;
+      size_t orow;
+      if (MODE == 0 || p.stride == 1) orow = (size_t)m;
+      else {
+        const int n = m / HW; const int rem = m - n * HW; const int a = rem / Wrow, b = rem - a * Wrow;
+        orow = ((size_t)n * p.Hd + (ph + p.stride * a)) * p.Wd + (pw + p.stride * b);
+      }
+      float4 v = *reinterpret_cast<const float4*>(lds + r * LDT + c4 * 4);
+      v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+      float* op = p.out + orow * p.Cd + nn;
+      if (p.accumulate) {
+        const float4 o = stream_load(reinterpret_cast<const float4*>(p.accumulate == 2 ? p.acc_src + orow * p.Cd + nn : op));
+        const unsigned mb = p.accumulate == 2 ? p.acc_mask[(orow * p.Cd + nn) >> 2] : 15u;
+        v.x += (mb & 1u) ? o.x : 0.f; v.y += (mb & 2u) ? o.y : 0.f;
+        v.z += (mb & 4u) ? o.z : 0.f; v.w += (mb & 8u) ? o.w : 0.f;
+      }
+      stream_store(reinterpret_cast<float4*>(op), v);
+    }
+  }
+  if (MODE == 0 && want_stats) {
+    constexpr int PARTS = 256 / BN;
+    const int tid = threadIdx.x;
+    const int c = tid % BN, part = tid / BN;
+    const int n = n0 + c;
+    const float pv = (p.stat_pivot && n < p.Cd) ? p.stat_pivot[n] : 0.f;
+    float s = 0.f, q = 0.f;
+#pragma unroll 8
+    for (int r = part; r < BM; r += PARTS) {
+      const float v = lds[r * LDT + c] - pv;
+      s += v; q = fmaf(v, v, q);
+    }
+    float* red = lds + BM * LDT;                       // [PARTS][BN][2]
+    red[(part * BN + c) * 2] = s; red[(part * BN + c) * 2 + 1] = q;
+    __syncthreads();
+    if (part == 0 && n < p.Cd) {
+#pragma unroll
+      for (int k = 1; k < PARTS; ++k) { s += red[(k * BN + c) * 2]; q += red[(k * BN + c) * 2 + 1]; }
+      *reinterpret_cast<float2*>(p.stat_partial + ((size_t)(m0 / BM) * p.Cd + n) * 2) = make_float2(s, q);
+    }
+  }
+}
+
+struct WgradParams {
+  const float* x; const float* dy; float* out;      // out: [splits][Cout][KK] slabs
+  int N, Hi, Wi, Cin, Cout, R, S, stride, pad, Ho, Wo;
+  int KK;                                            // R*S*Cin
+  int M;                                             // N*Ho*Wo
+  int m_per_split;
+  int nct, ntiles, nsplits;                           // Cout tiles, tiles per split, pixel splits
+  int tune;
+  FastDiv div_hw, div_w, div_cin, div_s;
+};
+
+constexpr int WBK = 32;       // pixels per K-step
+
+// Tile of the forward / data-gradient kernels for a problem (one rule for both kernel families, the launchers and
+// xas_conv_fwd_bnstats / xas_conv_dgrad_bn_bwd, whose partial-sum grids follow the tile grid).
+static inline void pick_tile(int Cd, long Mrows_max, int phases, int* bm, int* bn) {
+  if (Cd >= 96) {
+    // small problems (layer3/4: M = 8192 / 2048 rows per 32 images): 128x128 tiles leave most of the 256 CUs idle
+    const long blocks128 = cdiv(Mrows_max, 128) * cdiv(Cd, 128) * phases;
+    if (blocks128 <= 512) { *bm = 64; *bn = 64; } else { *bm = 128; *bn = 128; }
+  } else if (Cd >= 48) { *bm = 128; *bn = 64; }
+  else { *bm = 128; *bn = 32; }
+}
+
+// conv_x6.hip: bf16-split kernels (pieces = 3: bf16x6, fp32 accurate; 1: plain bf16).  mode: 0 forward, 1 data gradient.
+// p.wgt points to PRE-SPLIT weights (xas_split_weight).
+int launch_igemm_x6(const IgemmParams& p, int mode, int Mrows_max, int phases, int pieces, hipStream_t st);
+void wgrad_x6_tile(int Cout, long KK, int* bm, int* bn);
+int launch_wgrad_x6(const WgradParams& p, int bm, int bn, int splits, int pieces, hipStream_t st);
+
+}  // namespace xas

@@ -1,0 +1,562 @@
+// fp32-ACCURATE convolutions on the bf16 matrix pipe of gfx950 ("bf16x6"): forward, data gradient (== ConvTranspose2d
+// forward) and weight gradient, the default precision of the library since round 3 (xas_hip.h: XAS_PREC_BF16X6).
+//
+// Every fp32 operand x is split EXACTLY into three bf16 pieces x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1),
+// x3 = bf16(x - x1 - x2): 3 x 8 significant bits = the 24 of fp32).  Of the nine partial products of x * y the six
+//     x3 y1, x1 y3, x2 y2, x2 y1, x1 y2, x1 y1
+// are kept; each is exact in fp32 (8 x 8 bits) and the MFMA accumulates them in fp32, smallest first; the three dropped
+// ones are below 2^-25 |x y|, under the rounding error of ONE fp32 product.  Measured against float64 (r02):
+// 1.09e-7 relative at K = 64 (exact-fp32 MFMA: 1.06e-7), 1.0e-6 at K = 4608 (8.1e-7).  6 x 32 cycles per K = 16 of
+// v_mfma_f32_32x32x16_bf16 against 8 x 64 cycles of v_mfma_f32_32x32x2_f32: 2.67x the math rate, peak 2.5 PFLOP/s / 6 =
+// 419 TFLOP/s of fp32-equivalent work.  PIECES = 1 is the plain bf16 variant (operands rounded once; NOT fp32 accurate;
+// xas_hip.h: XAS_PREC_BF16), kept as the reported-separately variant of SURVEY 8 f-3.
+//
+// Kernel structure (both kernels): 256 threads = 4 waves, tile BM x BN, K-step of 32 (channels of a tap / pixels) loaded
+// two K-steps ahead into two register sets by buffer loads (hardware zero-fill for padding and ragged edges), processed as
+// two HALF-steps of 16: LDS holds two half-buffers of three bf16 planes per operand (73.7 KB for 128 x 128: two blocks per
+// CU), and during the 24 MFMAs of half-step t the wave splits and stores half-step t + 1 into the other buffer - ONE
+// barrier per 24 MFMAs, the conversion work (5.5 vector-ALU instructions per element) issues in the shadow of the matrix
+// pipe, the partner block on the CU covers the barrier.  Weights of forward / data gradient arrive PRE-SPLIT
+// (xas_split_weight, once per optimizer step): no conversion work on that operand, 16-byte LDS stores.
+//
+// Replaces the cuDNN kernels behind integral_base_modules/resnet.py:16-47, deconv_head.py:24-35,
+// physique_network.py:15-50 and torchvision's Bottleneck, like conv.hip.
+#include "conv_shared.h"
+
+namespace xas {
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+constexpr int XH = 16;             // k per half-step
+constexpr int XLDH = XH + 8;       // igemm LDS row in halfwords (48 B): ds_read_b128 of 16 lanes x 48 B hits 64 distinct banks
+
+// the six kept partial products, smallest first: (a piece, b piece)
+__device__ constexpr int kPA[6] = {2, 0, 1, 1, 0, 0};
+__device__ constexpr int kPB[6] = {0, 2, 1, 0, 1, 0};
+
+__device__ __forceinline__ bf16x8_t as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
+
+// ------------------------------------------------------------------------------------
+// weights: fp32 packed [rows][K] -> [rows][K / 16][P planes][16] bf16 (K % 16 == 0)
+// ------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                           long n4 /* float4 count */) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 r = reinterpret_cast<const float4*>(src)[i];
+  const long chunk = i >> 2, k4 = i & 3;                        // 16-element chunk, float4 slot inside it
+  unsigned short* o = dst + chunk * (P * 16) + k4 * 4;
+#pragma unroll
+  for (int pc = 0; pc < P; ++pc) {
+    const uint2 q = pack_bf16x4(r);
+    *reinterpret_cast<uint2*>(o + pc * 16) = q;
+    if (pc + 1 < P) r = sub_bf16x4(r, q);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// forward (MODE 0) and data gradient (MODE 1)
+// ------------------------------------------------------------------------------------
+template <int BM, int BN, int MODE, int P, bool BNB = false>
+__global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
+  using C = TileCfg<BM, BN>;
+  constexpr int ROWS = BM + BN;
+  constexpr int PLANE = ROWS * XLDH;            // halfwords
+  constexpr int HBUF = P * PLANE;               // halfwords per half-buffer
+  constexpr int AP = BM / 64;                   // activation float4 per thread per half-step (4 threads x 16 B per row)
+  constexpr int NPH = BN * 2 * P;               // weight 16-byte pieces per half-step
+  constexpr int BP = (NPH + 255) / 256;         // per thread
+  constexpr int NT = P == 3 ? 6 : 1;            // partial products
+  extern __shared__ __align__(16) float lds[];
+  unsigned short* S = reinterpret_cast<unsigned short*>(lds);     // [2][P][ROWS][XLDH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+  const int kq4 = tid & 3, arow = tid >> 2;
+
+  int Hrow = p.Hrow, Wrow = p.Wrow;
+  int ph = 0, pw = 0, base_r = 0, base_s = 0, nr = p.R, ns = p.S, off_h = -p.pad, off_w = -p.pad, rstep = 1;
+  int sa = p.stride;
+  if (MODE == 1) {                                   // one stride phase per blockIdx.z: no MFMA on structurally-zero taps
+    const int st = p.stride;
+    ph = blockIdx.z / st; pw = blockIdx.z % st;
+    Hrow = (p.Hd - ph + st - 1) / st; Wrow = (p.Wd - pw + st - 1) / st;
+    base_r = (ph + p.pad) % st; base_s = (pw + p.pad) % st;
+    nr = base_r < p.R ? (p.R - base_r + st - 1) / st : 0;
+    ns = base_s < p.S ? (p.S - base_s + st - 1) / st : 0;
+    off_h = (ph + p.pad - base_r) / st; off_w = (pw + p.pad - base_s) / st;
+    rstep = st; sa = 1;
+  }
+  const int Mrows = p.N * Hrow * Wrow;
+  const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;          // XCD-aware tile order (see igemm_kernel in conv.hip)
+  const int mt = xcd * p.mt_per_xcd + qb / p.nNt;
+  const int nt = qb - (qb / p.nNt) * p.nNt;
+  if (mt >= p.nMt) return;
+  const int m0 = mt * BM, n0 = nt * BN;
+  if (m0 >= Mrows) return;
+  const int HW = Hrow * Wrow;
+  const int cchunks = p.Cs / BK;
+  const int nk = nr * ns * cchunks;
+
+  // activation operand: buffer base moved down so that per-lane and scalar parts are non-negative (see igemm_buf_kernel)
+  const long dmin = MODE == 0 ? 0l : -((long)(nr - 1) * p.Ws + (ns - 1)) * p.Cs;
+  const long rmin = MODE == 0 ? -((long)p.pad * p.Ws + p.pad) * p.Cs : 0l;
+  const long bias = -(rmin + dmin);
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src) - bias, 0, (int)((bias + p.src_elems) * 4), 0x00020000);
+  // weight operand: pre-split [rows][K/16][P][16] bf16
+  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.wgt), 0, (int)(p.wgt_elems * 2 * P), 0x00020000);
+  unsigned voffA[AP], maskA[AP];
+#pragma unroll
+  for (int j = 0; j < AP; ++j) {
+    const int m = m0 + arow + 64 * j;
+    voffA[j] = kOOB; maskA[j] = 0u;
+    if (m < Mrows) {
+      int n, a, b;
+      if (MODE == 0) { n = p.div_hw.div(m); const int rem = m - n * HW; a = p.div_w.div(rem); b = rem - a * Wrow; }
+      else { n = m / HW; const int rem = m - n * HW; a = rem / Wrow; b = rem - a * Wrow; }
+      const int ra = a * sa + off_h, rb = b * sa + off_w;
+      const long rbase = (((long)n * p.Hs + ra) * p.Ws + rb) * p.Cs;
+      voffA[j] = (unsigned)((rbase + dmin + bias + kq4 * 4) * 4);
+      unsigned colmask = 0u, msk = 0u;                 // bit (jr*ns + js) = tap inside the image
+      for (int js = 0; js < ns; ++js) {
+        const int ws = rb + (MODE == 0 ? js : -js);
+        colmask |= ((unsigned)ws < (unsigned)p.Ws ? 1u : 0u) << js;
+      }
+      for (int jr = 0; jr < nr; ++jr) {
+        const int hs = ra + (MODE == 0 ? jr : -jr);
+        if ((unsigned)hs < (unsigned)p.Hs) msk |= colmask << (jr * ns);
+      }
+      maskA[j] = msk;
+    }
+  }
+  const unsigned wrow_bytes = (unsigned)(p.R * p.S * p.Cs) * 2u * P;
+  unsigned voffB[BP], dstB[BP];
+#pragma unroll
+  for (int j = 0; j < BP; ++j) {
+    const int id = tid + 256 * j;
+    const int brow = id / (2 * P), q = id - brow * (2 * P);       // q = plane * 2 + k8
+    const int n = n0 + brow;
+    voffB[j] = (id < NPH && n < p.Cd) ? (unsigned)n * wrow_bytes + (unsigned)q * 16u : kOOB;
+    dstB[j] = (unsigned)(((q >> 1) * ROWS + BM + brow) * XLDH + (q & 1) * 8);
+  }
+
+  f32x16 acc[C::MI][C::NI];
+#pragma unroll
+  for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+  f32x16 acc2;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+
+  // Load stream: K-steps in order; (chunk, js, jr) advance with scalar ALU only and stop at the last step (further calls
+  // re-load it: valid addresses, values never consumed).
+  int ld_chunk = 0, ld_js = 0, ld_jr = 0, ld_left = nk;
+  float4 ra_0[2 * AP], ra_1[2 * AP];
+  uint4 rb_0[2 * BP], rb_1[2 * BP];
+  auto load_k = [&](float4 (&ra)[2 * AP], uint4 (&rb)[2 * BP]) {
+    const int tap = ld_jr * ns + ld_js;
+    const int rel = MODE == 0 ? (ld_jr * p.Ws + ld_js) : ((nr - 1 - ld_jr) * p.Ws + (ns - 1 - ld_js));
+    const unsigned soffA = (unsigned)(rel * p.Cs + ld_chunk * BK) * 4u;
+    const int wtap = (base_r + rstep * ld_jr) * p.S + (base_s + rstep * ld_js);
+    const unsigned soffB = (unsigned)(wtap * p.Cs + ld_chunk * BK) * 2u * P;
+#pragma unroll
+    for (int j = 0; j < AP; ++j) {
+      const unsigned off = ((maskA[j] >> tap) & 1u) ? voffA[j] : kOOB;
+      ra[j] = buf_load16(rsrcA, off, soffA);
+      ra[AP + j] = buf_load16(rsrcA, off, soffA + XH * 4u);
+    }
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+      rb[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)voffB[j], (int)soffB, 0));
+      rb[BP + j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)voffB[j], (int)(soffB + XH * 2u * P), 0));
+    }
+    const bool more = ld_left > 1;
+    ld_left -= more ? 1 : 0;
+    int c = ld_chunk + 1, s2 = ld_js, r = ld_jr;
+    if (c == cchunks) { c = 0; ++s2; }
+    if (s2 == ns) { s2 = 0; ++r; }
+    ld_chunk = more ? c : ld_chunk; ld_js = more ? s2 : ld_js; ld_jr = more ? r : ld_jr;
+  };
+  // split + store half h of a register set into half-buffer `buf`
+  auto store_half = [&](int buf, int h, const float4 (&ra)[2 * AP], const uint4 (&rb)[2 * BP]) {
+    unsigned short* sb = S + buf * HBUF;
+#pragma unroll
+    for (int j = 0; j < AP; ++j) {
+      float4 r = ra[h * AP + j];
+#pragma unroll
+      for (int pc = 0; pc < P; ++pc) {
+        const uint2 q = pack_bf16x4(r);
+        *reinterpret_cast<uint2*>(sb + (pc * ROWS + arow + 64 * j) * XLDH + kq4 * 4) = q;
+        if (pc + 1 < P) r = sub_bf16x4(r, q);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BP; ++j)
+      if (256 * (j + 1) <= NPH || wave * 64 + 256 * j < NPH)          // compile-time true for full passes, else wave-uniform
+        *reinterpret_cast<uint4*>(sb + dstB[j]) = rb[h * BP + j];
+  };
+  const int i = lane & 31, hh = lane >> 5;
+  auto compute = [&](int buf) {
+    const unsigned short* sb = S + buf * HBUF;
+    bf16x8_t fa[P][C::MI], fb[P][C::NI];
+#pragma unroll
+    for (int pc = P - 1; pc >= 0; --pc) {              // smallest pieces first: they feed the first products
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi)
+        fa[pc][mi] = *reinterpret_cast<const bf16x8_t*>(sb + (pc * ROWS + wm * C::WM + mi * 32 + i) * XLDH + hh * 8);
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni)
+        fb[pc][ni] = *reinterpret_cast<const bf16x8_t*>(sb + (pc * ROWS + BM + wn * C::WN + ni * 32 + i) * XLDH + hh * 8);
+    }
+#pragma unroll
+    for (int t = (P == 3 ? 0 : 5); t < 6; ++t)
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[P == 3 ? kPB[t] : 0][ni], fa[P == 3 ? kPA[t] : 0][mi],
+                                                                acc[mi][ni], 0, 0, 0);
+  };
+  (void)NT;
+  if (nk > 0) {
+    load_k(ra_0, rb_0);                                // K-step 0
+    load_k(ra_1, rb_1);                                // K-step 1 (re-loads the last step when there is none)
+    store_half(0, 0, ra_0, rb_0);
+    int ks = 0;
+    for (; ks + 1 < nk; ks += 2) {
+      __syncthreads();
+      compute(0);                                      // half-step 2 ks
+      store_half(1, 1, ra_0, rb_0);
+      __syncthreads();
+      load_k(ra_0, rb_0);                              // K-step ks + 2: set 0 is free
+      compute(1);                                      // half-step 2 ks + 1
+      store_half(0, 0, ra_1, rb_1);
+      __syncthreads();
+      compute(0);                                      // half-step 2 ks + 2
+      store_half(1, 1, ra_1, rb_1);
+      __syncthreads();
+      load_k(ra_1, rb_1);                              // K-step ks + 3
+      compute(1);                                      // half-step 2 ks + 3
+      store_half(0, 0, ra_0, rb_0);                    // K-step ks + 2, first half (never computed when ks + 2 == nk)
+    }
+    if (ks < nk) {                                     // one K-step left: in set 0, its first half is in buffer 0
+      __syncthreads();
+      compute(0);
+      store_half(1, 1, ra_0, rb_0);
+      __syncthreads();
+      compute(1);
+    }
+  }
+  igemm_epilogue<BM, BN, MODE, BNB>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
+}
+
+template <int BM, int BN>
+constexpr size_t igemm_x6_lds(int P) {
+  size_t a = (size_t)2 * P * (BM + BN) * XLDH * sizeof(unsigned short);
+  size_t b = ((size_t)BM * (BN + 4) + 2 * 256) * sizeof(float);          // epilogue staging T[BM][BN+4] + partial-combine area
+  size_t c = ((size_t)2 * TileCfg<BM, BN>::WAVES_M * 32 * (BN + 4) + 2 * 256) * sizeof(float);   // bn-backward epilogue staging
+  return a > b ? (a > c ? a : c) : (b > c ? b : c);
+}
+
+template <int BM, int BN, int MODE, int P, bool BNB>
+static int launch_igemm_x6_t(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
+  constexpr size_t lds = igemm_x6_lds<BM, BN>(P);
+  static bool attr_set_dev[kMaxDevices] = {};
+  bool& attr_set = attr_set_dev[current_device()];
+  if (!attr_set && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x6_kernel<BM, BN, MODE, P, BNB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  IgemmParams q = p;
+  q.nMt = (int)cdiv(Mrows_max, BM); q.nNt = (int)cdiv(p.Cd, BN); q.mt_per_xcd = (int)cdiv(q.nMt, 8);
+  dim3 grid((unsigned)(8 * q.mt_per_xcd * q.nNt), 1, (unsigned)phases);
+  hipLaunchKernelGGL((igemm_x6_kernel<BM, BN, MODE, P, BNB>), grid, dim3(256), lds, st, q);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int MODE, int P>
+static int launch_igemm_x6_p(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
+  int bm, bn;
+  pick_tile(p.Cd, Mrows_max, phases, &bm, &bn);
+  if constexpr (MODE == 1) {
+    if (p.bnb_x) {
+      if (bn == 128) return launch_igemm_x6_t<128, 128, 1, P, true>(p, Mrows_max, phases, st);
+      if (bm == 64) return launch_igemm_x6_t<64, 64, 1, P, true>(p, Mrows_max, phases, st);
+      if (bn == 64) return launch_igemm_x6_t<128, 64, 1, P, true>(p, Mrows_max, phases, st);
+      return launch_igemm_x6_t<128, 32, 1, P, true>(p, Mrows_max, phases, st);
+    }
+  }
+  if (bn == 128) return launch_igemm_x6_t<128, 128, MODE, P, false>(p, Mrows_max, phases, st);
+  if (bm == 64) return launch_igemm_x6_t<64, 64, MODE, P, false>(p, Mrows_max, phases, st);
+  if (bn == 64) return launch_igemm_x6_t<128, 64, MODE, P, false>(p, Mrows_max, phases, st);
+  return launch_igemm_x6_t<128, 32, MODE, P, false>(p, Mrows_max, phases, st);
+}
+
+int launch_igemm_x6(const IgemmParams& p, int mode, int Mrows_max, int phases, int pieces, hipStream_t st) {
+  if (mode == 0) return pieces == 3 ? launch_igemm_x6_p<0, 3>(p, Mrows_max, phases, st) : launch_igemm_x6_p<0, 1>(p, Mrows_max, phases, st);
+  return pieces == 3 ? launch_igemm_x6_p<1, 3>(p, Mrows_max, phases, st) : launch_igemm_x6_p<1, 1>(p, Mrows_max, phases, st);
+}
+
+// ------------------------------------------------------------------------------------
+// weight gradient: dW[co][nn] = sum_m dY[m][co] * Xcol[m][nn],  nn = (r*S + s)*Cin + c;  K = pixels, split over blocks.
+// Both operands are activations ([pixel][channel] in memory): both are split in the kernel.  LDS tiles stay pixel-major
+// as they arrive, [plane][16 pixels][channels]; the MFMA operands (8 consecutive pixels of one channel per lane) come out
+// of ds_read_b64_tr_b16, the hardware transposing read (4 pixels x 16 channels per 16-lane group).  Row strides are
+// 64 or 192 mod 256 bytes: the four pixel rows of a read land on disjoint banks.
+// ------------------------------------------------------------------------------------
+template <int BMN>
+struct XStride { static constexpr int value = BMN * 2 + (BMN == 128 ? 64 : (BMN == 64 ? 64 : 0)); };   // 320 / 192 / 64 bytes
+
+template <int BM, int BN, int P>
+__global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgradParams p) {
+  using C = TileCfg<BM, BN>;
+  constexpr int SA = XStride<BM>::value, SB = XStride<BN>::value;      // bytes per pixel row of a plane
+  constexpr int ASZ = P * XH * SA, BSZ = P * XH * SB, HBUF = ASZ + BSZ; // bytes per half-buffer
+  constexpr int AQ = BM / 4, AROWS = 256 / AQ, APH = XH / AROWS;        // dy: float4 per pixel, pixels per pass, passes per half
+  constexpr int BPQ = BN / 64;                                          // x: float4 per thread per half (16 threads per pixel)
+  static_assert(APH >= 1 && BPQ >= 1, "tile too small for the staging scheme");
+  extern __shared__ __align__(16) float lds[];
+  unsigned char* S = reinterpret_cast<unsigned char*>(lds);             // [2][ A planes | B planes ]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+  // XCD-grouped order: the KK-tiles of one (pixel split, Cout tile) read the same dy tile and the same x pixels (see
+  // wgrad_buf_kernel in conv.hip)
+  const int nkt = p.ntiles / p.nct;
+  const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+  const int grp = xcd + 8 * (qb / nkt);
+  const int kt = qb - (qb / nkt) * nkt;
+  const int split = grp / p.nct;
+  const int tile = (grp - split * p.nct) + kt * p.nct;
+  if (split >= p.nsplits) return;
+  const int co0 = (tile % p.nct) * BM, nn0 = (tile / p.nct) * BN;
+  const int mbeg = split * p.m_per_split, mend = min(p.M, mbeg + p.m_per_split);
+  const int HWo = p.Ho * p.Wo;
+
+  // ---- dy operand: per-lane offset fixed, rows of a half-step from a scalar offset, split end = buffer range
+  const int aq = tid % AQ, apix = tid / AQ;
+  const __amdgpu_buffer_rsrc_t rsrcA =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)((long)mend * p.Cout * 4), 0x00020000);
+  const unsigned voffA = (co0 + aq * 4 < p.Cout) ? (unsigned)(apix * p.Cout + co0 + aq * 4) * 4u : kOOB;
+  const unsigned passA = (unsigned)(AROWS * p.Cout) * 4u;
+  const unsigned dstA = (unsigned)(apix * SA + aq * 8);
+
+  // ---- x operand: thread = (pixel bpix of the half-step, float4 slot bq); 16 threads x BPQ float4 cover the BN columns
+  const int bq = tid & 15, bpix = tid >> 4;
+  const long biasB = ((long)p.pad * p.Wi + p.pad) * p.Cin;
+  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x) - biasB, 0, (int)((biasB + (long)p.N * p.Hi * p.Wi * p.Cin) * 4), 0x00020000);
+  int tr[BPQ], ts[BPQ];
+  unsigned offq[BPQ];                                  // ((tr*Wi + ts)*Cin + c)*4 + bias bytes
+  bool colok[BPQ];
+#pragma unroll
+  for (int q = 0; q < BPQ; ++q) {
+    const int nn = nn0 + (bq + 16 * q) * 4;
+    colok[q] = nn < p.KK;
+    const int nc = colok[q] ? nn : 0;
+    const int tap = p.div_cin.div(nc), c = nc - tap * p.Cin;
+    tr[q] = p.div_s.div(tap); ts[q] = tap - tr[q] * p.S;
+    offq[q] = (unsigned)(((tr[q] * p.Wi + ts[q]) * p.Cin + c) * 4 + biasB * 4);
+  }
+  int dh_r[2], dw_r[2];                                // this thread's pixel of half 0 / half 1 relative to the step's first pixel
+#pragma unroll
+  for (int h = 0; h < 2; ++h) { dh_r[h] = (bpix + XH * h) / p.Wo; dw_r[h] = (bpix + XH * h) - dh_r[h] * p.Wo; }
+  const unsigned dstB = (unsigned)(ASZ + bpix * SB + bq * 8);
+
+  f32x16 acc[C::MI][C::NI];
+#pragma unroll
+  for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  float4 ra_0[2 * APH], rb_0[2 * BPQ], ra_1[2 * APH], rb_1[2 * BPQ];
+  auto load_k = [&](int mk, float4 (&ra)[2 * APH], float4 (&rb)[2 * BPQ]) {        // mk: first pixel of the K-step (uniform)
+    const unsigned soffA = (unsigned)mk * (unsigned)p.Cout * 4u;
+#pragma unroll
+    for (int j = 0; j < 2 * APH; ++j) ra[j] = buf_load16(rsrcA, voffA, soffA + j * passA);     // passes 0..APH-1 = half 0
+    const int n0 = p.div_hw.div(mk), rem = mk - n0 * HWo;
+    const int h0 = p.div_w.div(rem), w0 = rem - h0 * p.Wo;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int w = w0 + dw_r[h];
+      const int c1 = w >= p.Wo ? 1 : 0;
+      w -= c1 ? p.Wo : 0;
+      int hr = h0 + dh_r[h] + c1;
+      const int c2 = hr >= p.Ho ? 1 : 0;
+      hr -= c2 ? p.Ho : 0;
+      const int n = n0 + c2;
+      const int hb = hr * p.stride - p.pad, wb = w * p.stride - p.pad;
+      const unsigned pix = (unsigned)(((n * p.Hi + hb) * p.Wi + wb) * p.Cin) * 4u;
+#pragma unroll
+      for (int q = 0; q < BPQ; ++q) {
+        const bool ok = colok[q] && (unsigned)(hb + tr[q]) < (unsigned)p.Hi && (unsigned)(wb + ts[q]) < (unsigned)p.Wi;
+        rb[h * BPQ + q] = buf_load16(rsrcB, ok ? pix + offq[q] : kOOB, 0u);
+      }
+    }
+  };
+  auto store_half = [&](int buf, int h, const float4 (&ra)[2 * APH], const float4 (&rb)[2 * BPQ]) {
+    unsigned char* sb = S + buf * HBUF;
+#pragma unroll
+    for (int j = 0; j < APH; ++j) {
+      float4 r = ra[h * APH + j];
+#pragma unroll
+      for (int pc = 0; pc < P; ++pc) {
+        const uint2 q = pack_bf16x4(r);
+        *reinterpret_cast<uint2*>(sb + pc * XH * SA + AROWS * j * SA + dstA) = q;
+        if (pc + 1 < P) r = sub_bf16x4(r, q);
+      }
+    }
+#pragma unroll
+    for (int q4 = 0; q4 < BPQ; ++q4) {
+      float4 r = rb[h * BPQ + q4];
+#pragma unroll
+      for (int pc = 0; pc < P; ++pc) {
+        const uint2 q = pack_bf16x4(r);
+        *reinterpret_cast<uint2*>(sb + pc * XH * SB + q4 * 128 + dstB) = q;
+        if (pc + 1 < P) r = sub_bf16x4(r, q);
+      }
+    }
+  };
+  // transposing fragment read: lane (l16 = lane & 15 -> row qd = l16 >> 2, column quad pp = l16 & 3; g1 = channel half;
+  // hh = k half) supplies the address of pixel row 8 hh + 4 t + qd, channels 16 g1 + 4 pp .. + 3 of its 32-channel block
+  const int l16 = lane & 15, qd = l16 >> 2, pp = l16 & 3, g1 = (lane >> 4) & 1, hh = lane >> 5;
+  const unsigned fragA = (unsigned)((8 * hh + qd) * SA + (wm * C::WM + 16 * g1 + 4 * pp) * 2);
+  const unsigned fragB = (unsigned)(ASZ + (8 * hh + qd) * SB + (wn * C::WN + 16 * g1 + 4 * pp) * 2);
+  typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_p;
+  auto tr_read = [&](const unsigned char* base, unsigned off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(base + off));
+  };
+  auto compute = [&](int buf) {
+    const unsigned char* sb = S + buf * HBUF;
+    bf16x8_t fa[P][C::MI], fb[P][C::NI];
+#pragma unroll
+    for (int pc = P - 1; pc >= 0; --pc) {
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi) {
+        const s16x4_t lo = tr_read(sb, fragA + pc * XH * SA + mi * 64);
+        const s16x4_t hi = tr_read(sb, fragA + pc * XH * SA + mi * 64 + 4 * SA);
+        fa[pc][mi] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni) {
+        const s16x4_t lo = tr_read(sb, fragB + pc * XH * SB + ni * 64);
+        const s16x4_t hi = tr_read(sb, fragB + pc * XH * SB + ni * 64 + 4 * SB);
+        fb[pc][ni] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+    }
+#pragma unroll
+    for (int t = (P == 3 ? 0 : 5); t < 6; ++t)
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[P == 3 ? kPA[t] : 0][mi], fb[P == 3 ? kPB[t] : 0][ni],
+                                                                acc[mi][ni], 0, 0, 0);
+  };
+  const int nsteps = (mend > mbeg) ? (mend - mbeg + WBK - 1) / WBK : 0;
+  const int last = nsteps - 1;
+  auto mk_of = [&](int st) { return mbeg + (st < last ? st : last) * WBK; };
+  if (nsteps > 0) {
+    load_k(mk_of(0), ra_0, rb_0);
+    load_k(mk_of(1), ra_1, rb_1);
+    store_half(0, 0, ra_0, rb_0);
+    int st = 0;
+    for (; st + 1 < nsteps; st += 2) {
+      __syncthreads();
+      compute(0);
+      store_half(1, 1, ra_0, rb_0);
+      __syncthreads();
+      load_k(mk_of(st + 2), ra_0, rb_0);
+      compute(1);
+      store_half(0, 0, ra_1, rb_1);
+      __syncthreads();
+      compute(0);
+      store_half(1, 1, ra_1, rb_1);
+      __syncthreads();
+      load_k(mk_of(st + 3), ra_1, rb_1);
+      compute(1);
+      store_half(0, 0, ra_0, rb_0);
+    }
+    if (st < nsteps) {
+      __syncthreads();
+      compute(0);
+      store_half(1, 1, ra_0, rb_0);
+      __syncthreads();
+      compute(1);
+    }
+  }
+  // accumulators -> slab (row = channel co from the register index, column = nn from the lane)
+  float* slab = p.out + (size_t)split * p.Cout * p.KK;
+  const int col_l = lane & 31, rsub = 4 * (lane >> 5);
+#pragma unroll
+  for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int co = co0 + wm * C::WM + mi * 32 + (reg & 3) + 8 * (reg >> 2) + rsub;
+      if (co >= p.Cout) continue;
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni) {
+        const int nn = nn0 + wn * C::WN + ni * 32 + col_l;
+        if (nn < p.KK) slab[(size_t)co * p.KK + nn] = acc[mi][ni][reg];
+      }
+    }
+}
+
+template <int BM, int BN, int P>
+static int launch_wgrad_x6_t(const WgradParams& p, int splits, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * P * XH * (XStride<BM>::value + XStride<BN>::value);
+  WgradParams q = p;
+  q.nct = (int)cdiv(p.Cout, BM);
+  q.ntiles = q.nct * (int)cdiv(p.KK, BN);
+  q.nsplits = splits;
+  dim3 grid((unsigned)(8 * cdiv((long)splits * q.nct, 8) * (q.ntiles / q.nct)));
+  hipLaunchKernelGGL((wgrad_x6_kernel<BM, BN, P>), grid, dim3(256), lds, st, q);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+// tile of the bf16-split weight gradient: BM over Cout, BN over KK = R*S*Cin
+void wgrad_x6_tile(int Cout, long KK, int* bm, int* bn) {
+  *bm = Cout >= 96 ? 128 : 64;
+  *bn = KK <= 64 ? 64 : 128;
+}
+
+int launch_wgrad_x6(const WgradParams& p, int bm, int bn, int splits, int pieces, hipStream_t st) {
+  if (pieces == 3) {
+    if (bm == 128) return bn == 128 ? launch_wgrad_x6_t<128, 128, 3>(p, splits, st) : launch_wgrad_x6_t<128, 64, 3>(p, splits, st);
+    return bn == 128 ? launch_wgrad_x6_t<64, 128, 3>(p, splits, st) : launch_wgrad_x6_t<64, 64, 3>(p, splits, st);
+  }
+  if (bm == 128) return bn == 128 ? launch_wgrad_x6_t<128, 128, 1>(p, splits, st) : launch_wgrad_x6_t<128, 64, 1>(p, splits, st);
+  return bn == 128 ? launch_wgrad_x6_t<64, 128, 1>(p, splits, st) : launch_wgrad_x6_t<64, 64, 1>(p, splits, st);
+}
+
+}  // namespace xas
+
+using namespace xas;
+
+extern "C" size_t xas_split_weight_bytes(long elems, int pieces) { return (size_t)elems * 2 * (pieces == 3 ? 3 : 1); }
+
+extern "C" int xas_split_weight(const float* w_packed, void* w_split, long elems, int pieces, void* stream) {
+  XAS_REQUIRE(w_packed && w_split && elems > 0 && elems % 16 == 0, "split_weight: need a packed weight of a multiple of 16 elements");
+  XAS_REQUIRE(pieces == 1 || pieces == 3, "split_weight: pieces must be 1 (bf16) or 3 (bf16x6)");
+  XAS_REQUIRE((((uintptr_t)w_packed | (uintptr_t)w_split) & 15) == 0, "split_weight: buffers must be 16-byte aligned");
+  const long n4 = elems / 4;
+  hipStream_t st = as_stream(stream);
+  if (pieces == 3)
+    hipLaunchKernelGGL(split_weight_kernel<3>, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, st, w_packed,
+                       reinterpret_cast<unsigned short*>(w_split), n4);
+  else
+    hipLaunchKernelGGL(split_weight_kernel<1>, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, st, w_packed,
+                       reinterpret_cast<unsigned short*>(w_split), n4);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}

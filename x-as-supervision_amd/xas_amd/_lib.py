@@ -14,7 +14,12 @@ _T = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c
 
 class ConvShape(ctypes.Structure):
     """xas_conv_shape"""
-    _fields_ = [(n, ctypes.c_int) for n in ('N', 'Hi', 'Wi', 'Cin', 'Cout', 'R', 'S', 'stride', 'pad', 'Ho', 'Wo')]
+    _fields_ = [(n, ctypes.c_int) for n in ('N', 'Hi', 'Wi', 'Cin', 'Cout', 'R', 'S', 'stride', 'pad', 'Ho', 'Wo', 'mode')]
+
+
+# xas_hip.h XAS_PREC_*: arithmetic of the MFMA convolutions.  ConvShape.mode = 0 (process default) or 1 + one of these.
+PREC_F32, PREC_BF16, PREC_BF16X6 = 0, 1, 2
+PREC_NAMES = {'f32': PREC_F32, 'bf16': PREC_BF16, 'bf16x6': PREC_BF16X6}
 
 
 # name -> (argument codes, return code).  's' = pointer to ConvShape.  Last 'p' is the stream
@@ -23,7 +28,10 @@ SIGNATURES = {
     'xas_abi_version': ('', 'i'),
     'xas_set_tuning': ('i', 'i'),
     'xas_set_precision': ('i', 'i'),
-    'xas_set_debug_buffer': ('p', 'i'),
+    'xas_get_precision': ('', 'i'),
+    'xas_conv_weight_planes': ('si', 'i'),
+    'xas_split_weight_bytes': ('li', 'z'),
+    'xas_split_weight': ('pplip', 'i'),
     'xas_head_workspace_floats': ('iii', 'z'),
     'xas_head_softargmax_fwd': ('piiiiipppippp', 'i'),
     'xas_head_softargmax_bwd': ('ppppiiiiippp', 'i'),
@@ -104,8 +112,8 @@ def load():
     lib.xas_last_error.restype = ctypes.c_char_p
     lib.xas_last_error.argtypes = []
     _lib = lib
-    mode = os.environ.get('XAS_PRECISION', '')          # '' / '0' = fp32 MFMA (default); '1' = bf16; '2' = bf16x6 (see xas_hip.h)
-    if mode not in ('', '0'):
+    mode = os.environ.get('XAS_PRECISION', '')          # '' = library default (2, bf16x6); '0' = exact fp32 MFMA; '1' = bf16
+    if mode != '':
         lib.xas_set_precision.argtypes = [ctypes.c_int]
         lib.xas_set_precision.restype = ctypes.c_int
         if lib.xas_set_precision(int(mode)) != 0:

@@ -216,34 +216,52 @@ def stack_nchw(tensors):
     return y
 
 
-def _shape(n, hi, wi, cin, cout, r, s, stride, pad, ho, wo):
-    return ConvShape(n, hi, wi, cin, cout, r, s, stride, pad, ho, wo)
+def _shape(n, hi, wi, cin, cout, r, s, stride, pad, ho, wo, mode=0):
+    return ConvShape(n, hi, wi, cin, cout, r, s, stride, pad, ho, wo, mode)
+
+
+MODE_F32 = 1 + _lib.PREC_F32          # ConvShape.mode of a call that must run on the exact-fp32 kernels
 
 
 class _PackCache:
-    """Packed copies of a weight, rebuilt when the parameter changes."""
+    """Kernel-side copies of a weight, rebuilt when the parameter changes: packed fp32 ([rows][R][S][chan]) and, for the
+    bf16-split kernels, the pre-split bf16 planes of the packed weight (xas_split_weight) - built once per optimizer step."""
 
     def __init__(self):
         self.key = None
         self.packed = {}
 
-    def get(self, w, transposed):
+    def _fresh(self, w):
         # the optimizer that owns w bumps ITS epoch box when it rewrites the arena (raw-pointer update: w._version does
         # not move); weights outside any fused optimizer fall back to the global epoch
         box = getattr(w, '_xas_epoch', _weights_epoch)
         key = (w.data_ptr(), w._version, box[0])
         if key != self.key:
             self.key, self.packed = key, {}
-        if transposed not in self.packed:
+
+    def get(self, w, transposed, shp=None):
+        """Weight buffer for the forward-type (transposed = 0) / data-gradient-type (1) entry points.  shp: the call's
+        ConvShape - the library says which format that (shape, precision) wants; None: fp32 packed."""
+        self._fresh(w)
+        planes = query('xas_conv_weight_planes', shp, int(transposed)) if shp is not None else 0
+        k = (transposed, planes)
+        if k in self.packed:
+            return self.packed[k]
+        if (transposed, 0) not in self.packed:
             co, ci, r, s = w.shape
             if not transposed and r == 1 and s == 1 and w.is_contiguous() and w.data_ptr() % 16 == 0:
                 # a 1x1 filter in OIHW order IS the packed [Cout][R][S][Cin] layout: no copy (36 of ResNet-50's 53 convs)
-                self.packed[transposed] = w.detach().view(-1)
-                return self.packed[transposed]
-            p = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
-            call('xas_pack_weight', ptr(w.detach().contiguous()), ptr(p), co, ci, r, s, int(transposed))
-            self.packed[transposed] = p
-        return self.packed[transposed]
+                self.packed[(transposed, 0)] = w.detach().view(-1)
+            else:
+                p = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+                call('xas_pack_weight', ptr(w.detach().contiguous()), ptr(p), co, ci, r, s, int(transposed))
+                self.packed[(transposed, 0)] = p
+        if planes:
+            src = self.packed[(transposed, 0)]
+            sp = torch.empty(query('xas_split_weight_bytes', src.numel(), planes), device=w.device, dtype=torch.uint8)
+            call('xas_split_weight', ptr(src), ptr(sp), src.numel(), planes)
+            self.packed[k] = sp
+        return self.packed[k]
 
 
 def _col_sum(t2d_ptr_tensor, M, C):
@@ -280,7 +298,7 @@ class _Conv2d(torch.autograd.Function):
         ho, wo = (hi + 2 * pad - r) // stride + 1, (wi + 2 * pad - s) // stride + 1
         shp = _shape(n, hi, wi, ci, co, r, s, stride, pad, ho, wo)
         y = empty_cl(n, co, ho, wo, x)
-        call('xas_conv_fwd', ptr(x), ptr(cache.get(weight, 0)), ptr(bias), ptr(y), shp)
+        call('xas_conv_fwd', ptr(x), ptr(cache.get(weight, 0, shp)), ptr(bias), ptr(y), shp)
         ctx.save_for_backward(x, weight, *([bias] if bias is not None else []))
         ctx.shp, ctx.cache, ctx.has_bias = shp, cache, bias is not None
         if ctx.needs_input_grad[1]:
@@ -297,7 +315,7 @@ class _Conv2d(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            call('xas_conv_dgrad', ptr(dy), ptr(ctx.cache.get(weight, 1)), ptr(dx), shp)
+            call('xas_conv_dgrad', ptr(dy), ptr(ctx.cache.get(weight, 1, shp)), ptr(dx), shp)
         if ctx.needs_input_grad[1] and not _wgrad_into_grad(x, dy, shp, weight):
             dw = _wgrad(x, dy, shp, weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -320,7 +338,7 @@ def _conv_forward(x, weight, stride, pad, cache):
     ho, wo = (hi + 2 * pad - r) // stride + 1, (wi + 2 * pad - s) // stride + 1
     shp = _shape(n, hi, wi, ci, co, r, s, stride, pad, ho, wo)
     y = empty_cl(n, co, ho, wo, x)
-    call('xas_conv_fwd', ptr(x), ptr(cache.get(weight, 0)), None, ptr(y), shp)
+    call('xas_conv_fwd', ptr(x), ptr(cache.get(weight, 0, shp)), None, ptr(y), shp)
     return y, shp
 
 
@@ -345,7 +363,7 @@ def _conv_bn_forward(x, conv, bn, residual, group):
     ho, wo = (hi + 2 * pad - r) // stride + 1, (wi + 2 * pad - s) // stride + 1
     shp = _shape(n, hi, wi, ci, co, r, s, stride, pad, ho, wo)
     y = empty_cl(n, co, ho, wo, x)
-    wp = conv._cache.get(weight, 0)
+    wp = conv._cache.get(weight, 0, shp)
     G = _groups[0]
     # sums are taken around 0: a pivot taken from the running mean would make the last bits of the statistics depend on
     # optimisation state (a detector pass computed once and re-used - TrainStep(dedupe=True) - must equal the recomputed
@@ -389,7 +407,7 @@ def _conv_dgrad_bn_bwd(dy, conv, shp, saved, cfg, bn, want_param_grads):
               and gg.dtype == torch.float32 and gb.dtype == torch.float32)
     dz = torch.empty_like(xb)
     dx = torch.empty_like(xb)
-    call('xas_conv_dgrad_bn_bwd', ptr(dy), ptr(conv._cache.get(conv.weight, 1)), shp, ptr(xb), ptr(mean), ptr(var),
+    call('xas_conv_dgrad_bn_bwd', ptr(dy), ptr(conv._cache.get(conv.weight, 1, shp)), shp, ptr(xb), ptr(mean), ptr(var),
          ptr(gamma), ptr(beta), float(eps), G, float(count), ptr(dz), ptr(dx), ptr(sums), ptr(ws),
          ptr(gb) if direct else None, ptr(gg) if direct else None)
     if direct:
@@ -408,10 +426,10 @@ def _conv_backward(x, weight, dy, shp, cache, need_dx, need_dw, acc_into=None):
     if need_dx:
         if acc_into is not None:
             dx = acc_into
-            call('xas_conv_dgrad_acc', ptr(dy), ptr(cache.get(weight, 1)), ptr(dx), shp)
+            call('xas_conv_dgrad_acc', ptr(dy), ptr(cache.get(weight, 1, shp)), ptr(dx), shp)
         else:
             dx = torch.empty_like(x)
-            call('xas_conv_dgrad', ptr(dy), ptr(cache.get(weight, 1)), ptr(dx), shp)
+            call('xas_conv_dgrad', ptr(dy), ptr(cache.get(weight, 1, shp)), ptr(dx), shp)
     if need_dw and not _wgrad_into_grad(x, dy, shp, weight):
         dw = _wgrad(x, dy, shp, weight.shape)
     return dx, dw
@@ -502,7 +520,7 @@ class _Bottleneck(torch.autograd.Function):
             g, _ = bn_b(o + i - 1, bns[i - 1], g)
         if fuse_skip:
             dx = torch.empty_like(x)
-            call('xas_conv_dgrad_acc_masked', ptr(g), ptr(convs[0]._cache.get(convs[0].weight, 1)), ptr(dx), shps[o],
+            call('xas_conv_dgrad_acc_masked', ptr(g), ptr(convs[0]._cache.get(convs[0].weight, 1, shps[o])), ptr(dx), shps[o],
                  ptr(dout), ptr(saved[o + 2][1]))
             if id(convs[0].weight) in need and not _wgrad_into_grad(x, g, shps[o], convs[0].weight):
                 pgrads[id(convs[0].weight)] = _wgrad(x, g, shps[o], convs[0].weight.shape)
@@ -548,7 +566,7 @@ class _ConvTranspose2d(torch.autograd.Function):
         # equivalent conv: big side (hb,wb,cot) -> small side (h,w,cit)
         shp = _shape(n, hb, wb, cot, cit, r, s, stride, pad, h, w)
         y = empty_cl(n, cot, hb, wb, x)
-        call('xas_conv_dgrad', ptr(x), ptr(cache.get(weight, 1)), ptr(y), shp)
+        call('xas_conv_dgrad', ptr(x), ptr(cache.get(weight, 1, shp)), ptr(y), shp)
         ctx.save_for_backward(x, weight)
         ctx.shp, ctx.cache = shp, cache
         if ctx.needs_input_grad[1]:
@@ -563,7 +581,7 @@ class _ConvTranspose2d(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            call('xas_conv_fwd', ptr(dy), ptr(ctx.cache.get(weight, 0)), None, ptr(dx), shp)
+            call('xas_conv_fwd', ptr(dy), ptr(ctx.cache.get(weight, 0, shp)), None, ptr(dx), shp)
         if ctx.needs_input_grad[1] and not _wgrad_into_grad(dy, x, shp, weight):
             dw = _wgrad(dy, x, shp, weight.shape)
         return dx, dw, None, None, None
@@ -581,7 +599,7 @@ class _Linear(torch.autograd.Function):
         x = x.contiguous()
         rows, ci = x.shape
         co = weight.shape[0]
-        shp = _shape(rows, 1, 1, ci, co, 1, 1, 1, 0, 1, 1)
+        shp = _shape(rows, 1, 1, ci, co, 1, 1, 1, 0, 1, 1, MODE_F32)      # raw fp32 weights: the exact-fp32 kernels
         y = torch.empty(rows, co, device=x.device, dtype=torch.float32)
         call('xas_conv_fwd', ptr(x), ptr(weight.detach().contiguous()), ptr(bias), ptr(y), shp)
         ctx.save_for_backward(x, weight)
