@@ -134,12 +134,14 @@ typedef struct {
 } xas_conv_shape;
 
 /* Which weight buffer xas_conv_fwd* (pass 0) / xas_conv_dgrad* (pass 1) expect for this shape in its precision mode:
- * 0 = fp32 packed weights (xas_pack_weight); 1 or 3 = that many bf16 planes: xas_split_weight of the packed weights,
- * layout [rows][K / 16][planes][16] bf16 with K = R*S*Cin (pass 0, rows = Cout) or R*S*Cout (pass 1, rows = Cin).  Shapes
- * outside the MFMA tiles (stem, one-channel layers) always take fp32 weights.  Built once per optimizer step per weight. */
+ * 0 = fp32 packed weights (xas_pack_weight); 1 or 3 = that many bf16 planes: xas_split_weight of the packed weights
+ * [rows][K] with K = R*S*Cin (pass 0, rows = Cout) or R*S*Cout (pass 1, rows = Cin).  The split layout is the MFMA operand
+ * image [rows / 32][K / 16][planes][64 lanes][8 bf16] (rows zero-padded to a multiple of 32): the kernels load it straight
+ * into operand registers.  Shapes outside the MFMA tiles (stem, one-channel layers) always take fp32 weights.  Built once
+ * per optimizer step and weight. */
 int xas_conv_weight_planes(const xas_conv_shape* s, int pass);
-size_t xas_split_weight_bytes(long elems, int pieces);
-int xas_split_weight(const float* w_packed, void* w_split, long elems, int pieces, void* stream);
+size_t xas_split_weight_bytes(long rows, long K, int pieces);
+int xas_split_weight(const float* w_packed, void* w_split, long rows, long K, int pieces, void* stream);
 
 int xas_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
                  const xas_conv_shape* s, void* stream);

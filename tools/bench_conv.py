@@ -28,8 +28,10 @@ def weights_for(shp, w, transposed):
     planes = query('xas_conv_weight_planes', shp, transposed)
     if not planes:
         return w
-    sp = torch.empty(query('xas_split_weight_bytes', w.numel(), planes), device=w.device, dtype=torch.uint8)
-    call('xas_split_weight', ptr(w), ptr(sp), w.numel(), planes)
+    rows = shp.Cin if transposed else shp.Cout
+    kk = w.numel() // rows
+    sp = torch.empty(query('xas_split_weight_bytes', rows, kk, planes), device=w.device, dtype=torch.uint8)
+    call('xas_split_weight', ptr(w), ptr(sp), rows, kk, planes)
     return sp
 
 
@@ -39,8 +41,11 @@ def main():
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 128
     precs = (sys.argv[4] if len(sys.argv) > 4 else 'bf16x6,f32').split(',')
     dev = torch.device('cuda')
+    query('xas_set_tuning', int(os.environ.get('XAS_TUNE', '0')))
     tot = {}
-    for (hi, wi, ci, co, r, st, pad) in SHAPES:
+    sel = os.environ.get('XAS_SHAPES')
+    shapes = [SHAPES[int(i)] for i in sel.split(',')] if sel else SHAPES
+    for (hi, wi, ci, co, r, st, pad) in shapes:
         if n * hi * wi * max(ci, co) * 4 >= 2**31 - 2**24:
             nn = max(1, int((2**31 - 2**24) // (hi * wi * max(ci, co) * 4)))
         else:

@@ -38,40 +38,57 @@ __device__ constexpr int kPB[6] = {0, 2, 1, 0, 1, 0};
 __device__ __forceinline__ bf16x8_t as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
 
 // ------------------------------------------------------------------------------------
-// weights: fp32 packed [rows][K] -> [rows][K / 16][P planes][16] bf16 (K % 16 == 0)
+// weights: fp32 packed [rows][K] -> pre-split bf16 in FRAGMENT order
+//     [rows / 32 blocks][K / 16 half-chunks][P planes][64 lanes][8 bf16],  lane = 32 * (k half) + (row in block)
+// i.e. every (row block, 16-deep k slice, plane) is the 1 KiB image of one MFMA operand register set: a wave fetches it
+// with ONE fully coalesced 16-byte-per-lane load straight into the operand registers - the weights never pass through
+// LDS (rows beyond the matrix are zero).
 // ------------------------------------------------------------------------------------
 template <int P>
 __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
-                                                           long n4 /* float4 count */) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  float4 r = reinterpret_cast<const float4*>(src)[i];
-  const long chunk = i >> 2, k4 = i & 3;                        // 16-element chunk, float4 slot inside it
-  unsigned short* o = dst + chunk * (P * 16) + k4 * 4;
+                                                           int rows, int K, long total /* 8-element pieces */) {
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;
+  if (id >= total) return;
+  const int lane = (int)(id & 63);
+  const long blk = id >> 6;                                   // (row block, half-chunk)
+  const int nhc = K / 16;
+  const int hc = (int)(blk % nhc), rb = (int)(blk / nhc);
+  const int row = rb * 32 + (lane & 31), k0 = hc * 16 + (lane >> 5) * 8;
+  float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
+  if (row < rows) {
+    r0 = *reinterpret_cast<const float4*>(src + (size_t)row * K + k0);
+    r1 = *reinterpret_cast<const float4*>(src + (size_t)row * K + k0 + 4);
+  }
+  unsigned short* o = dst + (blk * P) * 512 + lane * 8;
 #pragma unroll
   for (int pc = 0; pc < P; ++pc) {
-    const uint2 q = pack_bf16x4(r);
-    *reinterpret_cast<uint2*>(o + pc * 16) = q;
-    if (pc + 1 < P) r = sub_bf16x4(r, q);
+    const uint2 q0 = pack_bf16x4(r0), q1 = pack_bf16x4(r1);
+    *reinterpret_cast<uint4*>(o + pc * 512) = make_uint4(q0.x, q0.y, q1.x, q1.y);
+    if (pc + 1 < P) { r0 = sub_bf16x4(r0, q0); r1 = sub_bf16x4(r1, q1); }
   }
 }
 
 // ------------------------------------------------------------------------------------
 // forward (MODE 0) and data gradient (MODE 1)
+//
+// Activations: buffer loads (two K-steps ahead, two register sets) -> split -> LDS half-buffers [2][P][BM][16 + 8 pad] ->
+// ds_read_b128 fragments.  Weights: pre-split, fragment-ordered (split_weight_kernel): each wave loads the fragments of its
+// own column blocks straight into MFMA operand registers, one half-step ahead, 1 KiB coalesced per instruction - no LDS
+// traffic, no conversion work, no LDS stores for that operand (the VGPR -> LDS store path, ~80 B/clk per CU, is what
+// bounded the first version of this kernel: 24 KB of stores per half-step and block).
 // ------------------------------------------------------------------------------------
 template <int BM, int BN, int MODE, int P, bool BNB = false>
 __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
   using C = TileCfg<BM, BN>;
-  constexpr int ROWS = BM + BN;
-  constexpr int PLANE = ROWS * XLDH;            // halfwords
+  constexpr int PLANE = BM * XLDH;              // halfwords
   constexpr int HBUF = P * PLANE;               // halfwords per half-buffer
   constexpr int AP = BM / 64;                   // activation float4 per thread per half-step (4 threads x 16 B per row)
-  constexpr int NPH = BN * 2 * P;               // weight 16-byte pieces per half-step
-  constexpr int BP = (NPH + 255) / 256;         // per thread
   constexpr int NT = P == 3 ? 6 : 1;            // partial products
+  constexpr int TILES = C::MI * C::NI, NMF = NT * TILES;
   extern __shared__ __align__(16) float lds[];
-  unsigned short* S = reinterpret_cast<unsigned short*>(lds);     // [2][P][ROWS][XLDH]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned short* S = reinterpret_cast<unsigned short*>(lds);     // [2][P][BM][XLDH]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: the weight-fragment offsets stay scalar
   const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
   const int kq4 = tid & 3, arow = tid >> 2;
 
@@ -105,9 +122,6 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
   const long bias = -(rmin + dmin);
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.src) - bias, 0, (int)((bias + p.src_elems) * 4), 0x00020000);
-  // weight operand: pre-split [rows][K/16][P][16] bf16
-  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.wgt), 0, (int)(p.wgt_elems * 2 * P), 0x00020000);
   unsigned voffA[AP], maskA[AP];
 #pragma unroll
   for (int j = 0; j < AP; ++j) {
@@ -132,16 +146,13 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
       maskA[j] = msk;
     }
   }
-  const unsigned wrow_bytes = (unsigned)(p.R * p.S * p.Cs) * 2u * P;
-  unsigned voffB[BP], dstB[BP];
-#pragma unroll
-  for (int j = 0; j < BP; ++j) {
-    const int id = tid + 256 * j;
-    const int brow = id / (2 * P), q = id - brow * (2 * P);       // q = plane * 2 + k8
-    const int n = n0 + brow;
-    voffB[j] = (id < NPH && n < p.Cd) ? (unsigned)n * wrow_bytes + (unsigned)q * 16u : kOOB;
-    dstB[j] = (unsigned)(((q >> 1) * ROWS + BM + brow) * XLDH + (q & 1) * 8);
-  }
+  // weight operand: [row blocks of 32][K/16][P][64 lanes][8]: the wave's NI column blocks, all address arithmetic scalar
+  const int Ktot = p.R * p.S * p.Cs;
+  const unsigned blk_bytes = (unsigned)(Ktot / 16) * P * 1024u;           // one 32-row block over the whole K
+  const long wbytes = (long)((p.Cd + 31) / 32) * blk_bytes;
+  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, (int)wbytes, 0x00020000);
+  const unsigned voffB = (unsigned)lane * 16u;
+  const unsigned nblk0 = (unsigned)(n0 / 32 + wn * (C::WN / 32));
 
   f32x16 acc[C::MI][C::NI];
 #pragma unroll
@@ -154,37 +165,44 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
 
-  // Load stream: K-steps in order; (chunk, js, jr) advance with scalar ALU only and stop at the last step (further calls
-  // re-load it: valid addresses, values never consumed).
-  int ld_chunk = 0, ld_js = 0, ld_jr = 0, ld_left = nk;
+  // K-step streams, advanced with scalar ALU only; both stop at the last step (further calls re-load it: valid addresses,
+  // values never consumed).  Stream A feeds the activation registers (two K-steps ahead), stream B the weight fragments.
+  struct Cur { int chunk, js, jr, left; };
+  Cur ca{0, 0, 0, nk}, cb{0, 0, 0, nk};
+  auto advance = [&](Cur& c) {
+    const bool more = c.left > 1;
+    c.left -= more ? 1 : 0;
+    int ch = c.chunk + 1, s2 = c.js, r = c.jr;
+    if (ch == cchunks) { ch = 0; ++s2; }
+    if (s2 == ns) { s2 = 0; ++r; }
+    c.chunk = more ? ch : c.chunk; c.js = more ? s2 : c.js; c.jr = more ? r : c.jr;
+  };
   float4 ra_0[2 * AP], ra_1[2 * AP];
-  uint4 rb_0[2 * BP], rb_1[2 * BP];
-  auto load_k = [&](float4 (&ra)[2 * AP], uint4 (&rb)[2 * BP]) {
-    const int tap = ld_jr * ns + ld_js;
-    const int rel = MODE == 0 ? (ld_jr * p.Ws + ld_js) : ((nr - 1 - ld_jr) * p.Ws + (ns - 1 - ld_js));
-    const unsigned soffA = (unsigned)(rel * p.Cs + ld_chunk * BK) * 4u;
-    const int wtap = (base_r + rstep * ld_jr) * p.S + (base_s + rstep * ld_js);
-    const unsigned soffB = (unsigned)(wtap * p.Cs + ld_chunk * BK) * 2u * P;
+  auto load_a = [&](float4 (&ra)[2 * AP]) {
+    const int tap = ca.jr * ns + ca.js;
+    const int rel = MODE == 0 ? (ca.jr * p.Ws + ca.js) : ((nr - 1 - ca.jr) * p.Ws + (ns - 1 - ca.js));
+    const unsigned soffA = (unsigned)(rel * p.Cs + ca.chunk * BK) * 4u;
 #pragma unroll
     for (int j = 0; j < AP; ++j) {
       const unsigned off = ((maskA[j] >> tap) & 1u) ? voffA[j] : kOOB;
       ra[j] = buf_load16(rsrcA, off, soffA);
       ra[AP + j] = buf_load16(rsrcA, off, soffA + XH * 4u);
     }
-#pragma unroll
-    for (int j = 0; j < BP; ++j) {
-      rb[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)voffB[j], (int)soffB, 0));
-      rb[BP + j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)voffB[j], (int)(soffB + XH * 2u * P), 0));
-    }
-    const bool more = ld_left > 1;
-    ld_left -= more ? 1 : 0;
-    int c = ld_chunk + 1, s2 = ld_js, r = ld_jr;
-    if (c == cchunks) { c = 0; ++s2; }
-    if (s2 == ns) { s2 = 0; ++r; }
-    ld_chunk = more ? c : ld_chunk; ld_js = more ? s2 : ld_js; ld_jr = more ? r : ld_jr;
+    advance(ca);
   };
-  // split + store half h of a register set into half-buffer `buf`
-  auto store_half = [&](int buf, int h, const float4 (&ra)[2 * AP], const uint4 (&rb)[2 * BP]) {
+  // weight fragments of one half-step (h = 0: first 16 k of the K-step at the cursor; h = 1: second 16, then advance)
+  auto load_b = [&](uint4 (&gb)[P][C::NI], int h) {
+    const int wtap = (base_r + rstep * cb.jr) * p.S + (base_s + rstep * cb.js);
+    const unsigned hc = (unsigned)((wtap * p.Cs + cb.chunk * BK) / 16 + h);
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+      for (int pc = 0; pc < P; ++pc)
+        gb[pc][ni] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+            rsrcB, (int)voffB, (int)((nblk0 + ni) * blk_bytes + (hc * P + pc) * 1024u), 0));
+    if (h) advance(cb);
+  };
+  auto split_store = [&](int buf, int h, const float4 (&ra)[2 * AP]) {
     unsigned short* sb = S + buf * HBUF;
 #pragma unroll
     for (int j = 0; j < AP; ++j) {
@@ -192,65 +210,64 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
 #pragma unroll
       for (int pc = 0; pc < P; ++pc) {
         const uint2 q = pack_bf16x4(r);
-        *reinterpret_cast<uint2*>(sb + (pc * ROWS + arow + 64 * j) * XLDH + kq4 * 4) = q;
+        *reinterpret_cast<uint2*>(sb + pc * PLANE + (arow + 64 * j) * XLDH + kq4 * 4) = q;
         if (pc + 1 < P) r = sub_bf16x4(r, q);
       }
     }
-#pragma unroll
-    for (int j = 0; j < BP; ++j)
-      if (256 * (j + 1) <= NPH || wave * 64 + 256 * j < NPH)          // compile-time true for full passes, else wave-uniform
-        *reinterpret_cast<uint4*>(sb + dstB[j]) = rb[h * BP + j];
   };
   const int i = lane & 31, hh = lane >> 5;
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, const uint4 (&gb)[P][C::NI]) {
     const unsigned short* sb = S + buf * HBUF;
-    bf16x8_t fa[P][C::MI], fb[P][C::NI];
+    bf16x8_t fa[P][C::MI];
 #pragma unroll
-    for (int pc = P - 1; pc >= 0; --pc) {              // smallest pieces first: they feed the first products
+    for (int pc = P - 1; pc >= 0; --pc)              // smallest pieces first: they feed the first products
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
-        fa[pc][mi] = *reinterpret_cast<const bf16x8_t*>(sb + (pc * ROWS + wm * C::WM + mi * 32 + i) * XLDH + hh * 8);
-#pragma unroll
-      for (int ni = 0; ni < C::NI; ++ni)
-        fb[pc][ni] = *reinterpret_cast<const bf16x8_t*>(sb + (pc * ROWS + BM + wn * C::WN + ni * 32 + i) * XLDH + hh * 8);
-    }
+        fa[pc][mi] = *reinterpret_cast<const bf16x8_t*>(sb + pc * PLANE + (wm * C::WM + mi * 32 + i) * XLDH + hh * 8);
 #pragma unroll
     for (int t = (P == 3 ? 0 : 5); t < 6; ++t)
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < C::NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[P == 3 ? kPB[t] : 0][ni], fa[P == 3 ? kPA[t] : 0][mi],
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(gb[P == 3 ? kPB[t] : 0][ni]), fa[P == 3 ? kPA[t] : 0][mi],
                                                                 acc[mi][ni], 0, 0, 0);
   };
-  (void)NT;
+  (void)NMF;
+  uint4 gb_0[P][C::NI], gb_1[P][C::NI];              // weight fragments of even / odd half-steps
   if (nk > 0) {
-    load_k(ra_0, rb_0);                                // K-step 0
-    load_k(ra_1, rb_1);                                // K-step 1 (re-loads the last step when there is none)
-    store_half(0, 0, ra_0, rb_0);
+    load_a(ra_0);                                      // K-step 0
+    load_a(ra_1);                                      // K-step 1 (re-loads the last step when there is none)
+    load_b(gb_0, 0);                                   // half-step 0
+    load_b(gb_1, 1);                                   // half-step 1
+    split_store(0, 0, ra_0);
     int ks = 0;
     for (; ks + 1 < nk; ks += 2) {
       __syncthreads();
-      compute(0);                                      // half-step 2 ks
-      store_half(1, 1, ra_0, rb_0);
+      compute(0, gb_0);                                // half-step 2 ks
+      load_b(gb_0, 0);                                 // weights of half-step 2 ks + 2
+      split_store(1, 1, ra_0);
       __syncthreads();
-      load_k(ra_0, rb_0);                              // K-step ks + 2: set 0 is free
-      compute(1);                                      // half-step 2 ks + 1
-      store_half(0, 0, ra_1, rb_1);
+      load_a(ra_0);                                    // activations of K-step ks + 2: set 0 is free
+      compute(1, gb_1);                                // half-step 2 ks + 1
+      load_b(gb_1, 1);                                 // weights of half-step 2 ks + 3
+      split_store(0, 0, ra_1);
       __syncthreads();
-      compute(0);                                      // half-step 2 ks + 2
-      store_half(1, 1, ra_1, rb_1);
+      compute(0, gb_0);                                // half-step 2 ks + 2
+      load_b(gb_0, 0);                                 // weights of half-step 2 ks + 4
+      split_store(1, 1, ra_1);
       __syncthreads();
-      load_k(ra_1, rb_1);                              // K-step ks + 3
-      compute(1);                                      // half-step 2 ks + 3
-      store_half(0, 0, ra_0, rb_0);                    // K-step ks + 2, first half (never computed when ks + 2 == nk)
+      load_a(ra_1);                                    // K-step ks + 3
+      compute(1, gb_1);                                // half-step 2 ks + 3
+      load_b(gb_1, 1);                                 // weights of half-step 2 ks + 5
+      split_store(0, 0, ra_0);                         // K-step ks + 2, first half (never computed when ks + 2 == nk)
     }
     if (ks < nk) {                                     // one K-step left: in set 0, its first half is in buffer 0
       __syncthreads();
-      compute(0);
-      store_half(1, 1, ra_0, rb_0);
+      compute(0, gb_0);
+      split_store(1, 1, ra_0);
       __syncthreads();
-      compute(1);
+      compute(1, gb_1);
     }
   }
   igemm_epilogue<BM, BN, MODE, BNB>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
@@ -258,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
 
 template <int BM, int BN>
 constexpr size_t igemm_x6_lds(int P) {
-  size_t a = (size_t)2 * P * (BM + BN) * XLDH * sizeof(unsigned short);
+  size_t a = (size_t)2 * P * BM * XLDH * sizeof(unsigned short);
   size_t b = ((size_t)BM * (BN + 4) + 2 * 256) * sizeof(float);          // epilogue staging T[BM][BN+4] + partial-combine area
   size_t c = ((size_t)2 * TileCfg<BM, BN>::WAVES_M * 32 * (BN + 4) + 2 * 256) * sizeof(float);   // bn-backward epilogue staging
   return a > b ? (a > c ? a : c) : (b > c ? b : c);
@@ -543,20 +560,23 @@ int launch_wgrad_x6(const WgradParams& p, int bm, int bn, int splits, int pieces
 
 using namespace xas;
 
-extern "C" size_t xas_split_weight_bytes(long elems, int pieces) { return (size_t)elems * 2 * (pieces == 3 ? 3 : 1); }
+extern "C" size_t xas_split_weight_bytes(long rows, long K, int pieces) {
+  return (size_t)((rows + 31) / 32) * 32 * (size_t)K * 2 * (pieces == 3 ? 3 : 1);
+}
 
-extern "C" int xas_split_weight(const float* w_packed, void* w_split, long elems, int pieces, void* stream) {
-  XAS_REQUIRE(w_packed && w_split && elems > 0 && elems % 16 == 0, "split_weight: need a packed weight of a multiple of 16 elements");
+extern "C" int xas_split_weight(const float* w_packed, void* w_split, long rows, long K, int pieces, void* stream) {
+  XAS_REQUIRE(w_packed && w_split && rows > 0 && K > 0 && K % 16 == 0, "split_weight: need a packed weight [rows][K] with K a multiple of 16");
   XAS_REQUIRE(pieces == 1 || pieces == 3, "split_weight: pieces must be 1 (bf16) or 3 (bf16x6)");
   XAS_REQUIRE((((uintptr_t)w_packed | (uintptr_t)w_split) & 15) == 0, "split_weight: buffers must be 16-byte aligned");
-  const long n4 = elems / 4;
+  XAS_REQUIRE(((rows + 31) / 32) * 32 * K * 6 < 0x7fffff00l, "split_weight: weight too large");
+  const long total = ((rows + 31) / 32) * (K / 16) * 64;
   hipStream_t st = as_stream(stream);
   if (pieces == 3)
-    hipLaunchKernelGGL(split_weight_kernel<3>, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, st, w_packed,
-                       reinterpret_cast<unsigned short*>(w_split), n4);
+    hipLaunchKernelGGL(split_weight_kernel<3>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, w_packed,
+                       reinterpret_cast<unsigned short*>(w_split), (int)rows, (int)K, total);
   else
-    hipLaunchKernelGGL(split_weight_kernel<1>, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, st, w_packed,
-                       reinterpret_cast<unsigned short*>(w_split), n4);
+    hipLaunchKernelGGL(split_weight_kernel<1>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, w_packed,
+                       reinterpret_cast<unsigned short*>(w_split), (int)rows, (int)K, total);
   XAS_LAUNCH_CHECK();
   return 0;
 }

@@ -30,8 +30,8 @@ SIGNATURES = {
     'xas_set_precision': ('i', 'i'),
     'xas_get_precision': ('', 'i'),
     'xas_conv_weight_planes': ('si', 'i'),
-    'xas_split_weight_bytes': ('li', 'z'),
-    'xas_split_weight': ('pplip', 'i'),
+    'xas_split_weight_bytes': ('lli', 'z'),
+    'xas_split_weight': ('ppllip', 'i'),
     'xas_head_workspace_floats': ('iii', 'z'),
     'xas_head_softargmax_fwd': ('piiiiipppippp', 'i'),
     'xas_head_softargmax_bwd': ('ppppiiiiippp', 'i'),

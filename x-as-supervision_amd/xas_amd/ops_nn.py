@@ -258,8 +258,10 @@ class _PackCache:
                 self.packed[(transposed, 0)] = p
         if planes:
             src = self.packed[(transposed, 0)]
-            sp = torch.empty(query('xas_split_weight_bytes', src.numel(), planes), device=w.device, dtype=torch.uint8)
-            call('xas_split_weight', ptr(src), ptr(sp), src.numel(), planes)
+            rows = w.shape[1] if transposed else w.shape[0]
+            kk = src.numel() // rows
+            sp = torch.empty(query('xas_split_weight_bytes', rows, kk, planes), device=w.device, dtype=torch.uint8)
+            call('xas_split_weight', ptr(src), ptr(sp), rows, kk, planes)
             self.packed[k] = sp
         return self.packed[k]
 
