@@ -25,7 +25,10 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC only on 
 import torch
 import torch.distributed as dist
 
-PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, 'Peak FP32 (matrix)'
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, 'Peak FP32 (matrix)': v_mfma_f32_32x32x2_f32
+PEAK_BF16_MFMA_TFLOPS = 16 * PEAK_FP32_MFMA_TFLOPS      # dense bf16 MFMA = 16 x the fp32 MFMA rate (same table): 2516.8
+# fp32-equivalent peak of a bf16x6 launch: six bf16 MFMAs per fp32 product (VERDICT r02 ruling): 419.5 TFLOP/s
+PEAK_BY_CLASS = {':f32': PEAK_FP32_MFMA_TFLOPS, ':bf16': PEAK_BF16_MFMA_TFLOPS, ':bf16x6': PEAK_BF16_MFMA_TFLOPS / 6.0}
 IMAGES_PER_SAMPLE = {'HM36': 8, 'MPI': 10}
 
 
@@ -39,8 +42,8 @@ def host_threads():
 
 
 def cpu_baseline(workload, threads):
-    """Oracle (CPU restatement of the reference step, stock PyTorch fp32) on a bounded sample: ONE full
-    disc+gen step at B=8 on the host cores."""
+    """Oracle (CPU restatement of the reference step, stock PyTorch fp32) on a bounded sample: full disc+gen steps at B=8
+    on the host cores, 1 warm-up + 3 timed steps, median (BASELINE.md section 3 protocol, bounded to ~60 s)."""
     from oracle import step as ostep
     from oracle.nets import GCNDecouple, PhysiqueNet
     from xas_amd.synthetic import model_config, synthetic_batch
@@ -54,14 +57,20 @@ def cpu_baseline(workload, threads):
     disc.parent_ids, disc.child_ids = skeleton_links(cfg['parent_ids'], cfg['line_select_ids'], False, False)
     o_det = torch.optim.Adam(list(reg.parameters()) + list(phys.parameters()), lr=2e-4, betas=(0.5, 0.999))
     o_disc = torch.optim.Adam(disc.parameters(), lr=2e-4, betas=(0.5, 0.999))
-    B = 8                      # ~10 s of host work on a 16-core share; the GPU leg runs B = 32
+    B = 8                      # ~12 s of host work per step on a 16-core share; the GPU leg runs B = 32
     x = synthetic_batch(B, cfg['cam_id_list'], torch.device('cpu'), seed=1)
-    t0 = time.perf_counter()
-    ostep.train_step(cfg, reg, phys, disc, o_det, o_disc, x)
-    dt = time.perf_counter() - t0
+    times = []
+    for i in range(4):
+        t0 = time.perf_counter()
+        ostep.train_step(cfg, reg, phys, disc, o_det, o_disc, x)
+        times.append(time.perf_counter() - t0)
+    timed = sorted(times[1:])
+    dt = timed[len(timed) // 2]
     per_sample = IMAGES_PER_SAMPLE['MPI' if workload.startswith('MPI') else 'HM36']
     return {'value': B * per_sample / dt, 'unit': 'images/s', 'cores': threads, 'kind': 'port',
-            'sample': '1 full disc+gen step incl. Adam, %s, B=%d, fp32, oracle on torch CPU (%.1f s)' % (workload, B, dt)}
+            'protocol': '1 warm-up + 3 timed steps, median',
+            'sample': 'full disc+gen steps incl. Adam, %s, B=%d, fp32, oracle on torch CPU (warm-up %.1f s, timed %s s)'
+                      % (workload, B, times[0], ' '.join('%.1f' % t for t in times[1:]))}
 
 
 def launch_ranks(n):
@@ -88,10 +97,16 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo to rehearse ranks on one GPU)')
     ap.add_argument('--tune', type=int, default=0, help='kernel tuning experiment flags (xas_set_tuning)')
-    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16', 'bf16x6'],
-                    help='f32 (default, the headline: exact fp32 MFMA) or bf16: NOT the headline - forward / data-gradient '
-                         'convolutions on bf16 MFMA (fp32 accumulate, fp32 master weights, fp32 weight gradients); the JSON line '
-                         'carries dtype "bf16" and peak = the bf16 MFMA peak for those launches')
+    ap.add_argument('--precision', default='bf16x6', choices=['bf16x6', 'f32', 'bf16'],
+                    help='arithmetic of the MFMA convolutions (xas_hip.h XAS_PREC_*).  bf16x6 (default, the headline): fp32 '
+                         'operands split exactly into three bf16 pieces, six exact partial products accumulated in fp32 - '
+                         'fp32-accurate (the whole parity suite runs in this mode), peak 2516.8 / 6 = 419.5 TFLOP/s fp32-'
+                         'equivalent.  f32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32, peak 157.3).  bf16: operands rounded '
+                         'once - NOT fp32 accurate (misses the 1e-4 joint bar), a variant that is reported separately, never '
+                         'the headline; peak 2516.8')
+    ap.add_argument('--f32-steps', type=int, default=2,
+                    help='extra UNTIMED-by-the-headline steps on the exact-fp32 MFMA kernels after the timed region, to print '
+                         'that figure beside the bf16x6 headline (0 = skip)')
     ap.add_argument('--dedupe', action='store_true',
                     help='NOT the headline: share the real-image detector forward between the discriminator and the '
                          'generator update (engine.TrainStep(dedupe=True)); the JSON line is marked config.dedupe')
@@ -125,7 +140,7 @@ def main():
     from xas_amd.synthetic import model_config, synthetic_batch
     from xas_amd import _lib as _xl
     _xl.query('xas_set_tuning', args.tune)
-    _xl.query('xas_set_precision', {'f32': 0, 'bf16': 1, 'bf16x6': 2}[args.precision])
+    _xl.query('xas_set_precision', _xl.PREC_NAMES[args.precision])
     cfg = model_config(args.workload)
     torch.manual_seed(1234)
     model, disc, opt_det, opt_disc = engine.prepare_model(cfg)
@@ -183,59 +198,110 @@ def main():
     sync()
     _ops._side['enabled'] = True
 
+    # the exact-fp32 MFMA figure beside the headline (VERDICT r02 ruling, condition d): the same step with every MFMA
+    # convolution on v_mfma_f32_32x32x2_f32, after the timed region (its weight copies are rebuilt in that format)
+    f32_ms = None
+    if args.precision != 'f32' and args.f32_steps > 0:
+        _xl.query('xas_set_precision', _xl.PREC_F32)
+        step(x)                                          # warm-up: re-packs the weights for the exact-fp32 kernels
+        sync()
+        tf0 = time.perf_counter()
+        for _ in range(args.f32_steps):
+            step(x)
+        sync()
+        f32_ms = (time.perf_counter() - tf0) / args.f32_steps * 1e3
+        _xl.query('xas_set_precision', _xl.PREC_NAMES[args.precision])
+        log('exact-fp32 MFMA kernels: %.1f ms/step (%d steps, untimed by the headline)' % (f32_ms, args.f32_steps))
+
     per_sample = IMAGES_PER_SAMPLE['MPI' if args.workload.startswith('MPI') else 'HM36']
     samples = world * args.batch * args.steps
     if rank == 0:
         summ = timer.summary()
         head = {k: summ.pop(k) for k in list(summ) if k.startswith('xas_head_')}
-        mfma = {k: v for k, v in summ.items() if not k.endswith(':direct')}
-        fl = sum(v['flops'] for v in mfma.values())
-        ms = sum(v['ms'] for v in mfma.values())
-        n_launch = sum(v['launches'] for v in mfma.values())
-        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+
+        def classes(sm):
+            """per kernel class (':f32', ':bf16', ':bf16x6'): launches, ms, flops, achieved TFLOP/s, peak, fraction"""
+            out = {}
+            for k, v in sm.items():
+                cls = ':' + k.rsplit(':', 1)[1]
+                if cls not in PEAK_BY_CLASS:
+                    continue
+                d = out.setdefault(cls, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
+                d['launches'] += v['launches']; d['ms'] += v['ms']; d['flops'] += v['flops']
+            for cls, d in out.items():
+                d['achieved'] = d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
+                d['peak'] = PEAK_BY_CLASS[cls]
+                d['frac'] = d['achieved'] / d['peak']
+            return out
+
+        cl = classes(summ)
+        dom = max(cl, key=lambda c: cl[c]['ms'])                 # the family the step spends its conv time in
+        fl = sum(d['flops'] for d in cl.values())
+        ms = sum(d['ms'] for d in cl.values())
+        n_launch = sum(d['launches'] for d in cl.values())
+        # whole conv family against the MIX of peaks: time each class would need at its own peak / time it took
+        mix_frac = sum(d['flops'] / (d['peak'] * 1e12) for d in cl.values()) / (ms * 1e-3) if ms > 0 else 0.0
+        scl = classes(serial.summary())
         traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r02_conv_traffic.json')
-        if os.path.exists(tpath) and args.workload == 'HM36_Multi_SurS1' and args.batch == 32:
-            with open(tpath) as tf:
-                pmc = json.load(tf)
-                traffic = pmc.get('bytes_per_launch')   # PMC passes of this same command (see file)
+        tsrc = None
+        for tname in ('r03_conv_traffic.json', 'r02_conv_traffic.json'):
+            tpath = os.path.join(ROOT, 'profiles', tname)
+            if os.path.exists(tpath) and args.workload == 'HM36_Multi_SurS1' and args.batch == 32:
+                with open(tpath) as tf:
+                    pmc = json.load(tf)
+                if pmc.get('precision', 'f32') == args.precision:
+                    traffic = pmc.get('bytes_per_launch')
+                    tsrc = ('profiles/%s: static constant from separate rocprofv3 --pmc passes of this command (%s), NOT '
+                            'measured in this run' % (tname, pmc.get('collected', 'see file')))
+                break
         variant_check = None
         if args.precision != 'f32':
-            # the variant's distance to the fp32-MFMA path, measured here (untimed): joints of one detector pass on 8 images
+            # this mode's distance to the exact-fp32 MFMA path, measured here (untimed): joints of one detector pass on 8 images
             reg = model.regressor
             was = reg.training
             reg.eval()                                  # running statistics: both passes see the same normalisation
             img = x['cam_%s_img' % cams[0]][:8]
             with torch.no_grad():
                 kv = reg(img)[0].clone()
-                _xl.query('xas_set_precision', 0)
+                _xl.query('xas_set_precision', _xl.PREC_F32)
                 k32 = reg(img)[0]
-                _xl.query('xas_set_precision', {'bf16': 1, 'bf16x6': 2}[args.precision])
+                _xl.query('xas_set_precision', _xl.PREC_NAMES[args.precision])
             reg.train(was)
-            variant_check = {'max_abs_joint_diff_vs_f32_path': float((kv - k32).abs().max()),
-                             'what': 'detector forward (eval-mode norms) on 8 images, this precision mode vs the fp32-MFMA path; parity bar 1e-4'}
+            variant_check = {'max_abs_joint_diff_vs_exact_fp32_mfma': float((kv - k32).abs().max()),
+                             'what': 'detector forward (eval-mode norms) on 8 images, this precision mode vs the exact-fp32 MFMA kernels; parity bar 1e-4'}
+        kernel_names = {':bf16x6': 'igemm_x6_kernel<.,.,.,3> (fwd / dgrad) + wgrad_x6_kernel<.,.,3>: bf16x6 MFMA implicit-GEMM conv family',
+                        ':bf16': 'igemm_x6_kernel<.,.,.,1> + wgrad_x6_kernel<.,.,1>: bf16 MFMA implicit-GEMM conv family',
+                        ':f32': 'igemm_buf_kernel + wgrad_buf_kernel (+ stem_fwd_kernel): exact-fp32 MFMA implicit-GEMM conv family'}
         line = {
             'metric': 'images/sec %s 256px bs%d (full disc+gen training step)' % (args.workload, args.batch),
             'value': samples * per_sample / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'f32': 'f32', 'bf16': 'bf16 fwd/dgrad MFMA + f32 wgrad (variant, not the headline)',
-                      'bf16x6': 'f32 products from 6 bf16 MFMA partial products in fwd/dgrad + f32 wgrad (variant, not the headline)'}[args.precision],
+            'dtype': {'f32': 'f32 (exact fp32 MFMA)', 'bf16x6': 'f32 (bf16x6 split, f32 accumulate)',
+                      'bf16': 'bf16 products, f32 accumulate (variant: NOT fp32 accurate, not the headline)'}[args.precision],
             'data': 'synthetic',
             'config': {'workload': args.workload, 'batch_per_gpu': args.batch, 'cameras': len(cams),
                        'image': '256x256', 'images_per_sample': per_sample, 'parallelism': 'dp%d' % world,
-                       'samples_per_s': samples / dt,
+                       'samples_per_s': samples / dt, 'ranks': world,
+                       'samples_per_s_per_rank': samples / dt / world,
                        'detector_forwards_per_s': samples * (2 if args.dedupe else 3) * len(cams) / dt,
+                       'precision': args.precision,
                        'dedupe': bool(args.dedupe), **({'variant_check': variant_check} if variant_check else {})},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+            'roofline': {'bound': 'mfma', 'achieved': cl[dom]['achieved'], 'peak': cl[dom]['peak'], 'unit': 'TFLOP/s',
+                         'frac': cl[dom]['frac'], 'traffic': traffic, 'traffic_source': tsrc,
+                         'kernel': kernel_names[dom],
+                         'what': 'dominant kernel family of the step: algorithmic FLOP (2 N Ho Wo Cout R S Cin per launch) of its '
+                                 'launches in the event-timed step / the sum of their HIP-event durations on the stream each was '
+                                 'launched on; peak: fp32 MFMA 157.3, bf16 MFMA 2516.8, bf16x6 = 2516.8 / 6 = 419.5 TFLOP/s '
+                                 'fp32-equivalent (MI355X_MICROARCH.md)',
+                         'by_kernel_class': {k.lstrip(':'): {kk: d[kk] for kk in ('launches', 'ms', 'achieved', 'peak', 'frac')} for k, d in cl.items()},
+                         'conv_family_frac_of_mixed_peak': mix_frac,
+                         'conv_family_tflops': fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
                          'algorithmic_bytes_per_launch': timer.bytes_total / max(1, n_launch),
-                         'kernel': 'igemm_kernel / wgrad_kernel (fp32 MFMA implicit-GEMM conv family)',
                          'note': 'weight-gradient kernels run on a side stream concurrently with the main chain, so '
                                  'per-launch durations include sharing; step_conv_tflops_over_wall is the whole-step view',
-                         'serial': (lambda sm: {'achieved': sum(v['flops'] for k, v in sm.items() if not k.endswith(':direct')) /
-                                                (sum(v['ms'] for k, v in sm.items() if not k.endswith(':direct')) * 1e-3) / 1e12,
-                                                'unit': 'TFLOP/s', 'what': 'same launches, one extra untimed step without stream overlap'})(serial.summary()),
+                         'serial': {'what': 'same launches, one extra untimed step without stream overlap (kernel quality)',
+                                    'by_kernel_class': {k.lstrip(':'): {kk: d[kk] for kk in ('launches', 'ms', 'achieved', 'peak', 'frac')} for k, d in scl.items()}},
                          'step_conv_tflops_over_wall': sum(v['flops'] for v in summ.values()) / timed_steps / (dt / args.steps) / 1e12,
                          'launches_per_step': n_launch / timed_steps, 'avg_launch_us': ms * 1e3 / max(1, n_launch),
                          'event_timed_steps': timed_steps,
@@ -244,6 +310,11 @@ def main():
                                           'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 else 0.0}
                                       for k, v in summ.items()}},
         }
+        if f32_ms is not None:
+            line['exact_fp32_mfma'] = {'ms_per_step': f32_ms, 'images_per_s': world * args.batch * per_sample / (f32_ms * 1e-3),
+                                       'steps': args.f32_steps, 'peak_TFLOPs': PEAK_FP32_MFMA_TFLOPS,
+                                       'what': 'the same step with every MFMA convolution on v_mfma_f32_32x32x2_f32 '
+                                               '(bench.py --precision f32 is that mode as the timed run)'}
         # soft-argmax head (HBM bound): entry-point time (partial + finalize kernels) of the calls in the event-timed step
         hd = {}
         for k, v in head.items():
@@ -257,7 +328,7 @@ def main():
                                         note='logits of one camera-batched pass (%d images x 18.87 MB): read once forward, read + '
                                              'written backward' % (args.batch * len(cams)))
         if traffic is not None:
-            line['roofline']['mfma_busy_pct_pmc'] = pmc.get('mfma_busy_pct')
+            line['roofline']['mfma_busy_pct_pmc'] = pmc.get('mfma_busy_pct')      # same static source as `traffic`
         if args.shape_report:
             with open(args.shape_report, 'w') as f:
                 f.write('entry (N,Hi,Wi,Cin,Cout,R,stride) launches ms_total TFLOP/s\n')
@@ -269,7 +340,7 @@ def main():
                     f.write('%-16s %-36s %5d %9.3f %7.2f\n' % (name, sig, n, ms_, tf))
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only (the other ranks would sit in a barrier)
             threads = host_threads()
-            log('timing the CPU oracle step (B=8) on %d host threads' % threads)
+            log('timing the CPU oracle (B=8, 1 warm-up + 3 timed steps) on %d host threads' % threads)
             line['cpu_baseline'] = cpu_baseline(args.workload, threads)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -140,6 +140,10 @@ typedef struct {
  * into operand registers.  Shapes outside the MFMA tiles (stem, one-channel layers) always take fp32 weights.  Built once
  * per optimizer step and weight. */
 int xas_conv_weight_planes(const xas_conv_shape* s, int pass);
+/* Kernel family a pass of this shape runs on (0 forward-type, 1 data-gradient-type, 2 weight gradient): 0 no MFMA (direct /
+ * one-channel kernels), 1 exact-fp32 MFMA, 2 bf16 MFMA, 3 bf16x6 MFMA.  For measurement (bench.py prices a launch against
+ * the peak of the pipe it uses). */
+int xas_conv_kernel_class(const xas_conv_shape* s, int pass);
 size_t xas_split_weight_bytes(long rows, long K, int pieces);
 int xas_split_weight(const float* w_packed, void* w_split, long rows, long K, int pieces, void* stream);
 

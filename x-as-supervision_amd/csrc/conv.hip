@@ -1388,6 +1388,8 @@ static int dispatch_igemm(const IgemmParams& p, int prec, int Mrows_max, int pha
 
 using namespace xas;
 
+static bool wgrad_on_x6(const xas_conv_shape* s, const float* x);
+
 // Images per launch so that a gathered tensor stays below the 2 GiB range of the 32-bit buffer offsets (camera-batched
 // passes: the logits of 128+ images are 2.4 GB and more).  Images are independent in all three convolution passes, so
 // a larger batch is processed as several launches over image ranges (weight gradients: the later ones accumulate).
@@ -1503,6 +1505,24 @@ extern "C" int xas_conv_weight_planes(const xas_conv_shape* s, int pass) {
   if (pass == 0) mfma = !thin && !(s->Cin == 3 && s->R == 7) && s->Cin % BK == 0 && s->Cout >= 16;
   else mfma = !thin && s->Cout % BK == 0 && s->Cin >= 16;
   return mfma ? (prec == XAS_PREC_BF16X6 ? 3 : 1) : 0;
+}
+
+// Which kernel family a pass of this shape runs on (for measurement: bench.py prices every launch against the peak of the
+// pipe it actually uses).  pass: 0 forward-type, 1 data-gradient-type, 2 weight gradient.
+// -> 0 no MFMA (direct / one-channel kernels), 1 exact-fp32 MFMA, 2 bf16 MFMA, 3 bf16x6 MFMA.
+extern "C" int xas_conv_kernel_class(const xas_conv_shape* s, int pass) {
+  if (!s) return 0;
+  const int prec = precision_of(s);
+  const int split = prec == XAS_PREC_BF16X6 ? 3 : (prec == XAS_PREC_BF16 ? 2 : 1);
+  const bool thin = (s->Cout == 1 && thin_ok(s, s->Cin)) || (s->Cin == 1 && thin_ok(s, s->Cout));
+  if (thin) return 0;
+  if (pass == 0) {
+    if (s->Cin == 3 && s->R == 7 && s->S == 7 && s->stride == 2 && s->pad == 3 && s->Cout == ST_CO) return 1;     // stem kernel
+    return (s->Cin % BK == 0 && s->Cout >= 16) ? split : 0;
+  }
+  if (pass == 1) return (s->Cout % BK == 0 && s->Cin >= 16) ? split : 0;
+  if (s->Cout == 1) return 0;
+  return wgrad_on_x6(s, nullptr) ? split : 1;
 }
 
 // Convolution (no bias) + the training-mode batch-norm statistics of its result.  When the tile grid lines up with the

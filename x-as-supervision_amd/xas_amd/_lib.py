@@ -30,6 +30,7 @@ SIGNATURES = {
     'xas_set_precision': ('i', 'i'),
     'xas_get_precision': ('', 'i'),
     'xas_conv_weight_planes': ('si', 'i'),
+    'xas_conv_kernel_class': ('si', 'i'),
     'xas_split_weight_bytes': ('lli', 'z'),
     'xas_split_weight': ('ppllip', 'i'),
     'xas_head_workspace_floats': ('iii', 'z'),

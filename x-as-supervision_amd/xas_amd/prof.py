@@ -24,7 +24,7 @@ def conv_bytes(shape):
 class KernelTimer:
     def __init__(self, names=CONV_ENTRIES):
         self.names = set(names)
-        self.records = []          # (name, start_event, end_event, flops, mfma_path)
+        self.records = []          # (name, start_event, end_event, flops, kernel class, shape signature)
         self.bytes_total = 0.0     # algorithmic bytes of the MFMA-path launches
 
     def __enter__(self):
@@ -42,14 +42,11 @@ class KernelTimer:
         b.record()
         if rc != 0:
             raise RuntimeError('%s failed (%d): %s' % (name, rc, _lib.load().xas_last_error().decode()))
-        mfma = False
+        mfma = 0                   # kernel class of the launch: 0 no MFMA, 1 exact-fp32 MFMA, 2 bf16 MFMA, 3 bf16x6 MFMA
         if shape is not None:
-            if name in ('xas_conv_fwd', 'xas_conv_fwd_bnstats'):
-                mfma = (shape.Cin % 32 == 0 and shape.Cout >= 16) or (shape.Cin == 3 and shape.R == 7 and shape.Cout == 64)
-            elif name in ('xas_conv_dgrad', 'xas_conv_dgrad_acc', 'xas_conv_dgrad_acc_masked'):
-                mfma = shape.Cout % 32 == 0 and shape.Cin >= 16
-            else:
-                mfma = shape.Cout != 1
+            kind = 0 if name in ('xas_conv_fwd', 'xas_conv_fwd_bnstats') else (
+                1 if name in ('xas_conv_dgrad', 'xas_conv_dgrad_acc', 'xas_conv_dgrad_acc_masked', 'xas_conv_dgrad_bn_bwd') else 2)
+            mfma = _lib.query('xas_conv_kernel_class', shape, kind)
         sig = None
         if shape is not None:
             sig = (shape.N, shape.Hi, shape.Wi, shape.Cin, shape.Cout, shape.R, shape.stride)
@@ -63,11 +60,14 @@ class KernelTimer:
         self.records.append((name, a, b, work, mfma, sig))
         self.bytes_total += conv_bytes(shape) if (shape is not None and mfma) else 0.0
 
+    CLASS = {0: ':direct', 1: ':f32', 2: ':bf16', 3: ':bf16x6'}
+
     def summary(self):
-        """-> dict per entry point: launches, total ms, total flops (call after torch.cuda.synchronize())."""
+        """-> dict per (entry point, kernel class): launches, total ms, total flops (call after torch.cuda.synchronize()).
+        Keys end in ':direct' (no MFMA), ':f32' (exact-fp32 MFMA), ':bf16', ':bf16x6'; the head entries carry no suffix."""
         out = {}
         for name, a, b, fl, mfma, _sig in self.records:
-            key = name + ('' if mfma else ':direct')
+            key = name + (self.CLASS[mfma] if name.startswith('xas_conv') else '')
             d = out.setdefault(key, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
             d['launches'] += 1
             d['ms'] += a.elapsed_time(b)
