@@ -233,3 +233,46 @@ def test_conv_beyond_2gib_splits_over_images():
     for i in range(n):
         ref_dw += (dy[i].permute(1, 2, 0).reshape(-1, cout).double().t() @ x[i].permute(1, 2, 0).reshape(-1, cin).double())
     assert rel(dw.view(cout, cin), ref_dw.float()) < 1e-5
+
+
+def test_two_chain_step_equals_single_stream_step(monkeypatch):
+    """xas_amd.streams.chains: the real-image pass and the pseudo-image pass of the generator step on two streams (forward
+    and backward; running statistics through the bookkeeping stream, norm-parameter gradients by hardware atomics, weight
+    gradients through the one side stream) against the default single-stream step with the joined G = 8 pass: same losses,
+    same parameters after the step (up to fp32 summation order), same running statistics and counters."""
+    import modules.model as mm
+    from xas_amd import engine, streams
+    from xas_amd.synthetic import model_config
+    cfg = model_config('HM36_Multi_SurS2')
+    cams = [0, 1, 2]
+    cfg['model_params']['cam_id_list'] = cams
+    xn = gi.synthetic_batch(2, cams, seed=98)
+    x = {k: T(v).cuda() for k, v in xn.items()}
+    res = []
+    for nchains in (1, 2, 2):
+        monkeypatch.setattr(streams, 'CHAINS', nchains)
+        torch.manual_seed(12)
+        model, disc, od, odisc = engine.prepare_model(cfg)
+        model.cuda().train(), disc.cuda().train()
+        disc.smpl_discriminator.header.p = 0.0
+        step = engine.TrainStep(cfg, model, disc, od, odisc)
+        ld, lk, tot, out = step(x)
+        torch.cuda.synchronize()
+        res.append((float(ld), {k: float(v.mean()) for k, v in lk.items()}, od.param_arena.clone(), odisc.param_arena.clone(),
+                    {k: v.clone() for k, v in model.state_dict().items() if 'running' in k or 'num_batches' in k}, sorted(out)))
+        step(x)                                            # a second step (re-used streams, re-armed state)
+        torch.cuda.synchronize()
+        res[-1] += (od.param_arena.clone(),)
+    a, b, c = res
+    assert torch.equal(b[2], c[2]) and torch.equal(b[3], c[3]) and torch.equal(b[6], c[6])     # deterministic run to run
+    assert abs(a[0] - b[0]) < 1e-6 + 1e-4 * abs(a[0])
+    for k in a[1]:
+        assert abs(a[1][k] - b[1][k]) < 1e-6 + 2e-4 * abs(a[1][k]), k
+    assert a[5] == b[5]
+    assert float((a[2] - b[2]).abs().max()) < 2.5e-4          # Adam's first step: 2 * lr at worst (sign flip of a ~zero gradient)
+    assert float(((a[2] - b[2]).abs() > 1e-5).float().mean()) < 0.02
+    for k in a[4]:
+        if 'num_batches' in k:
+            assert int(a[4][k]) == int(b[4][k]), k
+        else:
+            assert rel(b[4][k], a[4][k]) < 1e-4, k

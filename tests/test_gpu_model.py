@@ -347,6 +347,7 @@ def _check_wiring(gname, cfg, cams, seed, tol_loss=3e-4, rng_seed=None):
     tot = sum(v.mean() for v in losses.values())
     assert abs(float(tot) - float(g['total'])) < 1e-5 + tol_loss * abs(float(g['total']))
     tot.backward()
+    torch.cuda.synchronize()                 # gradients are written on several streams (weight-gradient stream, pass chains)
     c0, cl = 'cam_%d' % cams[0], 'cam_%d' % cams[-1]
     assert maxabs(out['pose_3d_depth_' + c0], T(g['pose_3d_cam_0'])) < 0.2      # mm, |coords| ~ 1e3..1e4
     assert maxabs(out['kp_gt_world'], T(g['kp_gt_world'])) < 0.05

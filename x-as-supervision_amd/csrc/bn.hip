@@ -62,6 +62,14 @@ static unsigned* take_tickets(int n) {
   return r;
 }
 
+// Parameter-gradient accumulation into the .grad arena: hardware float atomics (global_atomic_add_f32), because two
+// backward chains of one step (xas_amd/streams.py: chains) may finish the same layer's reduction concurrently on two
+// streams.  A parameter receives at most one contribution per chain starting from the zeroed arena, and a + b == b + a
+// bit for bit: the result does not depend on which chain arrives first.
+__device__ __forceinline__ void grad_add4(float* p, float4 v) {
+  unsafeAtomicAdd(p + 0, v.x); unsafeAtomicAdd(p + 1, v.y); unsafeAtomicAdd(p + 2, v.z); unsafeAtomicAdd(p + 3, v.w);
+}
+
 struct ColArgs {
   const float* x; const float* y; const float* dy; const float* mean; const float* var; const float* aux;
   float eps; int act; long M; int C; ColGeom g;
@@ -344,18 +352,13 @@ __device__ __forceinline__ void col_reduce_body(const ColArgs& a) {
     if (a.acc1) {
       const int half = C >> 1;
       float* ap = c < half ? a.acc1 + c : a.acc2 + (c - half);
-      float4 t1 = *reinterpret_cast<const float4*>(ap);
-      t1.x += accg1.x; t1.y += accg1.y; t1.z += accg1.z; t1.w += accg1.w;
-      *reinterpret_cast<float4*>(ap) = t1;
+      grad_add4(ap, accg1);
     }
     return;
   }
   if (MODE != 0 && a.acc1) {                                 // parameter gradients accumulated in place (.grad arena)
-    float4 t1 = *reinterpret_cast<const float4*>(a.acc1 + c), t2 = *reinterpret_cast<const float4*>(a.acc2 + c);
-    t1.x += accg1.x; t1.y += accg1.y; t1.z += accg1.z; t1.w += accg1.w;
-    t2.x += accg2.x; t2.y += accg2.y; t2.z += accg2.z; t2.w += accg2.w;
-    *reinterpret_cast<float4*>(a.acc1 + c) = t1;
-    *reinterpret_cast<float4*>(a.acc2 + c) = t2;
+    grad_add4(a.acc1 + c, accg1);
+    grad_add4(a.acc2 + c, accg2);
   }
 }
 

@@ -1389,6 +1389,7 @@ static int dispatch_igemm(const IgemmParams& p, int prec, int Mrows_max, int pha
 using namespace xas;
 
 static bool wgrad_on_x6(const xas_conv_shape* s, const float* x);
+static int images_per_launch(int N, long elems_per_image_a, long elems_per_image_b);
 
 // Images per launch so that a gathered tensor stays below the 2 GiB range of the 32-bit buffer offsets (camera-batched
 // passes: the logits of 128+ images are 2.4 GB and more).  Images are independent in all three convolution passes, so
@@ -1522,7 +1523,9 @@ extern "C" int xas_conv_kernel_class(const xas_conv_shape* s, int pass) {
   }
   if (pass == 1) return (s->Cout % BK == 0 && s->Cin >= 16) ? split : 0;
   if (s->Cout == 1) return 0;
-  return wgrad_on_x6(s, nullptr) ? split : 1;
+  xas_conv_shape part = *s;          // tensors beyond the 32-bit offset range run as several launches over image ranges
+  part.N = images_per_launch(s->N, (long)s->Hi * s->Wi * s->Cin, (long)s->Ho * s->Wo * s->Cout);
+  return wgrad_on_x6(&part, nullptr) ? split : 1;
 }
 
 // Convolution (no bias) + the training-mode batch-norm statistics of its result.  When the tile grid lines up with the
@@ -1722,8 +1725,12 @@ static void wgrad_plan(const xas_conv_shape* s, bool x6, int* bm, int* bn, int* 
     if (*bm == 32) *bn = 128;
   }
   const long tiles = cdiv(s->Cout, *bm) * cdiv(KK, *bn);
-  long sp = cdiv(1024, tiles);                     // ~4 blocks per CU in total
-  const long maxsp = M / 256 > 0 ? M / 256 : 1;    // >= 8 K-steps per block
+  // exact-fp32 kernels: ~4 blocks per CU in total, >= 8 K-steps per block.  bf16-split kernels: three times as many, shorter
+  // blocks - these kernels run beside the main chain of the step, whose blocks can only move onto a CU when a
+  // weight-gradient block retires (register file): short-lived blocks hand the CUs over within ~0.1 ms
+  const int xtarget = (g_tune >> 20) & 15 ? 256 * ((g_tune >> 20) & 15) : 3072;
+  long sp = cdiv(x6 ? xtarget : 1024, tiles);
+  const long maxsp = x6 ? (M / 128 > 0 ? M / 128 : 1) : (M / 256 > 0 ? M / 256 : 1);
   if (sp > maxsp) sp = maxsp;
   if (sp < 1) sp = 1;
   if (x6 || !(g_tune & 8192)) {                    // XCD-grouped order: (splits x Cout tiles) groups, 8 XCDs -> keep them balanced

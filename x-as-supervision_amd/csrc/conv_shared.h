@@ -174,7 +174,10 @@ __device__ __forceinline__ void bnb_epilogue(const IgemmParams& p, f32x16 (&acc)
 }
 
 // Epilogue shared by the igemm kernels: accumulators -> global memory (+ bias), float4 per four output channels.
-template <int BM, int BN, int MODE, bool BNB = false>
+// HALVES = 2: the LDS staging of the row / statistics epilogue is done in two passes over BN / 2 columns each, so that the
+// staging area is half as large (the bf16-split kernels need 36.9 KB of LDS for their operands; a full 128 x 128 staging
+// tile would double their footprint and halve their residency).
+template <int BM, int BN, int MODE, bool BNB = false, int HALVES = 1>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&acc)[TileCfg<BM, BN>::MI][TileCfg<BM, BN>::NI],
                                                f32x16& acc2, int m0, int n0, int wm, int wn, int lane, int Mrows, int HW,
                                                int Wrow, int ph, int pw, float* lds = nullptr) {
@@ -188,9 +191,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
     return;
   }
   // ---- per-channel sums of the tile for the batch norm that follows (forward only).  The accumulators go through the
-  // (now idle) operand LDS as T[pixel][channel]; after the global stores below, thread t sums column t % BN over the rows
-  // t / BN, t / BN + PARTS, ...  Launcher guarantees: every tile is full in M (rows-per-group % BM == 0), lds != null.
-  constexpr int LDT = BN + 4;
+  // (now idle) operand LDS as T[pixel][channel]; after the global stores below, thread t sums column t % BNH over the rows
+  // t / BNH, t / BNH + PARTS, ...  Launcher guarantees: every tile is full in M (rows-per-group % BM == 0), lds != null.
+  constexpr int BNH = BN / HALVES;
+  constexpr int LDT = BNH + 4;
+  static_assert(HALVES == 1 || (C::WN <= BNH && BNH % 32 == 0), "a wave's columns must fall into one staging half");
   const bool want_stats = MODE == 0 && p.stat_partial != nullptr;
   // Row epilogue (default for full tiles): the tile goes through the idle operand LDS as T[pixel][channel] and is written
   // to memory whole rows at a time - a wave stores 1 KiB of contiguous channels per instruction, old values / sign bytes
@@ -200,19 +205,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
   // barrier (215.3 vs 215.9 ms/step, r02).
   const bool rows_from_lds = lds != nullptr && (p.Cd & 3) == 0 && m0 + BM <= Mrows && n0 + BN <= p.Cd &&
                              !(MODE == 1 && !p.accumulate);
-  if (want_stats || rows_from_lds) {
-    __syncthreads();                                   // every wave has left the K-loop: the operand buffers are free
-    const int pl = lane & 31, cs = 4 * (lane >> 5);
-#pragma unroll
-    for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < C::NI; ++ni)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(lds + (wm * C::WM + mi * 32 + pl) * LDT + wn * C::WN + ni * 32 + 8 * g + cs) =
-              make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
-  }
-  // ---- epilogue.  Accumulator layout (operands swapped): column = lane & 31 = pixel row m of the tile,
+  // ---- register epilogue.  Accumulator layout (operands swapped): column = lane & 31 = pixel row m of the tile,
   // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) = output channel -> registers 4g..4g+3 are four
   // consecutive channels of one pixel: one 16-byte store each, row address computed once per lane.
   const int pix_l = lane & 31, csub = 4 * (lane >> 5);
@@ -272,56 +265,79 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
       }
     }
   }
-  if (want_stats || rows_from_lds) __syncthreads();    // T complete
-  if (rows_from_lds) {
-    constexpr int C4 = BN / 4, RPP = 256 / C4;         // float4 per row, rows per pass of the block
-    const int c4 = threadIdx.x % C4, r0 = threadIdx.x / C4;
-    const int nn = n0 + c4 * 4;
-    float4 bb = make_float4(0, 0, 0, 0);
-    if (MODE == 0 && p.bias) bb = *reinterpret_cast<const float4*>(p.bias + nn);
-#pragma unroll 4
-    for (int r = r0; r < BM; r += RPP) {
-      const int m = m0 + r;
-      size_t orow;
-      if (MODE == 0 || p.stride == 1) orow = (size_t)m;
-      else {
-        const int n = m / HW; const int rem = m - n * HW; const int a = rem / Wrow, b = rem - a * Wrow;
-        orow = ((size_t)n * p.Hd + (ph + p.stride * a)) * p.Wd + (pw + p.stride * b);
-      }
-      float4 v = *reinterpret_cast<const float4*>(lds + r * LDT + c4 * 4);
-      v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-      float* op = p.out + orow * p.Cd + nn;
-      if (p.accumulate) {
-        const float4 o = stream_load(reinterpret_cast<const float4*>(p.accumulate == 2 ? p.acc_src + orow * p.Cd + nn : op));
-        const unsigned mb = p.accumulate == 2 ? p.acc_mask[(orow * p.Cd + nn) >> 2] : 15u;
-        v.x += (mb & 1u) ? o.x : 0.f; v.y += (mb & 2u) ? o.y : 0.f;
-        v.z += (mb & 4u) ? o.z : 0.f; v.w += (mb & 8u) ? o.w : 0.f;
-      }
-      stream_store(reinterpret_cast<float4*>(op), v);
-    }
-  }
-  if (MODE == 0 && want_stats) {
-    constexpr int PARTS = 256 / BN;
-    const int tid = threadIdx.x;
-    const int c = tid % BN, part = tid / BN;
-    const int n = n0 + c;
-    const float pv = (p.stat_pivot && n < p.Cd) ? p.stat_pivot[n] : 0.f;
-    float s = 0.f, q = 0.f;
-#pragma unroll 8
-    for (int r = part; r < BM; r += PARTS) {
-      const float v = lds[r * LDT + c] - pv;
-      s += v; q = fmaf(v, v, q);
-    }
-    float* red = lds + BM * LDT;                       // [PARTS][BN][2]
-    red[(part * BN + c) * 2] = s; red[(part * BN + c) * 2 + 1] = q;
-    __syncthreads();
-    if (part == 0 && n < p.Cd) {
+  if (!(want_stats || rows_from_lds)) return;
+  // ---- staged passes: T[pixel][channel of this half] -> whole rows to memory and / or per-channel sums
 #pragma unroll
-      for (int k = 1; k < PARTS; ++k) { s += red[(k * BN + c) * 2]; q += red[(k * BN + c) * 2 + 1]; }
-      *reinterpret_cast<float2*>(p.stat_partial + ((size_t)(m0 / BM) * p.Cd + n) * 2) = make_float2(s, q);
+  for (int hf = 0; hf < HALVES; ++hf) {
+    __syncthreads();                                   // the operand buffers (first pass) / the previous half's tile are free
+    {
+      const int pl = lane & 31, cs = 4 * (lane >> 5);
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni) {
+          const int cl = wn * C::WN + ni * 32 - hf * BNH;           // first channel of this accumulator inside the half (wave-uniform)
+          if (HALVES == 1 || (cl >= 0 && cl < BNH)) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<float4*>(lds + (wm * C::WM + mi * 32 + pl) * LDT + cl + 8 * g + cs) =
+                  make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
+          }
+        }
+    }
+    __syncthreads();                                   // T complete
+    const int nh0 = n0 + hf * BNH;                     // first global channel of this half
+    if (rows_from_lds) {
+      constexpr int C4 = BNH / 4, RPP = 256 / C4;      // float4 per row, rows per pass of the block
+      const int c4 = threadIdx.x % C4, r0 = threadIdx.x / C4;
+      const int nn = nh0 + c4 * 4;
+      float4 bb = make_float4(0, 0, 0, 0);
+      if (MODE == 0 && p.bias) bb = *reinterpret_cast<const float4*>(p.bias + nn);
+#pragma unroll 4
+      for (int r = r0; r < BM; r += RPP) {
+        const int m = m0 + r;
+        size_t orow;
+        if (MODE == 0 || p.stride == 1) orow = (size_t)m;
+        else {
+          const int n = m / HW; const int rem = m - n * HW; const int a = rem / Wrow, b = rem - a * Wrow;
+          orow = ((size_t)n * p.Hd + (ph + p.stride * a)) * p.Wd + (pw + p.stride * b);
+        }
+        float4 v = *reinterpret_cast<const float4*>(lds + r * LDT + c4 * 4);
+        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        float* op = p.out + orow * p.Cd + nn;
+        if (p.accumulate) {
+          const float4 o = stream_load(reinterpret_cast<const float4*>(p.accumulate == 2 ? p.acc_src + orow * p.Cd + nn : op));
+          const unsigned mb = p.accumulate == 2 ? p.acc_mask[(orow * p.Cd + nn) >> 2] : 15u;
+          v.x += (mb & 1u) ? o.x : 0.f; v.y += (mb & 2u) ? o.y : 0.f;
+          v.z += (mb & 4u) ? o.z : 0.f; v.w += (mb & 8u) ? o.w : 0.f;
+        }
+        stream_store(reinterpret_cast<float4*>(op), v);
+      }
+    }
+    if (MODE == 0 && want_stats) {
+      constexpr int PARTS = 256 / BNH;
+      const int tid = threadIdx.x;
+      const int c = tid % BNH, part = tid / BNH;
+      const int n = nh0 + c;
+      const float pv = (p.stat_pivot && n < p.Cd) ? p.stat_pivot[n] : 0.f;
+      float s = 0.f, q = 0.f;
+#pragma unroll 8
+      for (int r = part; r < BM; r += PARTS) {
+        const float v = lds[r * LDT + c] - pv;
+        s += v; q = fmaf(v, v, q);
+      }
+      float* red = lds + BM * LDT;                       // [PARTS][BNH][2]
+      red[(part * BNH + c) * 2] = s; red[(part * BNH + c) * 2 + 1] = q;
+      __syncthreads();
+      if (part == 0 && n < p.Cd) {
+#pragma unroll
+        for (int k = 1; k < PARTS; ++k) { s += red[(k * BNH + c) * 2]; q += red[(k * BNH + c) * 2 + 1]; }
+        *reinterpret_cast<float2*>(p.stat_partial + ((size_t)(m0 / BM) * p.Cd + n) * 2) = make_float2(s, q);
+      }
     }
   }
 }
+
 
 struct WgradParams {
   const float* x; const float* dy; float* out;      // out: [splits][Cout][KK] slabs

@@ -112,6 +112,9 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
   if (mt >= p.nMt) return;
   const int m0 = mt * BM, n0 = nt * BN;
   if (m0 >= Mrows) return;
+  // These kernels sit on the critical chain of the step; the weight-gradient kernels of the side stream co-reside on the
+  // CUs (footprints are sized for it) and only exist to fill what this chain leaves idle: win the issue arbitration.
+  __builtin_amdgcn_s_setprio(3);
   const int HW = Hrow * Wrow;
   const int cchunks = p.Cs / BK;
   const int nk = nr * ns * cchunks;
@@ -270,20 +273,20 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
       compute(1, gb_1);
     }
   }
-  igemm_epilogue<BM, BN, MODE, BNB>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
+  igemm_epilogue<BM, BN, MODE, BNB, (BN == 128 ? 2 : 1)>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
 }
 
 template <int BM, int BN>
-constexpr size_t igemm_x6_lds(int P) {
+constexpr size_t igemm_x6_lds(int P, bool bnb) {
   size_t a = (size_t)2 * P * BM * XLDH * sizeof(unsigned short);
-  size_t b = ((size_t)BM * (BN + 4) + 2 * 256) * sizeof(float);          // epilogue staging T[BM][BN+4] + partial-combine area
-  size_t c = ((size_t)2 * TileCfg<BM, BN>::WAVES_M * 32 * (BN + 4) + 2 * 256) * sizeof(float);   // bn-backward epilogue staging
+  size_t b = ((size_t)BM * (BN / (BN == 128 ? 2 : 1) + 4) + 2 * 256) * sizeof(float);   // epilogue staging (two halves for BN = 128) + partial-combine area
+  size_t c = bnb ? ((size_t)2 * TileCfg<BM, BN>::WAVES_M * 32 * (BN + 4) + 2 * 256) * sizeof(float) : 0;   // bn-backward epilogue staging
   return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 template <int BM, int BN, int MODE, int P, bool BNB>
 static int launch_igemm_x6_t(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
-  constexpr size_t lds = igemm_x6_lds<BM, BN>(P);
+  constexpr size_t lds = igemm_x6_lds<BM, BN>(P, BNB);
   static bool attr_set_dev[kMaxDevices] = {};
   bool& attr_set = attr_set_dev[current_device()];
   if (!attr_set && lds > 64 * 1024) {
@@ -337,9 +340,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgradParams p) {
   using C = TileCfg<BM, BN>;
   constexpr int SA = XStride<BM>::value, SB = XStride<BN>::value;      // bytes per pixel row of a plane
   constexpr int ASZ = P * XH * SA, BSZ = P * XH * SB, HBUF = ASZ + BSZ; // bytes per half-buffer
-  constexpr int AQ = BM / 4, AROWS = 256 / AQ, APH = XH / AROWS;        // dy: float4 per pixel, pixels per pass, passes per half
+  constexpr int AQ = BM / 4, AROWS = 256 / AQ;                          // dy: float4 per pixel, pixels per pass of the block
+  constexpr int AK = WBK / AROWS;                                       // dy float4 per thread per K-step (BM = 32: 1, 64: 2, 128: 4)
+  constexpr bool AHALF = AK == 1;                                       // one pass covers both halves: a thread's float4 belongs to ONE half
+  constexpr int APH = AHALF ? 1 : AK / 2;                               // dy float4 per thread stored per half-step
+  constexpr int ASET = AHALF ? 1 : 2 * APH;                             // register set size
   constexpr int BPQ = BN / 64;                                          // x: float4 per thread per half (16 threads per pixel)
-  static_assert(APH >= 1 && BPQ >= 1, "tile too small for the staging scheme");
+  static_assert(AK >= 1 && BPQ >= 1, "tile too small for the staging scheme");
   extern __shared__ __align__(16) float lds[];
   unsigned char* S = reinterpret_cast<unsigned char*>(lds);             // [2][ A planes | B planes ]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -363,7 +370,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgradParams p) {
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)((long)mend * p.Cout * 4), 0x00020000);
   const unsigned voffA = (co0 + aq * 4 < p.Cout) ? (unsigned)(apix * p.Cout + co0 + aq * 4) * 4u : kOOB;
   const unsigned passA = (unsigned)(AROWS * p.Cout) * 4u;
-  const unsigned dstA = (unsigned)(apix * SA + aq * 8);
+  const unsigned dstA = (unsigned)((apix & (XH - 1)) * SA + aq * 8);
+  const int ahalf = __builtin_amdgcn_readfirstlane(apix >> 4);          // AHALF: which half-step this wave's dy rows belong to (wave-uniform)
 
   // ---- x operand: thread = (pixel bpix of the half-step, float4 slot bq); 16 threads x BPQ float4 cover the BN columns
   const int bq = tid & 15, bpix = tid >> 4;
@@ -395,11 +403,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgradParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  float4 ra_0[2 * APH], rb_0[2 * BPQ], ra_1[2 * APH], rb_1[2 * BPQ];
-  auto load_k = [&](int mk, float4 (&ra)[2 * APH], float4 (&rb)[2 * BPQ]) {        // mk: first pixel of the K-step (uniform)
+  float4 ra_0[ASET], rb_0[2 * BPQ], ra_1[ASET], rb_1[2 * BPQ];
+  auto load_k = [&](int mk, float4 (&ra)[ASET], float4 (&rb)[2 * BPQ]) {        // mk: first pixel of the K-step (uniform)
     const unsigned soffA = (unsigned)mk * (unsigned)p.Cout * 4u;
 #pragma unroll
-    for (int j = 0; j < 2 * APH; ++j) ra[j] = buf_load16(rsrcA, voffA, soffA + j * passA);     // passes 0..APH-1 = half 0
+    for (int j = 0; j < ASET; ++j) ra[j] = buf_load16(rsrcA, voffA, soffA + j * passA);     // passes 0..APH-1 = half 0
     const int n0 = p.div_hw.div(mk), rem = mk - n0 * HWo;
     const int h0 = p.div_w.div(rem), w0 = rem - h0 * p.Wo;
 #pragma unroll
@@ -420,11 +428,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgradParams p) {
       }
     }
   };
-  auto store_half = [&](int buf, int h, const float4 (&ra)[2 * APH], const float4 (&rb)[2 * BPQ]) {
+  auto store_half = [&](int buf, int h, const float4 (&ra)[ASET], const float4 (&rb)[2 * BPQ]) {
     unsigned char* sb = S + buf * HBUF;
 #pragma unroll
     for (int j = 0; j < APH; ++j) {
-      float4 r = ra[h * APH + j];
+      if (AHALF && ahalf != h) continue;               // (wave-uniform) this wave's dy rows belong to the other half
+      float4 r = ra[AHALF ? 0 : h * APH + j];
 #pragma unroll
       for (int pc = 0; pc < P; ++pc) {
         const uint2 q = pack_bf16x4(r);
@@ -543,11 +552,13 @@ static int launch_wgrad_x6_t(const WgradParams& p, int splits, hipStream_t st) {
 
 // tile of the bf16-split weight gradient: BM over Cout, BN over KK = R*S*Cin
 void wgrad_x6_tile(int Cout, long KK, int* bm, int* bn) {
-  *bm = Cout >= 96 ? 128 : 64;
+  *bm = Cout >= 96 ? 128 : (Cout > 32 ? 64 : 32);
   *bn = KK <= 64 ? 64 : 128;
+  if (*bm == 32) *bn = 128;
 }
 
 int launch_wgrad_x6(const WgradParams& p, int bm, int bn, int splits, int pieces, hipStream_t st) {
+  if (bm == 32) return pieces == 3 ? launch_wgrad_x6_t<32, 128, 3>(p, splits, st) : launch_wgrad_x6_t<32, 128, 1>(p, splits, st);
   if (pieces == 3) {
     if (bm == 128) return bn == 128 ? launch_wgrad_x6_t<128, 128, 3>(p, splits, st) : launch_wgrad_x6_t<128, 64, 3>(p, splits, st);
     return bn == 128 ? launch_wgrad_x6_t<64, 128, 3>(p, splits, st) : launch_wgrad_x6_t<64, 64, 3>(p, splits, st);

@@ -14,7 +14,7 @@ import torch
 from modules.base_losses.loss_func import (compute_disc_loss, compute_mask_reconstruction_loss,
                                            compute_supervision_min, compute_symmetry_min)
 from modules.util import convert_patch_to_world, draw_lines_max, random_rotation_3D
-from xas_amd import ops_nn
+from xas_amd import ops_nn, streams
 
 
 def cal_links(parent_ids, line_select_ids=None, use_root=False, extension=True):
@@ -107,42 +107,54 @@ class Counter3DModel(torch.nn.Module):
         if self.physique_network is not None:
             ops_nn.prepack(self.physique_network)
         keys = ['cam_{}'.format(c) for c in cams]
-        # detector on the real image of every camera (model.py:64); call order = camera order fixes the order of the
-        # batch-norm running-statistic updates
-        # the pseudo images of every camera join the same pass (XAS_CAM_BATCH_PSEUDO=0: a pass of their own); real cameras first:
-        # the order of the reference's detector calls.  231.3 -> 227.0 ms per step at B = 32 x 4 cameras
-        fuse_pseudo = pseudo and JOIN_PSEUDO and CAM_BATCH and 'smpl_pseudo_img_loss' in lc
-        imgs = [x[k + '_img'] for k in keys] + ([x[k + '_pseudo_img'] for k in keys] if fuse_pseudo else [])
-        dets = _grouped(self.regressor, imgs)
-        pseudo_dets = dets[len(keys):] if fuse_pseudo else None
+        want_pseudo = pseudo and 'smpl_pseudo_img_loss' in lc
+        # Two chains (xas_amd/streams.py: chains, default): the real-image pass (detector, geometry, mask renderer, physique
+        # net, mask losses) and the pseudo-image pass are independent until the losses are summed; each runs on its own
+        # stream, forward and backward, so the batch norms (HBM) of one fill the convolution (matrix pipe) time of the other.
+        # XAS_CHAINS=1: one stream, and the pseudo images of every camera join the real images' detector pass
+        # (XAS_CAM_BATCH_PSEUDO=0: a pass of their own).  Real cameras first either way: the order of the reference's
+        # detector calls, which fixes the order of the batch-norm running-statistic updates.
+        two_chains = want_pseudo and streams.CHAINS > 1 and CAM_BATCH and x[keys[0] + '_img'].is_cuda
+        fuse_pseudo = want_pseudo and JOIN_PSEUDO and CAM_BATCH and not two_chains
         per_cam = {}
-        for cam, key, (kps, depth_map) in zip(cams, keys, dets):
-            assert kps.dim() == 4, "use aligned multi-hypothesis settings"
-            # (slices, not the reference's `[[0]]` lists: a list index is an index TENSOR that torch uploads with a blocking
-            # copy - 46 pipeline drains per step; the values are the same)
-            out['pose_2d_pred_{}_ori'.format(key)] = kps[0:1, 0].detach().clone()
-            out['depth_map_{}'.format(key)] = depth_map
-            world = _to_world(kps, x, key, cam == 'mono')                  # [B, Hy, K, 3], one launch
-            out['pose_3d_depth_{}'.format(key)] = world[:, 0].detach().clone()
-            # multi-hypothesis only changes z, so one mask per camera (hypothesis 0's x, y)
-            recon = draw_lines_max(kps[:, 0, :, :2], x[key + '_img'].shape[-1], self.parent_ids, self.child_ids,
-                                   self.body_width)
-            out['mask_heatmap_line_{}'.format(key)] = recon.detach()
-            per_cam[key] = dict(kps=kps, world=world, recon=recon)
-        if 'physique_recons_loss' in lc and self.physique_network is not None:
-            use_w = lc['physique_recons_loss']['use_dis_map']
-            for key, phys in zip(keys, _grouped(self.physique_network, [per_cam[k]['recon'] for k in keys])):
-                out['mask_physique_{}'.format(key)] = phys[0:1].detach()
-                per_cam[key]['phys'] = compute_mask_reconstruction_loss(
-                    phys, x[key + '_mask'], weight=x[key + '_geodesic_dis'] if use_w else None)
-        if 'recons_loss' in lc:
-            use_w = lc['recons_loss']['use_dis_map']
-            for key in keys:
-                per_cam[key]['recons'] = compute_mask_reconstruction_loss(
-                    per_cam[key]['recon'], x[key + '_mask'], weight=x[key + '_geodesic_dis'] if use_w else None,
-                    use_clip=True)
-        if pseudo:
-            self.pseudo_passes(x, per_cam, out, pseudo_dets)
+        with streams.chains(2 if two_chains else 1) as ch:
+            with ch.run(0):
+                imgs = [x[k + '_img'] for k in keys] + ([x[k + '_pseudo_img'] for k in keys] if fuse_pseudo else [])
+                dets = _grouped(self.regressor, imgs)
+                pseudo_dets = dets[len(keys):] if fuse_pseudo else None
+                for cam, key, (kps, depth_map) in zip(cams, keys, dets):
+                    assert kps.dim() == 4, "use aligned multi-hypothesis settings"
+                    # (slices, not the reference's `[[0]]` lists: a list index is an index TENSOR that torch uploads with a
+                    # blocking copy - 46 pipeline drains per step; the values are the same)
+                    out['pose_2d_pred_{}_ori'.format(key)] = kps[0:1, 0].detach().clone()
+                    out['depth_map_{}'.format(key)] = depth_map
+                    world = _to_world(kps, x, key, cam == 'mono')                  # [B, Hy, K, 3], one launch
+                    out['pose_3d_depth_{}'.format(key)] = world[:, 0].detach().clone()
+                    # multi-hypothesis only changes z, so one mask per camera (hypothesis 0's x, y)
+                    recon = draw_lines_max(kps[:, 0, :, :2], x[key + '_img'].shape[-1], self.parent_ids, self.child_ids,
+                                           self.body_width)
+                    out['mask_heatmap_line_{}'.format(key)] = recon.detach()
+                    per_cam[key] = dict(kps=kps, world=world, recon=recon)
+                if 'physique_recons_loss' in lc and self.physique_network is not None:
+                    use_w = lc['physique_recons_loss']['use_dis_map']
+                    for key, phys in zip(keys, _grouped(self.physique_network, [per_cam[k]['recon'] for k in keys])):
+                        out['mask_physique_{}'.format(key)] = phys[0:1].detach()
+                        per_cam[key]['phys'] = compute_mask_reconstruction_loss(
+                            phys, x[key + '_mask'], weight=x[key + '_geodesic_dis'] if use_w else None)
+                if 'recons_loss' in lc:
+                    use_w = lc['recons_loss']['use_dis_map']
+                    for key in keys:
+                        per_cam[key]['recons'] = compute_mask_reconstruction_loss(
+                            per_cam[key]['recon'], x[key + '_mask'], weight=x[key + '_geodesic_dis'] if use_w else None,
+                            use_clip=True)
+                if pseudo and not two_chains:
+                    self.pseudo_passes(x, per_cam, out, pseudo_dets)
+            if two_chains:
+                with ch.run(1):
+                    self.pseudo_passes(x, per_cam, out, None)
+            for d in per_cam.values():                       # consumed by `finish` on the entering stream
+                ch.to_main(*d.values())
+            ch.to_main(*out.values())
         return per_cam, out
 
     def pseudo_passes(self, x, per_cam, out, dets=None):

@@ -115,10 +115,18 @@ class GradReducer:
             ev = torch.cuda.Event()
             ev.record()                                   # gradients of this bucket are complete on the compute stream
             ev_side = ops_nn.side_stream_event()          # ... and on the weight-gradient stream
+            from . import streams as _streams
+            ev_chain = []                                 # ... and on every pass chain of this step (streams.chains)
+            for cs in _streams.chain_streams_in_use():
+                e = torch.cuda.Event()
+                e.record(cs)
+                ev_chain.append(e)
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
                 if ev_side is not None:
                     self.stream.wait_event(ev_side)
+                for e in ev_chain:
+                    self.stream.wait_event(e)
                 work = dist.all_reduce(view, group=self.group, async_op=True)
         else:
             work = dist.all_reduce(view, group=self.group, async_op=True)

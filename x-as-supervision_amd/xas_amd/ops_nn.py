@@ -69,17 +69,22 @@ def _keep_for_side(*tensors):
     ev = torch.cuda.Event()
     ev.record(_side['stream'])
     q = _side.setdefault('keep', [])
-    q.append((ev, tensors))
+    q.append((ev, tensors, torch.cuda.current_stream()))      # the stream the tensors were produced (and allocated) on
     if len(q) > _KEEP_DEPTH:
-        old_ev, _ = q.pop(0)
-        torch.cuda.current_stream().wait_event(old_ev)
+        old_ev, _, owner = q.pop(0)
+        owner.wait_event(old_ev)
 
 
 def join_side_stream():
-    """Make the current stream wait for every weight gradient launched on the side stream."""
+    """Make the current stream wait for every weight gradient launched on the side stream, and for the pass chains of the
+    step (streams.chains: their backward kernels add norm-parameter gradients to the arena on their own streams)."""
+    cur = torch.cuda.current_stream()
     if _side['dirty'] and _side['stream'] is not None:
-        torch.cuda.current_stream().wait_stream(_side['stream'])
+        cur.wait_stream(_side['stream'])
         _side['dirty'] = False
+    for s in streams.chain_streams_in_use():
+        cur.wait_stream(s)
+    streams.reset_chain_use()
     if _side.get('keep'):
         _side['keep'] = []
 
@@ -352,7 +357,7 @@ def _conv_bn_forward(x, conv, bn, residual, group):
     statistics come out of the convolution's epilogue (xas_conv_fwd_bnstats): the conv result is not read a second time
     for them."""
     weight = conv.weight
-    if not (FUSE_CONV_STATS and bn.training) or streams.forked():
+    if not (FUSE_CONV_STATS and bn.training):
         y, shp = _conv_forward(x, weight, conv.stride, conv.padding, conv._cache)
         out, sv, cf = _bn_forward(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, bn.training,
                                   bn.momentum, bn.eps, bn.act, group)
@@ -712,9 +717,20 @@ def _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, m
             dist.all_gather_into_tensor(gathered, msg.view(-1), group=group)
             mean = torch.empty(G, c, device=dev, dtype=torch.float32)
             var = torch.empty(G, c, device=dev, dtype=torch.float32)
-            call('xas_bn_sync_merge', ptr(gathered), world, G, c, stride, ptr(mean), ptr(var),
-                 ptr(running_mean), ptr(running_var), float(momentum))
             count = float(Mg) * world                          # equal per-rank batches (train.py:274)
+            if streams.forked() and running_mean is not None:
+                # concurrent chains: the order-dependent running-statistic update goes to the bookkeeping stream
+                call('xas_bn_sync_merge', ptr(gathered), world, G, c, stride, ptr(mean), ptr(var), None, None, float(momentum))
+                book, cur = streams.book_stream(), torch.cuda.current_stream()
+                book.wait_stream(cur)
+                with torch.cuda.stream(book):
+                    call('xas_bn_update_running', ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
+                         float(momentum), int(count), c, G)
+                mean.record_stream(book)
+                var.record_stream(book)
+            else:
+                call('xas_bn_sync_merge', ptr(gathered), world, G, c, stride, ptr(mean), ptr(var),
+                     ptr(running_mean), ptr(running_var), float(momentum))
         if bn_log['on'] and running_mean is not None:
             bn_log['calls'].append((mean, var, running_mean, running_var, momentum, count, G))
     else:
@@ -888,11 +904,23 @@ def sigmoid(x):
 
 
 def prepack(module):
-    """Build the packed weight copies of every conv under `module` on the CURRENT stream (called on the main
-    stream before camera streams fork, so no two streams race to fill a cache)."""
+    """Build the kernel-side weight copies of every conv under `module` on the CURRENT stream - packed fp32 and, in the
+    bf16 modes, the pre-split planes - before streams fork (cameras / chains), so no two streams race to fill a cache and
+    every stream finds the copies complete.  The format only depends on the filter geometry and the precision, not on the
+    activation size: a small dummy shape asks the library."""
     for m in module.modules():
         cache = getattr(m, '_cache', None)
         w = getattr(m, 'weight', None)
         if isinstance(cache, _PackCache) and w is not None and w.dim() == 4 and w.is_cuda:
-            cache.get(w, 0)
-            cache.get(w, 1)
+            a, b, r, s = w.shape
+            stride, pad = int(getattr(m, 'stride', 1)), int(getattr(m, 'padding', 0))
+            if type(m).__name__ == 'ConvTranspose2d':          # weight [Cin_t, Cout_t, R, S]: the equivalent conv is Cout_t -> Cin_t
+                hs = 8
+                hb = (hs - 1) * stride - 2 * pad + r
+                shp = _shape(1, hb, hb, b, a, r, s, stride, pad, hs, hs)
+            else:
+                hi = 16
+                ho = (hi + 2 * pad - r) // stride + 1
+                shp = _shape(1, hi, hi, b, a, r, s, stride, pad, ho, ho)
+            cache.get(w, 0, shp)
+            cache.get(w, 1, shp)

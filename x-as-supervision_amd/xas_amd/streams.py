@@ -100,3 +100,86 @@ def to_main(*tensors):
     for t in tensors:
         if t is not None and t.is_cuda:
             t.record_stream(main)
+
+
+# ---- pass-level chains (round 3) -------------------------------------------------------------------------------------
+# With the bf16-split convolution kernels the step is no longer bound by the matrix pipe alone: on ONE stream the chain of a
+# pass is conv (matrix pipe) -> batch norm (HBM) -> conv -> ..., each kernel waiting for the one before, so the matrix pipe
+# idles during the norms and HBM during the convolutions (r03 timeline: main stream 156 ms busy = 87 conv + 48 norm + 21
+# other).  The generator step has two INDEPENDENT detector passes - the real images of all cameras (followed by geometry,
+# mask renderer, physique net) and the pseudo images - and autograd replays a node on the stream it was recorded on: each
+# runs as its own chain on its own stream, forward and backward, and the norms of one chain fill the matrix-pipe time of
+# the other.  Order-dependent state stays deterministic exactly as for camera streams: running statistics and batch
+# counters are updated on the bookkeeping stream in host program order (real pass first, as the reference's call order);
+# weight gradients of both chains go to the ONE side stream in host order; parameter gradients of the norms are added with
+# hardware atomics (one contribution per chain from a zeroed arena: order-independent bit for bit).
+# MEASURED (r03, MI355X, HM36_Multi_SurS1 B = 32): XAS_CHAINS=2 166.0 / 166.3 ms per step against 159.9 on one stream.  The
+# kernels of two chains do run side by side (per-launch durations of the forward convolutions grow from 23.9 to 40.4 ms per
+# step in total), but the sum does not shrink: at bf16x6 speed the convolution kernels are themselves within reach of the
+# HBM bound (~500 GB of traffic per step = ~100 ms at 5 TB/s against ~90 ms of matrix-pipe time), so a norm running beside a
+# convolution takes its bandwidth rather than idle time.  Default 1; the mode stays tested (tests/test_gpu_groups.py).
+CHAINS = max(1, int(os.environ.get('XAS_CHAINS', '1')))
+_chain = []
+_chain_used = []
+
+
+def chain_stream(i):
+    while len(_chain) <= i:
+        _chain.append(torch.cuda.Stream())
+    return _chain[i]
+
+
+def chain_streams_in_use():
+    """Streams that carried backward-relevant work of the current step (the data-parallel reducer waits on all of them)."""
+    return list(_chain_used)
+
+
+def reset_chain_use():
+    del _chain_used[:]
+
+
+class chains:
+    """Context: `run(i)` gives the stream context of chain i (the current stream when chains are off); on exit the
+    entering stream waits for every chain and for the bookkeeping stream."""
+
+    def __init__(self, num=None):
+        self.num = CHAINS if num is None else num
+        if not torch.cuda.is_available():
+            self.num = 1
+
+    def __enter__(self):
+        self.main = torch.cuda.current_stream()
+        self.was = _active[0]
+        self.used = []
+        if self.num > 1:
+            _active[0] = True
+            _main[0] = self.main
+            book_stream().wait_stream(self.main)
+        return self
+
+    def run(self, i):
+        if self.num <= 1:
+            return torch.cuda.stream(self.main)
+        s = chain_stream(i % self.num)
+        s.wait_stream(self.main)
+        if s not in self.used:
+            self.used.append(s)
+        if s not in _chain_used:
+            _chain_used.append(s)
+        return torch.cuda.stream(s)
+
+    def to_main(self, *tensors):
+        """Tensors produced on a chain and consumed on the entering stream: tell the caching allocator."""
+        if self.num <= 1:
+            return
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(self.main)
+
+    def __exit__(self, *exc):
+        if self.num > 1:
+            for s in self.used:
+                self.main.wait_stream(s)
+            self.main.wait_stream(book_stream())
+            _active[0] = self.was
+            _main[0] = None
