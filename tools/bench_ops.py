@@ -109,27 +109,4 @@ if __name__ == '__main__' and 'thin' in sys.argv[1:]:
     thin_fwd_cases()
 
 
-def precision_cases():
-    """One long-K and one short-K layer in the three precision modes (forward)."""
-    from xas_amd import ops_nn as F
-    from xas_amd._lib import query
-    dev = 'cuda'
-    for (n, cin, h, cout, k) in [(256, 256, 16, 256, 3), (256, 64, 64, 64, 3), (256, 1024, 16, 256, 1), (256, 64, 64, 256, 1)]:
-        x = torch.randn(n, h, h, cin, device=dev)
-        w = torch.randn(cout, k, k, cin, device=dev) * 0.05
-        y = torch.empty(n, h, h, cout, device=dev)
-        shp = F._shape(n, h, h, cin, cout, k, k, 1, k // 2, h, h)
-        fl = 2.0 * n * h * h * cin * cout * k * k
-        line = '%-28s' % str((n, cin, h, cout, k))
-        for mode, name in ((0, 'fp32'), (2, 'bf16x6'), (102, 'x6/128x64'), (1, 'bf16')):
-            query('xas_set_tuning', (1 << 26) if mode == 102 else 0)
-            mode = 2 if mode == 102 else mode
-            query('xas_set_precision', mode)
-            t = timed(lambda: call('xas_conv_fwd', ptr(x), ptr(w), None, ptr(y), shp))
-            line += '  %s %.3f ms %.0f TF' % (name, t * 1e3, fl / t / 1e12)
-        query('xas_set_precision', 0)
-        print(line)
-
-
-if __name__ == '__main__' and 'prec' in sys.argv[1:]:
-    precision_cases()
+# (per-shape timings in the three precision modes: tools/bench_conv.py)

@@ -27,5 +27,5 @@ for (n, cin, h, cout, k, stride, pad) in [(4, 64, 32, 256, 1, 1, 0), (4, 256, 32
         _lib.query('xas_set_precision', mode)
         with torch.no_grad():
             errs.append(rel(m(x.cuda()), exact))
-    _lib.query('xas_set_precision', 0)
+    _lib.query('xas_set_precision', 2)           # library default
     print('K = %5d  %s   fp32 MFMA %.2e   bf16x6 %.2e   bf16 %.2e' % (cin * k * k, (n, cin, h, cout, k, stride), *errs))

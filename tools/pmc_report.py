@@ -17,7 +17,7 @@ import re
 import sys
 
 SIMDS = 256 * 4
-CONV = ('igemm_kernel', 'igemm_buf_kernel', 'wgrad_kernel', 'wgrad_buf_kernel', 'stem_fwd_kernel')
+CONV = ('igemm_kernel', 'igemm_buf_kernel', 'wgrad_kernel', 'wgrad_buf_kernel', 'stem_fwd_kernel', 'igemm_x6_kernel', 'wgrad_x6_kernel')
 
 
 def short(name):
@@ -49,6 +49,9 @@ def load(dirname):
 def main():
     root, out_md = sys.argv[1], sys.argv[2]
     out_json = sys.argv[3] if len(sys.argv) > 3 else None
+    rnd = sys.argv[4] if len(sys.argv) > 4 else 'r03'
+    precision = sys.argv[5] if len(sys.argv) > 5 else 'bf16x6'
+    collected = sys.argv[6] if len(sys.argv) > 6 else ''
     mv, mn, md = load(os.path.join(root, 'mfma'))
     fv, fn_, _ = load(os.path.join(root, 'fetch'))
     wv, wn, _ = load(os.path.join(root, 'write'))
@@ -58,9 +61,12 @@ def main():
         g = v.get('GRBM_GUI_ACTIVE', 0.0)
         return 100.0 * v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (g / 8.0 * SIMDS) if g else 0.0
 
-    lines = ['# r02 - counter-based MFMA utilisation and HBM traffic per kernel (tools/pmc_report.py)', '',
-             'Source: three `rocprofv3 --pmc ... --kernel-trace` passes of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline`',
+    lines = ['# %s - counter-based MFMA utilisation and HBM traffic per kernel (tools/pmc_report.py), precision %s' % (rnd, precision), '',
+             'Source: three `rocprofv3 --pmc ... --kernel-trace` passes of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --f32-steps 0`',
              '(3 steps incl. warm-up and the serial step, B = 32 x 4 cameras per pass), collected by `tools/gpu/pmc.sh`.',
+             'MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs): the fraction of the cycles the kernel runs in which the',
+             'matrix pipe executes (a bf16x6 kernel at 100 % would deliver 419.5 TFLOP/s fp32-equivalent AT THE 2.4 GHz peak clock; the',
+             'clock under these kernels is 1.7-2.0 GHz, clk column = GRBM_GUI_ACTIVE / 8 / duration).',
              'Kernels are serialised under counter collection, so durations here are NOT the overlapped step timings.', '']
     if pv:
         lines.append('Calibration, register-only `v_mfma_f32_32x32x2_f32` loop (`tools/micro/mfma_peak`), same counters:')
@@ -68,15 +74,15 @@ def main():
             lines.append('* `%s`: MFMA busy %.1f %% (%d launches)' % (k, util(v), pn[k]))
         lines.append('')
     tot = sum(md.values()) or 1.0
-    lines += ['| kernel | launches | time share | avg us | MFMA busy % | MFMA F32 MOPS/launch | HBM MB/launch (2xFETCH+WRITE) |', '|---|---|---|---|---|---|---|']
+    lines += ['| kernel | launches | time share | avg us | MFMA busy % | clk GHz | HBM MB/launch (2xFETCH+WRITE) |', '|---|---|---|---|---|---|---|']
     conv_bytes, conv_launch, conv_busy, conv_gui = 0.0, 0, 0.0, 0.0
     for k in sorted(md, key=lambda k: -md[k])[:40]:
         n = mn[k]
         fb = 2 * fv.get(k, {}).get('FETCH_SIZE', 0.0) * 1024
         wb = wv.get(k, {}).get('WRITE_SIZE', 0.0) * 1024
         nn = max(1, fn_.get(k, n))
-        lines.append('| `%s` | %d | %.1f %% | %.1f | %.1f | %.3g | %.1f |' % (
-            k, n, 100 * md[k] / tot, md[k] / n / 1e3, util(mv[k]), mv[k].get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0.0) / n, (fb + wb) / nn / 1e6))
+        lines.append('| `%s` | %d | %.1f %% | %.1f | %.1f | %.2f | %.1f |' % (
+            k, n, 100 * md[k] / tot, md[k] / n / 1e3, util(mv[k]), mv[k].get('GRBM_GUI_ACTIVE', 0.0) / 8.0 / max(1.0, md[k]), (fb + wb) / nn / 1e6))
     for k in md:
         if any(c in k for c in CONV):
             conv_bytes += 2 * fv.get(k, {}).get('FETCH_SIZE', 0.0) * 1024 + wv.get(k, {}).get('WRITE_SIZE', 0.0) * 1024
@@ -94,6 +100,7 @@ def main():
             json.dump({'what': 'HBM bytes per conv-family launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from separate rocprofv3 '
                                '--pmc passes of bench.py --steps 1 --warmup 1 (camera-batched step, B=32 x 4 cameras); mfma_busy_pct = '
                                'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs) over the same launches',
+                       'precision': precision, 'collected': collected,
                        'launches': conv_launch, 'bytes_per_launch': conv_bytes / max(1, conv_launch), 'mfma_busy_pct': conv_util}, f, indent=1)
 
 

@@ -11,11 +11,16 @@ every member's gradient of this step is complete:
   * conv weights (weight-gradient side stream) and batch-norm parameters (reduce kernel) are ALSO reported by ops_nn,
     which counts their forward uses and reports a parameter when its last backward contribution of the step has been
     launched (ops_nn.grad_ready): this does not rely on the hook behaviour for gradient-less returns.
-The communication stream waits for an event on the compute stream AND one on the weight-gradient stream, so the
-collective overlaps the rest of backward.  How much overlaps is limited by the step itself: every detector
-parameter receives contributions from each detector backward pass, so a bucket is complete only inside the LAST
-pass.  xGMI is point-to-point (7 links x ~153 GB/s): a handful of large messages beats many small ones, so the
-default is 4 buckets of ~35 MB for the 139 MB generator arena.  `finish()` joins the weight-gradient stream,
+The communication stream waits for an event on the compute stream AND one on the weight-gradient stream (and on the pass
+chains of streams.chains when they are on), so the collective overlaps the rest of backward.  Since the real and the pseudo
+images of all cameras run as ONE camera-batched detector pass (modules/model.py), every detector parameter receives exactly
+one contribution per generator step, and the buckets complete progressively from the tail of the arena (head, layer4, ...)
+while backward walks towards the stem: only the LAST bucket (stem + layer1-2 side of the arena) is exposed after backward
+ends.  Tail estimate on one 8-GPU node: 35 MB per bucket; ring all-reduce over xGMI moves 2 * 7/8 * 35 MB = 61 MB per GPU
+over one ~153 GB/s link at a time -> ~0.4 ms (a direct reduce-scatter + all-gather over all seven links: ~0.06 ms), against
+~100 ms of backward that the three earlier buckets (104 MB) hide behind.  xGMI is point-to-point (7 links x ~153 GB/s): a
+handful of large messages beats many small ones, so the default is 4 buckets of ~35 MB for the 139 MB generator arena.
+`finish()` joins the weight-gradient stream,
 launches whatever is left, waits, and divides by world size (mean) before the optimizer step.
 
 Works with any torch.distributed backend: `nccl` (= RCCL on ROCm) on GPUs, `gloo` in the CPU tests.
