@@ -11,16 +11,9 @@ import torch
 
 from xas_amd import _lib
 from xas_amd._lib import ConvShape, call, ptr, query
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bench_conv_shapes import SHAPES, images_for
 
-SHAPES = [  # Hi, Wi, Cin, Cout, R, stride, pad
-    (64, 64, 64, 64, 1, 1, 0), (64, 64, 64, 64, 3, 1, 1), (64, 64, 64, 256, 1, 1, 0),
-    (64, 64, 256, 64, 1, 1, 0), (64, 64, 256, 128, 1, 1, 0), (64, 64, 128, 128, 3, 2, 1),
-    (32, 32, 128, 512, 1, 1, 0), (32, 32, 512, 128, 1, 1, 0), (32, 32, 128, 128, 3, 1, 1),
-    (32, 32, 256, 256, 3, 2, 1), (16, 16, 256, 1024, 1, 1, 0), (16, 16, 1024, 256, 1, 1, 0),
-    (16, 16, 256, 256, 3, 1, 1), (16, 16, 512, 512, 3, 2, 1), (8, 8, 512, 2048, 1, 1, 0),
-    (8, 8, 2048, 512, 1, 1, 0), (8, 8, 512, 512, 3, 1, 1), (64, 64, 256, 1152, 1, 1, 0),
-    (128, 128, 64, 64, 3, 1, 1), (256, 256, 32, 32, 3, 1, 1), (256, 256, 64, 32, 3, 1, 1),
-]
 
 
 def weights_for(shp, w, transposed):
@@ -43,13 +36,11 @@ def main():
     dev = torch.device('cuda')
     query('xas_set_tuning', int(os.environ.get('XAS_TUNE', '0')))
     tot = {}
+    once = os.environ.get('XAS_ONCE') == '1'      # counter passes: every entry point exactly once per shape
     sel = os.environ.get('XAS_SHAPES')
     shapes = [SHAPES[int(i)] for i in sel.split(',')] if sel else SHAPES
     for (hi, wi, ci, co, r, st, pad) in shapes:
-        if n * hi * wi * max(ci, co) * 4 >= 2**31 - 2**24:
-            nn = max(1, int((2**31 - 2**24) // (hi * wi * max(ci, co) * 4)))
-        else:
-            nn = n
+        nn = images_for(n, (hi, wi, ci, co, r, st, pad))
         ho, wo = (hi + 2 * pad - r) // st + 1, (wi + 2 * pad - r) // st + 1
         x = torch.randn(nn * hi * wi * ci, device=dev)
         dy = torch.randn(nn * ho * wo * co, device=dev)
@@ -72,6 +63,8 @@ def main():
                 if which not in ('all', k):
                     continue
                 fn()
+                if once:
+                    continue
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 for _ in range(reps):

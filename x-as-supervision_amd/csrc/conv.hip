@@ -1733,7 +1733,8 @@ static void wgrad_plan(const xas_conv_shape* s, bool x6, int* bm, int* bn, int* 
   const long maxsp = x6 ? (M / 128 > 0 ? M / 128 : 1) : (M / 256 > 0 ? M / 256 : 1);
   if (sp > maxsp) sp = maxsp;
   if (sp < 1) sp = 1;
-  if (x6 || !(g_tune & 8192)) {                    // XCD-grouped order: (splits x Cout tiles) groups, 8 XCDs -> keep them balanced
+  if (x6 && sp >= 8) sp -= sp % 8;                 // bf16-split kernel: whole pixel splits per XCD (wgrad_x6_kernel)
+  else if (x6 || !(g_tune & 8192)) {               // XCD-grouped order: (splits x Cout tiles) groups, 8 XCDs -> keep them balanced
     const long nct = cdiv(s->Cout, *bm);
     while (sp > 1 && (sp * nct) % 8 != 0 && (sp * nct) > 8) --sp;
   }

@@ -39,6 +39,7 @@ struct IgemmParams {
   int Hrow, Wrow;          // row grid (fwd: Ho x Wo; dgrad: per-phase grid, set in kernel)
   int tune;                // kernel-variant selectors kept for coverage tests (xas_set_tuning): bit5 plain K-loop, bit6 global-load kernel
   int nMt, nNt, mt_per_xcd;   // tile counts and M-tiles per XCD for the XCD-aware block order
+  int xn, nt_per_x;           // bf16-split kernels: the 8 XCDs form an (8 / xn) x xn grid over (M-tiles, N-tiles); xn = 1: every XCD owns all N-tiles of its M-tiles
   long src_elems, wgt_elems;  // sizes of src / wgt (buffer-load kernel: range of the buffer descriptors)
   int accumulate;             // epilogue: 1: out += result (residual gradient already in the buffer);
                               //           2: out = result + relu'(mask) * acc_src (the skip gradient is formed here from

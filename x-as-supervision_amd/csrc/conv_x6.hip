@@ -28,8 +28,16 @@ namespace xas {
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
 
+#ifndef XAS_X6_ABL
+#define XAS_X6_ABL 0               // timing ablations of igemm_x6_kernel (results wrong): tools/gpu/r3_abl3.sh
+#endif
 constexpr int XH = 16;             // k per half-step
-constexpr int XLDH = XH + 8;       // igemm LDS row in halfwords (48 B): ds_read_b128 of 16 lanes x 48 B hits 64 distinct banks
+constexpr int XLDH = XH;           // igemm LDS row in halfwords: 32 B, unpadded.  The two 16-byte halves of rows 8..15 (mod 16) are
+                                   // swapped (xswz): the 8-byte stores of a half-wave (8 rows x 32 B) and the 16-byte fragment reads
+                                   // of 16 lanes (16 rows x 16 B) each cover the 64 banks exactly once.  (Rows padded to 48 B read
+                                   // conflict-free too but their stores collided two-way on half the banks: PMC 0.4 conflict cycles
+                                   // per LDS instruction.)
+__device__ __forceinline__ int xswz(int row, int half) { return (half ^ ((row >> 3) & 1)) << 3; }   // halfword offset of a 16-byte half
 
 // the six kept partial products, smallest first: (a piece, b piece)
 __device__ constexpr int kPA[6] = {2, 0, 1, 1, 0, 0};
@@ -106,10 +114,15 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
     rstep = st; sa = 1;
   }
   const int Mrows = p.N * Hrow * Wrow;
-  const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;          // XCD-aware tile order (see igemm_kernel in conv.hip)
-  const int mt = xcd * p.mt_per_xcd + qb / p.nNt;
-  const int nt = qb - (qb / p.nNt) * p.nNt;
-  if (mt >= p.nMt) return;
+  // XCD-aware tile order: consecutive block ids go round the 8 XCDs; XCD (xi, xj) of the (8 / xn) x xn grid owns a
+  // contiguous range of M-tiles and of N-tiles, the N-tiles of one M-tile adjacent in its queue (they share the
+  // activation rows in that XCD's L2); launch_igemm_x6_t picks xn so that the weight slice of an XCD stays L2-resident
+  const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+  const int xi = xcd / p.xn, xj = xcd - xi * p.xn;
+  const int ml = qb / p.nt_per_x;
+  const int mt = xi * p.mt_per_xcd + ml;
+  const int nt = xj * p.nt_per_x + (qb - ml * p.nt_per_x);
+  if (mt >= p.nMt || nt >= p.nNt) return;
   const int m0 = mt * BM, n0 = nt * BN;
   if (m0 >= Mrows) return;
   // These kernels sit on the critical chain of the step; the weight-gradient kernels of the side stream co-reside on the
@@ -175,9 +188,12 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
   auto advance = [&](Cur& c) {
     const bool more = c.left > 1;
     c.left -= more ? 1 : 0;
-    int ch = c.chunk + 1, s2 = c.js, r = c.jr;
-    if (ch == cchunks) { ch = 0; ++s2; }
+    // taps innermost, channel chunks outermost: the nine taps of a 3x3 filter re-read the same 128-byte lines of the
+    // block's pixels in CONSECUTIVE K-steps (L2 hits); with the chunks innermost the re-use distance was a whole channel
+    // sweep of every resident block, beyond the 4 MB L2 of an XCD (PMC: 4.1x -> the algorithmic bytes on 128x32x32x128)
+    int s2 = c.js + 1, r = c.jr, ch = c.chunk;
     if (s2 == ns) { s2 = 0; ++r; }
+    if (r == nr) { r = 0; ++ch; }
     c.chunk = more ? ch : c.chunk; c.js = more ? s2 : c.js; c.jr = more ? r : c.jr;
   };
   float4 ra_0[2 * AP], ra_1[2 * AP];
@@ -212,21 +228,42 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
       float4 r = ra[h * AP + j];
 #pragma unroll
       for (int pc = 0; pc < P; ++pc) {
-        const uint2 q = pack_bf16x4(r);
-        *reinterpret_cast<uint2*>(sb + pc * PLANE + (arow + 64 * j) * XLDH + kq4 * 4) = q;
-        if (pc + 1 < P) r = sub_bf16x4(r, q);
+        uint2 q = (XAS_X6_ABL & 32) ? make_uint2(__float_as_uint(r.x) + pc, __float_as_uint(r.z)) : pack_bf16x4(r);
+#if XAS_X6_ABL & 64
+        {                                              // twice the conversion work, same stores
+          const unsigned z = (unsigned)p.tune & 0x40000000u;          // runtime zero
+          float4 r2 = make_float4(r.x * 1.0000002f, r.y * 1.0000002f, r.z * 1.0000002f, r.w * 1.0000002f);
+          const uint2 q2 = pack_bf16x4(r2);
+          const float4 r3 = sub_bf16x4(r2, q2);
+          q.x |= (q2.x ^ __float_as_uint(r3.x) ^ __float_as_uint(r3.y)) & z; q.y |= (q2.y ^ __float_as_uint(r3.z) ^ __float_as_uint(r3.w)) & z;
+        }
+#endif
+        *reinterpret_cast<uint2*>(sb + pc * PLANE + (arow + 64 * j) * XLDH + xswz(arow, kq4 >> 1) + (kq4 & 1) * 4) = q;
+        if (pc + 1 < P && !(XAS_X6_ABL & 32)) r = sub_bf16x4(r, q);
       }
     }
   };
   const int i = lane & 31, hh = lane >> 5;
+#if XAS_X6_ABL & 16
+  bf16x8_t fa[P][C::MI];
+#pragma unroll
+  for (int pc = P - 1; pc >= 0; --pc)
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+      fa[pc][mi] = *reinterpret_cast<const bf16x8_t*>(S + pc * PLANE + (wm * C::WM + mi * 32 + i) * XLDH + xswz(i, hh));
+#endif
   auto compute = [&](int buf, const uint4 (&gb)[P][C::NI]) {
     const unsigned short* sb = S + buf * HBUF;
+#if !(XAS_X6_ABL & 16)
     bf16x8_t fa[P][C::MI];
 #pragma unroll
     for (int pc = P - 1; pc >= 0; --pc)              // smallest pieces first: they feed the first products
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
-        fa[pc][mi] = *reinterpret_cast<const bf16x8_t*>(sb + pc * PLANE + (wm * C::WM + mi * 32 + i) * XLDH + hh * 8);
+        fa[pc][mi] = *reinterpret_cast<const bf16x8_t*>(sb + pc * PLANE + (wm * C::WM + mi * 32 + i) * XLDH + xswz(i, hh));
+#else
+    (void)sb;
+#endif
 #pragma unroll
     for (int t = (P == 3 ? 0 : 5); t < 6; ++t)
 #pragma unroll
@@ -237,6 +274,10 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
                                                                 acc[mi][ni], 0, 0, 0);
   };
   (void)NMF;
+#define SYNC() do { if (!(XAS_X6_ABL & 8)) __syncthreads(); } while (0)
+#define LOADB(g, h) do { if (!(XAS_X6_ABL & 1)) load_b(g, h); } while (0)
+#define LOADA(r) do { if (!(XAS_X6_ABL & 2)) load_a(r); } while (0)
+#define STORE(b, h, r) do { if (!(XAS_X6_ABL & 4)) split_store(b, h, r); } while (0)
   uint4 gb_0[P][C::NI], gb_1[P][C::NI];              // weight fragments of even / odd half-steps
   if (nk > 0) {
     load_a(ra_0);                                      // K-step 0
@@ -246,24 +287,24 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
     split_store(0, 0, ra_0);
     int ks = 0;
     for (; ks + 1 < nk; ks += 2) {
-      __syncthreads();
+      SYNC();
       compute(0, gb_0);                                // half-step 2 ks
-      load_b(gb_0, 0);                                 // weights of half-step 2 ks + 2
-      split_store(1, 1, ra_0);
-      __syncthreads();
-      load_a(ra_0);                                    // activations of K-step ks + 2: set 0 is free
+      LOADB(gb_0, 0);                                 // weights of half-step 2 ks + 2
+      STORE(1, 1, ra_0);
+      SYNC();
+      LOADA(ra_0);                                    // activations of K-step ks + 2: set 0 is free
       compute(1, gb_1);                                // half-step 2 ks + 1
-      load_b(gb_1, 1);                                 // weights of half-step 2 ks + 3
-      split_store(0, 0, ra_1);
-      __syncthreads();
+      LOADB(gb_1, 1);                                 // weights of half-step 2 ks + 3
+      STORE(0, 0, ra_1);
+      SYNC();
       compute(0, gb_0);                                // half-step 2 ks + 2
-      load_b(gb_0, 0);                                 // weights of half-step 2 ks + 4
-      split_store(1, 1, ra_1);
-      __syncthreads();
-      load_a(ra_1);                                    // K-step ks + 3
+      LOADB(gb_0, 0);                                 // weights of half-step 2 ks + 4
+      STORE(1, 1, ra_1);
+      SYNC();
+      LOADA(ra_1);                                    // K-step ks + 3
       compute(1, gb_1);                                // half-step 2 ks + 3
-      load_b(gb_1, 1);                                 // weights of half-step 2 ks + 5
-      split_store(0, 0, ra_0);                         // K-step ks + 2, first half (never computed when ks + 2 == nk)
+      LOADB(gb_1, 1);                                 // weights of half-step 2 ks + 5
+      STORE(0, 0, ra_0);                         // K-step ks + 2, first half (never computed when ks + 2 == nk)
     }
     if (ks < nk) {                                     // one K-step left: in set 0, its first half is in buffer 0
       __syncthreads();
@@ -286,7 +327,11 @@ constexpr size_t igemm_x6_lds(int P, bool bnb) {
 
 template <int BM, int BN, int MODE, int P, bool BNB>
 static int launch_igemm_x6_t(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
+#ifdef XAS_X6_LDS_FLOOR                              // ablation builds: same blocks per CU for every variant
+  constexpr size_t lds = igemm_x6_lds<BM, BN>(P, BNB) > XAS_X6_LDS_FLOOR ? igemm_x6_lds<BM, BN>(P, BNB) : XAS_X6_LDS_FLOOR;
+#else
   constexpr size_t lds = igemm_x6_lds<BM, BN>(P, BNB);
+#endif
   static bool attr_set_dev[kMaxDevices] = {};
   bool& attr_set = attr_set_dev[current_device()];
   if (!attr_set && lds > 64 * 1024) {
@@ -295,8 +340,28 @@ static int launch_igemm_x6_t(const IgemmParams& p, int Mrows_max, int phases, hi
     attr_set = true;
   }
   IgemmParams q = p;
-  q.nMt = (int)cdiv(Mrows_max, BM); q.nNt = (int)cdiv(p.Cd, BN); q.mt_per_xcd = (int)cdiv(q.nMt, 8);
-  dim3 grid((unsigned)(8 * q.mt_per_xcd * q.nNt), 1, (unsigned)phases);
+  q.nMt = (int)cdiv(Mrows_max, BM); q.nNt = (int)cdiv(p.Cd, BN);
+  // XCD grid (8 / xn) x xn.  Model of the bytes that miss the 4 MB L2 of an XCD: the activation rows are fetched by the
+  // xn XCDs of a grid row; an XCD's weight slice is fetched once when it stays resident (<= 2.5 MB), else once per
+  // round of resident M-tiles (64 blocks per XCD).  Layer4 of the detector (8 x 8 maps, 14 MB of split 3x3 weights):
+  // 878 -> 260 MB of L2 misses per launch at 256 images (PMC, tools/gpu/pmc_shapes.sh)
+  {
+    const double a_bytes = (double)Mrows_max * phases * p.Cs * 4.0 * (MODE == 0 ? p.stride * p.stride : 1);
+    const double b_bytes = (double)p.Cd * p.R * p.S * p.Cs * 2.0 * P;
+    double best = 0;
+    q.xn = 1;
+    for (int xn = 1; xn <= 8; xn *= 2) {
+      if (q.nNt % xn != 0 || q.nMt < 8 / xn) continue;
+      const int xm = 8 / xn, ntx = q.nNt / xn, mtx = (int)cdiv(q.nMt, xm);
+      const double slice = b_bytes / xn;
+      const double rounds = slice <= 2.5e6 ? 1.0 : (double)cdiv(mtx, 64 / ntx > 0 ? 64 / ntx : 1);
+      const double cost = a_bytes * xn + slice * 8 * rounds;
+      if (xn == 1 || cost < best * 0.9) { best = cost; q.xn = xn; }
+    }
+  }
+  q.nt_per_x = q.nNt / q.xn;
+  q.mt_per_xcd = (int)cdiv(q.nMt, 8 / q.xn);
+  dim3 grid((unsigned)(8 * q.mt_per_xcd * q.nt_per_x), 1, (unsigned)phases);
   hipLaunchKernelGGL((igemm_x6_kernel<BM, BN, MODE, P, BNB>), grid, dim3(256), lds, st, q);
   XAS_LAUNCH_CHECK();
   return 0;
@@ -355,10 +420,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgradParams p) {
   // wgrad_buf_kernel in conv.hip)
   const int nkt = p.ntiles / p.nct;
   const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
-  const int grp = xcd + 8 * (qb / nkt);
-  const int kt = qb - (qb / nkt) * nkt;
-  const int split = grp / p.nct;
-  const int tile = (grp - split * p.nct) + kt * p.nct;
+  int split, tile;
+  if (p.tune & 1) {                                  // ALL tiles of a pixel split on one XCD (splits a multiple of 8): x and dy
+    split = xcd + 8 * (qb / p.ntiles);               // of the split are fetched into ONE L2; KK-tiles of a Cout tile adjacent
+    const int t = qb - (qb / p.ntiles) * p.ntiles;
+    tile = (t / nkt) + (t - (t / nkt) * nkt) * p.nct;
+  } else {
+    const int grp = xcd + 8 * (qb / nkt);
+    const int kt = qb - (qb / nkt) * nkt;
+    split = grp / p.nct;
+    tile = (grp - split * p.nct) + kt * p.nct;
+  }
   if (split >= p.nsplits) return;
   const int co0 = (tile % p.nct) * BM, nn0 = (tile / p.nct) * BN;
   const int mbeg = split * p.m_per_split, mend = min(p.M, mbeg + p.m_per_split);
@@ -544,7 +616,8 @@ static int launch_wgrad_x6_t(const WgradParams& p, int splits, hipStream_t st) {
   q.nct = (int)cdiv(p.Cout, BM);
   q.ntiles = q.nct * (int)cdiv(p.KK, BN);
   q.nsplits = splits;
-  dim3 grid((unsigned)(8 * cdiv((long)splits * q.nct, 8) * (q.ntiles / q.nct)));
+  q.tune = (splits % 8 == 0) ? 1 : 0;                // wgrad_plan rounds the split count to a multiple of 8 when it can
+  dim3 grid(q.tune ? (unsigned)(splits * q.ntiles) : (unsigned)(8 * cdiv((long)splits * q.nct, 8) * (q.ntiles / q.nct)));
   hipLaunchKernelGGL((wgrad_x6_kernel<BM, BN, P>), grid, dim3(256), lds, st, q);
   XAS_LAUNCH_CHECK();
   return 0;
