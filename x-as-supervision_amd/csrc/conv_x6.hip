@@ -13,11 +13,15 @@
 //
 // Kernel structure (both kernels): 256 threads = 4 waves, tile BM x BN, K-step of 32 (channels of a tap / pixels) loaded
 // two K-steps ahead into two register sets by buffer loads (hardware zero-fill for padding and ragged edges), processed as
-// two HALF-steps of 16: LDS holds two half-buffers of three bf16 planes per operand (73.7 KB for 128 x 128: two blocks per
-// CU), and during the 24 MFMAs of half-step t the wave splits and stores half-step t + 1 into the other buffer - ONE
-// barrier per 24 MFMAs, the conversion work (5.5 vector-ALU instructions per element) issues in the shadow of the matrix
-// pipe, the partner block on the CU covers the barrier.  Weights of forward / data gradient arrive PRE-SPLIT
-// (xas_split_weight, once per optimizer step): no conversion work on that operand, 16-byte LDS stores.
+// two HALF-steps of 16: LDS holds two half-buffers of three bf16 planes for the operands that are split in the kernel
+// (24.6 KB for 128 activation rows; the epilogue staging, 36.9 KB, is the footprint: three blocks per CU), and during the
+// 24 MFMAs of half-step t the wave splits and stores half-step t + 1 into the other buffer - ONE barrier per 24 MFMAs, the
+// conversion work (5.5 vector-ALU instructions per element) issues in the shadow of the matrix pipe, the other blocks
+// on the CU cover the barrier.  Weights of forward / data gradient arrive PRE-SPLIT in MFMA fragment order
+// (xas_split_weight, once per optimizer step) and go straight to operand registers: no LDS traffic on that operand.
+// What bounds the forward kernel (occupancy-equalised timing ablations, profiles/r03_igemm_x6_v3_ablations.txt):
+// activation loads +13..18 %, the plane stores ~+10 %, fragment reads ~+10 %, weight-fragment loads +7..9 %, the
+// conversion work +3..7 % (doubling it: -15 %); MFMA-busy 55-70 % by counter at 1.9-2.1 GHz under load.
 //
 // Replaces the cuDNN kernels behind integral_base_modules/resnet.py:16-47, deconv_head.py:24-35,
 // physique_network.py:15-50 and torchvision's Bottleneck, like conv.hip.
@@ -317,214 +321,20 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
   igemm_epilogue<BM, BN, MODE, BNB, (BN == 128 ? 2 : 1)>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
 }
 
-// ------------------------------------------------------------------------------------
-// forward / data gradient, activations by LDS-DMA ("igemm_x6d"): the fp32 activation rows go global -> LDS directly
-// (buffer_load_dwordx4 ... lds: no VGPR staging, no ds_write; the VGPR -> LDS store path was what bounded igemm_x6_kernel:
-// tools/gpu/r3_abl3.sh, +33 % without its split + stores), into a ring of NB half-step slots of BM rows x 64 B; each wave
-// splits its fragments into the three bf16 pieces as it reads them.  A DMA wave-instruction writes 64 lanes x 16 B
-// LINEARLY into LDS, 16 rows x 64 B per piece: lane (g = row in piece, q = 16-byte position) fetches chunk
-// (q - (g >> 2)) & 3 of its row, so that the fragment reads (16 lanes = 16 rows x 16 B) cover the 64 banks exactly once
-// although the rows are 64 B apart (the swizzle is on the SOURCE address; cdna_hip_programming.md rule 21).
-// Ordering (cdna_hip_programming.md, "Read a staged buffer one phase after the wait that retires it"): a wave waits for
-// its own pieces of half-step u with a counted vmcnt, then the block barrier, then anybody reads slot u; the slot read in
-// half-step u - 1 is re-filled after that barrier (every wave's reads of it were consumed by MFMAs issued before it
-// arrived).  The DMA statements are inline asm - hipcc neither sees nor counts them, so its own vmcnt for the
-// weight-fragment loads (builtins) is merely stricter than needed; each iteration issues its weight loads BEFORE its DMA
-// pieces and always the same number of both (the cursors re-load the last K-step at the end), which makes the counted wait
-// exact: (D - 1) x (weight loads + pieces) younger operations.
-// ------------------------------------------------------------------------------------
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void lds_dma16(unsigned lds_byte, unsigned voff, i32x4_t rsrc, unsigned soff) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "s"(lds_byte), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
-
-template <int BM, int BN, int MODE, int P, bool BNB = false>
-__global__ __launch_bounds__(256, 2) void igemm_x6d_kernel(IgemmParams p) {
-  using C = TileCfg<BM, BN>;
-  constexpr int NB = 4, D = NB - 1;             // ring slots, half-steps a DMA runs ahead
-  constexpr int SLOT = BM * 64;                 // bytes: BM rows x 16 fp32
-  constexpr int NPW = BM / 64;                  // DMA pieces (16 rows) per wave and half-step
-  constexpr int NBL = C::NI * P;                // weight-fragment loads per wave and half-step
-  constexpr int VMN = (D - 1) * (NBL + NPW);    // operations younger than the pieces a wave is about to publish
-  static_assert(VMN < 64, "vmcnt range");
-  extern __shared__ __align__(16) float lds[];
-  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) float*)lds;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
-
-  int Hrow = p.Hrow, Wrow = p.Wrow;
-  int ph = 0, pw = 0, base_r = 0, base_s = 0, nr = p.R, ns = p.S, off_h = -p.pad, off_w = -p.pad, rstep = 1;
-  int sa = p.stride;
-  if (MODE == 1) {
-    const int st = p.stride;
-    ph = blockIdx.z / st; pw = blockIdx.z % st;
-    Hrow = (p.Hd - ph + st - 1) / st; Wrow = (p.Wd - pw + st - 1) / st;
-    base_r = (ph + p.pad) % st; base_s = (pw + p.pad) % st;
-    nr = base_r < p.R ? (p.R - base_r + st - 1) / st : 0;
-    ns = base_s < p.S ? (p.S - base_s + st - 1) / st : 0;
-    off_h = (ph + p.pad - base_r) / st; off_w = (pw + p.pad - base_s) / st;
-    rstep = st; sa = 1;
-  }
-  const int Mrows = p.N * Hrow * Wrow;
-  const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;          // XCD grid: see igemm_x6_kernel
-  const int xi = xcd / p.xn, xj = xcd - xi * p.xn;
-  const int ml = qb / p.nt_per_x;
-  const int mt = xi * p.mt_per_xcd + ml;
-  const int nt = xj * p.nt_per_x + (qb - ml * p.nt_per_x);
-  if (mt >= p.nMt || nt >= p.nNt) return;
-  const int m0 = mt * BM, n0 = nt * BN;
-  if (m0 >= Mrows) return;
-  __builtin_amdgcn_s_setprio(3);
-  const int HW = Hrow * Wrow;
-  const int cchunks = p.Cs / BK;
-  const int nk = nr * ns * cchunks;
-
-  // activation operand: descriptor words for the asm DMA (same range / zero-fill convention as igemm_x6_kernel)
-  const long dmin = MODE == 0 ? 0l : -((long)(nr - 1) * p.Ws + (ns - 1)) * p.Cs;
-  const long rmin = MODE == 0 ? -((long)p.pad * p.Ws + p.pad) * p.Cs : 0l;
-  const long bias = -(rmin + dmin);
-  const unsigned long abase = (unsigned long)(p.src - bias);
-  const i32x4_t rsrcA = {(int)(unsigned)abase, (int)((abase >> 32) & 0xffffu), (int)((bias + p.src_elems) * 4), 0x00020000};
-  unsigned voffA[NPW], maskA[NPW];
-  const int g = lane >> 2, cq = ((lane & 3) - (lane >> 4)) & 3;   // row in piece; the 16-byte chunk this lane fetches
-#pragma unroll
-  for (int j = 0; j < NPW; ++j) {
-    const int m = m0 + (wave * NPW + j) * 16 + g;
-    voffA[j] = kOOB; maskA[j] = 0u;
-    if (m < Mrows) {
-      int n, a, b;
-      if (MODE == 0) { n = p.div_hw.div(m); const int rem = m - n * HW; a = p.div_w.div(rem); b = rem - a * Wrow; }
-      else { n = m / HW; const int rem = m - n * HW; a = rem / Wrow; b = rem - a * Wrow; }
-      const int ra = a * sa + off_h, rb = b * sa + off_w;
-      const long rbase = (((long)n * p.Hs + ra) * p.Ws + rb) * p.Cs;
-      voffA[j] = (unsigned)((rbase + dmin + bias + cq * 4) * 4);
-      unsigned colmask = 0u, msk = 0u;
-      for (int js = 0; js < ns; ++js) {
-        const int ws = rb + (MODE == 0 ? js : -js);
-        colmask |= ((unsigned)ws < (unsigned)p.Ws ? 1u : 0u) << js;
-      }
-      for (int jr = 0; jr < nr; ++jr) {
-        const int hs = ra + (MODE == 0 ? jr : -jr);
-        if ((unsigned)hs < (unsigned)p.Hs) msk |= colmask << (jr * ns);
-      }
-      maskA[j] = msk;
-    }
-  }
-  const int Ktot = p.R * p.S * p.Cs;
-  const unsigned blk_bytes = (unsigned)(Ktot / 16) * P * 1024u;
-  const long wbytes = (long)((p.Cd + 31) / 32) * blk_bytes;
-  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, (int)wbytes, 0x00020000);
-  const unsigned voffB = (unsigned)lane * 16u;
-  const unsigned nblk0 = (unsigned)(n0 / 32 + wn * (C::WN / 32));
-
-  f32x16 acc[C::MI][C::NI];
-#pragma unroll
-  for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < C::NI; ++ni)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-  f32x16 acc2;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
-
-  struct Cur { int chunk, js, jr, left; };
-  Cur ca{0, 0, 0, nk}, cb{0, 0, 0, nk};
-  auto advance = [&](Cur& c) {                       // taps innermost (see igemm_x6_kernel)
-    const bool more = c.left > 1;
-    c.left -= more ? 1 : 0;
-    int s2 = c.js + 1, r = c.jr, ch = c.chunk;
-    if (s2 == ns) { s2 = 0; ++r; }
-    if (r == nr) { r = 0; ++ch; }
-    c.chunk = more ? ch : c.chunk; c.js = more ? s2 : c.js; c.jr = more ? r : c.jr;
-  };
-  auto dma_a = [&](int slot, int h) {                // the wave's pieces of one half-step into ring slot `slot`
-    const int tap = ca.jr * ns + ca.js;
-    const int rel = MODE == 0 ? (ca.jr * p.Ws + ca.js) : ((nr - 1 - ca.jr) * p.Ws + (ns - 1 - ca.js));
-    const unsigned soffA = (unsigned)__builtin_amdgcn_readfirstlane((rel * p.Cs + ca.chunk * BK + h * XH) * 4);   // uniform: an SGPR for the asm
-#pragma unroll
-    for (int j = 0; j < NPW; ++j) {
-      const unsigned off = ((maskA[j] >> tap) & 1u) ? voffA[j] : kOOB;
-      lds_dma16(lds0 + (unsigned)(slot * SLOT + (wave * NPW + j) * 1024), off, rsrcA, soffA);
-    }
-    if (h) advance(ca);
-  };
-  auto load_b = [&](uint4 (&gb)[P][C::NI], int h) {
-    const int wtap = (base_r + rstep * cb.jr) * p.S + (base_s + rstep * cb.js);
-    const unsigned hc = (unsigned)((wtap * p.Cs + cb.chunk * BK) / 16 + h);
-#pragma unroll
-    for (int ni = 0; ni < C::NI; ++ni)
-#pragma unroll
-      for (int pc = 0; pc < P; ++pc)
-        gb[pc][ni] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
-            rsrcB, (int)voffB, (int)((nblk0 + ni) * blk_bytes + (hc * P + pc) * 1024u), 0));
-    if (h) advance(cb);
-  };
-  // fragment of row block mi: lane (i = row, hh = k half) reads chunks 2 hh and 2 hh + 1 of its row
-  const int i = lane & 31, hh = lane >> 5;
-  const int frow = wm * C::WM + i;
-  const int fo0 = (frow >> 4) * 1024 + ((frow & 15) * 4 + ((2 * hh + ((frow & 15) >> 2)) & 3)) * 16;
-  const int fo1 = (frow >> 4) * 1024 + ((frow & 15) * 4 + ((2 * hh + 1 + ((frow & 15) >> 2)) & 3)) * 16;
-  auto compute = [&](int slot, const uint4 (&gb)[P][C::NI]) {
-    const char* sb = reinterpret_cast<const char*>(lds) + slot * SLOT;
-    bf16x8_t fa[P][C::MI];
-#pragma unroll
-    for (int mi = 0; mi < C::MI; ++mi) {
-      float4 lo = *reinterpret_cast<const float4*>(sb + mi * 2048 + fo0);
-      float4 hi = *reinterpret_cast<const float4*>(sb + mi * 2048 + fo1);
-#pragma unroll
-      for (int pc = 0; pc < P; ++pc) {
-        const uint2 q0 = pack_bf16x4(lo), q1 = pack_bf16x4(hi);
-        fa[pc][mi] = as_bf16x8(make_uint4(q0.x, q0.y, q1.x, q1.y));
-        if (pc + 1 < P) { lo = sub_bf16x4(lo, q0); hi = sub_bf16x4(hi, q1); }
-      }
-    }
-#pragma unroll
-    for (int t = (P == 3 ? 0 : 5); t < 6; ++t)
-#pragma unroll
-      for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < C::NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(gb[P == 3 ? kPB[t] : 0][ni]), fa[P == 3 ? kPA[t] : 0][mi],
-                                                                acc[mi][ni], 0, 0, 0);
-  };
-  uint4 gb_0[P][C::NI], gb_1[P][C::NI];
-  const int nhs = 2 * nk;
-#define XD_STEP(S_, GB_)                                                        \
-  do {                                                                          \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMN) : "memory");                  \
-    __builtin_amdgcn_s_barrier();                                               \
-    asm volatile("" ::: "memory");                                              \
-    compute(S_, GB_);                                                           \
-    load_b(GB_, (S_) & 1);                                                      \
-    dma_a(((S_) + D) % NB, ((S_) + D) & 1);                                     \
-  } while (0)
-  if (nk > 0) {
-    dma_a(0, 0); load_b(gb_0, 0);                    // same order as the loop: weights of u, then the pieces
-    dma_a(1, 1); load_b(gb_1, 1);
-    dma_a(2, 0);
-    for (int u = 0; u < nhs; u += 4) {
-      XD_STEP(0, gb_0);
-      XD_STEP(1, gb_1);
-      if (u + 2 >= nhs) break;
-      XD_STEP(2, gb_0);
-      XD_STEP(3, gb_1);
-    }
-  }
-#undef XD_STEP
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-loads of the last K-step land before the staging re-uses the ring
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  igemm_epilogue<BM, BN, MODE, BNB, (BN == 128 ? 2 : 1)>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
-}
+// Tried and dropped:
+// * (commit "Experiment: igemm_x6d_kernel", profiles/r03_igemm_x6_dma_vs_regstaged.txt) the fp32 activation rows by
+//   LDS-DMA (buffer_load_dwordx4 ... lds into a 4-slot ring, swizzle on the source address, counted vmcnt + raw s_barrier)
+//   with the split done at fragment-read time.  Parity-green, but 154.7 against 173.6 TFLOP/s on ten layer shapes: both
+//   waves that share a row block split it (92 instead of 44 vector-ALU instructions per wave and half-step, beside 24
+//   MFMAs), and hipcc's in-order vmcnt for the weight-fragment loads retires every older DMA with them, so the ring cannot
+//   run further ahead than the register sets of this kernel do.
+// * an L2 warm-up of the activation rows four K-steps ahead (one buffer_load_dword ... lds per row and K-step into a
+//   scratch strip): 163 against 169.5 TFLOP/s with the warm-up switched off in the same build - the activation-load
+//   stalls of the ablation are not HBM latency that a warmer L2 removes.
 
 template <int BM, int BN>
-constexpr size_t igemm_x6_lds(int P, bool bnb, bool dma) {
-  size_t a = dma ? (size_t)4 * BM * 64 : (size_t)2 * P * BM * XLDH * sizeof(unsigned short);   // DMA ring / two half-buffers of planes
+constexpr size_t igemm_x6_lds(int P, bool bnb) {
+  size_t a = (size_t)2 * P * BM * XLDH * sizeof(unsigned short);   // two half-buffers of planes
   size_t b = ((size_t)BM * (BN / (BN == 128 ? 2 : 1) + 4) + 2 * 256) * sizeof(float);   // epilogue staging (two halves for BN = 128) + partial-combine area
   size_t c = bnb ? ((size_t)2 * TileCfg<BM, BN>::WAVES_M * 32 * (BN + 4) + 2 * 256) * sizeof(float) : 0;   // bn-backward epilogue staging
   a = a > b ? (a > c ? a : c) : (b > c ? b : c);
@@ -536,13 +346,11 @@ constexpr size_t igemm_x6_lds(int P, bool bnb, bool dma) {
 
 template <int BM, int BN, int MODE, int P, bool BNB>
 static int launch_igemm_x6_t(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
-  const bool dma = !(p.tune & (1 << 20));            // tune bit 20: the register-staged kernel (igemm_x6_kernel)
-  const size_t lds = dma ? igemm_x6_lds<BM, BN>(P, BNB, true) : igemm_x6_lds<BM, BN>(P, BNB, false);
-  static bool attr_set_dev[kMaxDevices][2] = {};
-  bool& attr_set = attr_set_dev[current_device()][dma ? 1 : 0];
+  constexpr size_t lds = igemm_x6_lds<BM, BN>(P, BNB);
+  static bool attr_set_dev[kMaxDevices] = {};
+  bool& attr_set = attr_set_dev[current_device()];
   if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(dma ? reinterpret_cast<const void*>(&igemm_x6d_kernel<BM, BN, MODE, P, BNB>)
-                                  : reinterpret_cast<const void*>(&igemm_x6_kernel<BM, BN, MODE, P, BNB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_x6_kernel<BM, BN, MODE, P, BNB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -569,8 +377,7 @@ static int launch_igemm_x6_t(const IgemmParams& p, int Mrows_max, int phases, hi
   q.nt_per_x = q.nNt / q.xn;
   q.mt_per_xcd = (int)cdiv(q.nMt, 8 / q.xn);
   dim3 grid((unsigned)(8 * q.mt_per_xcd * q.nt_per_x), 1, (unsigned)phases);
-  if (dma) hipLaunchKernelGGL((igemm_x6d_kernel<BM, BN, MODE, P, BNB>), grid, dim3(256), lds, st, q);
-  else hipLaunchKernelGGL((igemm_x6_kernel<BM, BN, MODE, P, BNB>), grid, dim3(256), lds, st, q);
+  hipLaunchKernelGGL((igemm_x6_kernel<BM, BN, MODE, P, BNB>), grid, dim3(256), lds, st, q);
   XAS_LAUNCH_CHECK();
   return 0;
 }
