@@ -1,0 +1,9 @@
+# wave-specialised igemm (default) vs single-stream kernel (tune bit 22): parity tests, then the micro-benchmark
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-r3_v5}
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+timeout -k 5 150 python -m pytest tests/test_gpu_precision.py -x -q -m gpu -k "bf16x6_is_fp32_accurate" > $OUT/tests0.log 2>&1; rc=$?; tail -3 $OUT/tests0.log
+if [ $rc -ne 0 ]; then exit $rc; fi
+timeout -k 10 400 python -m pytest tests/test_gpu_precision.py tests/test_gpu_parity_r3.py tests/test_gpu_nn.py -x -q -m gpu > $OUT/tests.log 2>&1; rc=$?; tail -3 $OUT/tests.log
+if [ $rc -ne 0 ]; then exit $rc; fi
+bash tools/gpu/r3_tune_ab.sh ${1:-r3_v5}/ab "0 4194304"
