@@ -321,262 +321,6 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
   igemm_epilogue<BM, BN, MODE, BNB, (BN == 128 ? 2 : 1)>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
 }
 
-// ------------------------------------------------------------------------------------
-// forward / data gradient, WAVE-SPECIALISED ("igemm_x6s"): 512 threads = 4 MFMA waves + 4 producer waves, one block per CU.
-// In igemm_x6_kernel one in-order instruction stream carries the MFMAs, the conversion work, the plane stores and the
-// waits for the activation loads, and its ablations lose 13-18 % to the loads, ~10 % to the stores, ~10 % to fragment
-// reads landing right before their MFMAs (profiles/r03_igemm_x6_v3_ablations.txt).  Here the producer waves do what concerns
-// the activations (buffer loads two K-steps ahead, split, plane stores into a ring of THREE half-buffers) and the MFMA
-// waves only read fragments, load weight fragments and issue MFMAs - with the fragments of half-step u + 1 read during
-// the MFMAs of half-step u (two register sets), so no LDS latency sits in front of an MFMA.  One barrier per half-step:
-//   phase u:  MFMA waves      read fragments(u + 1) from buffer (u + 1) % 3; MFMAs(u); weight loads for u + 2
-//             producer waves  convert + store half-step u + 2 into buffer (u + 2) % 3
-// (buffer (u + 2) % 3 was last read in phase u - 2; fragments(u + 1) were stored in phase u - 1).  The producers end after
-// the K loop: s_barrier only waits for the surviving waves of a work-group, the MFMA waves run the shared epilogue alone.
-// ------------------------------------------------------------------------------------
-template <int BM, int BN, int MODE, int P, int PW, int NBQ>
-__global__ __launch_bounds__(256 + 64 * PW, PW == 4 ? 2 : 3) void igemm_x6s_kernel(IgemmParams p) {   // (threads, waves per SIMD)
-  using C = TileCfg<BM, BN>;
-  constexpr int PLANE = BM * XLDH;              // halfwords
-  constexpr int HBUF = P * PLANE;               // halfwords per half-buffer
-  constexpr int RPP = 16 * PW;                  // rows one pass of the producer threads covers (4 threads x 16 B per row)
-  constexpr int AP = BM / RPP;                  // activation float4 per producer thread per half-step
-  static_assert(NBQ == 2 || NBQ == 4, "weight fragments run 2 or 4 half-steps ahead");
-  extern __shared__ __align__(16) float lds[];
-  unsigned short* S = reinterpret_cast<unsigned short*>(lds);     // [3][P][BM][XLDH]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wave8 >= 4;
-  const int wave = wave8 & 3;
-
-  int Hrow = p.Hrow, Wrow = p.Wrow;
-  int ph = 0, pw = 0, base_r = 0, base_s = 0, nr = p.R, ns = p.S, off_h = -p.pad, off_w = -p.pad, rstep = 1;
-  int sa = p.stride;
-  if (MODE == 1) {
-    const int st = p.stride;
-    ph = blockIdx.z / st; pw = blockIdx.z % st;
-    Hrow = (p.Hd - ph + st - 1) / st; Wrow = (p.Wd - pw + st - 1) / st;
-    base_r = (ph + p.pad) % st; base_s = (pw + p.pad) % st;
-    nr = base_r < p.R ? (p.R - base_r + st - 1) / st : 0;
-    ns = base_s < p.S ? (p.S - base_s + st - 1) / st : 0;
-    off_h = (ph + p.pad - base_r) / st; off_w = (pw + p.pad - base_s) / st;
-    rstep = st; sa = 1;
-  }
-  const int Mrows = p.N * Hrow * Wrow;
-  const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;          // XCD grid: see igemm_x6_kernel
-  const int xi = xcd / p.xn, xj = xcd - xi * p.xn;
-  const int ml = qb / p.nt_per_x;
-  const int mt = xi * p.mt_per_xcd + ml;
-  const int nt = xj * p.nt_per_x + (qb - ml * p.nt_per_x);
-  if (mt >= p.nMt || nt >= p.nNt) return;
-  const int m0 = mt * BM, n0 = nt * BN;
-  if (m0 >= Mrows) return;
-  __builtin_amdgcn_s_setprio(3);
-  const int HW = Hrow * Wrow;
-  const int cchunks = p.Cs / BK;
-  const int nk = nr * ns * cchunks;
-  const int nhs = 2 * nk;
-
-  struct Cur { int chunk, js, jr, left; };
-  auto advance = [&](Cur& c) {                       // taps innermost (see igemm_x6_kernel)
-    const bool more = c.left > 1;
-    c.left -= more ? 1 : 0;
-    int s2 = c.js + 1, r = c.jr, ch = c.chunk;
-    if (s2 == ns) { s2 = 0; ++r; }
-    if (r == nr) { r = 0; ++ch; }
-    c.chunk = more ? ch : c.chunk; c.js = more ? s2 : c.js; c.jr = more ? r : c.jr;
-  };
-
-  if (producer) {
-    // ------------------------------------------------ producer waves: activations -> bf16 planes in LDS
-    const int ptid = tid - 256;
-    const int kq4 = ptid & 3, arow = ptid >> 2;          // rows arow + RPP * j
-    const long dmin = MODE == 0 ? 0l : -((long)(nr - 1) * p.Ws + (ns - 1)) * p.Cs;
-    const long rmin = MODE == 0 ? -((long)p.pad * p.Ws + p.pad) * p.Cs : 0l;
-    const long bias = -(rmin + dmin);
-    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.src) - bias, 0, (int)((bias + p.src_elems) * 4), 0x00020000);
-    unsigned voffA[AP], maskA[AP];
-#pragma unroll
-    for (int j = 0; j < AP; ++j) {
-      const int m = m0 + arow + RPP * j;
-      voffA[j] = kOOB; maskA[j] = 0u;
-      if (m < Mrows) {
-        int n, a, b;
-        if (MODE == 0) { n = p.div_hw.div(m); const int rem = m - n * HW; a = p.div_w.div(rem); b = rem - a * Wrow; }
-        else { n = m / HW; const int rem = m - n * HW; a = rem / Wrow; b = rem - a * Wrow; }
-        const int ra = a * sa + off_h, rb = b * sa + off_w;
-        const long rbase = (((long)n * p.Hs + ra) * p.Ws + rb) * p.Cs;
-        voffA[j] = (unsigned)((rbase + dmin + bias + kq4 * 4) * 4);
-        unsigned colmask = 0u, msk = 0u;
-        for (int js = 0; js < ns; ++js) {
-          const int ws = rb + (MODE == 0 ? js : -js);
-          colmask |= ((unsigned)ws < (unsigned)p.Ws ? 1u : 0u) << js;
-        }
-        for (int jr = 0; jr < nr; ++jr) {
-          const int hs = ra + (MODE == 0 ? jr : -jr);
-          if ((unsigned)hs < (unsigned)p.Hs) msk |= colmask << (jr * ns);
-        }
-        maskA[j] = msk;
-      }
-    }
-    Cur ca{0, 0, 0, nk};
-    float4 ra_0[2 * AP], ra_1[2 * AP];
-    auto load_a = [&](float4 (&ra)[2 * AP]) {
-      const int tap = ca.jr * ns + ca.js;
-      const int rel = MODE == 0 ? (ca.jr * p.Ws + ca.js) : ((nr - 1 - ca.jr) * p.Ws + (ns - 1 - ca.js));
-      const unsigned soffA = (unsigned)(rel * p.Cs + ca.chunk * BK) * 4u;
-#pragma unroll
-      for (int j = 0; j < AP; ++j) {
-        const unsigned off = ((maskA[j] >> tap) & 1u) ? voffA[j] : kOOB;
-        ra[j] = buf_load16(rsrcA, off, soffA);
-        ra[AP + j] = buf_load16(rsrcA, off, soffA + XH * 4u);
-      }
-      advance(ca);
-    };
-    int bufw = 0;                                      // ring slot of the next store
-    auto split_store = [&](int h, const float4 (&ra)[2 * AP]) {
-      unsigned short* sb = S + bufw * HBUF;
-#pragma unroll
-      for (int j = 0; j < AP; ++j) {
-        float4 r = ra[h * AP + j];
-#pragma unroll
-        for (int pc = 0; pc < P; ++pc) {
-          const uint2 q = pack_bf16x4(r);
-          *reinterpret_cast<uint2*>(sb + pc * PLANE + (arow + RPP * j) * XLDH + xswz(arow, kq4 >> 1) + (kq4 & 1) * 4) = q;
-          if (pc + 1 < P) r = sub_bf16x4(r, q);
-        }
-      }
-      bufw = bufw == 2 ? 0 : bufw + 1;
-    };
-    if (nk > 0) {
-      load_a(ra_0);                                    // K-step 0
-      load_a(ra_1);                                    // K-step 1 (re-loads the last step when there is none)
-      split_store(0, ra_0);                            // half-step 0 -> slot 0
-      split_store(1, ra_0);                            // half-step 1 -> slot 1
-      load_a(ra_0);                                    // K-step 2
-      __syncthreads();                                 // barrier 0
-      // phase u stores half-step u + 2 = half (u & 1) of K-step u / 2 + 1
-      for (int u = 0; u < nhs; u += 4) {
-        if (u + 2 < nhs) split_store(0, ra_1);
-        __syncthreads();
-        if (u + 3 < nhs) split_store(1, ra_1);
-        load_a(ra_1);                                  // K-step u / 2 + 3
-        __syncthreads();
-        if (u + 2 >= nhs) break;
-        if (u + 4 < nhs) split_store(0, ra_0);
-        __syncthreads();
-        if (u + 5 < nhs) split_store(1, ra_0);
-        load_a(ra_0);                                  // K-step u / 2 + 4
-        __syncthreads();
-      }
-    }
-    return;                                            // the epilogue barriers wait for the surviving (MFMA) waves only
-  }
-
-  // ------------------------------------------------ MFMA waves
-  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
-  const int Ktot = p.R * p.S * p.Cs;
-  const unsigned blk_bytes = (unsigned)(Ktot / 16) * P * 1024u;
-  const long wbytes = (long)((p.Cd + 31) / 32) * blk_bytes;
-  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, (int)wbytes, 0x00020000);
-  const unsigned voffB = (unsigned)lane * 16u;
-  const unsigned nblk0 = (unsigned)(n0 / 32 + wn * (C::WN / 32));
-  f32x16 acc[C::MI][C::NI];
-#pragma unroll
-  for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < C::NI; ++ni)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-  f32x16 acc2;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
-  Cur cb{0, 0, 0, nk};
-  auto load_b = [&](uint4 (&gb)[P][C::NI], int h) {
-    const int wtap = (base_r + rstep * cb.jr) * p.S + (base_s + rstep * cb.js);
-    const unsigned hc = (unsigned)((wtap * p.Cs + cb.chunk * BK) / 16 + h);
-#pragma unroll
-    for (int ni = 0; ni < C::NI; ++ni)
-#pragma unroll
-      for (int pc = 0; pc < P; ++pc)
-        gb[pc][ni] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
-            rsrcB, (int)voffB, (int)((nblk0 + ni) * blk_bytes + (hc * P + pc) * 1024u), 0));
-    if (h) advance(cb);
-  };
-  const int i = lane & 31, hh = lane >> 5;
-  int bufr = 0;                                        // ring slot of the next fragment read
-  auto read_frag = [&](bf16x8_t (&fa)[P][C::MI]) {
-    const unsigned short* sb = S + bufr * HBUF;
-#pragma unroll
-    for (int pc = P - 1; pc >= 0; --pc)
-#pragma unroll
-      for (int mi = 0; mi < C::MI; ++mi)
-        fa[pc][mi] = *reinterpret_cast<const bf16x8_t*>(sb + pc * PLANE + (wm * C::WM + mi * 32 + i) * XLDH + xswz(i, hh));
-    bufr = bufr == 2 ? 0 : bufr + 1;
-  };
-  auto mfmas = [&](const bf16x8_t (&fa)[P][C::MI], const uint4 (&gb)[P][C::NI]) {
-#pragma unroll
-    for (int t = (P == 3 ? 0 : 5); t < 6; ++t)
-#pragma unroll
-      for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < C::NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(gb[P == 3 ? kPB[t] : 0][ni]), fa[P == 3 ? kPA[t] : 0][mi],
-                                                                acc[mi][ni], 0, 0, 0);
-  };
-  bf16x8_t fa_0[P][C::MI], fa_1[P][C::MI];
-  if constexpr (NBQ == 2) {
-    uint4 gb_0[P][C::NI], gb_1[P][C::NI];
-    if (nk > 0) {
-      load_b(gb_0, 0);
-      load_b(gb_1, 1);
-      __syncthreads();                                 // barrier 0: half-steps 0 and 1 are in slots 0 and 1
-      read_frag(fa_0);
-      for (int u = 0; u < nhs; u += 2) {
-        read_frag(fa_1);                               // half-step u + 1 (always exists: nhs is even)
-        mfmas(fa_0, gb_0);
-        load_b(gb_0, 0);
-        __syncthreads();
-        if (u + 2 < nhs) read_frag(fa_0);              // half-step u + 2
-        mfmas(fa_1, gb_1);
-        load_b(gb_1, 1);
-        __syncthreads();
-      }
-    }
-  } else {
-    uint4 gb_0[P][C::NI], gb_1[P][C::NI], gb_2[P][C::NI], gb_3[P][C::NI];   // weight fragments four half-steps ahead
-    if (nk > 0) {
-      load_b(gb_0, 0);
-      load_b(gb_1, 1);
-      load_b(gb_2, 0);
-      load_b(gb_3, 1);
-      __syncthreads();
-      read_frag(fa_0);
-      for (int u = 0; u < nhs; u += 4) {
-        read_frag(fa_1);
-        mfmas(fa_0, gb_0);
-        load_b(gb_0, 0);
-        __syncthreads();
-        if (u + 2 < nhs) read_frag(fa_0);
-        mfmas(fa_1, gb_1);
-        load_b(gb_1, 1);
-        __syncthreads();
-        if (u + 2 >= nhs) break;
-        read_frag(fa_1);
-        mfmas(fa_0, gb_2);
-        load_b(gb_2, 0);
-        __syncthreads();
-        if (u + 4 < nhs) read_frag(fa_0);
-        mfmas(fa_1, gb_3);
-        load_b(gb_3, 1);
-        __syncthreads();
-      }
-    }
-  }
-  igemm_epilogue<BM, BN, MODE, false, (BN == 128 ? 2 : 1)>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
-}
-
 // Tried and dropped:
 // * (commit "Experiment: igemm_x6d_kernel", profiles/r03_igemm_x6_dma_vs_regstaged.txt) the fp32 activation rows by
 //   LDS-DMA (buffer_load_dwordx4 ... lds into a 4-slot ring, swizzle on the source address, counted vmcnt + raw s_barrier)
@@ -584,6 +328,12 @@ __global__ __launch_bounds__(256 + 64 * PW, PW == 4 ? 2 : 3) void igemm_x6s_kern
 //   waves that share a row block split it (92 instead of 44 vector-ALU instructions per wave and half-step, beside 24
 //   MFMAs), and hipcc's in-order vmcnt for the weight-fragment loads retires every older DMA with them, so the ring cannot
 //   run further ahead than the register sets of this kernel do.
+// * (commit "Experiment: igemm_x6s_kernel", profiles/r03_igemm_x6_wave_specialised_ab.txt) wave specialisation: 4 MFMA
+//   waves that only read fragments (one phase ahead, two register sets), load weight fragments and issue MFMAs + 2 or 4
+//   producer waves that load, split and store the activations into a three-slot plane ring, one barrier per half-step,
+//   producers end before the epilogue.  Parity-green; 154 TFLOP/s with 4 producers (one block per CU: a lone MFMA wave
+//   per SIMD has nobody to cover its barrier and weight-load waits), 138 with 2 producers and two blocks per CU, against
+//   179 for this kernel at three blocks per CU.
 // * an L2 warm-up of the activation rows four K-steps ahead (one buffer_load_dword ... lds per row and K-step into a
 //   scratch strip): 163 against 169.5 TFLOP/s with the warm-up switched off in the same build - the activation-load
 //   stalls of the ablation are not HBM latency that a warmer L2 removes.
@@ -598,13 +348,6 @@ constexpr size_t igemm_x6_lds(int P, bool bnb) {
   a = a > XAS_X6_LDS_FLOOR ? a : XAS_X6_LDS_FLOOR;
 #endif
   return a;
-}
-
-template <int BM, int BN>
-constexpr size_t igemm_x6s_lds(int P) {
-  size_t a = (size_t)3 * P * BM * XLDH * sizeof(unsigned short);   // ring of three half-buffers of planes
-  size_t b = ((size_t)BM * (BN / (BN == 128 ? 2 : 1) + 4) + 2 * 256) * sizeof(float);   // epilogue staging
-  return a > b ? a : b;
 }
 
 template <int BM, int BN, int MODE, int P, bool BNB>
@@ -640,18 +383,6 @@ static int launch_igemm_x6_t(const IgemmParams& p, int Mrows_max, int phases, hi
   q.nt_per_x = q.nNt / q.xn;
   q.mt_per_xcd = (int)cdiv(q.nMt, 8 / q.xn);
   dim3 grid((unsigned)(8 * q.mt_per_xcd * q.nt_per_x), 1, (unsigned)phases);
-  if constexpr (!BNB) {
-    if (!(p.tune & (1 << 22))) {                       // tune bit 22: the single-stream kernel (igemm_x6_kernel)
-      constexpr size_t lds_s = igemm_x6s_lds<BM, BN>(P);
-      const int variant = (p.tune >> 23) & 3;            // experiment: 0: 2 producer waves, 2 blocks per CU; 1: 4 + depth 4; 2: 4 + depth 2; 3: 2 + depth 4
-      if (variant == 0) hipLaunchKernelGGL((igemm_x6s_kernel<BM, BN, MODE, P, 2, 2>), grid, dim3(384), lds_s, st, q);
-      else if (variant == 1) hipLaunchKernelGGL((igemm_x6s_kernel<BM, BN, MODE, P, 4, 4>), grid, dim3(512), lds_s, st, q);
-      else if (variant == 2) hipLaunchKernelGGL((igemm_x6s_kernel<BM, BN, MODE, P, 4, 2>), grid, dim3(512), lds_s, st, q);
-      else hipLaunchKernelGGL((igemm_x6s_kernel<BM, BN, MODE, P, 2, 4>), grid, dim3(384), lds_s, st, q);
-      XAS_LAUNCH_CHECK();
-      return 0;
-    }
-  }
   hipLaunchKernelGGL((igemm_x6_kernel<BM, BN, MODE, P, BNB>), grid, dim3(256), lds, st, q);
   XAS_LAUNCH_CHECK();
   return 0;
