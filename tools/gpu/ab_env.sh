@@ -1,6 +1,15 @@
-# A/B of an environment switch on ONE box: bash tools/gpu/ab_env.sh VAR  (runs tools/ab_step.py with VAR=0 then VAR=1, twice)
-V=$1
-for r in 1 2; do
-  env $V=0 python tools/ab_step.py 0 | head -1 | sed "s/^/$V=0  /"
-  env $V=1 python tools/ab_step.py 0 | head -1 | sed "s/^/$V=1  /"
+# in-box A/B of environment settings on the benchmark step: bash tools/gpu/ab_env.sh "<VAR=val ...>" [rounds]
+SET="$1"
+R=${2:-3}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/ab_env
+mkdir -p $OUT
+: > $OUT/ab.txt
+for i in $(seq 1 $R); do
+  for which in base other; do
+    if [ $which = base ]; then E=""; else E="$SET"; fi
+    env $E timeout -k 10 300 python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --f32-steps 0 > $OUT/b.json 2> $OUT/b.err || exit 1
+    python3 -c "
+import json; d=json.load(open('$OUT/b.json')); print('$which [$E]', round(d['ms_per_step'],2))" >> $OUT/ab.txt
+  done
 done
+cat $OUT/ab.txt

@@ -5,7 +5,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('XAS_HIP_LIB') or os.path.join(_HERE, 'libxas_hip.so')   # override: diagnostic builds (tools/build_diag.py)
+LIB_PATH = os.environ.get('XAS_HIP_LIB') or os.path.join(_HERE, 'libxas_hip.so')   # override: ablation / A-B builds (tools/build_abl.py, tools/gpu/ab_lib.sh)
 _lib = None
 
 _T = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float, 'u': ctypes.c_uint,
