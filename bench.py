@@ -296,6 +296,12 @@ def main():
                                  'fp32-equivalent (MI355X_MICROARCH.md)',
                          'by_kernel_class': {k.lstrip(':'): {kk: d[kk] for kk in ('launches', 'ms', 'achieved', 'peak', 'frac')} for k, d in cl.items()},
                          'conv_family_frac_of_mixed_peak': mix_frac,
+                         'sustained_mfma_ceiling': {
+                             'bf16_TFLOPs': 1892.0, 'bf16x6_equivalent_TFLOPs': 315.3,
+                             'what': 'static constant, NOT measured in this run: a register-only v_mfma_f32_32x32x16_bf16 loop '
+                                     'with random (non-zero) operands sustains 1 892 TFLOP/s on this part (2 486 with zero '
+                                     'operands: the clock drops under the power limit), tools/micro/mfma_bf16_peak.hip, '
+                                     'profiles/r03_mfma_bf16_sustained_peak.txt; frac above is against the nominal 419.5'},
                          'conv_family_tflops': fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
                          'algorithmic_bytes_per_launch': timer.bytes_total / max(1, n_launch),
                          'note': 'weight-gradient kernels run on a side stream concurrently with the main chain, so '
