@@ -1728,7 +1728,10 @@ static void wgrad_plan(const xas_conv_shape* s, bool x6, int* bm, int* bn, int* 
   // exact-fp32 kernels: ~4 blocks per CU in total, >= 8 K-steps per block.  bf16-split kernels: three times as many, shorter
   // blocks - these kernels run beside the main chain of the step, whose blocks can only move onto a CU when a
   // weight-gradient block retires (register file): short-lived blocks hand the CUs over within ~0.1 ms
-  const int xtarget = 2048;
+#ifndef XAS_WGRAD_XTARGET
+#define XAS_WGRAD_XTARGET 2048          // blocks per launch the pixel splits aim for (r03 sweep, in-box: 1024 -0.2, 4096 +2.5 ms/step)
+#endif
+  const int xtarget = XAS_WGRAD_XTARGET;
   long sp = cdiv(x6 ? xtarget : 1024, tiles);
   const long maxsp = x6 ? (M / 128 > 0 ? M / 128 : 1) : (M / 256 > 0 ? M / 256 : 1);
   if (sp > maxsp) sp = maxsp;

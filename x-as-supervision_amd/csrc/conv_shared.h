@@ -355,11 +355,14 @@ constexpr int WBK = 32;       // pixels per K-step
 
 // Tile of the forward / data-gradient kernels for a problem (one rule for both kernel families, the launchers and
 // xas_conv_fwd_bnstats / xas_conv_dgrad_bn_bwd, whose partial-sum grids follow the tile grid).
+#ifndef XAS_TILE128_MIN_BLOCKS
+#define XAS_TILE128_MIN_BLOCKS 256     // fewer 128 x 128 tiles than this: 64 x 64 tiles (r03 sweep, in-box: 512 -> 256 -1.4 ms/step, 128 / 192 the same, 1024 +2.6)
+#endif
 static inline void pick_tile(int Cd, long Mrows_max, int phases, int* bm, int* bn) {
   if (Cd >= 96) {
     // small problems (layer3/4: M = 8192 / 2048 rows per 32 images): 128x128 tiles leave most of the 256 CUs idle
     const long blocks128 = cdiv(Mrows_max, 128) * cdiv(Cd, 128) * phases;
-    if (blocks128 <= 512) { *bm = 64; *bn = 64; } else { *bm = 128; *bn = 128; }
+    if (blocks128 <= XAS_TILE128_MIN_BLOCKS) { *bm = 64; *bn = 64; } else { *bm = 128; *bn = 128; }
   } else if (Cd >= 48) { *bm = 128; *bn = 64; }
   else { *bm = 128; *bn = 32; }
 }
