@@ -39,6 +39,8 @@ struct IgemmParams {
   int Hrow, Wrow;          // row grid (fwd: Ho x Wo; dgrad: per-phase grid, set in kernel)
   int tune;                // kernel-variant selectors kept for coverage tests (xas_set_tuning): bit5 plain K-loop, bit6 global-load kernel
   int nMt, nNt, mt_per_xcd;   // tile counts and M-tiles per XCD for the XCD-aware block order
+  int t2d_tw;                 // != 0: the rows of a 128-row tile are an 8 x t2d_tw pixel patch of one image (t2d_tw = 16) or of two
+                              // images (t2d_tw = 8) instead of 128 consecutive pixels (igemm_x6t_kernel); the epilogue maps rows with tile_row()
   int xn, nt_per_x;           // bf16-split kernels: the 8 XCDs form an (8 / xn) x xn grid over (M-tiles, N-tiles); xn = 1: every XCD owns all N-tiles of its M-tiles
   long src_elems, wgt_elems;  // sizes of src / wgt (buffer-load kernel: range of the buffer descriptors)
   int accumulate;             // epilogue: 1: out += result (residual gradient already in the buffer);
@@ -174,6 +176,17 @@ __device__ __forceinline__ void bnb_epilogue(const IgemmParams& p, f32x16 (&acc)
   }
 }
 
+// Output row (pixel index n*H*W + y*W + x) of local row ml of tile m0 / 128 when the tile is a 2-D patch (IgemmParams::t2d_tw).
+__device__ __forceinline__ size_t tile_row(const IgemmParams& p, int m0, int ml) {
+  const int tws = p.t2d_tw == 16 ? 4 : 3, tw = p.t2d_tw;
+  const int tn = ml >> (3 + tws), ty = (ml >> tws) & 7, tx = ml & (tw - 1);
+  const int tiles_x = p.Wd / tw, per_img = tiles_x * (p.Hd >> 3);
+  const int tile = m0 >> 7, tn_cnt = 128 >> (3 + tws);
+  const int img = (tile / per_img) * tn_cnt + tn, t = tile % per_img;
+  const int y = (t / tiles_x) * 8 + ty, x = (t % tiles_x) * tw + tx;
+  return ((size_t)img * p.Hd + y) * p.Wd + x;
+}
+
 // Epilogue shared by the igemm kernels: accumulators -> global memory (+ bias), float4 per four output channels.
 // HALVES = 2: the LDS staging of the row / statistics epilogue is done in two passes over BN / 2 columns each, so that the
 // staging area is half as large (the bf16-split kernels need 36.9 KB of LDS for their operands; a full 128 x 128 staging
@@ -216,7 +229,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
     const int m = m0 + wm * C::WM + mi * 32 + pix_l;
     if (m >= Mrows || rows_from_lds) continue;
     size_t orow;
-    if (MODE == 0) orow = (size_t)m;
+    if (p.t2d_tw) orow = tile_row(p, m0, m - m0);
+    else if (MODE == 0) orow = (size_t)m;
     else {
       const int n = m / HW; const int rem = m - n * HW; const int a = rem / Wrow, b = rem - a * Wrow;
       orow = ((size_t)n * p.Hd + (ph + p.stride * a)) * p.Wd + (pw + p.stride * b);
@@ -298,7 +312,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
       for (int r = r0; r < BM; r += RPP) {
         const int m = m0 + r;
         size_t orow;
-        if (MODE == 0 || p.stride == 1) orow = (size_t)m;
+        if (p.t2d_tw) orow = tile_row(p, m0, r);
+        else if (MODE == 0 || p.stride == 1) orow = (size_t)m;
         else {
           const int n = m / HW; const int rem = m - n * HW; const int a = rem / Wrow, b = rem - a * Wrow;
           orow = ((size_t)n * p.Hd + (ph + p.stride * a)) * p.Wd + (pw + p.stride * b);

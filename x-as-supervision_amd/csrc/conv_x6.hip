@@ -131,7 +131,10 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
   if (m0 >= Mrows) return;
   // These kernels sit on the critical chain of the step; the weight-gradient kernels of the side stream co-reside on the
   // CUs (footprints are sized for it) and only exist to fill what this chain leaves idle: win the issue arbitration.
-  __builtin_amdgcn_s_setprio(3);
+#ifndef XAS_X6_PRIO
+#define XAS_X6_PRIO 3
+#endif
+  __builtin_amdgcn_s_setprio(XAS_X6_PRIO);
   const int HW = Hrow * Wrow;
   const int cchunks = p.Cs / BK;
   const int nk = nr * ns * cchunks;
@@ -321,6 +324,191 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
   igemm_epilogue<BM, BN, MODE, BNB, (BN == 128 ? 2 : 1)>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
 }
 
+// ------------------------------------------------------------------------------------
+// forward / data gradient of STRIDE-1 3x3 convolutions with tap re-use ("igemm_x6t").  In the implicit GEMM above every
+// activation element is loaded, split and stored once PER TAP - nine times for a 3x3 filter - and that conversion work,
+// not the matrix pipe, bounds the kernel (and utterly so for the 32-channel layers of the physique net, whose 32-column
+// tiles amortise it over six MFMAs per half-step).  Here the 128 rows of a tile are an 8 x 16 pixel patch of one image
+// (8 x 8 patches of two images for 8-pixel-wide maps): per 32-channel chunk the block stages the patch WITH ITS HALO
+// ((8 + 2) x (16 + 2) pixels) as three bf16 planes ONCE, and the nine taps read their fragments from the same staging at
+// a constant offset per tap ((dy * halo width + dx) pixels): 1.4 instead of 9 conversions per element, two barriers per
+// chunk (18 half-steps) instead of 18, 6.4 x fewer activation bytes through the vector memory path.  Pixels are 80 B apart
+// in a plane (64 B of channels + 16 B pad): the 16 lanes of a fragment read cover the 64 banks once.  The next chunk's
+// halo is fetched into registers at the start of the MFMA phase.  Weights: pre-split fragments straight to registers,
+// as in igemm_x6_kernel.  Epilogue: the shared one, rows mapped by tile_row().
+// ------------------------------------------------------------------------------------
+constexpr int XT_PIXB = 80;                    // bytes per halo pixel and plane
+constexpr int XT_NJ = 7;                       // float4 per thread per chunk: 200 halo pixels x 8 float4 / 256 threads
+constexpr int XT_PLANE_MAX = 200 * XT_PIXB;    // two 10 x 10 halos (8-wide maps); 10 x 18 = 180 pixels for 16-wide patches
+
+template <int BN, int MODE, int P>
+__global__ __launch_bounds__(256, 2) void igemm_x6t_kernel(IgemmParams p) {
+  constexpr int BM = 128;
+  using C = TileCfg<BM, BN>;
+  extern __shared__ __align__(16) float lds[];
+  unsigned char* S = reinterpret_cast<unsigned char*>(lds);       // [P][halo pixels][80 B]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+  const int H = p.Hd, W = p.Wd;                                   // stride 1, same-size: input and output maps coincide
+  const int tw = p.t2d_tw, tws = tw == 16 ? 4 : 3;
+  const int tn_cnt = 128 >> (3 + tws);                            // images per tile
+  const int hw = tw + 2, npix_img = 10 * hw, npix = tn_cnt * npix_img;
+  const int plane_b = npix * XT_PIXB;
+
+  const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;           // XCD grid: see igemm_x6_kernel
+  const int xi = xcd / p.xn, xj = xcd - xi * p.xn;
+  const int ml = qb / p.nt_per_x;
+  const int mt = xi * p.mt_per_xcd + ml;
+  const int nt = xj * p.nt_per_x + (qb - ml * p.nt_per_x);
+  if (mt >= p.nMt || nt >= p.nNt) return;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int Mrows = p.N * H * W;
+  __builtin_amdgcn_s_setprio(XAS_X6_PRIO);
+  const int tiles_x = W / tw, per_img = tiles_x * (H >> 3);
+  const int img0 = (mt / per_img) * tn_cnt, tt = mt % per_img;
+  const int y0 = (tt / tiles_x) * 8, x0 = (tt % tiles_x) * tw;
+  const int cchunks = p.Cs / BK;
+  const int ntap = p.R * p.S;
+
+  // ---- staging: item = tid + 256 j -> (halo pixel, float4 of the chunk's 32 channels); 8 lanes fetch a pixel's 128 bytes
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, (int)(p.src_elems * 4), 0x00020000);
+  unsigned voffA[XT_NJ];
+#pragma unroll
+  for (int j = 0; j < XT_NJ; ++j) {
+    const int item = tid + 256 * j, pix = item >> 3, q = item & 7;
+    voffA[j] = kOOB;
+    if (pix < npix) {
+      const int tn = pix / npix_img, pr = pix - tn * npix_img;
+      const int hy = pr / hw, hx = pr - hy * hw;
+      const int gy = y0 + hy - 1, gx = x0 + hx - 1, img = img0 + tn;
+      if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && img < p.N)
+        voffA[j] = (unsigned)(((((long)img * H + gy) * W + gx) * p.Cs + q * 4) * 4);
+    }
+  }
+  float4 ra[XT_NJ];
+  auto load_chunk = [&](int chunk) {
+    const unsigned soff = (unsigned)(chunk * BK) * 4u;
+#pragma unroll
+    for (int j = 0; j < XT_NJ; ++j) ra[j] = buf_load16(rsrcA, voffA[j], soff);
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int j = 0; j < XT_NJ; ++j) {
+      const int item = tid + 256 * j, pix = item >> 3, q = item & 7;
+      if (pix < npix) {
+        float4 r = ra[j];
+        unsigned char* d = S + pix * XT_PIXB + q * 8;
+#pragma unroll
+        for (int pc = 0; pc < P; ++pc) {
+          const uint2 v = pack_bf16x4(r);
+          *reinterpret_cast<uint2*>(d + pc * plane_b) = v;
+          if (pc + 1 < P) r = sub_bf16x4(r, v);
+        }
+      }
+    }
+  };
+  // ---- fragments: lane (i = row of a 32-row block, hh = k half); row -> (image of the tile, patch y, patch x)
+  const int i = lane & 31, hh = lane >> 5;
+  int fbase[C::MI];
+#pragma unroll
+  for (int mi = 0; mi < C::MI; ++mi) {
+    const int r = wm * C::WM + mi * 32 + i;
+    const int tn = r >> (3 + tws), ty = (r >> tws) & 7, tx = r & (tw - 1);
+    fbase[mi] = (tn * npix_img + (ty + 1) * hw + (tx + 1)) * XT_PIXB + hh * 16;
+  }
+  // ---- weights (as igemm_x6_kernel)
+  const int Ktot = ntap * p.Cs;
+  const unsigned blk_bytes = (unsigned)(Ktot / 16) * P * 1024u;
+  const long wbytes = (long)((p.Cd + 31) / 32) * blk_bytes;
+  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, (int)wbytes, 0x00020000);
+  const unsigned voffB = (unsigned)lane * 16u;
+  const unsigned nblk0 = (unsigned)(n0 / 32 + wn * (C::WN / 32));
+  // half-step stream of the weights: chunk outermost, taps, the two halves of a chunk innermost
+  int b_chunk = 0, b_tap = 0;
+  const int nhs = 2 * ntap * cchunks;
+  int b_left = nhs;
+  auto load_b = [&](uint4 (&gb)[P][C::NI], int h) {
+    const unsigned hc = (unsigned)((b_tap * p.Cs + b_chunk * BK) / 16 + h);
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+      for (int pc = 0; pc < P; ++pc)
+        gb[pc][ni] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+            rsrcB, (int)voffB, (int)((nblk0 + ni) * blk_bytes + (hc * P + pc) * 1024u), 0));
+    if (h) {                                           // next tap; past the end: stay (re-loads, never consumed)
+      const bool more = b_left > 2;
+      b_left -= more ? 2 : 0;
+      int t2 = b_tap + 1, c2 = b_chunk;
+      if (t2 == ntap) { t2 = 0; ++c2; }
+      b_tap = more ? t2 : b_tap; b_chunk = more ? c2 : b_chunk;
+    }
+  };
+  f32x16 acc[C::MI][C::NI];
+#pragma unroll
+  for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+  f32x16 acc2;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+  auto compute = [&](int tapoff, const uint4 (&gb)[P][C::NI]) {       // tapoff: byte offset of the tap + half inside a plane
+    bf16x8_t fa[P][C::MI];
+#pragma unroll
+    for (int pc = P - 1; pc >= 0; --pc)
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi)
+        fa[pc][mi] = *reinterpret_cast<const bf16x8_t*>(S + pc * plane_b + fbase[mi] + tapoff);
+#pragma unroll
+    for (int t = (P == 3 ? 0 : 5); t < 6; ++t)
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(gb[P == 3 ? kPB[t] : 0][ni]), fa[P == 3 ? kPA[t] : 0][mi],
+                                                                acc[mi][ni], 0, 0, 0);
+  };
+  uint4 gb_0[P][C::NI], gb_1[P][C::NI];
+  load_chunk(0);
+  load_b(gb_0, 0);
+  load_b(gb_1, 1);
+  for (int chunk = 0; chunk < cchunks; ++chunk) {
+    stage();                                           // (waits for the chunk's loads)
+    __syncthreads();
+    load_chunk(chunk + 1 < cchunks ? chunk + 1 : chunk);
+    for (int jr = 0; jr < p.R; ++jr)
+      for (int js = 0; js < p.S; ++js) {
+        const int dy = MODE == 0 ? jr - p.pad : p.pad - jr, dx = MODE == 0 ? js - p.pad : p.pad - js;
+        const int tapoff = (dy * hw + dx) * XT_PIXB;
+        compute(tapoff, gb_0);
+        load_b(gb_0, 0);
+        compute(tapoff + 32, gb_1);
+        load_b(gb_1, 1);
+      }
+    __syncthreads();                                   // every wave has read the staging before it is overwritten
+  }
+  igemm_epilogue<BM, BN, MODE, false, (BN == 128 ? 2 : 1)>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, H * W, W, 0, 0, lds);
+}
+
+template <int BN>
+constexpr size_t igemm_x6t_lds(int P) {
+  size_t a = (size_t)P * XT_PLANE_MAX;
+  size_t b = ((size_t)128 * (BN / (BN == 128 ? 2 : 1) + 4) + 2 * 256) * sizeof(float);
+  return a > b ? a : b;
+}
+
+// does the tap-reuse kernel take this problem?  (stride-1 3x3, same-size maps, 128-row tiles that are whole patches)
+static bool x6t_takes(const IgemmParams& p, int bm, int phases) {
+  if (p.tune & (1 << 22)) return false;                // tune bit 22: implicit-GEMM kernel for every shape
+  if (bm != 128 || phases != 1 || p.R != 3 || p.S != 3 || p.stride != 1 || p.pad != 1) return false;
+  if (p.Hd != p.Hs || p.Wd != p.Ws || p.Cs % BK != 0 || p.bnb_x) return false;
+  if (p.Hd % 8 != 0) return false;
+  if (p.Wd % 16 == 0) return true;
+  return p.Wd == 8 && p.N % 2 == 0;
+}
+
 // Tried and dropped:
 // * (commit "Experiment: igemm_x6d_kernel", profiles/r03_igemm_x6_dma_vs_regstaged.txt) the fp32 activation rows by
 //   LDS-DMA (buffer_load_dwordx4 ... lds into a 4-slot ring, swizzle on the source address, counted vmcnt + raw s_barrier)
@@ -388,10 +576,28 @@ static int launch_igemm_x6_t(const IgemmParams& p, int Mrows_max, int phases, hi
   return 0;
 }
 
+template <int BN, int MODE, int P>
+static int launch_igemm_x6t(const IgemmParams& p, int Mrows_max, hipStream_t st) {
+  constexpr size_t lds = igemm_x6t_lds<BN>(P);
+  IgemmParams q = p;
+  q.t2d_tw = p.Wd % 16 == 0 ? 16 : 8;
+  q.nMt = Mrows_max / 128; q.nNt = (int)cdiv(p.Cd, BN);
+  q.xn = 1; q.nt_per_x = q.nNt; q.mt_per_xcd = (int)cdiv(q.nMt, 8);
+  dim3 grid((unsigned)(8 * q.mt_per_xcd * q.nt_per_x), 1, 1);
+  hipLaunchKernelGGL((igemm_x6t_kernel<BN, MODE, P>), grid, dim3(256), lds, st, q);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int MODE, int P>
 static int launch_igemm_x6_p(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
   int bm, bn;
   pick_tile(p.Cd, Mrows_max, phases, &bm, &bn);
+  if (x6t_takes(p, bm, phases)) {
+    if (bn == 128) return launch_igemm_x6t<128, MODE, P>(p, Mrows_max, st);
+    if (bn == 64) return launch_igemm_x6t<64, MODE, P>(p, Mrows_max, st);
+    return launch_igemm_x6t<32, MODE, P>(p, Mrows_max, st);
+  }
   if constexpr (MODE == 1) {
     if (p.bnb_x) {
       if (bn == 128) return launch_igemm_x6_t<128, 128, 1, P, true>(p, Mrows_max, phases, st);
@@ -456,6 +662,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgradParams p) {
   const int co0 = (tile % p.nct) * BM, nn0 = (tile / p.nct) * BN;
   const int mbeg = split * p.m_per_split, mend = min(p.M, mbeg + p.m_per_split);
   const int HWo = p.Ho * p.Wo;
+#ifdef XAS_WGRAD_PRIO
+  __builtin_amdgcn_s_setprio(XAS_WGRAD_PRIO);
+#endif
 
   // ---- dy operand: per-lane offset fixed, rows of a half-step from a scalar offset, split end = buffer range
   const int aq = tid % AQ, apix = tid / AQ;
