@@ -454,13 +454,14 @@ __global__ __launch_bounds__(256, 2) void igemm_x6t_kernel(IgemmParams p) {
   f32x16 acc2;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
-  auto compute = [&](int tapoff, const uint4 (&gb)[P][C::NI]) {       // tapoff: byte offset of the tap + half inside a plane
-    bf16x8_t fa[P][C::MI];
+  auto read_frag = [&](bf16x8_t (&fa)[P][C::MI], int tapoff) {       // tapoff: byte offset of the tap + half inside a plane
 #pragma unroll
     for (int pc = P - 1; pc >= 0; --pc)
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
         fa[pc][mi] = *reinterpret_cast<const bf16x8_t*>(S + pc * plane_b + fbase[mi] + tapoff);
+  };
+  auto mfmas = [&](const bf16x8_t (&fa)[P][C::MI], const uint4 (&gb)[P][C::NI]) {
 #pragma unroll
     for (int t = (P == 3 ? 0 : 5); t < 6; ++t)
 #pragma unroll
@@ -470,7 +471,13 @@ __global__ __launch_bounds__(256, 2) void igemm_x6t_kernel(IgemmParams p) {
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(gb[P == 3 ? kPB[t] : 0][ni]), fa[P == 3 ? kPA[t] : 0][mi],
                                                                 acc[mi][ni], 0, 0, 0);
   };
+  auto tap_off = [&](int t) {                          // byte offset of tap t (= jr * S + js) inside a plane
+    const int jr = t / p.S, js = t - jr * p.S;
+    const int dy = MODE == 0 ? jr - p.pad : p.pad - jr, dx = MODE == 0 ? js - p.pad : p.pad - js;
+    return (dy * hw + dx) * XT_PIXB;
+  };
   uint4 gb_0[P][C::NI], gb_1[P][C::NI];
+  bf16x8_t fa_0[P][C::MI], fa_1[P][C::MI];             // fragments of the half-step in flight and of the next one
   load_chunk(0);
   load_b(gb_0, 0);
   load_b(gb_1, 1);
@@ -478,15 +485,17 @@ __global__ __launch_bounds__(256, 2) void igemm_x6t_kernel(IgemmParams p) {
     stage();                                           // (waits for the chunk's loads)
     __syncthreads();
     load_chunk(chunk + 1 < cchunks ? chunk + 1 : chunk);
-    for (int jr = 0; jr < p.R; ++jr)
-      for (int js = 0; js < p.S; ++js) {
-        const int dy = MODE == 0 ? jr - p.pad : p.pad - jr, dx = MODE == 0 ? js - p.pad : p.pad - js;
-        const int tapoff = (dy * hw + dx) * XT_PIXB;
-        compute(tapoff, gb_0);
-        load_b(gb_0, 0);
-        compute(tapoff + 32, gb_1);
-        load_b(gb_1, 1);
-      }
+    int off = tap_off(0);
+    read_frag(fa_0, off);
+    for (int t = 0; t < ntap; ++t) {
+      read_frag(fa_1, off + 32);                       // second half of this tap, read during the MFMAs of the first
+      mfmas(fa_0, gb_0);
+      load_b(gb_0, 0);
+      off = tap_off(t + 1 < ntap ? t + 1 : t);
+      read_frag(fa_0, off);                            // first half of the next tap (a re-read after the last one)
+      mfmas(fa_1, gb_1);
+      load_b(gb_1, 1);
+    }
     __syncthreads();                                   // every wave has read the staging before it is overwritten
   }
   igemm_epilogue<BM, BN, MODE, false, (BN == 128 ? 2 : 1)>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, H * W, W, 0, 0, lds);
