@@ -1757,9 +1757,13 @@ extern "C" size_t xas_conv_wgrad_workspace_floats(const xas_conv_shape* s) {
   }
   if (s->Cout == 1) return (size_t)cdiv((long)s->N * s->Ho * s->Wo, kCout1Chunk) * s->R * s->S * s->Cin;
   int bm, bn, sp, mps, sp2;
-  wgrad_plan(s, false, &bm, &bn, &sp, &mps);       // the larger of the two kernels' slab counts: the choice between them
+  wgrad_plan(s, false, &bm, &bn, &sp, &mps);       // the largest of the kernels' slab counts: the choice between them
   wgrad_plan(s, true, &bm, &bn, &sp2, &mps);       // also depends on the alignment of x, unknown here
-  return (size_t)(sp > sp2 ? sp : sp2) * s->Cout * s->R * s->S * s->Cin;
+  int sp3 = 0, pps = 0;
+  if (!wgrad_x6t_plan(s->N, s->Hi, s->Wi, s->Cin, s->Cout, s->R, s->S, s->stride, s->pad, s->Ho, s->Wo, &bm, &sp3, &pps)) sp3 = 0;
+  if (sp2 > sp) sp = sp2;
+  if (sp3 > sp) sp = sp3;
+  return (size_t)sp * s->Cout * s->R * s->S * s->Cin;
 }
 
 template <int BM, int BN, bool VEC>
@@ -1914,6 +1918,13 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
   const long xbytes = ((long)s->N * s->Hi * s->Wi + (long)s->pad * s->Wi + s->pad) * s->Cin * 4;
   const long dybytes = (long)p.M * s->Cout * 4;
   const bool buf_ok = vec && s->Cin % 32 == 0 && xbytes < 0x7fffff00l && dybytes < 0x7fffff00l && 31 / s->Wo + 1 <= s->Ho && !(g_tune & 128);
+  int tbm = 0, tsplits = 0, tpps = 0;
+  if (x6 && !(g_tune & (1 << 22)) &&                  // tune bit 22: no tap re-use kernels
+      wgrad_x6t_plan(s->N, s->Hi, s->Wi, s->Cin, s->Cout, s->R, s->S, s->stride, s->pad, s->Ho, s->Wo, &tbm, &tsplits, &tpps)) {
+    splits = tsplits;
+    p.out = (splits == 1 && !oihw) ? dw_packed : workspace;
+    rc = launch_wgrad_x6t(p, tbm, tsplits, tpps, precision_of(s) == XAS_PREC_BF16X6 ? 3 : 1, st);
+  } else
   if (x6) rc = launch_wgrad_x6(p, bm, bn, splits, precision_of(s) == XAS_PREC_BF16X6 ? 3 : 1, st);
   else if (buf_ok) {
     if (bm == 32) rc = launch_wgrad_buf<32, 128>(p, splits, st);

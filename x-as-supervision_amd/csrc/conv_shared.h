@@ -363,6 +363,7 @@ struct WgradParams {
   int m_per_split;
   int nct, ntiles, nsplits;                           // Cout tiles, tiles per split, pixel splits
   int tune;
+  int t2d_tw, pps;                                    // wgrad_x6t_kernel: patch width (16 / 8), pixel patches per split
   FastDiv div_hw, div_w, div_cin, div_s;
 };
 
@@ -387,5 +388,7 @@ static inline void pick_tile(int Cd, long Mrows_max, int phases, int* bm, int* b
 int launch_igemm_x6(const IgemmParams& p, int mode, int Mrows_max, int phases, int pieces, hipStream_t st);
 void wgrad_x6_tile(int Cout, long KK, int* bm, int* bn);
 int launch_wgrad_x6(const WgradParams& p, int bm, int bn, int splits, int pieces, hipStream_t st);
+bool wgrad_x6t_plan(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int Ho, int Wo, int* bm, int* splits, int* pps);
+int launch_wgrad_x6t(const WgradParams& p, int bm, int splits, int pps, int pieces, hipStream_t st);
 
 }  // namespace xas

@@ -341,8 +341,11 @@ constexpr int XT_PIXB = 80;                    // bytes per halo pixel and plane
 constexpr int XT_NJ = 7;                       // float4 per thread per chunk: 200 halo pixels x 8 float4 / 256 threads
 constexpr int XT_PLANE_MAX = 200 * XT_PIXB;    // two 10 x 10 halos (8-wide maps); 10 x 18 = 180 pixels for 16-wide patches
 
+#ifndef XAS_X6T_WAVES
+#define XAS_X6T_WAVES 2                // launch-bounds waves per SIMD of igemm_x6t_kernel (3: 168 VGPRs)
+#endif
 template <int BN, int MODE, int P>
-__global__ __launch_bounds__(256, 2) void igemm_x6t_kernel(IgemmParams p) {
+__global__ __launch_bounds__(256, XAS_X6T_WAVES) void igemm_x6t_kernel(IgemmParams p) {
   constexpr int BM = 128;
   using C = TileCfg<BM, BN>;
   extern __shared__ __align__(16) float lds[];
@@ -846,6 +849,247 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgradParams p) {
         if (nn < p.KK) slab[(size_t)co * p.KK + nn] = acc[mi][ni][reg];
       }
     }
+}
+
+// ------------------------------------------------------------------------------------
+// weight gradient of STRIDE-1 3x3 convolutions with tap re-use ("wgrad_x6t"), the counterpart of igemm_x6t_kernel.
+// In wgrad_x6_kernel a block owns (pixel split, 128 output channels, 128 columns of (tap, input channel)): the x pixels of
+// a split are loaded and split once per tap AND per Cout tile, the dy pixels once per column tile (18 for 3x3 x 256).
+// Here a block owns (pixel split, BM output channels, 32 input channels) and ALL NINE TAPS: per 8 x 16 pixel patch the x
+// halo (10 x 18 pixels x 32 channels) is staged as bf16 planes once and the nine taps take their operands (8 consecutive
+// pixels of one channel per lane, by the transposing LDS read) from it at a constant pixel offset per tap; dy is staged
+// per K-slice of 16 pixels (one patch row), two buffers.  4 waves = (BM / 32 output-channel blocks) x (tap groups): a wave
+// holds one 32 x 32 accumulator per tap of its group (9 / 5 / 3 for BM = 128 / 64 / 32).
+// ------------------------------------------------------------------------------------
+template <int BM, int P>
+__global__ __launch_bounds__(256, 2) void wgrad_x6t_kernel(WgradParams p) {
+  constexpr int NCB = BM / 32, NTG = 4 / NCB;          // output-channel blocks, tap groups
+  constexpr int NTW = (9 + NTG - 1) / NTG;             // taps per wave (at most)
+  constexpr int SA = XStride<BM>::value;               // bytes per dy pixel row of a plane
+  constexpr int DYB = P * XH * SA;                     // bytes per dy buffer
+  constexpr int XPB = 64;                              // bytes per x halo pixel of a plane (32 bf16)
+  constexpr int DQ = BM / 4;                           // dy float4 per pixel
+  constexpr int DJ = (XH * DQ + 255) / 256;            // dy float4 per thread per K-slice (2 / 1 / 1)
+  extern __shared__ __align__(16) float lds[];
+  unsigned char* S = reinterpret_cast<unsigned char*>(lds);       // [2 dy buffers][x planes]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = wave % NCB, tg = wave / NCB;
+  const int H = p.Ho, W = p.Wo;
+  const int tw = p.t2d_tw, tws = tw == 16 ? 4 : 3;
+  const int tn_cnt = 128 >> (3 + tws);
+  const int hw = tw + 2, npix_img = 10 * hw, npix = tn_cnt * npix_img;
+  const int xplane = npix * XPB;
+  unsigned char* SX = S + 2 * DYB;
+  // block -> (split, Cout tile, 32-channel tile): the tiles of a split are adjacent (they share its x and dy in L2)
+  const int nci = p.Cin / 32;
+  const int tiles = p.nct * nci;
+  const int split = blockIdx.x / tiles, tile = blockIdx.x - split * tiles;
+  const int co0 = (tile / nci) * BM, c0 = (tile - (tile / nci) * nci) * 32;
+  const int tiles_x = W / tw, per_img = tiles_x * (H >> 3);
+  const int np_total = p.M >> 7;
+  const int pbeg = split * p.pps, pend = min(np_total, pbeg + p.pps);
+  if (pbeg >= pend) return;
+
+  const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((long)p.N * H * W * p.Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)((long)p.M * p.Cout * 4), 0x00020000);
+  // x halo item = tid + 256 j -> (halo pixel, float4 of the 32 channels): the pixel offset INSIDE a patch is fixed per thread
+  int hpy[XT_NJ], hpx[XT_NJ], hpt[XT_NJ];
+#pragma unroll
+  for (int j = 0; j < XT_NJ; ++j) {
+    const int item = tid + 256 * j, pix = item >> 3;
+    hpt[j] = -1; hpy[j] = 0; hpx[j] = 0;
+    if (pix < npix) {
+      const int tn = pix / npix_img, pr = pix - tn * npix_img;
+      hpt[j] = tn; hpy[j] = pr / hw - 1; hpx[j] = pr - (pr / hw) * hw - 1;
+    }
+  }
+  float4 rx[XT_NJ];
+  auto load_x = [&](int patch) {                       // the halo of patch `patch` -> registers
+    const int img0 = (patch / per_img) * tn_cnt, tt = patch % per_img;
+    const int y0 = (tt / tiles_x) * 8, x0 = (tt % tiles_x) * tw;
+#pragma unroll
+    for (int j = 0; j < XT_NJ; ++j) {
+      const int gy = y0 + hpy[j], gx = x0 + hpx[j], img = img0 + hpt[j];
+      const bool ok = hpt[j] >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && img < p.N;
+      const unsigned off = ok ? (unsigned)(((((long)img * H + gy) * W + gx) * p.Cin + c0 + ((tid + 256 * j) & 7) * 4) * 4) : kOOB;
+      rx[j] = buf_load16(rsrcX, off, 0u);
+    }
+  };
+  auto stage_x = [&]() {
+#pragma unroll
+    for (int j = 0; j < XT_NJ; ++j) {
+      const int item = tid + 256 * j, pix = item >> 3, q = item & 7;
+      if (pix < npix) {
+        float4 r = rx[j];
+        unsigned char* d = SX + pix * XPB + q * 8;
+#pragma unroll
+        for (int pc = 0; pc < P; ++pc) {
+          const uint2 v = pack_bf16x4(r);
+          *reinterpret_cast<uint2*>(d + pc * xplane) = v;
+          if (pc + 1 < P) r = sub_bf16x4(r, v);
+        }
+      }
+    }
+  };
+  // dy K-slice: 16 consecutive pixels (one patch row; two rows of an 8-wide map) x BM channels
+  float4 rd[DJ];
+  auto slice_row0 = [&](int patch, int ks) {           // global pixel index of the slice's first pixel
+    const int img0 = (patch / per_img) * tn_cnt, tt = patch % per_img;
+    const int y0 = (tt / tiles_x) * 8, x0 = (tt % tiles_x) * tw;
+    if (tw == 16) return (img0 * H + y0 + ks) * W + x0;
+    return ((img0 + (ks >> 2)) * H + y0 + 2 * (ks & 3)) * W + x0;
+  };
+  auto load_dy = [&](int patch, int ks) {
+    const unsigned soff = (unsigned)slice_row0(patch, ks) * (unsigned)p.Cout * 4u;
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) {
+      const int item = tid + 256 * j, apix = item / DQ, aq = item - apix * DQ;
+      const bool ok = item < XH * DQ && co0 + aq * 4 < p.Cout;
+      rd[j] = buf_load16(rsrcD, ok ? (unsigned)(apix * p.Cout + co0 + aq * 4) * 4u : kOOB, soff);
+    }
+  };
+  auto store_dy = [&](int buf) {
+    unsigned char* sb = S + buf * DYB;
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) {
+      const int item = tid + 256 * j, apix = item / DQ, aq = item - apix * DQ;
+      if (item < XH * DQ) {
+        float4 r = rd[j];
+#pragma unroll
+        for (int pc = 0; pc < P; ++pc) {
+          const uint2 v = pack_bf16x4(r);
+          *reinterpret_cast<uint2*>(sb + pc * XH * SA + apix * SA + aq * 8) = v;
+          if (pc + 1 < P) r = sub_bf16x4(r, v);
+        }
+      }
+    }
+  };
+  // transposing fragment reads (see wgrad_x6_kernel): lane -> pixel row 8 hh + qd (+ 4), channels 16 g1 + 4 pp .. + 3
+  const int l16 = lane & 15, qd = l16 >> 2, pp = l16 & 3, g1 = (lane >> 4) & 1, hh = lane >> 5;
+  const unsigned fragA = (unsigned)((8 * hh + qd) * SA + (cb * 32 + 16 * g1 + 4 * pp) * 2);
+  const int rs = tw == 16 ? 8 : hw;                    // pixels between the two k-halves of a slice inside the halo
+  const unsigned fragX = (unsigned)((hh * rs + qd) * XPB + (16 * g1 + 4 * pp) * 2);
+  typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_p;
+  auto tr_read = [&](const unsigned char* base, unsigned off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(base + off));
+  };
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  auto compute = [&](int buf, int ks) {
+    const unsigned char* sb = S + buf * DYB;
+    bf16x8_t fa[P];
+#pragma unroll
+    for (int pc = P - 1; pc >= 0; --pc) {
+      const s16x4_t lo = tr_read(sb, fragA + pc * XH * SA);
+      const s16x4_t hi = tr_read(sb, fragA + pc * XH * SA + 4 * SA);
+      fa[pc] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+    // halo pixel of the slice's first pixel for tap (0, 0) offset: row ks (two rows 2 (ks & 3) of image ks >> 2 when 8-wide)
+    const int wbase = tw == 16 ? (ks + 1) * hw + 1 : (ks >> 2) * npix_img + (2 * (ks & 3) + 1) * hw + 1;
+#pragma unroll
+    for (int ti = 0; ti < NTW; ++ti) {
+      const int t = tg + ti * NTG;
+      if (t < 9) {
+        const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+        const unsigned xo = (unsigned)((wbase + dy * hw + dx) * XPB) + fragX;
+        bf16x8_t fb[P];
+#pragma unroll
+        for (int pc = P - 1; pc >= 0; --pc) {
+          const s16x4_t lo = tr_read(SX, xo + pc * xplane);
+          const s16x4_t hi = tr_read(SX, xo + pc * xplane + 4 * XPB);
+          fb[pc] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int k = (P == 3 ? 0 : 5); k < 6; ++k)
+          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[P == 3 ? kPA[k] : 0], fb[P == 3 ? kPB[k] : 0], acc[ti], 0, 0, 0);
+      }
+    }
+  };
+  // ---- slice stream: 8 K-slices per patch; dy one slice ahead in registers, x halo one patch ahead in registers
+  load_x(pbeg);
+  load_dy(pbeg, 0);
+  int buf = 0;
+  for (int patch = pbeg; patch < pend; ++patch) {
+    __syncthreads();                                   // every wave is done with the previous patch's x planes
+    stage_x();
+    if (patch + 1 < pend) load_x(patch + 1);
+    for (int ks = 0; ks < 8; ++ks) {
+      store_dy(buf);
+      if (ks < 7) load_dy(patch, ks + 1);
+      else if (patch + 1 < pend) load_dy(patch + 1, 0);
+      __syncthreads();
+      compute(buf, ks);
+      buf ^= 1;
+    }
+  }
+  // ---- accumulators -> slab [split][co][tap * Cin + c]
+  float* slab = p.out + (size_t)split * p.Cout * p.KK;
+  const int col_l = lane & 31, rsub = 4 * (lane >> 5);
+#pragma unroll
+  for (int ti = 0; ti < NTW; ++ti) {
+    const int t = tg + ti * NTG;
+    if (t < 9) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int co = co0 + cb * 32 + (reg & 3) + 8 * (reg >> 2) + rsub;
+        if (co < p.Cout) slab[(size_t)co * p.KK + t * p.Cin + c0 + col_l] = acc[ti][reg];
+      }
+    }
+  }
+}
+
+// plan of the tap-reuse weight gradient; false: the shape is not taken (wgrad_x6_kernel does it)
+bool wgrad_x6t_plan(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int Ho, int Wo, int* bm, int* splits, int* pps) {
+  if (R != 3 || S != 3 || stride != 1 || pad != 1 || Ho != H || Wo != W) return false;
+  if (Cin % 32 != 0 || H % 8 != 0) return false;
+  if (!(W % 16 == 0 || (W == 8 && N % 2 == 0))) return false;
+  // measured (profiles/r03_wgrad_x6t_ab.txt): 64 and 32 output channels +15..63 %; 128 and more -5..6 % with 128- and with
+  // 64-channel blocks (nine accumulators per wave: 245 VGPRs) - those stay on wgrad_x6_kernel
+  if (Cout == 64) *bm = 64;
+  else if (Cout == 32) *bm = 32;
+  else return false;
+  const long np = (long)N * H * W / 128;
+  const long tiles = (long)(Cout / *bm) * (Cin / 32);
+  long sp = cdiv(1536, tiles);                         // ~1 500 blocks; a block should see at least 2 patches
+  if (sp > np / 2) sp = np / 2;
+  if (sp < 1) sp = 1;
+  *pps = (int)cdiv(np, sp);
+  *splits = (int)cdiv(np, *pps);
+  return true;
+}
+
+template <int BM, int P>
+static int launch_wgrad_x6t_t(const WgradParams& p, int splits, int pps, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * P * XH * XStride<BM>::value + (size_t)P * 200 * 64;
+  static bool attr_set_dev[kMaxDevices] = {};
+  bool& attr_set = attr_set_dev[current_device()];
+  if (!attr_set && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x6t_kernel<BM, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  WgradParams q = p;
+  q.nct = p.Cout / BM;
+  q.nsplits = splits; q.pps = pps;
+  q.t2d_tw = p.Wo % 16 == 0 ? 16 : 8;
+  dim3 grid((unsigned)(splits * q.nct * (p.Cin / 32)));
+  hipLaunchKernelGGL((wgrad_x6t_kernel<BM, P>), grid, dim3(256), lds, st, q);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_wgrad_x6t(const WgradParams& p, int bm, int splits, int pps, int pieces, hipStream_t st) {
+  if (pieces == 3) {
+    if (bm == 128) return launch_wgrad_x6t_t<128, 3>(p, splits, pps, st);
+    if (bm == 64) return launch_wgrad_x6t_t<64, 3>(p, splits, pps, st);
+    return launch_wgrad_x6t_t<32, 3>(p, splits, pps, st);
+  }
+  if (bm == 128) return launch_wgrad_x6t_t<128, 1>(p, splits, pps, st);
+  if (bm == 64) return launch_wgrad_x6t_t<64, 1>(p, splits, pps, st);
+  return launch_wgrad_x6t_t<32, 1>(p, splits, pps, st);
 }
 
 template <int BM, int BN, int P>
