@@ -1430,6 +1430,11 @@ static int fwd_stats_tile_rows(const xas_conv_shape* s, int groups) {
   const long M = (long)s->N * s->Ho * s->Wo, Mg = M / groups;
   int bm, bn;
   pick_tile(s->Cout, M, 1, &bm, &bn);
+  // the bf16-split kernels use 64 x 256 tiles for wide layers, unless the tap re-use kernel (128-row patches) takes the shape
+  const bool x6 = precision_of(s) != XAS_PREC_F32;
+  const bool tap = x6 && bm == 128 && !(g_tune & (1 << 22)) &&
+                   tap_tile_ok(s->R, s->S, s->stride, s->pad, s->Hi, s->Wi, s->Ho, s->Wo, s->Cin, s->N);
+  if (x6 && !tap && !(g_tune & (1 << 23))) pick_tile(s->Cout, M, 1, &bm, &bn, true);
   if (Mg % bm) return 0;
   if ((M / bm) * 2 * (long)s->Cout * 4 >= 0x7fffff00l) return 0;
   return bm;

@@ -74,7 +74,9 @@ static inline int current_device() {
 // ------------------------------------------------------------------------------------
 template <int BM, int BN>
 struct TileCfg {
-  static constexpr int WAVES_M = (BM >= 64 && BN >= 64) ? 2 : (BM < 64 ? 1 : 4);
+  // 64 x 256 (bf16-split kernels, wide layers): the four waves sit side by side, each 64 rows x 64 columns - the same wave
+  // tile as 128 x 128, but the activation rows a block loads, splits and stores serve twice the MFMAs
+  static constexpr int WAVES_M = (BM == 64 && BN == 256) ? 1 : (BM >= 64 && BN >= 64) ? 2 : (BM < 64 ? 1 : 4);
   static constexpr int WAVES_N = 4 / WAVES_M;
   static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   static constexpr int MI = WM / 32, NI = WN / 32;
@@ -371,14 +373,22 @@ constexpr int WBK = 32;       // pixels per K-step
 
 // Tile of the forward / data-gradient kernels for a problem (one rule for both kernel families, the launchers and
 // xas_conv_fwd_bnstats / xas_conv_dgrad_bn_bwd, whose partial-sum grids follow the tile grid).
+// stride-1 3x3 problems the tap re-use kernels take (igemm_x6t_kernel): 128-row tiles that are whole 8 x 16 / 8 x 8 patches
+static inline bool tap_tile_ok(int R, int S, int stride, int pad, int Hs, int Ws, int Hd, int Wd, int Cs, int N) {
+  if (R != 3 || S != 3 || stride != 1 || pad != 1 || Hd != Hs || Wd != Ws || Cs % 32 != 0 || Hd % 8 != 0) return false;
+  return Wd % 16 == 0 || (Wd == 8 && N % 2 == 0);
+}
+
 #ifndef XAS_TILE128_MIN_BLOCKS
 #define XAS_TILE128_MIN_BLOCKS 256     // fewer 128 x 128 tiles than this: 64 x 64 tiles (r03 sweep, in-box: 512 -> 256 -1.4 ms/step, 128 / 192 the same, 1024 +2.6)
 #endif
-static inline void pick_tile(int Cd, long Mrows_max, int phases, int* bm, int* bn) {
+static inline void pick_tile(int Cd, long Mrows_max, int phases, int* bm, int* bn, bool wide = false) {
   if (Cd >= 96) {
     // small problems (layer3/4: M = 8192 / 2048 rows per 32 images): 128x128 tiles leave most of the 256 CUs idle
     const long blocks128 = cdiv(Mrows_max, 128) * cdiv(Cd, 128) * phases;
-    if (blocks128 <= XAS_TILE128_MIN_BLOCKS) { *bm = 64; *bn = 64; } else { *bm = 128; *bn = 128; }
+    if (blocks128 <= XAS_TILE128_MIN_BLOCKS) { *bm = 64; *bn = 64; }
+    else if (wide && Cd % 256 == 0) { *bm = 64; *bn = 256; }      // bf16-split kernels only (TileCfg<64, 256>)
+    else { *bm = 128; *bn = 128; }
   } else if (Cd >= 48) { *bm = 128; *bn = 64; }
   else { *bm = 128; *bn = 32; }
 }

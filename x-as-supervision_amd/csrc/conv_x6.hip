@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
       compute(1, gb_1);
     }
   }
-  igemm_epilogue<BM, BN, MODE, BNB, (BN == 128 ? 2 : 1)>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
+  igemm_epilogue<BM, BN, MODE, BNB, (BN >= 128 ? BN / 64 : 1)>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
 }
 
 // ------------------------------------------------------------------------------------
@@ -514,11 +514,8 @@ constexpr size_t igemm_x6t_lds(int P) {
 // does the tap-reuse kernel take this problem?  (stride-1 3x3, same-size maps, 128-row tiles that are whole patches)
 static bool x6t_takes(const IgemmParams& p, int bm, int phases) {
   if (p.tune & (1 << 22)) return false;                // tune bit 22: implicit-GEMM kernel for every shape
-  if (bm != 128 || phases != 1 || p.R != 3 || p.S != 3 || p.stride != 1 || p.pad != 1) return false;
-  if (p.Hd != p.Hs || p.Wd != p.Ws || p.Cs % BK != 0 || p.bnb_x) return false;
-  if (p.Hd % 8 != 0) return false;
-  if (p.Wd % 16 == 0) return true;
-  return p.Wd == 8 && p.N % 2 == 0;
+  if (bm != 128 || phases != 1 || p.bnb_x) return false;
+  return tap_tile_ok(p.R, p.S, p.stride, p.pad, p.Hs, p.Ws, p.Hd, p.Wd, p.Cs, p.N);
 }
 
 // Tried and dropped:
@@ -541,7 +538,7 @@ static bool x6t_takes(const IgemmParams& p, int bm, int phases) {
 template <int BM, int BN>
 constexpr size_t igemm_x6_lds(int P, bool bnb) {
   size_t a = (size_t)2 * P * BM * XLDH * sizeof(unsigned short);   // two half-buffers of planes
-  size_t b = ((size_t)BM * (BN / (BN == 128 ? 2 : 1) + 4) + 2 * 256) * sizeof(float);   // epilogue staging (two halves for BN = 128) + partial-combine area
+  size_t b = ((size_t)BM * (BN / (BN >= 128 ? BN / 64 : 1) + 4) + 2 * 256) * sizeof(float);   // epilogue staging (64-column passes for BN >= 128) + partial-combine area
   size_t c = bnb ? ((size_t)2 * TileCfg<BM, BN>::WAVES_M * 32 * (BN + 4) + 2 * 256) * sizeof(float) : 0;   // bn-backward epilogue staging
   a = a > b ? (a > c ? a : c) : (b > c ? b : c);
 #ifdef XAS_X6_LDS_FLOOR                              // ablation builds: same blocks per CU for every variant
@@ -617,6 +614,10 @@ static int launch_igemm_x6_p(const IgemmParams& p, int Mrows_max, int phases, hi
       if (bn == 64) return launch_igemm_x6_t<128, 64, 1, P, true>(p, Mrows_max, phases, st);
       return launch_igemm_x6_t<128, 32, 1, P, true>(p, Mrows_max, phases, st);
     }
+  }
+  if (!(p.tune & (1 << 23))) {                         // tune bit 23: no 64 x 256 tiles
+    pick_tile(p.Cd, Mrows_max, phases, &bm, &bn, true);
+    if (bn == 256) return launch_igemm_x6_t<64, 256, MODE, P, false>(p, Mrows_max, phases, st);
   }
   if (bn == 128) return launch_igemm_x6_t<128, 128, MODE, P, false>(p, Mrows_max, phases, st);
   if (bm == 64) return launch_igemm_x6_t<64, 64, MODE, P, false>(p, Mrows_max, phases, st);
