@@ -147,6 +147,15 @@ int xas_conv_kernel_class(const xas_conv_shape* s, int pass);
 size_t xas_split_weight_bytes(long rows, long K, int pieces);
 int xas_split_weight(const float* w_packed, void* w_split, long rows, long K, int pieces, void* stream);
 
+/* Pack + split of MANY layers in one launch (the head of every optimisation step: the reference hands cuDNN the fp32
+ * parameters, modules/integral_base_modules/resnet.py:16-47; this library wants fragment-ordered bf16 planes of them, rebuilt
+ * after every optimizer step).  descs: device array of n entries of 12 int64 each:
+ *   { src (OIHW fp32, device), dst (device, xas_split_weight_bytes(rows, K, planes) bytes), Cout, Cin, R, S,
+ *     transposed (0: rows = Cout, K = (r, s, ci); 1: rows = Cin, K = (r, s, co), as xas_pack_weight),
+ *     planes (3 or 1), rows, K, first block of the entry (prefix sum of ceil(ceil(rows / 32) * (K / 16) * 64 / 256)), 0 }
+ * blocks: total number of blocks.  Results are bit-identical to xas_pack_weight followed by xas_split_weight. */
+int xas_prepare_weights(const void* descs, int n, long blocks, void* stream);
+
 int xas_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
                  const xas_conv_shape* s, void* stream);
 /* Bias-free convolution followed by training-mode batch norm (resnet.py:17-18 conv1/bn1 and every torchvision Bottleneck

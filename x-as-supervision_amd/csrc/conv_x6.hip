@@ -1128,6 +1128,60 @@ int launch_wgrad_x6(const WgradParams& p, int bm, int bn, int splits, int pieces
 
 using namespace xas;
 
+// ------------------------------------------------------------------------------------
+// all layers of a network in ONE launch: OIHW fp32 -> pre-split fragment-ordered planes (pack + split of every conv; the
+// per-layer launches were 189 small kernels = 1.1 ms at the head of every step).  Descriptor = 12 int64 per entry:
+// src, dst, Cout, Cin, R, S, transposed, planes, rows, K, first block, -.  Same arithmetic as xas_pack_weight followed by
+// xas_split_weight (the packing is a pure permutation), so the results are bit-identical to the per-layer path.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prepare_weights_kernel(const long* __restrict__ d, int n) {
+  int lo = 0, hi = n - 1;                              // entry whose block range holds blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (d[mid * 12 + 10] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long* e = d + lo * 12;
+  const float* src = reinterpret_cast<const float*>(e[0]);
+  unsigned short* dst = reinterpret_cast<unsigned short*>(e[1]);
+  const int Cout = (int)e[2], Cin = (int)e[3], R = (int)e[4], S = (int)e[5], transposed = (int)e[6], P = (int)e[7];
+  const int rows = (int)e[8], K = (int)e[9];
+  const int nhc = K / 16;
+  const long total = (long)((rows + 31) / 32) * nhc * 64;
+  const long id = ((long)blockIdx.x - e[10]) * 256 + threadIdx.x;
+  if (id >= total) return;
+  const int lane = (int)(id & 63);
+  const long blk = id >> 6;
+  const int hc = (int)(blk % nhc), rb = (int)(blk / nhc);
+  const int row = rb * 32 + (lane & 31), k0 = hc * 16 + (lane >> 5) * 8;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    v[j] = 0.f;
+    if (row < rows) {
+      const int k = k0 + j;
+      int co, ci, tap;
+      if (!transposed) { ci = k % Cin; tap = k / Cin; co = row; }
+      else { co = k % Cout; tap = k / Cout; ci = row; }
+      const int q = tap % S, r = tap / S;
+      v[j] = src[(((long)co * Cin + ci) * R + r) * S + q];
+    }
+  }
+  float4 r0 = make_float4(v[0], v[1], v[2], v[3]), r1 = make_float4(v[4], v[5], v[6], v[7]);
+  unsigned short* o = dst + (blk * P) * 512 + lane * 8;
+  for (int pc = 0; pc < P; ++pc) {
+    const uint2 q0 = pack_bf16x4(r0), q1 = pack_bf16x4(r1);
+    *reinterpret_cast<uint4*>(o + pc * 512) = make_uint4(q0.x, q0.y, q1.x, q1.y);
+    if (pc + 1 < P) { r0 = sub_bf16x4(r0, q0); r1 = sub_bf16x4(r1, q1); }
+  }
+}
+
+extern "C" int xas_prepare_weights(const void* descs, int n, long blocks, void* stream) {
+  XAS_REQUIRE(descs && n > 0 && blocks > 0 && blocks < 0x7fffffffl, "prepare_weights: bad arguments");
+  hipLaunchKernelGGL(prepare_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), reinterpret_cast<const long*>(descs), n);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" size_t xas_split_weight_bytes(long rows, long K, int pieces) {
   return (size_t)((rows + 31) / 32) * 32 * (size_t)K * 2 * (pieces == 3 ? 3 : 1);
 }

@@ -33,6 +33,7 @@ SIGNATURES = {
     'xas_conv_kernel_class': ('si', 'i'),
     'xas_split_weight_bytes': ('lli', 'z'),
     'xas_split_weight': ('ppllip', 'i'),
+    'xas_prepare_weights': ('pilp', 'i'),
     'xas_head_workspace_floats': ('iii', 'z'),
     'xas_head_softargmax_fwd': ('piiiiipppippp', 'i'),
     'xas_head_softargmax_bwd': ('ppppiiiiippp', 'i'),

@@ -903,11 +903,12 @@ def sigmoid(x):
     return _Sigmoid.apply(x)
 
 
-def prepack(module):
-    """Build the kernel-side weight copies of every conv under `module` on the CURRENT stream - packed fp32 and, in the
-    bf16 modes, the pre-split planes - before streams fork (cameras / chains), so no two streams race to fill a cache and
-    every stream finds the copies complete.  The format only depends on the filter geometry and the precision, not on the
-    activation size: a small dummy shape asks the library."""
+BATCH_PREP = os.environ.get('XAS_BATCH_PREP', '1') != '0'
+
+
+def _conv_entries(module):
+    """(conv module, cache, weight, dummy shape) of every conv under `module` that keeps kernel-side weight copies."""
+    out = []
     for m in module.modules():
         cache = getattr(m, '_cache', None)
         w = getattr(m, 'weight', None)
@@ -922,5 +923,61 @@ def prepack(module):
                 hi = 16
                 ho = (hi + 2 * pad - r) // stride + 1
                 shp = _shape(1, hi, hi, b, a, r, s, stride, pad, ho, ho)
+            out.append((m, cache, w, shp))
+    return out
+
+
+def prepack(module):
+    """Build the kernel-side weight copies of every conv under `module` on the CURRENT stream - packed fp32 and, in the
+    bf16 modes, the pre-split planes - before streams fork (cameras / chains), so no two streams race to fill a cache and
+    every stream finds the copies complete.  The format only depends on the filter geometry and the precision, not on the
+    activation size: a small dummy shape asks the library.  The pre-split planes of ALL layers are written by ONE launch
+    (xas_prepare_weights: a descriptor table built once per module and precision) into one persistent buffer."""
+    entries = _conv_entries(module)
+    if not entries:
+        return
+    if not BATCH_PREP:
+        for _, cache, w, shp in entries:
             cache.get(w, 0, shp)
             cache.get(w, 1, shp)
+        return
+    prec = query('xas_get_precision')
+    key = (prec, tuple(w.data_ptr() for _, _, w, _ in entries))
+    tab = getattr(module, '_xas_prep', None)
+    if tab is None or tab['key'] != key:
+        rows_of, views, desc, blk, off = [], [], [], 0, 0
+        sizes = []
+        for idx, (_, cache, w, shp) in enumerate(entries):
+            for t in (0, 1):
+                planes = query('xas_conv_weight_planes', shp, t)
+                if not planes or not w.is_contiguous():
+                    continue
+                co, ci, r, s = w.shape
+                rows = ci if t else co
+                kk = w.numel() // rows
+                nbytes = query('xas_split_weight_bytes', rows, kk, planes)
+                nblk = (((rows + 31) // 32) * (kk // 16) * 64 + 255) // 256
+                sizes.append((idx, t, planes, off, nbytes))
+                desc.append([w.data_ptr(), off, co, ci, r, s, t, planes, rows, kk, blk, 0])
+                off += (nbytes + 255) // 256 * 256
+                blk += nblk
+        buf = torch.empty(max(1, off), device=entries[0][2].device, dtype=torch.uint8)
+        for d in desc:
+            d[1] += buf.data_ptr()
+        table = torch.tensor(desc, dtype=torch.int64).to(buf.device) if desc else None
+        tab = {'key': key, 'buf': buf, 'table': table, 'blocks': blk, 'n': len(desc),
+               'views': [(idx, t, planes, buf[o:o + nb]) for idx, t, planes, o, nb in sizes], 'epoch': None}
+        module._xas_prep = tab
+    # fresh for this parameter state?  (prepack runs at the head of every pass; the caches know their epoch)
+    stamp = tuple((w._version, getattr(w, '_xas_epoch', _weights_epoch)[0]) for _, _, w, _ in entries)
+    if tab['epoch'] != stamp:
+        if tab['n']:
+            call('xas_prepare_weights', ptr(tab['table']), tab['n'], tab['blocks'])
+        tab['epoch'] = stamp
+    for idx, t, planes, view in tab['views']:
+        _, cache, w, _ = entries[idx]
+        cache._fresh(w)
+        cache.packed[(t, planes)] = view
+    for _, cache, w, shp in entries:                   # whatever the table does not cover (fp32-packed formats)
+        cache.get(w, 0, shp)
+        cache.get(w, 1, shp)
