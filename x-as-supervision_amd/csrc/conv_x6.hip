@@ -1055,7 +1055,10 @@ bool wgrad_x6t_plan(int N, int H, int W, int Cin, int Cout, int R, int S, int st
   else return false;
   const long np = (long)N * H * W / 128;
   const long tiles = (long)(Cout / *bm) * (Cin / 32);
-  long sp = cdiv(1536, tiles);                         // ~1 500 blocks; a block should see at least 2 patches
+#ifndef XAS_WX6T_BLOCKS
+#define XAS_WX6T_BLOCKS 1536
+#endif
+  long sp = cdiv(XAS_WX6T_BLOCKS, tiles);              // ~1 500 blocks; a block should see at least 2 patches
   if (sp > np / 2) sp = np / 2;
   if (sp < 1) sp = 1;
   *pps = (int)cdiv(np, sp);
