@@ -28,11 +28,15 @@ extern "C" {
 
 const char* xas_last_error(void);
 /* Kernel-variant selectors kept for coverage tests (tests/test_gpu_nn.py::test_conv_kernel_variants): 0 = the shipped
- * configuration, results are identical under every flag.  They only concern the exact-fp32 kernels (XAS_PREC_F32).
+ * configuration; results agree to accumulation-order noise under every flag.  The first group only concerns the exact-fp32
+ * kernels (XAS_PREC_F32).
  *   32      plain K-loop in fwd / dgrad instead of the pipelined one      524288  same for the weight gradient
  *   64      global-load fwd / dgrad kernels (the >= 2 GiB fallback)       128     same for the weight gradient
  *   8192    plain (not XCD-grouped) weight-gradient block order
- *   32768 / 65536 / 98304  column-reduce slab target 512 / 128 / 64       262144  86-VGPR build of the backward column sums */
+ *   32768 / 65536 / 98304  column-reduce slab target 512 / 128 / 64       262144  86-VGPR build of the backward column sums
+ * and two that concern the bf16-split kernels (tests/test_gpu_tap_kernels.py compares both settings):
+ *   4194304 (bit 22)  no tap re-use kernels: stride-1 3x3 layers on the implicit-GEMM kernels (forward, data and weight gradient)
+ *   8388608 (bit 23)  no 64 x 256 tiles for layers whose output channels are a multiple of 256 */
 int xas_set_tuning(int flags);
 /* Arithmetic of the MFMA convolutions (forward, data gradient, weight gradient).  All three keep fp32 activations, fp32
  * master weights and fp32 accumulation; they differ in how a product of two fp32 operands is formed:
