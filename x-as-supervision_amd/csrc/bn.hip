@@ -364,6 +364,9 @@ __device__ __forceinline__ void col_reduce_body(const ColArgs& a) {
 
 template <int MODE>
 __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs a) {
+#ifdef XAS_BN_PRIO
+  __builtin_amdgcn_s_setprio(XAS_BN_PRIO);
+#endif
   col_reduce_body<MODE, 4, 4>(a);
 }
 
@@ -372,6 +375,9 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs a) {
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void col_reduce_lean_kernel(ColArgs a) {
+#ifdef XAS_BN_PRIO
+  __builtin_amdgcn_s_setprio(XAS_BN_PRIO);
+#endif
   col_reduce_body<MODE, 2, 2>(a);
 }
 
@@ -512,6 +518,9 @@ __global__ __launch_bounds__(256) void bn_apply_stream_kernel(const float4* __re
                                                              const float* __restrict__ beta, const float4* __restrict__ res,
                                                              float eps, long n4g, int C4, float4* __restrict__ y,
                                                              uint8_t* __restrict__ mask_out) {
+#ifdef XAS_BN_PRIO
+  __builtin_amdgcn_s_setprio(XAS_BN_PRIO);
+#endif
   const long goff = (long)blockIdx.y * n4g;
   const long stride = (long)gridDim.x * blockDim.x;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -550,6 +559,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(
     const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ sums, float eps, long n4g, int C4, float inv_count, float4* __restrict__ dx,
     float4* __restrict__ dres, const uint8_t* __restrict__ mask) {
+#ifdef XAS_BN_PRIO
+  __builtin_amdgcn_s_setprio(XAS_BN_PRIO);
+#endif
   const long goff = (long)blockIdx.y * n4g;
   const long stride = (long)gridDim.x * blockDim.x;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

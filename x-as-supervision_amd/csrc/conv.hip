@@ -1734,7 +1734,7 @@ static void wgrad_plan(const xas_conv_shape* s, bool x6, int* bm, int* bn, int* 
   // blocks - these kernels run beside the main chain of the step, whose blocks can only move onto a CU when a
   // weight-gradient block retires (register file): short-lived blocks hand the CUs over within ~0.1 ms
 #ifndef XAS_WGRAD_XTARGET
-#define XAS_WGRAD_XTARGET 2048          // blocks per launch the pixel splits aim for (r03 sweep, in-box: 1024 -0.2, 4096 +2.5 ms/step)
+#define XAS_WGRAD_XTARGET 1024          // blocks per launch the pixel splits aim for (r03 sweeps, in-box: at the final kernels 512..1024 are 1 ms/step better than 2048 - fewer slabs to write and reduce -, 256 / 384 and 4096 worse)
 #endif
   const int xtarget = XAS_WGRAD_XTARGET;
   long sp = cdiv(x6 ? xtarget : 1024, tiles);
