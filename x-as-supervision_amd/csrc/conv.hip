@@ -1730,9 +1730,9 @@ static void wgrad_plan(const xas_conv_shape* s, bool x6, int* bm, int* bn, int* 
     if (*bm == 32) *bn = 128;
   }
   const long tiles = cdiv(s->Cout, *bm) * cdiv(KK, *bn);
-  // exact-fp32 kernels: ~4 blocks per CU in total, >= 8 K-steps per block.  bf16-split kernels: three times as many, shorter
-  // blocks - these kernels run beside the main chain of the step, whose blocks can only move onto a CU when a
-  // weight-gradient block retires (register file): short-lived blocks hand the CUs over within ~0.1 ms
+  // ~4 blocks per CU in total, >= 8 K-steps (4 for the bf16-split kernel) per block.  These kernels run beside the main
+  // chain of the step: shorter blocks hand the CUs over sooner, but every split costs a slab of dW to write and to reduce;
+  // with the round-3 kernels the slab traffic weighs more (sweeps in the define below)
 #ifndef XAS_WGRAD_XTARGET
 #define XAS_WGRAD_XTARGET 1024          // blocks per launch the pixel splits aim for (r03 sweeps, in-box: at the final kernels 512..1024 are 1 ms/step better than 2048 - fewer slabs to write and reduce -, 256 / 384 and 4096 worse)
 #endif
