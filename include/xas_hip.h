@@ -36,7 +36,8 @@ const char* xas_last_error(void);
  *   32768 / 65536 / 98304  column-reduce slab target 512 / 128 / 64       262144  86-VGPR build of the backward column sums
  * and two that concern the bf16-split kernels (tests/test_gpu_tap_kernels.py compares both settings):
  *   4194304 (bit 22)  no tap re-use kernels: stride-1 3x3 layers on the implicit-GEMM kernels (forward, data and weight gradient)
- *   8388608 (bit 23)  no 64 x 256 tiles for layers whose output channels are a multiple of 256 */
+ *   8388608 (bit 23)  no 64 x 256 tiles for layers whose output channels are a multiple of 256
+ *   16777216 (bit 24) the general weight-gradient kernel for the 7x7 stem instead of stem_wgrad_kernel */
 int xas_set_tuning(int flags);
 /* Arithmetic of the MFMA convolutions (forward, data gradient, weight gradient).  All three keep fp32 activations, fp32
  * master weights and fp32 accumulation; they differ in how a product of two fp32 operands is formed:

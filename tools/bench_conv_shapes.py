@@ -7,6 +7,7 @@ SHAPES = [  # Hi, Wi, Cin, Cout, R, stride, pad
     (16, 16, 256, 256, 3, 1, 1), (16, 16, 512, 512, 3, 2, 1), (8, 8, 512, 2048, 1, 1, 0),
     (8, 8, 2048, 512, 1, 1, 0), (8, 8, 512, 512, 3, 1, 1), (64, 64, 256, 1152, 1, 1, 0),
     (128, 128, 64, 64, 3, 1, 1), (256, 256, 32, 32, 3, 1, 1), (256, 256, 64, 32, 3, 1, 1),
+    (256, 256, 3, 64, 7, 2, 3),                          # stem
 ]
 
 

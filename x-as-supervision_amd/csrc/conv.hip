@@ -1003,6 +1003,92 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------
+// Stem weight gradient: dW[co][k] = sum over pixels dy[p][co] * x[tap k of p], k = (r * 7 + s) * 3 + c, K = pixels.
+// It is the LAST weight gradient of a backward pass (its dy is the last gradient the pass produces), so it runs alone at the
+// tail of every step: the general global-load kernel took 2.03 ms there (38.9 TFLOP/s: three-channel scalar gathers).
+// Same staging as stem_fwd_kernel: a block walks 8 x 16 output patches of its share; per patch the 21 x 37 x 3 input patch
+// and the 128 x 64 dy patch go to LDS, every MFMA operand is one ds_read_b32.  Output 64 x 147 = 2 row blocks x 5 column
+// blocks of 32: wave w owns row block w & 1 and column blocks {0, 1, 2} (w < 2) or {3, 4}; partial sums per block -> slabs.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         float* __restrict__ slabs, int N, int H, int W, int Ho, int Wo,
+                                                         int patches, int ppb) {
+  __shared__ float patch[ST_PH * ST_PW * 3 + 8];
+  __shared__ __align__(16) float dys[ST_TH * ST_TW * ST_CO];        // [pixel][co]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cb = wave & 1, half = wave >> 1;
+  const int nblk = half ? 2 : 3, blk0 = half ? 3 : 0;
+  const int tiles_w = Wo / ST_TW, tiles_h = Ho / ST_TH, per_img = tiles_w * tiles_h;
+  const int i = lane & 31, kh = lane >> 5;
+  int toff[3];                                         // tap offset of this lane's column in each of the wave's column blocks
+  bool tok[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const int nn = (blk0 + b) * 32 + i;
+    tok[b] = b < nblk && nn < ST_K;
+    const int k = tok[b] ? nn : 0;
+    toff[b] = ((k / 21) * ST_PW + (k / 3) % 7) * 3 + k % 3;
+  }
+  f32x16 acc[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+  const int pbeg = blockIdx.x * ppb, pend = min(patches, pbeg + ppb);
+  for (int pt = pbeg; pt < pend; ++pt) {
+    const int n = pt / per_img, t = pt - n * per_img;
+    const int oy0 = (t / tiles_w) * ST_TH, ox0 = (t % tiles_w) * ST_TW;
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    __syncthreads();                                   // the previous patch has been consumed
+    for (int e = tid; e < ST_PH * ST_PW * 3; e += 256) {
+      const int c = e % 3, px = (e / 3) % ST_PW, py = e / (3 * ST_PW);
+      const int iy = iy0 + py, ix = ix0 + px;
+      patch[e] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? x[(((size_t)n * H + iy) * W + ix) * 3 + c] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < ST_TH * ST_TW * ST_CO / 4 / 256; ++j) {     // 8 float4 per thread
+      const int e = tid + 256 * j, pix = e >> 4, q = e & 15;
+      const int oy = oy0 + (pix >> 4), ox = ox0 + (pix & 15);
+      *reinterpret_cast<float4*>(dys + pix * ST_CO + q * 4) =
+          *reinterpret_cast<const float4*>(dy + (((size_t)n * Ho + oy) * Wo + ox) * ST_CO + q * 4);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int ks = 0; ks < ST_TH * ST_TW / 2; ++ks) {
+      const int p = 2 * ks + kh;                       // the pixel this lane supplies (k index of the MFMA)
+      const int pbase = (((p >> 4) * 2) * ST_PW + (p & 15) * 2) * 3;
+      const float a = dys[p * ST_CO + cb * 32 + i];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        if (b < nblk) {                                // (wave-uniform)
+          const float v = tok[b] ? patch[pbase + toff[b]] : 0.f;
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v, acc[b], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* slab = slabs + (size_t)blockIdx.x * ST_CO * ST_K;
+  const int col = lane & 31, rsub = 4 * (lane >> 5);
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const int k = (blk0 + b) * 32 + col;
+    if (b < nblk && k < ST_K) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + rsub;
+        slab[(size_t)co * ST_K + k] = acc[b][reg];
+      }
+    }
+  }
+}
+
+static bool stem_wgrad_ok(const xas_conv_shape* s) {
+  return s->Cin == 3 && s->Cout == ST_CO && s->R == 7 && s->S == 7 && s->stride == 2 && s->pad == 3 &&
+         s->Ho % ST_TH == 0 && s->Wo % ST_TW == 0 && s->Ho * 2 == s->Hi && s->Wo * 2 == s->Wi;
+}
+constexpr int kStemWgradBlocks = 1024;
+
+// ------------------------------------------------------------------------------------
 // "Thin" 3x3 convolutions with ONE channel on one side (physique_network.py:41 first conv 1 -> 32,
 // :50 last conv 32 -> 1): HBM-bound, no GEMM shape; vector side C <= 64, C % 4 == 0.
 //   T1 vec->scalar : out[m]    = b + sum_tap sum_c V[src(m,tap)][c] * W[tap][c]   (fwd Cout=1, dgrad Cin=1)
@@ -1761,6 +1847,7 @@ extern "C" size_t xas_conv_wgrad_workspace_floats(const xas_conv_shape* s) {
     return (size_t)(cdiv((long)s->N * s->Hi * s->Wi, kThinChunk) + 1) * C * 9;
   }
   if (s->Cout == 1) return (size_t)cdiv((long)s->N * s->Ho * s->Wo, kCout1Chunk) * s->R * s->S * s->Cin;
+  if (stem_wgrad_ok(s)) return (size_t)kStemWgradBlocks * ST_CO * ST_K;
   int bm, bn, sp, mps, sp2;
   wgrad_plan(s, false, &bm, &bn, &sp, &mps);       // the largest of the kernels' slab counts: the choice between them
   wgrad_plan(s, true, &bm, &bn, &sp2, &mps);       // also depends on the alignment of x, unknown here
@@ -1901,6 +1988,18 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
                        workspace, *s, kCout1Chunk);
     XAS_LAUNCH_CHECK();
     hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(KK, 64)), dim3(slab_threads()), 0, st, workspace, chunks, (long)KK,
+                       rflag, s->Cin, s->R, s->S, dw_packed);
+    XAS_LAUNCH_CHECK();
+    return 0;
+  }
+  if (stem_wgrad_ok(s) && !(g_tune & (1 << 24))) {    // (tune bit 24: the general kernel)
+    const int patches = s->N * (s->Ho / ST_TH) * (s->Wo / ST_TW);
+    const int ppb = (int)cdiv(patches, kStemWgradBlocks), blocks = (int)cdiv(patches, ppb);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, dy, workspace, s->N, s->Hi, s->Wi,
+                       s->Ho, s->Wo, patches, ppb);
+    XAS_LAUNCH_CHECK();
+    const long n = (long)ST_CO * ST_K;
+    hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(n, 64)), dim3(slab_threads()), 0, st, workspace, blocks, n,
                        rflag, s->Cin, s->R, s->S, dw_packed);
     XAS_LAUNCH_CHECK();
     return 0;
