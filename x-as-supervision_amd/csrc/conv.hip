@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 // tail of every step: the general global-load kernel took 2.03 ms there (38.9 TFLOP/s: three-channel scalar gathers).
 // Same staging as stem_fwd_kernel: a block walks 8 x 16 output patches of its share; per patch the 21 x 37 x 3 input patch
 // and the 128 x 64 dy patch go to LDS, every MFMA operand is one ds_read_b32.  Output 64 x 147 = 2 row blocks x 5 column
-// blocks of 32: wave w owns row block w & 1 and column blocks {0, 1, 2} (w < 2) or {3, 4}; partial sums per block -> slabs.
+// blocks of 32: wave w owns row block w & 1, all five column blocks and every other K-step (pixel pair): two slabs per block.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          float* __restrict__ slabs, int N, int H, int W, int Ho, int Wo,
@@ -1016,22 +1016,21 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   __shared__ float patch[ST_PH * ST_PW * 3 + 8];
   __shared__ __align__(16) float dys[ST_TH * ST_TW * ST_CO];        // [pixel][co]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cb = wave & 1, half = wave >> 1;
-  const int nblk = half ? 2 : 3, blk0 = half ? 3 : 0;
+  const int cb = wave & 1, kp = wave >> 1;             // output-channel block; which half of the K-steps (pixel pairs)
   const int tiles_w = Wo / ST_TW, tiles_h = Ho / ST_TH, per_img = tiles_w * tiles_h;
   const int i = lane & 31, kh = lane >> 5;
-  int toff[3];                                         // tap offset of this lane's column in each of the wave's column blocks
-  bool tok[3];
+  int toff[5];                                         // tap offset of this lane's column in each of the five column blocks
+  bool tok[5];
 #pragma unroll
-  for (int b = 0; b < 3; ++b) {
-    const int nn = (blk0 + b) * 32 + i;
-    tok[b] = b < nblk && nn < ST_K;
+  for (int b = 0; b < 5; ++b) {
+    const int nn = b * 32 + i;
+    tok[b] = nn < ST_K;
     const int k = tok[b] ? nn : 0;
     toff[b] = ((k / 21) * ST_PW + (k / 3) % 7) * 3 + k % 3;
   }
-  f32x16 acc[3];
+  f32x16 acc[5];
 #pragma unroll
-  for (int b = 0; b < 3; ++b)
+  for (int b = 0; b < 5; ++b)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
   const int pbeg = blockIdx.x * ppb, pend = min(patches, pbeg + ppb);
@@ -1053,26 +1052,24 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
           *reinterpret_cast<const float4*>(dy + (((size_t)n * Ho + oy) * Wo + ox) * ST_CO + q * 4);
     }
     __syncthreads();
-#pragma unroll 4
-    for (int ks = 0; ks < ST_TH * ST_TW / 2; ++ks) {
+#pragma unroll 2
+    for (int ks = kp; ks < ST_TH * ST_TW / 2; ks += 2) {
       const int p = 2 * ks + kh;                       // the pixel this lane supplies (k index of the MFMA)
       const int pbase = (((p >> 4) * 2) * ST_PW + (p & 15) * 2) * 3;
       const float a = dys[p * ST_CO + cb * 32 + i];
 #pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        if (b < nblk) {                                // (wave-uniform)
-          const float v = tok[b] ? patch[pbase + toff[b]] : 0.f;
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v, acc[b], 0, 0, 0);
-        }
+      for (int b = 0; b < 5; ++b) {
+        const float v = tok[b] ? patch[pbase + toff[b]] : 0.f;
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v, acc[b], 0, 0, 0);
       }
     }
   }
-  float* slab = slabs + (size_t)blockIdx.x * ST_CO * ST_K;
+  float* slab = slabs + ((size_t)blockIdx.x * 2 + kp) * ST_CO * ST_K;   // (the other output-channel block fills the other rows)
   const int col = lane & 31, rsub = 4 * (lane >> 5);
 #pragma unroll
-  for (int b = 0; b < 3; ++b) {
-    const int k = (blk0 + b) * 32 + col;
-    if (b < nblk && k < ST_K) {
+  for (int b = 0; b < 5; ++b) {
+    const int k = b * 32 + col;
+    if (k < ST_K) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + rsub;
@@ -1847,7 +1844,7 @@ extern "C" size_t xas_conv_wgrad_workspace_floats(const xas_conv_shape* s) {
     return (size_t)(cdiv((long)s->N * s->Hi * s->Wi, kThinChunk) + 1) * C * 9;
   }
   if (s->Cout == 1) return (size_t)cdiv((long)s->N * s->Ho * s->Wo, kCout1Chunk) * s->R * s->S * s->Cin;
-  if (stem_wgrad_ok(s)) return (size_t)kStemWgradBlocks * ST_CO * ST_K;
+  if (stem_wgrad_ok(s)) return (size_t)2 * kStemWgradBlocks * ST_CO * ST_K;
   int bm, bn, sp, mps, sp2;
   wgrad_plan(s, false, &bm, &bn, &sp, &mps);       // the largest of the kernels' slab counts: the choice between them
   wgrad_plan(s, true, &bm, &bn, &sp2, &mps);       // also depends on the alignment of x, unknown here
@@ -1999,7 +1996,7 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
                        s->Ho, s->Wo, patches, ppb);
     XAS_LAUNCH_CHECK();
     const long n = (long)ST_CO * ST_K;
-    hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(n, 64)), dim3(slab_threads()), 0, st, workspace, blocks, n,
+    hipLaunchKernelGGL(slab_reduce_kernel2, dim3((unsigned)cdiv(n, 64)), dim3(slab_threads()), 0, st, workspace, 2 * blocks, n,
                        rflag, s->Cin, s->R, s->S, dw_packed);
     XAS_LAUNCH_CHECK();
     return 0;
