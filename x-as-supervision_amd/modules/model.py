@@ -240,6 +240,16 @@ class Counter3DDisc(torch.nn.Module):
         self.DISC_SUP_DIMENSION = cfg['smpl_disc_params'].get('disc_sup_dim', 3)
         self.use_aug = cfg['smpl_disc_params'].get('use_aug', False)
 
+    def detector_pass(self, x, regressor):
+        """The detector on the real images of every camera for the discriminator update (model.py:231): -> {cam_key: kps}.
+        The reference builds (and discards) an autograd graph here (output detached at model.py:243); only the values and
+        the train-mode BN running-statistic updates matter, so no graph is recorded."""
+        keys = ['cam_{}'.format(c) for c in _cams(x, self.cam_id_list)]
+        ops_nn.prepack(regressor)
+        with torch.no_grad():
+            dets = _grouped(regressor, [x[k + '_img'] for k in keys])
+        return {k: kp for k, (kp, _) in zip(keys, dets)}
+
     def forward(self, x, regressor, preds=None):
         """`preds` (optional, {cam_key: kps [B,Hy,K,3]}): detector outputs already computed on the same images with
         the same weights (engine.TrainStep(dedupe=True)); the detector is then not run again here."""
@@ -252,12 +262,7 @@ class Counter3DDisc(torch.nn.Module):
         if preds is not None:
             preds = {k: v.detach() for k, v in preds.items()}
         else:
-            # The reference builds (and discards) an autograd graph here (model.py:231, output detached at :243);
-            # only the values and the train-mode BN running-statistic updates matter, so no graph is recorded.
-            ops_nn.prepack(regressor)
-            with torch.no_grad():
-                dets = _grouped(regressor, [x[k + '_img'] for k in keys])
-            preds = {k: kp for k, (kp, _) in zip(keys, dets)}
+            preds = self.detector_pass(x, regressor)
         for cam in cams:
             key = 'cam_{}'.format(cam)
             inputs += [preds[key][:, h, :, :d] for h in range(preds[key].shape[1])] + [reals[key][..., :d]]

@@ -21,6 +21,18 @@ from . import ops_nn
 from .dp import GradReducer, dp_active, sync_buffers
 from .optim import FusedAdam
 
+# The discriminator's own forward / backward / Adam (a few hundred small launches, ~4 ms of an otherwise idle GPU) runs on a
+# second stream beside the generator step's detector passes, which do not depend on it (only the generator LOSSES do).
+DISC_BESIDE_GEN = os.environ.get('XAS_DISC_BESIDE_GEN', '1') != '0'
+_aux = {}
+
+
+def _aux_stream():
+    dev = torch.cuda.current_device()
+    if dev not in _aux:
+        _aux[dev] = torch.cuda.Stream()
+    return _aux[dev]
+
 
 def prepare_model(config, smpl_arrays=None):
     """-> unsup_model, unsup_disc, optimizer_detector, optimizer_discriminator  (train.py:212-269)."""
@@ -114,24 +126,45 @@ class TrainStep:
                 if c is not None:
                     for _ in range(len(self.model.cam_id_list)):
                         c.bump()
-        if do_disc:
-            preds = {k: v['kps'] for k, v in shared[0].items()} if shared is not None else None
-            loss_disc, info = self.disc(x, self.model.regressor, preds) if preds is not None else \
-                self.disc(x, self.model.regressor)
+        def disc_update(preds):
+            ld, info = self.disc(x, self.model.regressor, preds)
             out.update(info)
-            loss_disc = loss_disc.mean()
+            ld = ld.mean()
             if self.red_disc:
                 self.red_disc.arm()
-            loss_disc.backward()
+            ld.backward()
             ops_nn.join_side_stream()
             if self.red_disc:
                 self.red_disc.finish()
             self.opt_disc.step()
             self.opt_disc.zero_grad()
+            return ld, info
+
+        aux = None
+        if do_disc:
+            if shared is not None:
+                loss_disc, _ = disc_update({k: v['kps'] for k, v in shared[0].items()})
+            elif DISC_BESIDE_GEN and do_gen and next(self.model.regressor.parameters()).is_cuda:
+                preds = self.disc.detector_pass(x, self.model.regressor)      # the detector pass stays on the main chain
+                main, aux = torch.cuda.current_stream(), _aux_stream()
+                aux.wait_stream(main)
+                with torch.cuda.stream(aux):
+                    loss_disc, info = disc_update(preds)
+                for t in preds.values():
+                    t.record_stream(aux)
+                for t in list(info.values()) + [loss_disc]:
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(main)
+            else:
+                loss_disc, _ = disc_update(None)
         if do_gen:
             if shared is not None:
                 self.model.pseudo_passes(x, *shared)
                 loss_kp, info = self.model.finish(x, self.disc.smpl_discriminator, *shared)
+            elif aux is not None:
+                cams = self.model.camera_passes(x)                            # beside the discriminator update
+                torch.cuda.current_stream().wait_stream(aux)                  # the losses use the UPDATED discriminator
+                loss_kp, info = self.model.finish(x, self.disc.smpl_discriminator, *cams)
             else:
                 loss_kp, info = self.model(x, self.disc.smpl_discriminator)
             out.update(info)
