@@ -173,8 +173,11 @@ class Counter3DModel(torch.nn.Module):
             out['pose_3d_gt_{}_pseudo'.format(key)] = _to_world(gt, x, key, True)[0:1]
             per_cam[key]['pseudo'] = compute_supervision_min(pred, gt)
 
-    def finish(self, x, smpl_discriminator, per_cam, out):
-        """Losses from the per-camera results (model.py:98-190)."""
+    def finish(self, x, smpl_discriminator, per_cam, out, aux=None):
+        """Losses from the per-camera results (model.py:98-190).  aux: a second stream that already holds the updated
+        discriminator (engine.TrainStep): the adversarial term - the discriminator on the DETACHED poses (model.py:128), so
+        its forward and backward share nothing with the rest of the graph - runs there, beside the other losses and, in
+        the backward pass, beside the physique / detector backward (autograd replays a node on the stream it was recorded on)."""
         cams = _cams(x, self.cam_id_list)
         lc = self.loss_config
         losses = {}
@@ -183,17 +186,7 @@ class Counter3DModel(torch.nn.Module):
         if 'mono' not in cams:
             out['kp_gt_world'] = convert_patch_to_world(x['cam_0_joints'], x, 'cam_0', is_norm=False)[0:1]
 
-        if 'symmetry_loss' in lc:
-            w = lc['symmetry_loss']['weight']
-            total = 0
-            for cam in cams:
-                if cam == 'mono':
-                    continue
-                key = 'cam_{}'.format(cam)
-                total = total + compute_symmetry_min(world[key], w['bone'], w['kp'], kps[key], w.get('kp_2d'))
-            losses['symmetry'] = total
-
-        if 'smpl_gen_loss' in lc:
+        def adversarial():
             total = 0
             rels = {}
             for cam in cams:
@@ -211,7 +204,29 @@ class Counter3DModel(torch.nn.Module):
                     rot = torch.stack([smpl_discriminator(random_rotation_3D((world[key] - world[key][:, 0:1])[:, h] / 1000)
                                                           [..., :self.DISC_SUP_DIMENSION]) for h in range(rel.shape[1])], dim=1)
                     total = total + compute_disc_loss(logits, None) * 0.7 + compute_disc_loss(rot, None) * 0.3
-            losses['smpl_gen'] = total * lc['smpl_gen_loss']['weight']
+            return total * lc['smpl_gen_loss']['weight']
+
+        gen_val, cur = None, None
+        if 'smpl_gen_loss' in lc and aux is not None:
+            cur = torch.cuda.current_stream()
+            aux.wait_stream(cur)
+            for t in world.values():
+                t.record_stream(aux)
+            with torch.cuda.stream(aux):
+                gen_val = adversarial()
+
+        if 'symmetry_loss' in lc:
+            w = lc['symmetry_loss']['weight']
+            total = 0
+            for cam in cams:
+                if cam == 'mono':
+                    continue
+                key = 'cam_{}'.format(cam)
+                total = total + compute_symmetry_min(world[key], w['bone'], w['kp'], kps[key], w.get('kp_2d'))
+            losses['symmetry'] = total
+
+        if 'smpl_gen_loss' in lc:
+            losses['smpl_gen'] = gen_val if gen_val is not None else adversarial()
 
         if 'smpl_pseudo_img_loss' in lc:
             losses['smpl_pseudo_img'] = sum(per_cam['cam_{}'.format(c)]['pseudo'] for c in cams) \
@@ -221,6 +236,9 @@ class Counter3DModel(torch.nn.Module):
                 * lc['physique_recons_loss']['weight']
         if 'recons_loss' in lc:
             losses['reconstruction'] = sum(per_cam['cam_{}'.format(c)]['recons'] for c in cams) * lc['recons_loss']['weight']
+        if cur is not None:
+            cur.wait_stream(aux)                       # the adversarial term joins the sum of the losses
+            gen_val.record_stream(cur)
         return losses, out
 
 

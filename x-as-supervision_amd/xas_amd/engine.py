@@ -163,8 +163,8 @@ class TrainStep:
                 loss_kp, info = self.model.finish(x, self.disc.smpl_discriminator, *shared)
             elif aux is not None:
                 cams = self.model.camera_passes(x)                            # beside the discriminator update
-                torch.cuda.current_stream().wait_stream(aux)                  # the losses use the UPDATED discriminator
-                loss_kp, info = self.model.finish(x, self.disc.smpl_discriminator, *cams)
+                # the adversarial term (the only user of the UPDATED discriminator) stays on the second stream
+                loss_kp, info = self.model.finish(x, self.disc.smpl_discriminator, *cams, aux=aux)
             else:
                 loss_kp, info = self.model(x, self.disc.smpl_discriminator)
             out.update(info)
