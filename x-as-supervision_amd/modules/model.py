@@ -97,7 +97,7 @@ class Counter3DModel(torch.nn.Module):
     def forward(self, x, smpl_discriminator):
         return self.finish(x, smpl_discriminator, *self.camera_passes(x))
 
-    def camera_passes(self, x, pseudo=True):
+    def camera_passes(self, x, pseudo=True, after_geometry=None):
         """Detector / geometry / mask part of the step for every camera (everything that does not involve the
         discriminator).  `pseudo=False` leaves the pseudo-image branch to a later `pseudo_passes` call."""
         cams = _cams(x, self.cam_id_list)
@@ -135,6 +135,8 @@ class Counter3DModel(torch.nn.Module):
                                            self.body_width)
                     out['mask_heatmap_line_{}'.format(key)] = recon.detach()
                     per_cam[key] = dict(kps=kps, world=world, recon=recon)
+                if after_geometry is not None:           # the world joints of every camera exist: engine.TrainStep starts the
+                    after_geometry(per_cam)              # adversarial term on its second stream, beside the physique net
                 if 'physique_recons_loss' in lc and self.physique_network is not None:
                     use_w = lc['physique_recons_loss']['use_dis_map']
                     for key, phys in zip(keys, _grouped(self.physique_network, [per_cam[k]['recon'] for k in keys])):
@@ -173,7 +175,39 @@ class Counter3DModel(torch.nn.Module):
             out['pose_3d_gt_{}_pseudo'.format(key)] = _to_world(gt, x, key, True)[0:1]
             per_cam[key]['pseudo'] = compute_supervision_min(pred, gt)
 
-    def finish(self, x, smpl_discriminator, per_cam, out, aux=None):
+    def adversarial_term(self, x, smpl_discriminator, world):
+        """smpl_gen_loss (model.py:118-143): the discriminator on the DETACHED, root-relative predicted poses of every camera
+        and hypothesis (use_aug: plus on randomly rotated, NOT detached ones)."""
+        cams = _cams(x, self.cam_id_list)
+        total = 0
+        rels = {}
+        for cam in cams:
+            key = 'cam_{}'.format(cam)
+            rels[key] = ((world[key] - world[key][:, 0:1]) / 1000)[..., :self.DISC_SUP_DIMENSION].detach()
+        hy = world['cam_{}'.format(cams[0])].shape[1]
+        flat = _disc_many(smpl_discriminator, [rels['cam_{}'.format(c)][:, h] for c in cams for h in range(hy)])
+        for ci, cam in enumerate(cams):
+            key = 'cam_{}'.format(cam)
+            rel = rels[key]
+            logits = torch.stack(flat[ci * hy:(ci + 1) * hy], dim=1)
+            if not self.use_aug:
+                total = total + compute_disc_loss(logits, None)
+            else:
+                rot = torch.stack([smpl_discriminator(random_rotation_3D((world[key] - world[key][:, 0:1])[:, h] / 1000)
+                                                      [..., :self.DISC_SUP_DIMENSION]) for h in range(rel.shape[1])], dim=1)
+                total = total + compute_disc_loss(logits, None) * 0.7 + compute_disc_loss(rot, None) * 0.3
+        return total * self.loss_config['smpl_gen_loss']['weight']
+
+    def adversarial_on(self, aux, x, smpl_discriminator, world):
+        """adversarial_term on stream `aux` (which holds the updated discriminator): forward now, backward replayed there."""
+        cur = torch.cuda.current_stream()
+        aux.wait_stream(cur)
+        for t in world.values():
+            t.record_stream(aux)
+        with torch.cuda.stream(aux):
+            return self.adversarial_term(x, smpl_discriminator, world)
+
+    def finish(self, x, smpl_discriminator, per_cam, out, aux=None, gen_val_early=None):
         """Losses from the per-camera results (model.py:98-190).  aux: a second stream that already holds the updated
         discriminator (engine.TrainStep): the adversarial term - the discriminator on the DETACHED poses (model.py:128), so
         its forward and backward share nothing with the rest of the graph - runs there, beside the other losses and, in
@@ -186,34 +220,11 @@ class Counter3DModel(torch.nn.Module):
         if 'mono' not in cams:
             out['kp_gt_world'] = convert_patch_to_world(x['cam_0_joints'], x, 'cam_0', is_norm=False)[0:1]
 
-        def adversarial():
-            total = 0
-            rels = {}
-            for cam in cams:
-                key = 'cam_{}'.format(cam)
-                rels[key] = ((world[key] - world[key][:, 0:1]) / 1000)[..., :self.DISC_SUP_DIMENSION].detach()
-            hy = world['cam_{}'.format(cams[0])].shape[1]
-            flat = _disc_many(smpl_discriminator, [rels['cam_{}'.format(c)][:, h] for c in cams for h in range(hy)])
-            for ci, cam in enumerate(cams):
-                key = 'cam_{}'.format(cam)
-                rel = rels[key]
-                logits = torch.stack(flat[ci * hy:(ci + 1) * hy], dim=1)
-                if not self.use_aug:
-                    total = total + compute_disc_loss(logits, None)
-                else:
-                    rot = torch.stack([smpl_discriminator(random_rotation_3D((world[key] - world[key][:, 0:1])[:, h] / 1000)
-                                                          [..., :self.DISC_SUP_DIMENSION]) for h in range(rel.shape[1])], dim=1)
-                    total = total + compute_disc_loss(logits, None) * 0.7 + compute_disc_loss(rot, None) * 0.3
-            return total * lc['smpl_gen_loss']['weight']
-
-        gen_val, cur = None, None
+        gen_val, cur = gen_val_early, None
         if 'smpl_gen_loss' in lc and aux is not None:
             cur = torch.cuda.current_stream()
-            aux.wait_stream(cur)
-            for t in world.values():
-                t.record_stream(aux)
-            with torch.cuda.stream(aux):
-                gen_val = adversarial()
+            if gen_val is None:
+                gen_val = self.adversarial_on(aux, x, smpl_discriminator, world)
 
         if 'symmetry_loss' in lc:
             w = lc['symmetry_loss']['weight']
@@ -226,7 +237,7 @@ class Counter3DModel(torch.nn.Module):
             losses['symmetry'] = total
 
         if 'smpl_gen_loss' in lc:
-            losses['smpl_gen'] = gen_val if gen_val is not None else adversarial()
+            losses['smpl_gen'] = gen_val if gen_val is not None else self.adversarial_term(x, smpl_discriminator, world)
 
         if 'smpl_pseudo_img_loss' in lc:
             losses['smpl_pseudo_img'] = sum(per_cam['cam_{}'.format(c)]['pseudo'] for c in cams) \

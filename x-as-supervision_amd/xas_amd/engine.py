@@ -162,9 +162,16 @@ class TrainStep:
                 self.model.pseudo_passes(x, *shared)
                 loss_kp, info = self.model.finish(x, self.disc.smpl_discriminator, *shared)
             elif aux is not None:
-                cams = self.model.camera_passes(x)                            # beside the discriminator update
-                # the adversarial term (the only user of the UPDATED discriminator) stays on the second stream
-                loss_kp, info = self.model.finish(x, self.disc.smpl_discriminator, *cams, aux=aux)
+                # the adversarial term (the only user of the UPDATED discriminator) stays on the second stream; it starts as
+                # soon as the world joints exist, beside the physique net
+                early = {}
+
+                def after_geometry(per_cam):
+                    if 'smpl_gen_loss' in self.model.loss_config:
+                        early['v'] = self.model.adversarial_on(aux, x, self.disc.smpl_discriminator,
+                                                               {k: v['world'] for k, v in per_cam.items()})
+                cams = self.model.camera_passes(x, after_geometry=after_geometry)   # beside the discriminator update
+                loss_kp, info = self.model.finish(x, self.disc.smpl_discriminator, *cams, aux=aux, gen_val_early=early.get('v'))
             else:
                 loss_kp, info = self.model(x, self.disc.smpl_discriminator)
             out.update(info)
