@@ -184,5 +184,7 @@ class TrainStep:
                 self.red_det.finish()
             self.opt_det.step()
             self.opt_det.zero_grad()
+        if aux is not None:
+            torch.cuda.current_stream().wait_stream(aux)     # (already joined when the adversarial term is part of the losses)
         self.cur_step += 1
         return loss_disc, loss_kp, total, out
