@@ -947,57 +947,68 @@ constexpr int ST_PH = (ST_TH - 1) * 2 + 7;           // 21
 constexpr int ST_PW = (ST_TW - 1) * 2 + 7;           // 37
 constexpr int ST_K = 147, ST_KP = 148, ST_CO = 64, ST_LDW = ST_CO + 1;
 
+#ifndef XAS_ST_TPB
+#define XAS_ST_TPB 4
+#endif
+constexpr int ST_TPB = XAS_ST_TPB;                   // output tiles a block walks with ONE copy of the weights in LDS
+
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        float* __restrict__ y, int N, int H, int W, int Ho, int Wo) {
   __shared__ float patch[ST_PH * ST_PW * 3 + 8];
   __shared__ float ws[ST_KP * ST_LDW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_w = (Wo + ST_TW - 1) / ST_TW;
-  const int ty = blockIdx.x / tiles_w, tx = blockIdx.x % tiles_w, n = blockIdx.y;
-  const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
-  const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
-  // input patch [21][37][3], zero padded
-  for (int e = tid; e < ST_PH * ST_PW * 3; e += 256) {
-    const int c = e % 3, px = (e / 3) % ST_PW, py = e / (3 * ST_PW);
-    const int iy = iy0 + py, ix = ix0 + px;
-    patch[e] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                   ? x[(((size_t)n * H + iy) * W + ix) * 3 + c] : 0.f;
-  }
-  // weights packed [co][r][s][c] = [co][k] -> ws[k][co]; row 147 is the zero pad
+  const int tiles_w = (Wo + ST_TW - 1) / ST_TW, tiles = tiles_w * ((Ho + ST_TH - 1) / ST_TH);
+  const int n = blockIdx.y;
+  // weights packed [co][r][s][c] = [co][k] -> ws[k][co]; row 147 is the zero pad.  Staged once per block: the 37.6 KB of
+  // weights were re-read for every 8 x 16 tile (r03: a block walks ST_TPB tiles: 72.7 -> 77.8 TFLOP/s at 4 tiles, 76 at 8, 73 at 16)
   for (int e = tid; e < ST_CO * ST_K; e += 256) {
     const int co = e / ST_K, k = e % ST_K;
     ws[k * ST_LDW + co] = w[e];
   }
   if (tid < ST_CO) ws[ST_K * ST_LDW + tid] = 0.f;
-  __syncthreads();
-
   const int i = lane & 31, h = lane >> 5;
   const int ly = wave * 2 + (i >> 4), lx = i & 15;            // pixel of this lane inside the tile
   const int base = ((ly * 2) * ST_PW + lx * 2) * 3;
-  f32x16 acc0, acc1;
+  for (int tt = 0; tt < ST_TPB; ++tt) {
+    const int tile = blockIdx.x * ST_TPB + tt;
+    if (tile >= tiles) break;
+    const int ty = tile / tiles_w, tx = tile % tiles_w;
+    const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    __syncthreads();                                   // the previous tile's patch has been consumed (and ws is complete)
+    // input patch [21][37][3], zero padded
+    for (int e = tid; e < ST_PH * ST_PW * 3; e += 256) {
+      const int c = e % 3, px = (e / 3) % ST_PW, py = e / (3 * ST_PW);
+      const int iy = iy0 + py, ix = ix0 + px;
+      patch[e] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                     ? x[(((size_t)n * H + iy) * W + ix) * 3 + c] : 0.f;
+    }
+    __syncthreads();
+    f32x16 acc0, acc1;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
 #pragma unroll
-  for (int kk = 0; kk < ST_KP / 2; ++kk) {
-    // tap offsets of k = 2kk and 2kk+1 in the patch (k = (r*7 + s)*3 + c); k = 147 reads tap 0 (weight is 0)
-    const int k0 = 2 * kk, k1 = (2 * kk + 1 < ST_K) ? 2 * kk + 1 : 0;
-    const int o0 = ((k0 / 21) * ST_PW + (k0 / 3) % 7) * 3 + k0 % 3;
-    const int o1 = ((k1 / 21) * ST_PW + (k1 / 3) % 7) * 3 + k1 % 3;
-    const float a = patch[base + (h ? o1 : o0)];
-    const float b0 = ws[(2 * kk + h) * ST_LDW + i];
-    const float b1 = ws[(2 * kk + h) * ST_LDW + 32 + i];
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
-  }
-  const int col = lane & 31, rsub = 4 * (lane >> 5);
+    for (int kk = 0; kk < ST_KP / 2; ++kk) {
+      // tap offsets of k = 2kk and 2kk+1 in the patch (k = (r*7 + s)*3 + c); k = 147 reads tap 0 (weight is 0)
+      const int k0 = 2 * kk, k1 = (2 * kk + 1 < ST_K) ? 2 * kk + 1 : 0;
+      const int o0 = ((k0 / 21) * ST_PW + (k0 / 3) % 7) * 3 + k0 % 3;
+      const int o1 = ((k1 / 21) * ST_PW + (k1 / 3) % 7) * 3 + k1 % 3;
+      const float a = patch[base + (h ? o1 : o0)];
+      const float b0 = ws[(2 * kk + h) * ST_LDW + i];
+      const float b1 = ws[(2 * kk + h) * ST_LDW + 32 + i];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    }
+    const int col = lane & 31, rsub = 4 * (lane >> 5);
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int pi = (reg & 3) + 8 * (reg >> 2) + rsub;          // pixel index within the wave's 2 x 16 strip
-    const int oy = oy0 + wave * 2 + (pi >> 4), ox = ox0 + (pi & 15);
-    if (oy < Ho && ox < Wo) {
-      float* o = y + (((size_t)n * Ho + oy) * Wo + ox) * ST_CO;
-      o[col] = acc0[reg];
-      o[32 + col] = acc1[reg];
+    for (int reg = 0; reg < 16; ++reg) {
+      const int pi = (reg & 3) + 8 * (reg >> 2) + rsub;        // pixel index within the wave's 2 x 16 strip
+      const int oy = oy0 + wave * 2 + (pi >> 4), ox = ox0 + (pi & 15);
+      if (oy < Ho && ox < Wo) {
+        float* o = y + (((size_t)n * Ho + oy) * Wo + ox) * ST_CO;
+        o[col] = acc0[reg];
+        o[32 + col] = acc1[reg];
+      }
     }
   }
 }
@@ -1544,8 +1555,8 @@ static int conv_fwd_impl(const float* x, const float* w_packed, const float* bia
   hipStream_t st = as_stream(stream);
   if (s->Cin == 3 && s->R == 7 && s->S == 7 && s->stride == 2 && s->pad == 3 && s->Cout == ST_CO && bias == nullptr) {
     const int tiles = (int)(cdiv(s->Ho, ST_TH) * cdiv(s->Wo, ST_TW));
-    hipLaunchKernelGGL(stem_fwd_kernel, dim3(tiles, s->N), dim3(256), 0, st, x, w_packed, y, s->N, s->Hi, s->Wi, s->Ho,
-                       s->Wo);
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)cdiv(tiles, ST_TPB), s->N), dim3(256), 0, st, x, w_packed, y, s->N, s->Hi,
+                       s->Wi, s->Ho, s->Wo);
     XAS_LAUNCH_CHECK();
     return 0;
   }
