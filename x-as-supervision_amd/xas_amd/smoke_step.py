@@ -25,6 +25,7 @@ def run():
     print('[smoke] detector ok: max|dkps| vs oracle = %.2e' % err)
     cfg = model_config('HM36_Multi_SurS1')
     cfg['model_params']['cam_id_list'] = [0]
+    torch.manual_seed(0)                                   # reproducible weights: the printed losses are comparable between runs
     model, disc, od, odisc = engine.prepare_model(cfg)
     model.cuda().train(), disc.cuda().train()
     step = engine.TrainStep(cfg, model, disc, od, odisc)
