@@ -77,3 +77,57 @@ def test_tap_and_wide_tile_kernels_equal_the_implicit_gemm():
     for a, b in zip(outs[0], outs[(1 << 22) | (1 << 23)]):
         for ta, tb in zip(a, b):
             assert rel(ta, tb) < 2e-6
+
+
+def test_batched_weight_preparation_is_bit_identical(monkeypatch):
+    """xas_prepare_weights (all layers, one launch, OIHW -> planes) against xas_pack_weight + xas_split_weight per layer."""
+    from xas_amd import layers as L
+    from xas_amd import ops_nn as F
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(L.Conv2d(32, 64, 3, 1, 1, bias=False), L.Conv2d(64, 256, 1, 1, 0, bias=False),
+                              L.Conv2d(256, 96, 3, 2, 1, bias=False), L.ConvTranspose2d(96, 32, 4, 2, 1)).cuda()
+    got = {}
+    for batched in (True, False):
+        monkeypatch.setattr(F, 'BATCH_PREP', batched)
+        for m in net:
+            m._cache = F._PackCache()
+        if hasattr(net, '_xas_prep'):
+            del net._xas_prep
+        F.prepack(net)
+        torch.cuda.synchronize()
+        got[batched] = [{k: v.clone() for k, v in m._cache.packed.items() if k[1]} for m in net]
+    n = 0
+    for a, b in zip(got[True], got[False]):
+        assert a.keys() == b.keys() and a
+        for k in a:
+            assert torch.equal(a[k].view(torch.uint8), b[k].view(torch.uint8)), k
+            n += 1
+    assert n >= 8
+
+
+def test_stem_weight_gradient_kernel_equals_the_general_kernel():
+    """stem_wgrad_kernel (LDS patches, tune bit 24 switches it off) against the general weight-gradient kernel and float64."""
+    from xas_amd import layers as L
+    from xas_amd._lib import query
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(6, 3, 64, 96, generator=g)
+    wt = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    xc, wc = x.double(), wt.double().requires_grad_(True)
+    yc = TF.conv2d(xc, wc, None, 2, 3)
+    gy = torch.randn(yc.shape, generator=g)
+    (yc * gy.double()).sum().backward()
+    res = {}
+    for tune in (0, 1 << 24):
+        query('xas_set_tuning', tune)
+        try:
+            m = L.Conv2d(3, 64, 7, 2, 3, bias=False).cuda()
+            with torch.no_grad():
+                m.weight.copy_(wt)
+            y = m(x.cuda())
+            (y * gy.cuda()).sum().backward()
+            torch.cuda.synchronize()
+            res[tune] = m.weight.grad.clone()
+        finally:
+            query('xas_set_tuning', 0)
+    assert rel(res[0], wc.grad) < 3e-6 and rel(res[1 << 24], wc.grad) < 3e-6
+    assert rel(res[0], res[1 << 24]) < 2e-6
