@@ -284,8 +284,34 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
   }
   if (!(want_stats || rows_from_lds)) return;
   // ---- staged passes: T[pixel][channel of this half] -> whole rows to memory and / or per-channel sums
+  constexpr int C4 = BNH / 4, RPP = 256 / C4, NR = BM / RPP;   // float4 per row, rows per pass of the block, rows per thread
+  static_assert(BM % RPP == 0, "row pass does not tile the block rows");
+  const int c4 = threadIdx.x % C4, r0 = threadIdx.x / C4;
+  auto out_row = [&](int r) -> size_t {
+    const int m = m0 + r;
+    if (p.t2d_tw) return tile_row(p, m0, r);
+    if (MODE == 0 || p.stride == 1) return (size_t)m;
+    const int n = m / HW; const int rem = m - n * HW; const int a = rem / Wrow, b = rem - a * Wrow;
+    return ((size_t)n * p.Hd + (ph + p.stride * a)) * p.Wd + (pw + p.stride * b);
+  };
 #pragma unroll
   for (int hf = 0; hf < HALVES; ++hf) {
+    const int nh0 = n0 + hf * BNH;                     // first global channel of this half
+    const int nn = nh0 + c4 * 4;
+    // accumulating forms: the old values / skip-gradient rows and sign bytes of this pass are requested BEFORE the staging
+    // and its two barriers, so that their HBM latency is spent there (the short-K layers that use these forms are all
+    // epilogue: 3.6 TB/s with the loads issued after the barriers)
+    float4 prevv[NR];
+    unsigned pmask[NR];
+    const bool pre = rows_from_lds && p.accumulate;
+    if (pre) {
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const size_t orow = out_row(r0 + RPP * j);
+        prevv[j] = stream_load(reinterpret_cast<const float4*>((p.accumulate == 2 ? p.acc_src : p.out) + orow * p.Cd + nn));
+        pmask[j] = p.accumulate == 2 ? p.acc_mask[(orow * p.Cd + nn) >> 2] : 15u;
+      }
+    }
     __syncthreads();                                   // the operand buffers (first pass) / the previous half's tile are free
     {
       const int pl = lane & 31, cs = 4 * (lane >> 5);
@@ -303,33 +329,22 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
         }
     }
     __syncthreads();                                   // T complete
-    const int nh0 = n0 + hf * BNH;                     // first global channel of this half
     if (rows_from_lds) {
-      constexpr int C4 = BNH / 4, RPP = 256 / C4;      // float4 per row, rows per pass of the block
-      const int c4 = threadIdx.x % C4, r0 = threadIdx.x / C4;
-      const int nn = nh0 + c4 * 4;
       float4 bb = make_float4(0, 0, 0, 0);
       if (MODE == 0 && p.bias) bb = *reinterpret_cast<const float4*>(p.bias + nn);
-#pragma unroll 4
-      for (int r = r0; r < BM; r += RPP) {
-        const int m = m0 + r;
-        size_t orow;
-        if (p.t2d_tw) orow = tile_row(p, m0, r);
-        else if (MODE == 0 || p.stride == 1) orow = (size_t)m;
-        else {
-          const int n = m / HW; const int rem = m - n * HW; const int a = rem / Wrow, b = rem - a * Wrow;
-          orow = ((size_t)n * p.Hd + (ph + p.stride * a)) * p.Wd + (pw + p.stride * b);
-        }
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const int r = r0 + RPP * j;
+        const size_t orow = out_row(r);
         float4 v = *reinterpret_cast<const float4*>(lds + r * LDT + c4 * 4);
         v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-        float* op = p.out + orow * p.Cd + nn;
         if (p.accumulate) {
-          const float4 o = stream_load(reinterpret_cast<const float4*>(p.accumulate == 2 ? p.acc_src + orow * p.Cd + nn : op));
-          const unsigned mb = p.accumulate == 2 ? p.acc_mask[(orow * p.Cd + nn) >> 2] : 15u;
+          const float4 o = prevv[j];
+          const unsigned mb = pmask[j];
           v.x += (mb & 1u) ? o.x : 0.f; v.y += (mb & 2u) ? o.y : 0.f;
           v.z += (mb & 4u) ? o.z : 0.f; v.w += (mb & 8u) ? o.w : 0.f;
         }
-        stream_store(reinterpret_cast<float4*>(op), v);
+        stream_store(reinterpret_cast<float4*>(p.out + orow * p.Cd + nn), v);
       }
     }
     if (MODE == 0 && want_stats) {
