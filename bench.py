@@ -28,7 +28,9 @@ import torch.distributed as dist
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, 'Peak FP32 (matrix)': v_mfma_f32_32x32x2_f32
 PEAK_BF16_MFMA_TFLOPS = 16 * PEAK_FP32_MFMA_TFLOPS      # dense bf16 MFMA = 16 x the fp32 MFMA rate (same table): 2516.8
 # fp32-equivalent peak of a bf16x6 launch: six bf16 MFMAs per fp32 product (VERDICT r02 ruling): 419.5 TFLOP/s
-PEAK_BY_CLASS = {':f32': PEAK_FP32_MFMA_TFLOPS, ':bf16': PEAK_BF16_MFMA_TFLOPS, ':bf16x6': PEAK_BF16_MFMA_TFLOPS / 6.0}
+# f16x3: three fp16 MFMAs (same rate as bf16) per fp32 product: 2516.8 / 3 = 838.9 TFLOP/s fp32-equivalent
+PEAK_BY_CLASS = {':f32': PEAK_FP32_MFMA_TFLOPS, ':bf16': PEAK_BF16_MFMA_TFLOPS, ':bf16x6': PEAK_BF16_MFMA_TFLOPS / 6.0,
+                 ':f16x3': PEAK_BF16_MFMA_TFLOPS / 3.0}
 IMAGES_PER_SAMPLE = {'HM36': 8, 'MPI': 10}
 
 
@@ -97,7 +99,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo to rehearse ranks on one GPU)')
     ap.add_argument('--tune', type=int, default=0, help='kernel tuning experiment flags (xas_set_tuning)')
-    ap.add_argument('--precision', default='bf16x6', choices=['bf16x6', 'f32', 'bf16'],
+    ap.add_argument('--precision', default='bf16x6', choices=['bf16x6', 'f16x3', 'f32', 'bf16'],
                     help='arithmetic of the MFMA convolutions (xas_hip.h XAS_PREC_*).  bf16x6 (default, the headline): fp32 '
                          'operands split exactly into three bf16 pieces, six exact partial products accumulated in fp32 - '
                          'fp32-accurate (the whole parity suite runs in this mode), peak 2516.8 / 6 = 419.5 TFLOP/s fp32-'
@@ -270,6 +272,7 @@ def main():
             variant_check = {'max_abs_joint_diff_vs_exact_fp32_mfma': float((kv - k32).abs().max()),
                              'what': 'detector forward (eval-mode norms) on 8 images, this precision mode vs the exact-fp32 MFMA kernels; parity bar 1e-4'}
         kernel_names = {':bf16x6': 'igemm_x6_kernel<.,.,.,3> (fwd / dgrad) + wgrad_x6_kernel<.,.,3>: bf16x6 MFMA implicit-GEMM conv family',
+                        ':f16x3': 'igemm_x6_kernel<.,.,0,2> / igemm_x6t_kernel<.,0,2> (fwd): f16x3 MFMA implicit-GEMM conv family',
                         ':bf16': 'igemm_x6_kernel<.,.,.,1> + wgrad_x6_kernel<.,.,1>: bf16 MFMA implicit-GEMM conv family',
                         ':f32': 'igemm_buf_kernel + wgrad_buf_kernel (+ stem_fwd_kernel): exact-fp32 MFMA implicit-GEMM conv family'}
         line = {
@@ -278,6 +281,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'f32': 'f32 (exact fp32 MFMA)', 'bf16x6': 'f32 (bf16x6 split, f32 accumulate)',
+                      'f16x3': 'f32 (forward: f16x3 split, gradients: bf16x6 split; f32 accumulate)',
                       'bf16': 'bf16 products, f32 accumulate (variant: NOT fp32 accurate, not the headline)'}[args.precision],
             'data': 'synthetic',
             'config': {'workload': args.workload, 'batch_per_gpu': args.batch, 'cameras': len(cams),
@@ -292,7 +296,7 @@ def main():
                          'kernel': kernel_names[dom],
                          'what': 'dominant kernel family of the step: algorithmic FLOP (2 N Ho Wo Cout R S Cin per launch) of its '
                                  'launches in the event-timed step / the sum of their HIP-event durations on the stream each was '
-                                 'launched on; peak: fp32 MFMA 157.3, bf16 MFMA 2516.8, bf16x6 = 2516.8 / 6 = 419.5 TFLOP/s '
+                                 'launched on; peak: fp32 MFMA 157.3, bf16 / fp16 MFMA 2516.8, bf16x6 = 2516.8 / 6 = 419.5, f16x3 = 2516.8 / 3 = 838.9 TFLOP/s '
                                  'fp32-equivalent (MI355X_MICROARCH.md)',
                          'by_kernel_class': {k.lstrip(':'): {kk: d[kk] for kk in ('launches', 'ms', 'achieved', 'peak', 'frac')} for k, d in cl.items()},
                          'conv_family_frac_of_mixed_peak': mix_frac,

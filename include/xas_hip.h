@@ -48,7 +48,7 @@ int xas_set_tuning(int flags);
  *   XAS_PREC_BF16   operands rounded to bf16 once (NOT fp32 accurate; a variant that is reported separately).
  * xas_set_precision sets the process default; a call overrides it with xas_conv_shape.mode = 1 + XAS_PREC_* (0 = default).
  * In the bf16 modes forward / data gradient take PRE-SPLIT weights: see xas_conv_weight_planes / xas_split_weight. */
-enum { XAS_PREC_F32 = 0, XAS_PREC_BF16 = 1, XAS_PREC_BF16X6 = 2 };
+enum { XAS_PREC_F32 = 0, XAS_PREC_BF16 = 1, XAS_PREC_BF16X6 = 2, XAS_PREC_F16X3 = 3 };
 int xas_set_precision(int mode);
 int xas_get_precision(void);
 int xas_abi_version(void);

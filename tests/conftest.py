@@ -26,12 +26,12 @@ def load_golden():
 
 @pytest.fixture(autouse=True)
 def _library_defaults(request):
-    """GPU tests leave the library as they found it: default precision (bf16x6, fp32 accurate), no variant selectors."""
+    """GPU tests leave the library as they found it: default precision (fp32 accurate), no variant selectors."""
     yield
     if request.node.get_closest_marker('gpu') is not None:
         from xas_amd import _lib
         if _lib._lib is not None:
-            _lib.query('xas_set_precision', _lib.PREC_BF16X6)
+            _lib.query('xas_set_precision', _lib.PREC_DEFAULT)
             _lib.query('xas_set_tuning', 0)
 
 

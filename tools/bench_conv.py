@@ -77,13 +77,15 @@ def main():
                 t[0] += flops
                 t[1] += ms
             outs[prec] = {'fwd': y, 'dgrad': dx, 'wgrad': dw}
-        if 'bf16x6' in outs and 'f32' in outs:
+        for pz in precs:
+            if pz == 'f32' or 'f32' not in outs:
+                continue
             errs = []
             for k in ('fwd', 'dgrad', 'wgrad'):
                 if which in ('all', k):
-                    a, b = outs['bf16x6'][k].double(), outs['f32'][k].double()
+                    a, b = outs[pz][k].double(), outs['f32'][k].double()
                     errs.append('%s %.1e' % (k, float((a - b).norm() / (b.norm() + 1e-30))))
-            line += ' | x6 vs f32: ' + ' '.join(errs)
+            line += ' | %s vs f32: ' % pz + ' '.join(errs)
         print(line, flush=True)
         del x, dy, w, outs
     for (prec, k), (f, ms) in tot.items():

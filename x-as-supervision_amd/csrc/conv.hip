@@ -1461,6 +1461,13 @@ static int launch_tile(const IgemmParams& p, int Mrows_max, int phases, hipStrea
 static int g_precision = XAS_PREC_BF16X6;    // process default (xas_set_precision); a call overrides it with xas_conv_shape.mode
 
 static inline int precision_of(const xas_conv_shape* s) { return s->mode > 0 ? s->mode - 1 : g_precision; }
+// operand planes of a pass in a precision mode (pass 0: forward-type launch, otherwise data / weight gradient):
+// XAS_PREC_F16X3 runs its forward-type launches on two fp16 planes and everything else as bf16x6
+static inline int planes_of(int prec, int pass) {
+  if (prec == XAS_PREC_F32) return 0;
+  if (prec == XAS_PREC_BF16) return 1;
+  return (prec == XAS_PREC_F16X3 && pass == 0) ? 2 : 3;
+}
 
 // prec: XAS_PREC_*.  The bf16-split kernels (conv_x6.hip) take PRE-SPLIT weights (xas_split_weight); the exact-fp32 kernels
 // take fp32 packed weights: xas_conv_weight_planes tells the caller which of the two a (shape, pass) wants.
@@ -1468,7 +1475,7 @@ template <int MODE>
 static int dispatch_igemm(const IgemmParams& p, int prec, int Mrows_max, int phases, hipStream_t st) {
   if (prec != XAS_PREC_F32) {
     XAS_REQUIRE(igemm_fits(p), "conv: tensor beyond the 32-bit offset range of the bf16-split kernels (use XAS_PREC_F32)");
-    return launch_igemm_x6(p, MODE, Mrows_max, phases, prec == XAS_PREC_BF16X6 ? 3 : 1, st);
+    return launch_igemm_x6(p, MODE, Mrows_max, phases, planes_of(prec, MODE), st);
   }
   int bm, bn;
   pick_tile(p.Cd, Mrows_max, phases, &bm, &bn);
@@ -1500,7 +1507,8 @@ static int images_per_launch(int N, long elems_per_image_a, long elems_per_image
 
 extern "C" int xas_set_tuning(int flags) { g_tune = flags; return 0; }
 extern "C" int xas_set_precision(int mode) {
-  XAS_REQUIRE(mode >= 0 && mode <= 2, "set_precision: 0 = exact fp32 MFMA, 1 = bf16 MFMA (not fp32 accurate), 2 = bf16x6 (fp32-accurate, default)");
+  XAS_REQUIRE(mode >= 0 && mode <= 3, "set_precision: 0 = exact fp32 MFMA, 1 = bf16 MFMA (not fp32 accurate), 2 = bf16x6 (fp32-accurate, default), "
+              "3 = f16x3 forward passes + bf16x6 gradient passes");
   g_precision = mode;
   return 0;
 }
@@ -1604,16 +1612,16 @@ extern "C" int xas_conv_weight_planes(const xas_conv_shape* s, int pass) {
   bool mfma;
   if (pass == 0) mfma = !thin && !(s->Cin == 3 && s->R == 7) && s->Cin % BK == 0 && s->Cout >= 16;
   else mfma = !thin && s->Cout % BK == 0 && s->Cin >= 16;
-  return mfma ? (prec == XAS_PREC_BF16X6 ? 3 : 1) : 0;
+  return mfma ? planes_of(prec, pass) : 0;
 }
 
 // Which kernel family a pass of this shape runs on (for measurement: bench.py prices every launch against the peak of the
 // pipe it actually uses).  pass: 0 forward-type, 1 data-gradient-type, 2 weight gradient.
-// -> 0 no MFMA (direct / one-channel kernels), 1 exact-fp32 MFMA, 2 bf16 MFMA, 3 bf16x6 MFMA.
+// -> 0 no MFMA (direct / one-channel kernels), 1 exact-fp32 MFMA, 2 bf16 MFMA, 3 bf16x6 MFMA, 4 f16x3 MFMA.
 extern "C" int xas_conv_kernel_class(const xas_conv_shape* s, int pass) {
   if (!s) return 0;
   const int prec = precision_of(s);
-  const int split = prec == XAS_PREC_BF16X6 ? 3 : (prec == XAS_PREC_BF16 ? 2 : 1);
+  const int split = prec == XAS_PREC_F32 ? 1 : (prec == XAS_PREC_BF16 ? 2 : (prec == XAS_PREC_F16X3 && pass == 0 ? 4 : 3));
   const bool thin = (s->Cout == 1 && thin_ok(s, s->Cin)) || (s->Cin == 1 && thin_ok(s, s->Cout));
   if (thin) return 0;
   if (pass == 0) {
@@ -2035,9 +2043,9 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
       wgrad_x6t_plan(s->N, s->Hi, s->Wi, s->Cin, s->Cout, s->R, s->S, s->stride, s->pad, s->Ho, s->Wo, &tbm, &tsplits, &tpps)) {
     splits = tsplits;
     p.out = (splits == 1 && !oihw) ? dw_packed : workspace;
-    rc = launch_wgrad_x6t(p, tbm, tsplits, tpps, precision_of(s) == XAS_PREC_BF16X6 ? 3 : 1, st);
+    rc = launch_wgrad_x6t(p, tbm, tsplits, tpps, planes_of(precision_of(s), 2), st);
   } else
-  if (x6) rc = launch_wgrad_x6(p, bm, bn, splits, precision_of(s) == XAS_PREC_BF16X6 ? 3 : 1, st);
+  if (x6) rc = launch_wgrad_x6(p, bm, bn, splits, planes_of(precision_of(s), 2), st);
   else if (buf_ok) {
     if (bm == 32) rc = launch_wgrad_buf<32, 128>(p, splits, st);
     else if (bn == 64) rc = bm == 128 ? launch_wgrad_buf<128, 64>(p, splits, st) : launch_wgrad_buf<64, 64>(p, splits, st);

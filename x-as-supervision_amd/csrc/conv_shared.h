@@ -108,6 +108,35 @@ __device__ __forceinline__ float4 sub_bf16x4(float4 v, uint2 q) {
                      v.z - __uint_as_float(q.y << 16), v.w - __uint_as_float(q.y & 0xffff0000u));
 }
 
+// ---- two-piece fp16 split ("f16x3", forward passes of XAS_PREC_F16X3): x = h1 + h2 + e, h1 = fp16(x), h2 = fp16(x - h1),
+// |e| <= 2^-22 |x| (11 + 11 significant bits, round to nearest); three of the four partial products are kept.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+constexpr float kF16WScale = 1024.f;           // weights are split as 2^10 w: their second pieces stay clear of fp16's subnormals
+                                               // (|w| < 64 assumed - larger weights become inf, loudly); results are scaled back
+
+__device__ __forceinline__ uint2 pack_f16x4(float4 v) {
+  const f16x2_t lo = {(_Float16)v.x, (_Float16)v.y}, hi = {(_Float16)v.z, (_Float16)v.w};      // v_cvt_pk_f16_f32 (RNE)
+  return make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+}
+__device__ __forceinline__ float4 sub_f16x4(float4 v, uint2 q) {
+  const f16x2_t lo = __builtin_bit_cast(f16x2_t, q.x), hi = __builtin_bit_cast(f16x2_t, q.y);
+  return make_float4(v.x - (float)lo.x, v.y - (float)lo.y, v.z - (float)hi.x, v.w - (float)hi.y);
+}
+// piece formats by plane count: 3 / 1 planes = bf16 pieces, 2 planes = fp16 pieces
+template <int P> __device__ __forceinline__ uint2 pack_piece4(float4 v) { return P == 2 ? pack_f16x4(v) : pack_bf16x4(v); }
+template <int P> __device__ __forceinline__ float4 sub_piece4(float4 v, uint2 q) { return P == 2 ? sub_f16x4(v, q) : sub_bf16x4(v, q); }
+// kept partial products (a piece, b piece), smallest first
+template <int P> struct Products;
+template <> struct Products<3> { static constexpr int N = 6; static constexpr int A[6] = {2, 0, 1, 1, 0, 0}; static constexpr int B[6] = {0, 2, 1, 0, 1, 0}; };
+template <> struct Products<2> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}; static constexpr int B[3] = {0, 1, 0}; };
+template <> struct Products<1> { static constexpr int N = 1; static constexpr int A[1] = {0}; static constexpr int B[1] = {0}; };
+template <int P>
+__device__ __forceinline__ f32x16 mfma_piece(uint4 a, uint4 b, f32x16 c) {
+  if constexpr (P == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
 // dgrad epilogue with the batch-norm backward reduction folded in (see IgemmParams::bnb_x).  Stride 1: output row = m.
 // Per (channel quad) the norm's parameters are loaded and 1/std formed ONCE, then applied to the MI row blocks; the two
 // sums are pre-reduced over the row blocks in registers, so both [WAVES_M * 32][BN] arrays fit the operand LDS together:

@@ -72,11 +72,15 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
     r1 = *reinterpret_cast<const float4*>(src + (size_t)row * K + k0 + 4);
   }
   unsigned short* o = dst + (blk * P) * 512 + lane * 8;
+  if (P == 2) {                                              // fp16 pieces of 2^10 w (exact scaling)
+    r0.x *= kF16WScale; r0.y *= kF16WScale; r0.z *= kF16WScale; r0.w *= kF16WScale;
+    r1.x *= kF16WScale; r1.y *= kF16WScale; r1.z *= kF16WScale; r1.w *= kF16WScale;
+  }
 #pragma unroll
   for (int pc = 0; pc < P; ++pc) {
-    const uint2 q0 = pack_bf16x4(r0), q1 = pack_bf16x4(r1);
+    const uint2 q0 = pack_piece4<P>(r0), q1 = pack_piece4<P>(r1);
     *reinterpret_cast<uint4*>(o + pc * 512) = make_uint4(q0.x, q0.y, q1.x, q1.y);
-    if (pc + 1 < P) { r0 = sub_bf16x4(r0, q0); r1 = sub_bf16x4(r1, q1); }
+    if (pc + 1 < P) { r0 = sub_piece4<P>(r0, q0); r1 = sub_piece4<P>(r1, q1); }
   }
 }
 
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
   constexpr int PLANE = BM * XLDH;              // halfwords
   constexpr int HBUF = P * PLANE;               // halfwords per half-buffer
   constexpr int AP = BM / 64;                   // activation float4 per thread per half-step (4 threads x 16 B per row)
-  constexpr int NT = P == 3 ? 6 : 1;            // partial products
+  constexpr int NT = Products<P>::N;            // partial products
   constexpr int TILES = C::MI * C::NI, NMF = NT * TILES;
   extern __shared__ __align__(16) float lds[];
   unsigned short* S = reinterpret_cast<unsigned short*>(lds);     // [2][P][BM][XLDH]
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
       float4 r = ra[h * AP + j];
 #pragma unroll
       for (int pc = 0; pc < P; ++pc) {
-        uint2 q = (XAS_X6_ABL & 32) ? make_uint2(__float_as_uint(r.x) + pc, __float_as_uint(r.z)) : pack_bf16x4(r);
+        uint2 q = (XAS_X6_ABL & 32) ? make_uint2(__float_as_uint(r.x) + pc, __float_as_uint(r.z)) : pack_piece4<P>(r);
 #if XAS_X6_ABL & 64
         {                                              // twice the conversion work, same stores
           const unsigned z = (unsigned)p.tune & 0x40000000u;          // runtime zero
@@ -246,39 +250,38 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
         }
 #endif
         *reinterpret_cast<uint2*>(sb + pc * PLANE + (arow + 64 * j) * XLDH + xswz(arow, kq4 >> 1) + (kq4 & 1) * 4) = q;
-        if (pc + 1 < P && !(XAS_X6_ABL & 32)) r = sub_bf16x4(r, q);
+        if (pc + 1 < P && !(XAS_X6_ABL & 32)) r = sub_piece4<P>(r, q);
       }
     }
   };
   const int i = lane & 31, hh = lane >> 5;
 #if XAS_X6_ABL & 16
-  bf16x8_t fa[P][C::MI];
+  uint4 fa[P][C::MI];
 #pragma unroll
   for (int pc = P - 1; pc >= 0; --pc)
 #pragma unroll
     for (int mi = 0; mi < C::MI; ++mi)
-      fa[pc][mi] = *reinterpret_cast<const bf16x8_t*>(S + pc * PLANE + (wm * C::WM + mi * 32 + i) * XLDH + xswz(i, hh));
+      fa[pc][mi] = *reinterpret_cast<const uint4*>(S + pc * PLANE + (wm * C::WM + mi * 32 + i) * XLDH + xswz(i, hh));
 #endif
   auto compute = [&](int buf, const uint4 (&gb)[P][C::NI]) {
     const unsigned short* sb = S + buf * HBUF;
 #if !(XAS_X6_ABL & 16)
-    bf16x8_t fa[P][C::MI];
+    uint4 fa[P][C::MI];
 #pragma unroll
     for (int pc = P - 1; pc >= 0; --pc)              // smallest pieces first: they feed the first products
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
-        fa[pc][mi] = *reinterpret_cast<const bf16x8_t*>(sb + pc * PLANE + (wm * C::WM + mi * 32 + i) * XLDH + xswz(i, hh));
+        fa[pc][mi] = *reinterpret_cast<const uint4*>(sb + pc * PLANE + (wm * C::WM + mi * 32 + i) * XLDH + xswz(i, hh));
 #else
     (void)sb;
 #endif
 #pragma unroll
-    for (int t = (P == 3 ? 0 : 5); t < 6; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < C::NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(gb[P == 3 ? kPB[t] : 0][ni]), fa[P == 3 ? kPA[t] : 0][mi],
-                                                                acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = mfma_piece<P>(gb[Products<P>::B[t]][ni], fa[Products<P>::A[t]][mi], acc[mi][ni]);
   };
   (void)NMF;
 #define SYNC() do { if (!(XAS_X6_ABL & 8)) __syncthreads(); } while (0)
@@ -320,6 +323,14 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
       __syncthreads();
       compute(1, gb_1);
     }
+  }
+  if constexpr (P == 2) {                              // the weights were split as 2^10 w
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= 1.f / kF16WScale;
   }
   igemm_epilogue<BM, BN, MODE, BNB, (BN >= 128 ? BN / 64 : 1)>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
 }
@@ -404,9 +415,9 @@ __global__ __launch_bounds__(256, XAS_X6T_WAVES) void igemm_x6t_kernel(IgemmPara
         unsigned char* d = S + pix * XT_PIXB + q * 8;
 #pragma unroll
         for (int pc = 0; pc < P; ++pc) {
-          const uint2 v = pack_bf16x4(r);
+          const uint2 v = pack_piece4<P>(r);
           *reinterpret_cast<uint2*>(d + pc * plane_b) = v;
-          if (pc + 1 < P) r = sub_bf16x4(r, v);
+          if (pc + 1 < P) r = sub_piece4<P>(r, v);
         }
       }
     }
@@ -457,22 +468,21 @@ __global__ __launch_bounds__(256, XAS_X6T_WAVES) void igemm_x6t_kernel(IgemmPara
   f32x16 acc2;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
-  auto read_frag = [&](bf16x8_t (&fa)[P][C::MI], int tapoff) {       // tapoff: byte offset of the tap + half inside a plane
+  auto read_frag = [&](uint4 (&fa)[P][C::MI], int tapoff) {          // tapoff: byte offset of the tap + half inside a plane
 #pragma unroll
     for (int pc = P - 1; pc >= 0; --pc)
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
-        fa[pc][mi] = *reinterpret_cast<const bf16x8_t*>(S + pc * plane_b + fbase[mi] + tapoff);
+        fa[pc][mi] = *reinterpret_cast<const uint4*>(S + pc * plane_b + fbase[mi] + tapoff);
   };
-  auto mfmas = [&](const bf16x8_t (&fa)[P][C::MI], const uint4 (&gb)[P][C::NI]) {
+  auto mfmas = [&](const uint4 (&fa)[P][C::MI], const uint4 (&gb)[P][C::NI]) {
 #pragma unroll
-    for (int t = (P == 3 ? 0 : 5); t < 6; ++t)
+    for (int t = 0; t < Products<P>::N; ++t)
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < C::NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(gb[P == 3 ? kPB[t] : 0][ni]), fa[P == 3 ? kPA[t] : 0][mi],
-                                                                acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = mfma_piece<P>(gb[Products<P>::B[t]][ni], fa[Products<P>::A[t]][mi], acc[mi][ni]);
   };
   auto tap_off = [&](int t) {                          // byte offset of tap t (= jr * S + js) inside a plane
     const int jr = t / p.S, js = t - jr * p.S;
@@ -480,7 +490,7 @@ __global__ __launch_bounds__(256, XAS_X6T_WAVES) void igemm_x6t_kernel(IgemmPara
     return (dy * hw + dx) * XT_PIXB;
   };
   uint4 gb_0[P][C::NI], gb_1[P][C::NI];
-  bf16x8_t fa_0[P][C::MI], fa_1[P][C::MI];             // fragments of the half-step in flight and of the next one
+  uint4 fa_0[P][C::MI], fa_1[P][C::MI];                // fragments of the half-step in flight and of the next one
   load_chunk(0);
   load_b(gb_0, 0);
   load_b(gb_1, 1);
@@ -500,6 +510,14 @@ __global__ __launch_bounds__(256, XAS_X6T_WAVES) void igemm_x6t_kernel(IgemmPara
       load_b(gb_1, 1);
     }
     __syncthreads();                                   // every wave has read the staging before it is overwritten
+  }
+  if constexpr (P == 2) {                              // the weights were split as 2^10 w
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= 1.f / kF16WScale;
   }
   igemm_epilogue<BM, BN, MODE, false, (BN == 128 ? 2 : 1)>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, H * W, W, 0, 0, lds);
 }
@@ -625,8 +643,14 @@ static int launch_igemm_x6_p(const IgemmParams& p, int Mrows_max, int phases, hi
   return launch_igemm_x6_t<128, 32, MODE, P, false>(p, Mrows_max, phases, st);
 }
 
+// pieces: 3 = bf16x6, 1 = bf16, 2 = f16x3 (forward only: the operand of a data gradient is a gradient tensor, whose range
+// the fixed fp16 scaling of this format does not cover)
 int launch_igemm_x6(const IgemmParams& p, int mode, int Mrows_max, int phases, int pieces, hipStream_t st) {
-  if (mode == 0) return pieces == 3 ? launch_igemm_x6_p<0, 3>(p, Mrows_max, phases, st) : launch_igemm_x6_p<0, 1>(p, Mrows_max, phases, st);
+  if (mode == 0) {
+    if (pieces == 2) return launch_igemm_x6_p<0, 2>(p, Mrows_max, phases, st);
+    return pieces == 3 ? launch_igemm_x6_p<0, 3>(p, Mrows_max, phases, st) : launch_igemm_x6_p<0, 1>(p, Mrows_max, phases, st);
+  }
+  XAS_REQUIRE(pieces != 2, "conv: the f16x3 format is a forward format");
   return pieces == 3 ? launch_igemm_x6_p<1, 3>(p, Mrows_max, phases, st) : launch_igemm_x6_p<1, 1>(p, Mrows_max, phases, st);
 }
 
@@ -1171,6 +1195,16 @@ __global__ __launch_bounds__(256) void prepare_weights_kernel(const long* __rest
   }
   float4 r0 = make_float4(v[0], v[1], v[2], v[3]), r1 = make_float4(v[4], v[5], v[6], v[7]);
   unsigned short* o = dst + (blk * P) * 512 + lane * 8;
+  if (P == 2) {                                        // two fp16 pieces of 2^10 w (split_weight_kernel<2>)
+    r0.x *= kF16WScale; r0.y *= kF16WScale; r0.z *= kF16WScale; r0.w *= kF16WScale;
+    r1.x *= kF16WScale; r1.y *= kF16WScale; r1.z *= kF16WScale; r1.w *= kF16WScale;
+    const uint2 q0 = pack_f16x4(r0), q1 = pack_f16x4(r1);
+    *reinterpret_cast<uint4*>(o) = make_uint4(q0.x, q0.y, q1.x, q1.y);
+    r0 = sub_f16x4(r0, q0); r1 = sub_f16x4(r1, q1);
+    const uint2 t0 = pack_f16x4(r0), t1 = pack_f16x4(r1);
+    *reinterpret_cast<uint4*>(o + 512) = make_uint4(t0.x, t0.y, t1.x, t1.y);
+    return;
+  }
   for (int pc = 0; pc < P; ++pc) {
     const uint2 q0 = pack_bf16x4(r0), q1 = pack_bf16x4(r1);
     *reinterpret_cast<uint4*>(o + pc * 512) = make_uint4(q0.x, q0.y, q1.x, q1.y);
@@ -1186,18 +1220,21 @@ extern "C" int xas_prepare_weights(const void* descs, int n, long blocks, void* 
 }
 
 extern "C" size_t xas_split_weight_bytes(long rows, long K, int pieces) {
-  return (size_t)((rows + 31) / 32) * 32 * (size_t)K * 2 * (pieces == 3 ? 3 : 1);
+  return (size_t)((rows + 31) / 32) * 32 * (size_t)K * 2 * (pieces == 3 ? 3 : (pieces == 2 ? 2 : 1));
 }
 
 extern "C" int xas_split_weight(const float* w_packed, void* w_split, long rows, long K, int pieces, void* stream) {
   XAS_REQUIRE(w_packed && w_split && rows > 0 && K > 0 && K % 16 == 0, "split_weight: need a packed weight [rows][K] with K a multiple of 16");
-  XAS_REQUIRE(pieces == 1 || pieces == 3, "split_weight: pieces must be 1 (bf16) or 3 (bf16x6)");
+  XAS_REQUIRE(pieces >= 1 && pieces <= 3, "split_weight: pieces must be 1 (bf16), 2 (two fp16 pieces of 2^10 w: f16x3) or 3 (bf16x6)");
   XAS_REQUIRE((((uintptr_t)w_packed | (uintptr_t)w_split) & 15) == 0, "split_weight: buffers must be 16-byte aligned");
   XAS_REQUIRE(((rows + 31) / 32) * 32 * K * 6 < 0x7fffff00l, "split_weight: weight too large");
   const long total = ((rows + 31) / 32) * (K / 16) * 64;
   hipStream_t st = as_stream(stream);
   if (pieces == 3)
     hipLaunchKernelGGL(split_weight_kernel<3>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, w_packed,
+                       reinterpret_cast<unsigned short*>(w_split), (int)rows, (int)K, total);
+  else if (pieces == 2)
+    hipLaunchKernelGGL(split_weight_kernel<2>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, w_packed,
                        reinterpret_cast<unsigned short*>(w_split), (int)rows, (int)K, total);
   else
     hipLaunchKernelGGL(split_weight_kernel<1>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, w_packed,

@@ -18,8 +18,8 @@ class ConvShape(ctypes.Structure):
 
 
 # xas_hip.h XAS_PREC_*: arithmetic of the MFMA convolutions.  ConvShape.mode = 0 (process default) or 1 + one of these.
-PREC_F32, PREC_BF16, PREC_BF16X6 = 0, 1, 2
-PREC_NAMES = {'f32': PREC_F32, 'bf16': PREC_BF16, 'bf16x6': PREC_BF16X6}
+PREC_F32, PREC_BF16, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3
+PREC_NAMES = {'f32': PREC_F32, 'bf16': PREC_BF16, 'bf16x6': PREC_BF16X6, 'f16x3': PREC_F16X3}
 
 
 # name -> (argument codes, return code).  's' = pointer to ConvShape.  Last 'p' is the stream
@@ -120,7 +120,13 @@ def load():
         lib.xas_set_precision.restype = ctypes.c_int
         if lib.xas_set_precision(int(mode)) != 0:
             raise RuntimeError('XAS_PRECISION=%s: %s' % (mode, lib.xas_last_error().decode()))
+    global PREC_DEFAULT
+    lib.xas_get_precision.restype = ctypes.c_int
+    PREC_DEFAULT = int(lib.xas_get_precision())         # the process default: the library's, or XAS_PRECISION's
     return lib
+
+
+PREC_DEFAULT = None
 
 
 _bound = {}

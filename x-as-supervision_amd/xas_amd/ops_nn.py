@@ -167,10 +167,10 @@ def _wgrad_into_grad(x, dy, shp, weight):
 BIAS_ON_SIDE = os.environ.get('XAS_BIAS_SIDE', '0') == '1'
 
 
-def _bias_into_grad(dy, M, C, bias):
+def _bias_into_grad(dy, M, C, bias, force=False):
     """bias.grad += column sums of dy [M, C] on the side stream (off the critical stream); False if not applicable."""
     g = bias.grad
-    if (not BIAS_ON_SIDE or not _side['enabled'] or g is None or not g.is_contiguous() or g.dtype != torch.float32 or C % 4
+    if (not (BIAS_ON_SIDE or force) or not _side['enabled'] or g is None or not g.is_contiguous() or g.dtype != torch.float32 or C % 4
             or g.data_ptr() % 16):
         return False
     main, side = torch.cuda.current_stream(), side_stream()
@@ -226,6 +226,16 @@ def _shape(n, hi, wi, cin, cout, r, s, stride, pad, ho, wo, mode=0):
 
 
 MODE_F32 = 1 + _lib.PREC_F32          # ConvShape.mode of a call that must run on the exact-fp32 kernels
+
+
+def grad_operand_shape(shp):
+    """ConvShape for a FORWARD-type launch whose input is a gradient tensor (the data gradient of a ConvTranspose2d is a
+    forward convolution of dy).  XAS_PREC_F16X3 splits the inputs of forward launches into fp16 pieces at a fixed scale
+    that suits activations, not gradients: such a call is pinned to the bf16x6 kernels."""
+    if shp.mode == 0 and query('xas_get_precision') == _lib.PREC_F16X3:
+        return ConvShape(shp.N, shp.Hi, shp.Wi, shp.Cin, shp.Cout, shp.R, shp.S, shp.stride, shp.pad, shp.Ho, shp.Wo,
+                         1 + _lib.PREC_BF16X6)
+    return shp
 
 
 class _PackCache:
@@ -588,7 +598,8 @@ class _ConvTranspose2d(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            call('xas_conv_fwd', ptr(dy), ptr(ctx.cache.get(weight, 0, shp)), None, ptr(dx), shp)
+            shp_g = grad_operand_shape(shp)
+            call('xas_conv_fwd', ptr(dy), ptr(ctx.cache.get(weight, 0, shp_g)), None, ptr(dx), shp_g)
         if ctx.needs_input_grad[1] and not _wgrad_into_grad(dy, x, shp, weight):
             dw = _wgrad(dy, x, shp, weight.shape)
         return dx, dw, None, None, None
@@ -596,6 +607,12 @@ class _ConvTranspose2d(torch.autograd.Function):
 
 def conv_transpose2d(x, weight, stride, pad, cache):
     return _ConvTranspose2d.apply(x, weight, stride, pad, cache)
+
+
+# Parameter gradients of the discriminator's linear layers go to the weight-gradient stream and straight into .grad, like
+# the convolutions': the backward of the adversarial term is a chain of 21 small layers on the second stream that the
+# detector's backward waits for, and two of the three launches of every layer (weight and bias gradient) are not on it.
+LINEAR_SIDE = os.environ.get('XAS_LINEAR_SIDE', '1') == '1'
 
 
 class _Linear(torch.autograd.Function):
@@ -611,6 +628,9 @@ class _Linear(torch.autograd.Function):
         call('xas_conv_fwd', ptr(x), ptr(weight.detach().contiguous()), ptr(bias), ptr(y), shp)
         ctx.save_for_backward(x, weight)
         ctx.shp, ctx.has_bias = shp, bias is not None
+        # the parameters whose .grad take the sums directly (leaves only: a derived tensor has no gradient buffer)
+        ctx.bias_ref = bias if (bias is not None and bias.is_leaf) else None
+        ctx.weight_ref = weight if weight.is_leaf else None
         return y
 
     @staticmethod
@@ -623,12 +643,15 @@ class _Linear(torch.autograd.Function):
             wt = weight.detach().t().contiguous()            # [Cin][Cout]
             dx = torch.empty_like(x)
             call('xas_conv_dgrad', ptr(dy), ptr(wt), ptr(dx), shp)
-        if ctx.needs_input_grad[1]:
+        wref = ctx.weight_ref
+        if ctx.needs_input_grad[1] and not (LINEAR_SIDE and dy.is_cuda and wref is not None and _wgrad_into_grad(x, dy, shp, wref)):
             dw = torch.empty_like(weight)
             ws = torch.empty(max(1, query('xas_conv_wgrad_workspace_floats', shp)), device=x.device, dtype=torch.float32)
             call('xas_conv_wgrad', ptr(x), ptr(dy), ptr(dw), ptr(ws), shp)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _bias_grad(dy, shp.N, shp.Cout)
+            bias = ctx.bias_ref
+            if not (LINEAR_SIDE and dy.is_cuda and bias is not None and _bias_into_grad(dy, shp.N, shp.Cout, bias, force=True)):
+                db = _bias_grad(dy, shp.N, shp.Cout)
         return dx, dw, db
 
 
@@ -918,7 +941,7 @@ def _conv_entries(module):
             if type(m).__name__ == 'ConvTranspose2d':          # weight [Cin_t, Cout_t, R, S]: the equivalent conv is Cout_t -> Cin_t
                 hs = 8
                 hb = (hs - 1) * stride - 2 * pad + r
-                shp = _shape(1, hb, hb, b, a, r, s, stride, pad, hs, hs)
+                shp = grad_operand_shape(_shape(1, hb, hb, b, a, r, s, stride, pad, hs, hs))   # (its forward-type launch is a backward)
             else:
                 hi = 16
                 ho = (hi + 2 * pad - r) // stride + 1

@@ -42,7 +42,7 @@ class KernelTimer:
         b.record()
         if rc != 0:
             raise RuntimeError('%s failed (%d): %s' % (name, rc, _lib.load().xas_last_error().decode()))
-        mfma = 0                   # kernel class of the launch: 0 no MFMA, 1 exact-fp32 MFMA, 2 bf16 MFMA, 3 bf16x6 MFMA
+        mfma = 0                   # kernel class of the launch: 0 no MFMA, 1 exact-fp32 MFMA, 2 bf16 MFMA, 3 bf16x6 MFMA, 4 f16x3 MFMA
         if shape is not None:
             kind = 0 if name in ('xas_conv_fwd', 'xas_conv_fwd_bnstats') else (
                 1 if name in ('xas_conv_dgrad', 'xas_conv_dgrad_acc', 'xas_conv_dgrad_acc_masked', 'xas_conv_dgrad_bn_bwd') else 2)
@@ -60,11 +60,11 @@ class KernelTimer:
         self.records.append((name, a, b, work, mfma, sig))
         self.bytes_total += conv_bytes(shape) if (shape is not None and mfma) else 0.0
 
-    CLASS = {0: ':direct', 1: ':f32', 2: ':bf16', 3: ':bf16x6'}
+    CLASS = {0: ':direct', 1: ':f32', 2: ':bf16', 3: ':bf16x6', 4: ':f16x3'}
 
     def summary(self):
         """-> dict per (entry point, kernel class): launches, total ms, total flops (call after torch.cuda.synchronize()).
-        Keys end in ':direct' (no MFMA), ':f32' (exact-fp32 MFMA), ':bf16', ':bf16x6'; the head entries carry no suffix."""
+        Keys end in ':direct' (no MFMA), ':f32' (exact-fp32 MFMA), ':bf16', ':bf16x6', ':f16x3'; the head entries carry no suffix."""
         out = {}
         for name, a, b, fl, mfma, _sig in self.records:
             key = name + (self.CLASS[mfma] if name.startswith('xas_conv') else '')
