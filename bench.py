@@ -99,10 +99,13 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo to rehearse ranks on one GPU)')
     ap.add_argument('--tune', type=int, default=0, help='kernel tuning experiment flags (xas_set_tuning)')
-    ap.add_argument('--precision', default='bf16x6', choices=['bf16x6', 'f16x3', 'f32', 'bf16'],
-                    help='arithmetic of the MFMA convolutions (xas_hip.h XAS_PREC_*).  bf16x6 (default, the headline): fp32 '
+    ap.add_argument('--precision', default='f16x3', choices=['bf16x6', 'f16x3', 'f32', 'bf16'],
+                    help='arithmetic of the MFMA convolutions (xas_hip.h XAS_PREC_*).  f16x3 (default, the headline; the '
+                         'whole parity suite runs in this mode): forward launches split every fp32 operand into two fp16 '
+                         'pieces (22 bits) and accumulate three partial products in fp32 (peak 2516.8 / 3 = 838.9 TFLOP/s fp32-'
+                         'equivalent), gradient launches run as bf16x6.  bf16x6: every pass with fp32 '
                          'operands split exactly into three bf16 pieces, six exact partial products accumulated in fp32 - '
-                         'fp32-accurate (the whole parity suite runs in this mode), peak 2516.8 / 6 = 419.5 TFLOP/s fp32-'
+                         'fp32-accurate, peak 2516.8 / 6 = 419.5 TFLOP/s fp32-'
                          'equivalent.  f32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32, peak 157.3).  bf16: operands rounded '
                          'once - NOT fp32 accurate (misses the 1e-4 joint bar), a variant that is reported separately, never '
                          'the headline; peak 2516.8')

@@ -1,12 +1,14 @@
 """Arithmetic modes of the MFMA convolutions (xas_hip.h XAS_PREC_*).
 
-The library default is bf16x6 (fp32-ACCURATE products from six exact bf16 partial products, fp32 accumulation): every other
+The library default is f16x3 (forward launches: every fp32 operand as two fp16 pieces, three partial products; gradient
+launches: bf16x6, three bf16 pieces, six partial products; fp32 accumulation everywhere - both fp32 ACCURATE): every other
 GPU test therefore exercises that mode, including every oracle / reference-golden parity test, with tolerances unchanged
 from the rounds in which exact-fp32 MFMA was the default.  This file
 
-* re-runs the parity tests of the convolution stack on the EXACT fp32 MFMA kernels (XAS_PREC_F32), so both fp32-accurate
-  paths stay pinned ("make it the default and keep an fp32-MFMA parametrisation");
-* checks that the two fp32-accurate modes agree to fp32 rounding;
+* re-runs the parity tests of the convolution stack on the EXACT fp32 MFMA kernels (XAS_PREC_F32) and on bf16x6 for every
+  pass (XAS_PREC_BF16X6), so all fp32-accurate paths stay pinned ("make it the default and keep an fp32-MFMA
+  parametrisation");
+* checks that the fp32-accurate modes agree to fp32 rounding;
 * checks the plain bf16 variant (XAS_PREC_BF16: operands rounded once, NOT fp32 accurate, reported separately) against an
   fp32 convolution of the bf16-ROUNDED operands (2e-5 relative: summation order only)."""
 import pytest
@@ -28,52 +30,63 @@ CASES = [(2, 64, 16, 16, 64, 1, 1, 0), (2, 64, 16, 16, 64, 3, 1, 1), (2, 128, 17
 
 
 # ---- the exact-fp32 MFMA kernels under the same parity tests -----------------------------------------------------------
-def test_default_precision_is_bf16x6():
+def test_default_precision_is_f16x3():
     from xas_amd import _lib
-    assert _lib.query('xas_get_precision') == _lib.PREC_BF16X6
+    import os
+    if os.environ.get('XAS_PRECISION', '') == '':
+        assert _lib.query('xas_get_precision') == _lib.PREC_F16X3
 
 
-def test_f32_mode_isolated_conv_kernels():
+OTHER_MODES = ['f32', 'bf16x6']        # the fp32-accurate modes that are not the default
+
+
+@pytest.mark.parametrize('mode', OTHER_MODES)
+def test_other_mode_isolated_conv_kernels(mode):
     import test_gpu_nn as T
-    with precision_mode('f32'):
+    with precision_mode(mode):
         for case in T.CONV_CASES:
             T.test_conv2d_fwd_bwd(*case)
         T.test_conv_random_shapes()
         T.test_conv_transpose_random_shapes()
 
 
-def test_f32_mode_every_layer_shape():
+@pytest.mark.parametrize('mode', OTHER_MODES)
+def test_other_mode_every_layer_shape(mode):
     import test_gpu_parity_r3 as T
-    with precision_mode('f32'):
+    with precision_mode(mode):
         T.test_every_layer_shape_all_passes_vs_float64()
 
 
-def test_f32_mode_detector_goldens():
+@pytest.mark.parametrize('mode', OTHER_MODES)
+def test_other_mode_detector_goldens(mode):
     import test_gpu_nn as T
     import test_gpu_parity_r3 as R
-    with precision_mode('f32'):
+    with precision_mode(mode):
         T.test_detector_vs_golden_and_oracle()
         T.test_detector_single_hypothesis()
         R.test_detector_all_parameter_gradients()
 
 
+@pytest.mark.parametrize('mode', OTHER_MODES)
 @pytest.mark.parametrize('stage', ['S1', 'S2'])
-def test_f32_mode_model_wiring(stage):
+def test_other_mode_model_wiring(stage, mode):
     import test_gpu_model as T
-    with precision_mode('f32'):
+    with precision_mode(mode):
         T.test_model_wiring_vs_golden(stage)
 
 
-def test_f32_mode_full_train_step_vs_oracle():
+@pytest.mark.parametrize('mode', OTHER_MODES)
+def test_other_mode_full_train_step_vs_oracle(mode):
     import test_gpu_model as T
-    with precision_mode('f32'):
+    with precision_mode(mode):
         T.test_full_train_step_vs_oracle()
 
 
-def test_f32_mode_epilogue_variants():
-    """accumulating / masked data gradients, statistics epilogue, batch-norm-backward epilogue on the exact-fp32 kernels"""
+@pytest.mark.parametrize('mode', OTHER_MODES)
+def test_other_mode_epilogue_variants(mode):
+    """accumulating / masked data gradients, statistics epilogue, batch-norm-backward epilogue in the other modes"""
     import test_gpu_kernels_isolated as T
-    with precision_mode('f32'):
+    with precision_mode(mode):
         for case in T.ACC_CASES:
             T.test_conv_dgrad_acc(*case)
             T.test_conv_wgrad_acc(*case)
@@ -86,12 +99,38 @@ def test_f32_mode_epilogue_variants():
             T.test_conv_dgrad_bn_bwd(*case)
 
 
-# ---- the two fp32-accurate modes agree ----------------------------------------------------------------------------------
+# ---- the fp32-accurate modes agree --------------------------------------------------------------------------------------
+@pytest.mark.parametrize('mode', ['f16x3', 'bf16x6'])
 @pytest.mark.parametrize('n,cin,h,w,cout,k,stride,pad', CASES + [(2, 64, 9, 11, 48, 3, 1, 1), (2, 2048, 4, 4, 512, 1, 1, 0)])
-def test_conv_bf16x6_is_fp32_accurate(n, cin, h, w, cout, k, stride, pad):
-    """Every operand is split exactly into three bf16 pieces and six exact partial products are accumulated in fp32: forward,
-    data gradient AND weight gradient must meet the SAME bar as the exact-fp32 MFMA path (3e-6 relative against a float64
-    convolution of the unrounded operands, inputs with a non-zero mean) - three orders of magnitude tighter than plain bf16."""
+def test_conv_split_modes_are_fp32_accurate(n, cin, h, w, cout, k, stride, pad, mode):
+    """bf16x6: every operand is split exactly into three bf16 pieces and six exact partial products are accumulated in fp32;
+    f16x3 (forward launches): two fp16 pieces (22 bits; weights as 2^10 w), three partial products.  Forward, data gradient
+    AND weight gradient must meet the SAME bar as the exact-fp32 MFMA path (3e-6 relative against a float64 convolution of
+    the unrounded operands, inputs with a non-zero mean) - three orders of magnitude tighter than plain bf16."""
+    with precision_mode(mode):
+        _split_mode_case(n, cin, h, w, cout, k, stride, pad)
+
+
+def test_conv_f16x3_small_and_large_operands():
+    """The fp16 pieces have a fixed scale (conv_shared.h: 2^4 x, 2^10 w): activations of 1e-2 .. 3e2 and weights of 3e-5 .. 1
+    stay within the 3e-6 bar; below that range the second piece reaches fp16's subnormals (absolute error floor 2^-29 for
+    activations), above it the first piece overflows - every conv input of this network is an image, a mask or a normalised
+    activation."""
+    from xas_amd import layers as L
+    for xs, ws in ((1e-2, 1.0), (3e2, 1.0), (1.0, 1e-3), (1.0, 30.0), (30.0, 1e-2)):
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(2, 128, 16, 16, generator=g) * xs
+        wt = torch.randn(64, 128, 3, 3, generator=g) * ws / 34.0
+        m = L.Conv2d(128, 64, 3, 1, 1, bias=False).cuda()
+        with torch.no_grad():
+            m.weight.copy_(wt)
+        with precision_mode('f16x3'):
+            y = m(x.cuda())
+        exact = TF.conv2d(x.double(), wt.double(), None, 1, 1)
+        assert rel(y, exact) < 3e-6, (xs, ws, rel(y, exact))
+
+
+def _split_mode_case(n, cin, h, w, cout, k, stride, pad):
     from xas_amd import layers as L
     g = torch.Generator().manual_seed(cin + cout + k + n)
     x = torch.randn(n, cin, h, w, generator=g) * 3.0 + 0.5
@@ -126,19 +165,21 @@ def _planted_detector():
     return det.cuda().train(), ora
 
 
-def test_detector_bf16x6_matches_fp32_path():
-    """End to end through 56 conv layers and the soft-argmax head: joints of the default mode against the exact-fp32 MFMA
+@pytest.mark.parametrize('mode', ['f16x3', 'bf16x6'])
+def test_detector_split_modes_match_fp32_path(mode):
+    """End to end through 56 conv layers and the soft-argmax head: joints of the split modes against the exact-fp32 MFMA
     path on the same weights and images - within the fp32 path's own distance to the reference golden, far inside 1e-4."""
     import inputs as gi
     det, ora = _planted_detector()
     img = torch.from_numpy(gi.synthetic_batch(2, [0], seed=5)['cam_0_img']).cuda()
     with torch.no_grad():
-        k6, _ = det(img)
+        with precision_mode(mode):
+            k6, _ = det(img)
         det.load_state_dict(ora.state_dict())          # same running statistics for the second pass
         with precision_mode('f32'):
             k32, _ = det(img)
     d = float((k6 - k32).abs().max())
-    print('bf16x6 vs fp32 MFMA, max |d joint| =', d)
+    print(mode, 'vs fp32 MFMA, max |d joint| =', d)
     assert d < 1e-5
 
 

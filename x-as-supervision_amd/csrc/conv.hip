@@ -1458,7 +1458,7 @@ static int launch_tile(const IgemmParams& p, int Mrows_max, int phases, hipStrea
   return launch_igemm<BM, BN, MODE, 2, true>(p, Mrows_max, phases, st);
 }
 
-static int g_precision = XAS_PREC_BF16X6;    // process default (xas_set_precision); a call overrides it with xas_conv_shape.mode
+static int g_precision = XAS_PREC_F16X3;     // process default (xas_set_precision); a call overrides it with xas_conv_shape.mode
 
 static inline int precision_of(const xas_conv_shape* s) { return s->mode > 0 ? s->mode - 1 : g_precision; }
 // operand planes of a pass in a precision mode (pass 0: forward-type launch, otherwise data / weight gradient):

@@ -114,6 +114,9 @@ typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 constexpr float kF16WScale = 1024.f;           // weights are split as 2^10 w: their second pieces stay clear of fp16's subnormals
                                                // (|w| < 64 assumed - larger weights become inf, loudly); results are scaled back
+constexpr float kF16AScale = 16.f;             // activations (images, normalised activations, masks) as 2^4 x: full 22-bit
+                                               // accuracy for |x| in [2^-10, 2^11], an absolute floor of 2^-29 below, inf above
+constexpr float kF16Descale = 1.f / (kF16WScale * kF16AScale);
 
 __device__ __forceinline__ uint2 pack_f16x4(float4 v) {
   const f16x2_t lo = {(_Float16)v.x, (_Float16)v.y}, hi = {(_Float16)v.z, (_Float16)v.w};      // v_cvt_pk_f16_f32 (RNE)

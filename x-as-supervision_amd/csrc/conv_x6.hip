@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < AP; ++j) {
       float4 r = ra[h * AP + j];
+      if (P == 2) { r.x *= kF16AScale; r.y *= kF16AScale; r.z *= kF16AScale; r.w *= kF16AScale; }
 #pragma unroll
       for (int pc = 0; pc < P; ++pc) {
         uint2 q = (XAS_X6_ABL & 32) ? make_uint2(__float_as_uint(r.x) + pc, __float_as_uint(r.z)) : pack_piece4<P>(r);
@@ -324,13 +325,13 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
       compute(1, gb_1);
     }
   }
-  if constexpr (P == 2) {                              // the weights were split as 2^10 w
+  if constexpr (P == 2) {                              // the operands were split as 2^10 w and 2^4 x
 #pragma unroll
     for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < C::NI; ++ni)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= 1.f / kF16WScale;
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= kF16Descale;
   }
   igemm_epilogue<BM, BN, MODE, BNB, (BN >= 128 ? BN / 64 : 1)>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
 }
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(256, XAS_X6T_WAVES) void igemm_x6t_kernel(IgemmPara
       const int item = tid + 256 * j, pix = item >> 3, q = item & 7;
       if (pix < npix) {
         float4 r = ra[j];
+        if (P == 2) { r.x *= kF16AScale; r.y *= kF16AScale; r.z *= kF16AScale; r.w *= kF16AScale; }
         unsigned char* d = S + pix * XT_PIXB + q * 8;
 #pragma unroll
         for (int pc = 0; pc < P; ++pc) {
@@ -511,13 +513,13 @@ __global__ __launch_bounds__(256, XAS_X6T_WAVES) void igemm_x6t_kernel(IgemmPara
     }
     __syncthreads();                                   // every wave has read the staging before it is overwritten
   }
-  if constexpr (P == 2) {                              // the weights were split as 2^10 w
+  if constexpr (P == 2) {                              // the operands were split as 2^10 w and 2^4 x
 #pragma unroll
     for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < C::NI; ++ni)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= 1.f / kF16WScale;
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= kF16Descale;
   }
   igemm_epilogue<BM, BN, MODE, false, (BN == 128 ? 2 : 1)>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, H * W, W, 0, 0, lds);
 }
