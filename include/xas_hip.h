@@ -136,6 +136,11 @@ typedef struct {
   int stride, pad;
   int Ho, Wo;
   int mode;          /* 0: process default precision (xas_set_precision); otherwise 1 + XAS_PREC_* for this call */
+  const float* grad_amax;   /* NULL, or a DEVICE pointer to max |g| over the gradient tensor this call reads (dy of a data /
+                              * weight gradient; the input of a forward launch that is itself a backward, e.g. the data gradient of
+                              * a ConvTranspose2d), complete on the call's stream.  XAS_PREC_F16X3 then splits that tensor into two
+                              * fp16 pieces at the power-of-two scale that puts the maximum just below 2^15 (f16x3 for the gradient
+                              * pass); without it gradient passes run as bf16x6.  xas_bn_bwd_apply_amax produces it. */
 } xas_conv_shape;
 
 /* Which weight buffer xas_conv_fwd* (pass 0) / xas_conv_dgrad* (pass 1) expect for this shape in its precision mode:
@@ -292,6 +297,13 @@ int xas_bn_bwd_apply(const float* x, const float* y, const float* dy, const floa
                      const float* var_biased, const float* gamma, const float* beta, const float* sums,
                      float eps, int act, long M, int C, int groups, double count,
                      float* dx, float* dresidual, const uint8_t* mask, void* stream);
+/* Same, and max |dx| over the whole result is merged into *amax_out (device float, zeroed by the caller before the first
+ * launch that merges into it; atomic maximum on the bit pattern): the scale of dx as the gradient operand of the f16x3
+ * data / weight gradients (xas_conv_shape.grad_amax).  amax_out == NULL: xas_bn_bwd_apply. */
+int xas_bn_bwd_apply_amax(const float* x, const float* y, const float* dy, const float* mean,
+                          const float* var_biased, const float* gamma, const float* beta, const float* sums,
+                          float eps, int act, long M, int C, int groups, double count, float* dx,
+                          float* dresidual, const uint8_t* mask, float* amax_out, void* stream);
 
 /* 3x3 stride-2 pad-1 max pool (resnet.py:20), NHWC. idx: int8 argmax tap 0..8 for backward */
 int xas_maxpool3x3s2_fwd(const float* x, int N, int H, int W, int C, float* y, int8_t* idx, void* stream);

@@ -130,6 +130,34 @@ def test_conv_f16x3_small_and_large_operands():
         assert rel(y, exact) < 3e-6, (xs, ws, rel(y, exact))
 
 
+@pytest.mark.parametrize('scale', [1e-9, 1e-5, 1.0, 1e4])
+@pytest.mark.parametrize('n,cin,h,w,cout,k,stride,pad', [(2, 64, 16, 16, 64, 3, 1, 1), (3, 256, 8, 8, 512, 1, 2, 0),
+                                                         (2, 128, 17, 13, 96, 3, 2, 1), (4, 256, 32, 32, 256, 3, 1, 1),
+                                                         (2, 1024, 16, 16, 256, 1, 1, 0)])
+def test_f16x3_data_gradient_with_amax(n, cin, h, w, cout, k, stride, pad, scale):
+    """Gradient launches of XAS_PREC_F16X3: dy is split into two fp16 pieces at the power-of-two scale given by max |dy|
+    (xas_conv_shape.grad_amax).  Any magnitude of the gradient tensor - 1e-9 .. 1e4 - meets the bar of the other
+    fp32-accurate modes, with a heavy-tailed dy (elements down to 1e-6 of the maximum)."""
+    from xas_amd import ops_nn as O
+    from xas_amd._lib import ConvShape, call, ptr, query
+    g = torch.Generator().manual_seed(n + cin + k)
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    dy = torch.randn(n, cout, ho, wo, generator=g) * torch.exp(torch.randn(n, cout, ho, wo, generator=g) * 2.0) * scale
+    dref = torch.nn.grad.conv2d_input((n, cin, h, w), wt.double(), dy.double(), stride, pad)
+    with precision_mode('f16x3'):
+        dyc = O.to_cl(dy.cuda())
+        amax = dyc.abs().max().reshape(1).contiguous()
+        shp = ConvShape(n, h, w, cin, cout, k, k, stride, pad, ho, wo, 0, amax.data_ptr())
+        assert query('xas_conv_weight_planes', shp, 1) == 2
+        cache = O._PackCache()
+        wc = wt.cuda()
+        dx = O.empty_cl(n, cin, h, w, dyc)
+        call('xas_conv_dgrad', ptr(dyc), ptr(cache.get(wc, 1, shp)), ptr(dx), shp)
+        torch.cuda.synchronize()
+    assert rel(dx, dref) < 3e-6, rel(dx, dref)
+
+
 def _split_mode_case(n, cin, h, w, cout, k, stride, pad):
     from xas_amd import layers as L
     g = torch.Generator().manual_seed(cin + cout + k + n)

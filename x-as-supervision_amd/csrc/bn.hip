@@ -446,6 +446,14 @@ __global__ void bn_apply_kernel(const float4* __restrict__ x, const float* __res
   }
 }
 
+// max |v| of a launch -> *out (zeroed by the caller before the launch): non-negative floats order like their bit patterns;
+// NaN / inf sort above every finite value, so a poisoned gradient stays visible downstream
+__device__ __forceinline__ void publish_amax(float* out, float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(v));
+}
+
 // grid.y = group; sums: [G][2][C] = sum_dz | sum_dz_xhat of each group
 __global__ void bn_bwd_apply_kernel(const float4* __restrict__ x, const float4* __restrict__ y,
                                     const float4* __restrict__ dy, const float* __restrict__ mean,
@@ -453,7 +461,8 @@ __global__ void bn_bwd_apply_kernel(const float4* __restrict__ x, const float4* 
                                     const float* __restrict__ beta, const float* __restrict__ sums,
                                     float eps, int act, long n4g, int C4,
                                     float inv_count, float4* __restrict__ dx, float4* __restrict__ dres,
-                                    const uint8_t* __restrict__ mask) {
+                                    const uint8_t* __restrict__ mask, float* __restrict__ amax_out) {
+  float amx = 0.f;
   const long goff = (long)blockIdx.y * n4g;
   mean += (size_t)blockIdx.y * C4 * 4; var += (size_t)blockIdx.y * C4 * 4;
   const float* sdz = sums + (size_t)blockIdx.y * C4 * 8;
@@ -504,8 +513,10 @@ __global__ void bn_bwd_apply_kernel(const float4* __restrict__ x, const float4* 
     o.y = g.y * is.y * (dz.y - a.y * inv_count - xh.y * b.y * inv_count);
     o.z = g.z * is.z * (dz.z - a.z * inv_count - xh.z * b.z * inv_count);
     o.w = g.w * is.w * (dz.w - a.w * inv_count - xh.w * b.w * inv_count);
+    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     dx[i] = o;
   }
+  if (amax_out) publish_amax(amax_out, amx);
 }
 
 // ---- streaming forms of the two apply kernels.  When the number of threads in a grid row is a multiple of C/4 a thread
@@ -558,10 +569,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(
     const float4* __restrict__ x, const float4* __restrict__ y, const float4* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ sums, float eps, long n4g, int C4, float inv_count, float4* __restrict__ dx,
-    float4* __restrict__ dres, const uint8_t* __restrict__ mask) {
+    float4* __restrict__ dres, const uint8_t* __restrict__ mask, float* __restrict__ amax_out) {
 #ifdef XAS_BN_PRIO
   __builtin_amdgcn_s_setprio(XAS_BN_PRIO);
 #endif
+  float amx = 0.f;                                     // max |dx| of this thread (amax_out != null: xas_bn_bwd_apply_amax)
   const long goff = (long)blockIdx.y * n4g;
   const long stride = (long)gridDim.x * blockDim.x;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -598,6 +610,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(
     o.y = g.y * is.y * (dz.y - a.y * inv_count - xh.y * b.y * inv_count);
     o.z = g.z * is.z * (dz.z - a.z * inv_count - xh.z * b.z * inv_count);
     o.w = g.w * is.w * (dz.w - a.w * inv_count - xh.w * b.w * inv_count);
+    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     stream_store(dx + goff + k, o);
   };
   const float4 z4 = make_float4(0, 0, 0, 0);
@@ -620,6 +633,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(
     const long k = goff + i;
     one(i, NEEDX ? x[k] : z4, NEEDY ? y[k] : z4, dy[k], SIGN == 3 ? mask[k] : 0u);
   }
+  if (amax_out) publish_amax(amax_out, amx);
 }
 
 // one update per group, in group order (mean / var: [G][C])
@@ -1024,6 +1038,14 @@ extern "C" int xas_bn_bwd_apply(const float* x, const float* y, const float* dy,
                                 const float* var_biased, const float* gamma, const float* beta, const float* sums,
                                 float eps, int act, long M, int C, int groups, double count, float* dx,
                                 float* dresidual, const uint8_t* mask, void* stream) {
+  return xas_bn_bwd_apply_amax(x, y, dy, mean, var_biased, gamma, beta, sums, eps, act, M, C, groups, count, dx, dresidual, mask,
+                               nullptr, stream);
+}
+
+extern "C" int xas_bn_bwd_apply_amax(const float* x, const float* y, const float* dy, const float* mean,
+                                     const float* var_biased, const float* gamma, const float* beta, const float* sums,
+                                     float eps, int act, long M, int C, int groups, double count, float* dx,
+                                     float* dresidual, const uint8_t* mask, float* amax_out, void* stream) {
   XAS_REQUIRE(!mask || x, "bn_bwd_apply: the sign-mask form needs x");
   XAS_REQUIRE(dy && mean && var_biased && gamma && sums && dx && (act == 0 || y || mask || (x && beta)),
               "bn_bwd_apply: null buffer (an activation needs y, or x with beta)");
@@ -1056,7 +1078,7 @@ extern "C" int xas_bn_bwd_apply(const float* x, const float* y, const float* dy,
       const float ic = (float)(1.0 / count);
 #define XAS_BN_BWD(ACT, SIGN, XH, DR)                                                                                      \
   hipLaunchKernelGGL((bn_bwd_apply_stream_kernel<ACT, SIGN, XH, DR>), grid, dim3(256), 0, as_stream(stream), x4, y4, d4, mean, \
-                     var_biased, gamma, beta, sums, eps, n4g, C4, ic, o4, r4, mask)
+                     var_biased, gamma, beta, sums, eps, n4g, C4, ic, o4, r4, mask, amax_out)
       switch (mode) {
         case 0: XAS_BN_BWD(0, 0, true, false); break;
         case 1: XAS_BN_BWD(1, 2, true, false); break;
@@ -1074,7 +1096,7 @@ extern "C" int xas_bn_bwd_apply(const float* x, const float* y, const float* dy,
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid_g(n4g, groups), groups), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(y),
                      reinterpret_cast<const float4*>(dy), mean, var_biased, gamma, beta, sums, eps, act, n4g,
-                     C / 4, (float)(1.0 / count), reinterpret_cast<float4*>(dx), reinterpret_cast<float4*>(dresidual), mask);
+                     C / 4, (float)(1.0 / count), reinterpret_cast<float4*>(dx), reinterpret_cast<float4*>(dresidual), mask, amax_out);
   XAS_LAUNCH_CHECK();
   return 0;
 }

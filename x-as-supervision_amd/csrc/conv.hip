@@ -1461,12 +1461,14 @@ static int launch_tile(const IgemmParams& p, int Mrows_max, int phases, hipStrea
 static int g_precision = XAS_PREC_F16X3;     // process default (xas_set_precision); a call overrides it with xas_conv_shape.mode
 
 static inline int precision_of(const xas_conv_shape* s) { return s->mode > 0 ? s->mode - 1 : g_precision; }
-// operand planes of a pass in a precision mode (pass 0: forward-type launch, otherwise data / weight gradient):
-// XAS_PREC_F16X3 runs its forward-type launches on two fp16 planes and everything else as bf16x6
-static inline int planes_of(int prec, int pass) {
+// operand planes of a pass in a precision mode (pass 0: forward-type launch, 1 data gradient, 2 weight gradient):
+// XAS_PREC_F16X3 runs on two fp16 planes where the scale of the split operands is known - forward-type launches
+// (activations: fixed scale) and gradient launches that come with the maximum of their gradient tensor
+// (xas_conv_shape.grad_amax) - and as bf16x6 otherwise
+static inline int planes_of(int prec, int pass, bool has_amax) {
   if (prec == XAS_PREC_F32) return 0;
   if (prec == XAS_PREC_BF16) return 1;
-  return (prec == XAS_PREC_F16X3 && pass == 0) ? 2 : 3;
+  return (prec == XAS_PREC_F16X3 && (pass == 0 || (has_amax && pass == 1))) ? 2 : 3;
 }
 
 // prec: XAS_PREC_*.  The bf16-split kernels (conv_x6.hip) take PRE-SPLIT weights (xas_split_weight); the exact-fp32 kernels
@@ -1475,7 +1477,7 @@ template <int MODE>
 static int dispatch_igemm(const IgemmParams& p, int prec, int Mrows_max, int phases, hipStream_t st) {
   if (prec != XAS_PREC_F32) {
     XAS_REQUIRE(igemm_fits(p), "conv: tensor beyond the 32-bit offset range of the bf16-split kernels (use XAS_PREC_F32)");
-    return launch_igemm_x6(p, MODE, Mrows_max, phases, planes_of(prec, MODE), st);
+    return launch_igemm_x6(p, MODE, Mrows_max, phases, planes_of(prec, MODE, p.a_amax != nullptr && !p.bnb_x), st);
   }
   int bm, bn;
   pick_tile(p.Cd, Mrows_max, phases, &bm, &bn);
@@ -1592,6 +1594,7 @@ static int conv_fwd_impl(const float* x, const float* w_packed, const float* bia
   XAS_REQUIRE((((uintptr_t)x | (uintptr_t)w_packed) & 15) == 0, "conv_fwd: operands must be 16-byte aligned");
   IgemmParams p{};
   p.src = x; p.wgt = w_packed; p.bias = bias; p.out = y; p.N = s->N;
+  p.a_amax = s->grad_amax;
   p.Hs = s->Hi; p.Ws = s->Wi; p.Cs = s->Cin; p.Hd = s->Ho; p.Wd = s->Wo; p.Cd = s->Cout;
   p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.Hrow = s->Ho; p.Wrow = s->Wo; p.tune = g_tune;
   p.div_hw.init((unsigned)(s->Ho * s->Wo)); p.div_w.init((unsigned)s->Wo);
@@ -1612,7 +1615,7 @@ extern "C" int xas_conv_weight_planes(const xas_conv_shape* s, int pass) {
   bool mfma;
   if (pass == 0) mfma = !thin && !(s->Cin == 3 && s->R == 7) && s->Cin % BK == 0 && s->Cout >= 16;
   else mfma = !thin && s->Cout % BK == 0 && s->Cin >= 16;
-  return mfma ? planes_of(prec, pass) : 0;
+  return mfma ? planes_of(prec, pass, s->grad_amax != nullptr) : 0;
 }
 
 // Which kernel family a pass of this shape runs on (for measurement: bench.py prices every launch against the peak of the
@@ -1621,7 +1624,7 @@ extern "C" int xas_conv_weight_planes(const xas_conv_shape* s, int pass) {
 extern "C" int xas_conv_kernel_class(const xas_conv_shape* s, int pass) {
   if (!s) return 0;
   const int prec = precision_of(s);
-  const int split = prec == XAS_PREC_F32 ? 1 : (prec == XAS_PREC_BF16 ? 2 : (prec == XAS_PREC_F16X3 && pass == 0 ? 4 : 3));
+  const int split = prec == XAS_PREC_F32 ? 1 : (prec == XAS_PREC_BF16 ? 2 : (planes_of(prec, pass, s->grad_amax != nullptr) == 2 ? 4 : 3));
   const bool thin = (s->Cout == 1 && thin_ok(s, s->Cin)) || (s->Cin == 1 && thin_ok(s, s->Cout));
   if (thin) return 0;
   if (pass == 0) {
@@ -1738,6 +1741,7 @@ static int conv_dgrad_impl(const float* dy, const float* w_packed_t, float* dx, 
   XAS_REQUIRE((((uintptr_t)dy | (uintptr_t)w_packed_t) & 15) == 0, "conv_dgrad: operands must be 16-byte aligned");
   IgemmParams p{};
   p.src = dy; p.wgt = w_packed_t; p.bias = nullptr; p.out = dx; p.N = s->N;
+  p.a_amax = s->grad_amax;
   p.Hs = s->Ho; p.Ws = s->Wo; p.Cs = s->Cout; p.Hd = s->Hi; p.Wd = s->Wi; p.Cd = s->Cin;
   p.R = s->R; p.S = s->S; p.stride = s->stride; p.pad = s->pad; p.tune = g_tune;
   p.accumulate = accumulate; p.acc_src = acc_src; p.acc_mask = acc_mask;
@@ -2043,9 +2047,9 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
       wgrad_x6t_plan(s->N, s->Hi, s->Wi, s->Cin, s->Cout, s->R, s->S, s->stride, s->pad, s->Ho, s->Wo, &tbm, &tsplits, &tpps)) {
     splits = tsplits;
     p.out = (splits == 1 && !oihw) ? dw_packed : workspace;
-    rc = launch_wgrad_x6t(p, tbm, tsplits, tpps, planes_of(precision_of(s), 2), st);
+    rc = launch_wgrad_x6t(p, tbm, tsplits, tpps, planes_of(precision_of(s), 2, s->grad_amax != nullptr), st);
   } else
-  if (x6) rc = launch_wgrad_x6(p, bm, bn, splits, planes_of(precision_of(s), 2), st);
+  if (x6) rc = launch_wgrad_x6(p, bm, bn, splits, planes_of(precision_of(s), 2, s->grad_amax != nullptr), st);
   else if (buf_ok) {
     if (bm == 32) rc = launch_wgrad_buf<32, 128>(p, splits, st);
     else if (bn == 64) rc = bm == 128 ? launch_wgrad_buf<128, 64>(p, splits, st) : launch_wgrad_buf<64, 64>(p, splits, st);

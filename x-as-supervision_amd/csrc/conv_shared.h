@@ -61,6 +61,9 @@ struct IgemmParams {
   float bnb_eps;
   int bnb_rows_per_group;
   float* bnb_partial;
+  // f16x3 launches: null -> the gathered tensor is an activation (fixed scale kF16AScale); else device pointer to
+  // max |v| over the gathered (gradient) tensor: scale = the power of two that puts the maximum just below 2^15
+  const float* a_amax;
 };
 
 constexpr int kMaxDevices = 16;
@@ -117,6 +120,15 @@ constexpr float kF16WScale = 1024.f;           // weights are split as 2^10 w: t
 constexpr float kF16AScale = 16.f;             // activations (images, normalised activations, masks) as 2^4 x: full 22-bit
                                                // accuracy for |x| in [2^-10, 2^11], an absolute floor of 2^-29 below, inf above
 constexpr float kF16Descale = 1.f / (kF16WScale * kF16AScale);
+// scale of a gradient operand from its maximum magnitude (wave-uniform): amax in [2^(e-127), 2^(e-126)) -> 2^(141 - e), i.e.
+// amax * scale in [2^14, 2^15).  Zero / denormal-range maxima: 1 (nothing to resolve).  *inv = 1 / scale (exact).
+__device__ __forceinline__ float f16_grad_scale(const float* amax, float* inv) {
+  const unsigned bits = __builtin_amdgcn_readfirstlane(__float_as_uint(*amax));
+  const int e = (int)((bits >> 23) & 0xffu);
+  if (e < 40 || e > 250) { *inv = 1.f; return 1.f; }
+  *inv = __uint_as_float((unsigned)(e - 14) << 23);           // 2^(e - 141)
+  return __uint_as_float((unsigned)(268 - e) << 23);           // 2^(141 - e)
+}
 
 __device__ __forceinline__ uint2 pack_f16x4(float4 v) {
   const f16x2_t lo = {(_Float16)v.x, (_Float16)v.y}, hi = {(_Float16)v.z, (_Float16)v.w};      // v_cvt_pk_f16_f32 (RNE)

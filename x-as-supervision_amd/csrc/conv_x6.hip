@@ -142,6 +142,8 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
   const int HW = Hrow * Wrow;
   const int cchunks = p.Cs / BK;
   const int nk = nr * ns * cchunks;
+  float f16_sa = kF16AScale, f16_desc = kF16Descale;   // P == 2: scale of the gathered operand, scale of the result
+  if (P == 2 && p.a_amax) { float inv; f16_sa = f16_grad_scale(p.a_amax, &inv); f16_desc = inv * (1.f / kF16WScale); }
 
   // activation operand: buffer base moved down so that per-lane and scalar parts are non-negative (see igemm_buf_kernel)
   const long dmin = MODE == 0 ? 0l : -((long)(nr - 1) * p.Ws + (ns - 1)) * p.Cs;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < AP; ++j) {
       float4 r = ra[h * AP + j];
-      if (P == 2) { r.x *= kF16AScale; r.y *= kF16AScale; r.z *= kF16AScale; r.w *= kF16AScale; }
+      if (P == 2) { r.x *= f16_sa; r.y *= f16_sa; r.z *= f16_sa; r.w *= f16_sa; }
 #pragma unroll
       for (int pc = 0; pc < P; ++pc) {
         uint2 q = (XAS_X6_ABL & 32) ? make_uint2(__float_as_uint(r.x) + pc, __float_as_uint(r.z)) : pack_piece4<P>(r);
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
 #pragma unroll
       for (int ni = 0; ni < C::NI; ++ni)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= kF16Descale;
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= f16_desc;
   }
   igemm_epilogue<BM, BN, MODE, BNB, (BN >= 128 ? BN / 64 : 1)>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
 }
@@ -380,6 +382,8 @@ __global__ __launch_bounds__(256, XAS_X6T_WAVES) void igemm_x6t_kernel(IgemmPara
   const int m0 = mt * BM, n0 = nt * BN;
   const int Mrows = p.N * H * W;
   __builtin_amdgcn_s_setprio(XAS_X6_PRIO);
+  float f16_sa = kF16AScale, f16_desc = kF16Descale;   // P == 2: scale of the gathered operand, scale of the result
+  if (P == 2 && p.a_amax) { float inv; f16_sa = f16_grad_scale(p.a_amax, &inv); f16_desc = inv * (1.f / kF16WScale); }
   const int tiles_x = W / tw, per_img = tiles_x * (H >> 3);
   const int img0 = (mt / per_img) * tn_cnt, tt = mt % per_img;
   const int y0 = (tt / tiles_x) * 8, x0 = (tt % tiles_x) * tw;
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(256, XAS_X6T_WAVES) void igemm_x6t_kernel(IgemmPara
       const int item = tid + 256 * j, pix = item >> 3, q = item & 7;
       if (pix < npix) {
         float4 r = ra[j];
-        if (P == 2) { r.x *= kF16AScale; r.y *= kF16AScale; r.z *= kF16AScale; r.w *= kF16AScale; }
+        if (P == 2) { r.x *= f16_sa; r.y *= f16_sa; r.z *= f16_sa; r.w *= f16_sa; }
         unsigned char* d = S + pix * XT_PIXB + q * 8;
 #pragma unroll
         for (int pc = 0; pc < P; ++pc) {
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(256, XAS_X6T_WAVES) void igemm_x6t_kernel(IgemmPara
 #pragma unroll
       for (int ni = 0; ni < C::NI; ++ni)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= kF16Descale;
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= f16_desc;
   }
   igemm_epilogue<BM, BN, MODE, false, (BN == 128 ? 2 : 1)>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, H * W, W, 0, 0, lds);
 }
@@ -627,7 +631,7 @@ static int launch_igemm_x6_p(const IgemmParams& p, int Mrows_max, int phases, hi
     if (bn == 64) return launch_igemm_x6t<64, MODE, P>(p, Mrows_max, st);
     return launch_igemm_x6t<32, MODE, P>(p, Mrows_max, st);
   }
-  if constexpr (MODE == 1) {
+  if constexpr (MODE == 1 && P != 2) {
     if (p.bnb_x) {
       if (bn == 128) return launch_igemm_x6_t<128, 128, 1, P, true>(p, Mrows_max, phases, st);
       if (bm == 64) return launch_igemm_x6_t<64, 64, 1, P, true>(p, Mrows_max, phases, st);
@@ -645,14 +649,17 @@ static int launch_igemm_x6_p(const IgemmParams& p, int Mrows_max, int phases, hi
   return launch_igemm_x6_t<128, 32, MODE, P, false>(p, Mrows_max, phases, st);
 }
 
-// pieces: 3 = bf16x6, 1 = bf16, 2 = f16x3 (forward only: the operand of a data gradient is a gradient tensor, whose range
-// the fixed fp16 scaling of this format does not cover)
+// pieces: 3 = bf16x6, 1 = bf16, 2 = f16x3 (the gathered operand at a fixed scale when it is an activation, at a scale
+// derived from IgemmParams::a_amax when it is a gradient)
 int launch_igemm_x6(const IgemmParams& p, int mode, int Mrows_max, int phases, int pieces, hipStream_t st) {
   if (mode == 0) {
     if (pieces == 2) return launch_igemm_x6_p<0, 2>(p, Mrows_max, phases, st);
     return pieces == 3 ? launch_igemm_x6_p<0, 3>(p, Mrows_max, phases, st) : launch_igemm_x6_p<0, 1>(p, Mrows_max, phases, st);
   }
-  XAS_REQUIRE(pieces != 2, "conv: the f16x3 format is a forward format");
+  if (pieces == 2) {
+    XAS_REQUIRE(p.a_amax && !p.bnb_x, "conv: an f16x3 data gradient needs the maximum of its gradient operand (xas_conv_shape.grad_amax)");
+    return launch_igemm_x6_p<1, 2>(p, Mrows_max, phases, st);
+  }
   return pieces == 3 ? launch_igemm_x6_p<1, 3>(p, Mrows_max, phases, st) : launch_igemm_x6_p<1, 1>(p, Mrows_max, phases, st);
 }
 

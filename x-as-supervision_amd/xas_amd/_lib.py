@@ -14,7 +14,8 @@ _T = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c
 
 class ConvShape(ctypes.Structure):
     """xas_conv_shape"""
-    _fields_ = [(n, ctypes.c_int) for n in ('N', 'Hi', 'Wi', 'Cin', 'Cout', 'R', 'S', 'stride', 'pad', 'Ho', 'Wo', 'mode')]
+    _fields_ = [(n, ctypes.c_int) for n in ('N', 'Hi', 'Wi', 'Cin', 'Cout', 'R', 'S', 'stride', 'pad', 'Ho', 'Wo', 'mode')] + [
+        ('grad_amax', ctypes.c_void_p)]      # device pointer to max |g| of the call's gradient operand, or None
 
 
 # xas_hip.h XAS_PREC_*: arithmetic of the MFMA convolutions.  ConvShape.mode = 0 (process default) or 1 + one of these.
@@ -67,6 +68,7 @@ SIGNATURES = {
     'xas_bn_update_running': ('ppppfliip', 'i'),
     'xas_bn_bwd_reduce': ('pppppppfiliipppppp', 'i'),
     'xas_bn_bwd_apply': ('ppppppppfiliidpppp', 'i'),
+    'xas_bn_bwd_apply_amax': ('ppppppppfiliidppppp', 'i'),
     'xas_maxpool3x3s2_fwd': ('piiiippp', 'i'),
     'xas_maxpool3x3s2_bwd': ('ppiiiipp', 'i'),
     'xas_upsample2x_fwd': ('piiiipp', 'i'),

@@ -112,6 +112,7 @@ class TrainStep:
     def __call__(self, x):
         out = {}
         loss_disc, loss_kp, total = None, {}, None
+        ops_nn.reset_grad_amax()                    # (every stream of the previous step has joined this one)
         do_disc = self.opt_disc is not None and self.cur_step % self.disc_every == 0
         do_gen = self.cur_step % self.gen_every == 0
         shared = None

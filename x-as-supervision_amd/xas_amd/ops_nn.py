@@ -228,6 +228,46 @@ def _shape(n, hi, wi, cin, cout, r, s, stride, pad, ho, wo, mode=0):
 MODE_F32 = 1 + _lib.PREC_F32          # ConvShape.mode of a call that must run on the exact-fp32 kernels
 
 
+# ---- maxima of gradient tensors (XAS_PREC_F16X3) -----------------------------------------------------------------
+# The f16x3 gradient kernels split dy into two fp16 pieces at a power-of-two scale taken from max |dy|.  The kernel that
+# WRITES a gradient tensor merges that maximum into a float of this arena (xas_bn_bwd_apply_amax: every conv of the
+# detector and of the physique net is followed by a norm, so its dy is a norm's dx); the tensor object carries the slot
+# (`_xas_amax`) to the conv backward that reads it, which passes the pointer on in its ConvShape.  A gradient that
+# arrives without a slot runs on the bf16x6 kernels.  Slots are handed out in order from a zeroed arena;
+# reset_grad_amax() (engine.TrainStep, once per step, after the streams have joined) rewinds and re-zeroes it.
+_amax = {'arena': None, 'next': 0, 'retired': []}
+_AMAX_SLOTS = 4096
+GRAD_F16 = os.environ.get('XAS_GRAD_F16', '1') == '1'
+
+
+def reset_grad_amax():
+    if _amax['arena'] is not None and _amax['next'] > 0:
+        _amax['arena'].zero_()
+    _amax['next'] = 0
+    _amax['retired'] = []
+
+
+def _amax_slot(device):
+    a = _amax['arena']
+    if a is None or a.device != device or _amax['next'] >= _AMAX_SLOTS:
+        if a is not None:
+            _amax['retired'].append(a)          # kernels in flight may still read it
+        a = _amax['arena'] = torch.zeros(_AMAX_SLOTS, device=device, dtype=torch.float32)
+        _amax['next'] = 0
+    i = _amax['next']
+    _amax['next'] = i + 1
+    return a[i:i + 1]
+
+
+def with_grad_amax(shp, dy):
+    """ConvShape of a gradient launch that reads `dy`: with the pointer to max |dy| when its producer recorded one."""
+    slot = getattr(dy, '_xas_amax', None)
+    if slot is None or shp.mode != 0 or not GRAD_F16 or query('xas_get_precision') != _lib.PREC_F16X3:
+        return shp
+    return ConvShape(shp.N, shp.Hi, shp.Wi, shp.Cin, shp.Cout, shp.R, shp.S, shp.stride, shp.pad, shp.Ho, shp.Wo, 0,
+                     slot.data_ptr())
+
+
 def grad_operand_shape(shp):
     """ConvShape for a FORWARD-type launch whose input is a gradient tensor (the data gradient of a ConvTranspose2d is a
     forward convolution of dy).  XAS_PREC_F16X3 splits the inputs of forward launches into fp16 pieces at a fixed scale
@@ -327,7 +367,7 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight, *rest = ctx.saved_tensors
-        shp = ctx.shp
+        shp = with_grad_amax(ctx.shp, dy)
         dy = to_cl(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -440,6 +480,7 @@ def _conv_backward(x, weight, dy, shp, cache, need_dx, need_dw, acc_into=None):
     """-> (dx, dw).  acc_into: a gradient buffer of x's shape that already holds the other branch's gradient; the
     data gradient is added to it in the kernel epilogue.  dw is None when it went straight into weight.grad."""
     dx = dw = None
+    shp = with_grad_amax(shp, dy)
     if need_dx:
         if acc_into is not None:
             dx = acc_into
@@ -537,10 +578,11 @@ class _Bottleneck(torch.autograd.Function):
             g, _ = bn_b(o + i - 1, bns[i - 1], g)
         if fuse_skip:
             dx = torch.empty_like(x)
-            call('xas_conv_dgrad_acc_masked', ptr(g), ptr(convs[0]._cache.get(convs[0].weight, 1, shps[o])), ptr(dx), shps[o],
+            shp0 = with_grad_amax(shps[o], g)
+            call('xas_conv_dgrad_acc_masked', ptr(g), ptr(convs[0]._cache.get(convs[0].weight, 1, shp0)), ptr(dx), shp0,
                  ptr(dout), ptr(saved[o + 2][1]))
-            if id(convs[0].weight) in need and not _wgrad_into_grad(x, g, shps[o], convs[0].weight):
-                pgrads[id(convs[0].weight)] = _wgrad(x, g, shps[o], convs[0].weight.shape)
+            if id(convs[0].weight) in need and not _wgrad_into_grad(x, g, shp0, convs[0].weight):
+                pgrads[id(convs[0].weight)] = _wgrad(x, g, shp0, convs[0].weight.shape)
             return (dx, None) + tuple(pgrads.get(id(p)) for p in ctx.blk._fused_params)
         if ctx.has_ds:
             ds = blk.downsample
@@ -825,8 +867,11 @@ def _bn_backward(saved, cfg, gamma, beta, dy, want_param_grads, want_dres=True):
         dist.all_reduce(sums, group=group)                # one coalesced message per layer (all groups)
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if (has_res and (want_dres or not masked)) else None
-    call('xas_bn_bwd_apply', px, py, ptr(dy), ptr(mean), ptr(var), ptr(gamma),
-         ptr(beta), ptr(sums), eps, act, M, c, G, float(count), ptr(dx), ptr(dres), ptr(mask))
+    slot = _amax_slot(dev) if (GRAD_F16 and query('xas_get_precision') == _lib.PREC_F16X3) else None
+    call('xas_bn_bwd_apply_amax', px, py, ptr(dy), ptr(mean), ptr(var), ptr(gamma),
+         ptr(beta), ptr(sums), eps, act, M, c, G, float(count), ptr(dx), ptr(dres), ptr(mask), ptr(slot))
+    if slot is not None:
+        dx._xas_amax = slot                      # max |dx|: the conv backward that reads dx scales its fp16 pieces with it
     return dx, dgamma, dbeta, dres
 
 
@@ -971,8 +1016,12 @@ def prepack(module):
         rows_of, views, desc, blk, off = [], [], [], 0, 0
         sizes = []
         for idx, (_, cache, w, shp) in enumerate(entries):
-            for t in (0, 1):
+            for t, extra in ((0, False), (1, False), (1, True)):
                 planes = query('xas_conv_weight_planes', shp, t)
+                if extra:                      # f16x3: the data gradient also runs on two fp16 planes when its dy comes with
+                    if not (planes == 3 and prec == _lib.PREC_F16X3 and GRAD_F16 and shp.mode == 0):   # its maximum
+                        continue
+                    planes = 2
                 if not planes or not w.is_contiguous():
                     continue
                 co, ci, r, s = w.shape
