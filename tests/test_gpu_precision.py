@@ -134,7 +134,7 @@ def test_conv_f16x3_small_and_large_operands():
 @pytest.mark.parametrize('n,cin,h,w,cout,k,stride,pad', [(2, 64, 16, 16, 64, 3, 1, 1), (3, 256, 8, 8, 512, 1, 2, 0),
                                                          (2, 128, 17, 13, 96, 3, 2, 1), (4, 256, 32, 32, 256, 3, 1, 1),
                                                          (2, 1024, 16, 16, 256, 1, 1, 0)])
-def test_f16x3_data_gradient_with_amax(n, cin, h, w, cout, k, stride, pad, scale):
+def test_f16x3_gradients_with_amax(n, cin, h, w, cout, k, stride, pad, scale):
     """Gradient launches of XAS_PREC_F16X3: dy is split into two fp16 pieces at the power-of-two scale given by max |dy|
     (xas_conv_shape.grad_amax).  Any magnitude of the gradient tensor - 1e-9 .. 1e4 - meets the bar of the other
     fp32-accurate modes, with a heavy-tailed dy (elements down to 1e-6 of the maximum)."""
@@ -154,8 +154,17 @@ def test_f16x3_data_gradient_with_amax(n, cin, h, w, cout, k, stride, pad, scale
         wc = wt.cuda()
         dx = O.empty_cl(n, cin, h, w, dyc)
         call('xas_conv_dgrad', ptr(dyc), ptr(cache.get(wc, 1, shp)), ptr(dx), shp)
+        # weight gradient: x at the fixed activation scale, dy at the scale of its maximum
+        x = torch.randn(n, cin, h, w, generator=g) * 2.0 + 0.3
+        xc = O.to_cl(x.cuda())
+        assert query('xas_conv_kernel_class', shp, 2) in (4, 1)          # (shapes outside the split kernels: exact fp32)
+        dw = torch.empty(cout, cin, k, k, device='cuda')
+        ws = torch.empty(max(1, query('xas_conv_wgrad_workspace_floats', shp)), device='cuda')
+        call('xas_conv_wgrad_oihw', ptr(xc), ptr(dyc), ptr(dw), ptr(ws), shp)
         torch.cuda.synchronize()
     assert rel(dx, dref) < 3e-6, rel(dx, dref)
+    wref = torch.nn.grad.conv2d_weight(x.double(), wt.shape, dy.double(), stride, pad)
+    assert rel(dw, wref) < 3e-6, rel(dw, wref)
 
 
 def _split_mode_case(n, cin, h, w, cout, k, stride, pad):

@@ -1468,7 +1468,7 @@ static inline int precision_of(const xas_conv_shape* s) { return s->mode > 0 ? s
 static inline int planes_of(int prec, int pass, bool has_amax) {
   if (prec == XAS_PREC_F32) return 0;
   if (prec == XAS_PREC_BF16) return 1;
-  return (prec == XAS_PREC_F16X3 && (pass == 0 || (has_amax && pass == 1))) ? 2 : 3;
+  return (prec == XAS_PREC_F16X3 && (pass == 0 || has_amax)) ? 2 : 3;
 }
 
 // prec: XAS_PREC_*.  The bf16-split kernels (conv_x6.hip) take PRE-SPLIT weights (xas_split_weight); the exact-fp32 kernels
@@ -2029,6 +2029,7 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
   wgrad_plan(s, x6, &bm, &bn, &splits, &mps);
   WgradParams p{};
   p.x = x; p.dy = dy; p.out = (splits == 1 && !oihw) ? dw_packed : workspace;
+  p.a_amax = s->grad_amax;
   p.N = s->N; p.Hi = s->Hi; p.Wi = s->Wi; p.Cin = s->Cin; p.Cout = s->Cout; p.R = s->R; p.S = s->S;
   p.stride = s->stride; p.pad = s->pad; p.Ho = s->Ho; p.Wo = s->Wo;
   p.KK = s->R * s->S * s->Cin; p.M = s->N * s->Ho * s->Wo; p.m_per_split = mps;

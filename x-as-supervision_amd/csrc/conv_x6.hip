@@ -43,11 +43,7 @@ constexpr int XLDH = XH;           // igemm LDS row in halfwords: 32 B, unpadded
                                    // per LDS instruction.)
 __device__ __forceinline__ int xswz(int row, int half) { return (half ^ ((row >> 3) & 1)) << 3; }   // halfword offset of a 16-byte half
 
-// the six kept partial products, smallest first: (a piece, b piece)
-__device__ constexpr int kPA[6] = {2, 0, 1, 1, 0, 0};
-__device__ constexpr int kPB[6] = {0, 2, 1, 0, 1, 0};
-
-__device__ __forceinline__ bf16x8_t as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
+// (the kept partial products of a piece format, smallest first: Products<P> in conv_shared.h)
 
 // ------------------------------------------------------------------------------------
 // weights: fp32 packed [rows][K] -> pre-split bf16 in FRAGMENT order
@@ -711,6 +707,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgradParams p) {
 #ifdef XAS_WGRAD_PRIO
   __builtin_amdgcn_s_setprio(XAS_WGRAD_PRIO);
 #endif
+  float f16_sd = 1.f, f16_desc = 1.f;                  // P == 2: scale of dy (from its maximum), scale of the result
+  if (P == 2) { float inv; f16_sd = f16_grad_scale(p.a_amax, &inv); f16_desc = inv * (1.f / kF16AScale); }
 
   // ---- dy operand: per-lane offset fixed, rows of a half-step from a scalar offset, split end = buffer range
   const int aq = tid % AQ, apix = tid / AQ;
@@ -782,21 +780,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgradParams p) {
     for (int j = 0; j < APH; ++j) {
       if (AHALF && ahalf != h) continue;               // (wave-uniform) this wave's dy rows belong to the other half
       float4 r = ra[AHALF ? 0 : h * APH + j];
+      if (P == 2) { r.x *= f16_sd; r.y *= f16_sd; r.z *= f16_sd; r.w *= f16_sd; }
 #pragma unroll
       for (int pc = 0; pc < P; ++pc) {
-        const uint2 q = pack_bf16x4(r);
+        const uint2 q = pack_piece4<P>(r);
         *reinterpret_cast<uint2*>(sb + pc * XH * SA + AROWS * j * SA + dstA) = q;
-        if (pc + 1 < P) r = sub_bf16x4(r, q);
+        if (pc + 1 < P) r = sub_piece4<P>(r, q);
       }
     }
 #pragma unroll
     for (int q4 = 0; q4 < BPQ; ++q4) {
       float4 r = rb[h * BPQ + q4];
+      if (P == 2) { r.x *= kF16AScale; r.y *= kF16AScale; r.z *= kF16AScale; r.w *= kF16AScale; }
 #pragma unroll
       for (int pc = 0; pc < P; ++pc) {
-        const uint2 q = pack_bf16x4(r);
+        const uint2 q = pack_piece4<P>(r);
         *reinterpret_cast<uint2*>(sb + pc * XH * SB + q4 * 128 + dstB) = q;
-        if (pc + 1 < P) r = sub_bf16x4(r, q);
+        if (pc + 1 < P) r = sub_piece4<P>(r, q);
       }
     }
   };
@@ -811,30 +811,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgradParams p) {
   };
   auto compute = [&](int buf) {
     const unsigned char* sb = S + buf * HBUF;
-    bf16x8_t fa[P][C::MI], fb[P][C::NI];
+    uint4 fa[P][C::MI], fb[P][C::NI];
 #pragma unroll
     for (int pc = P - 1; pc >= 0; --pc) {
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi) {
         const s16x4_t lo = tr_read(sb, fragA + pc * XH * SA + mi * 64);
         const s16x4_t hi = tr_read(sb, fragA + pc * XH * SA + mi * 64 + 4 * SA);
-        fa[pc][mi] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        fa[pc][mi] = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
       }
 #pragma unroll
       for (int ni = 0; ni < C::NI; ++ni) {
         const s16x4_t lo = tr_read(sb, fragB + pc * XH * SB + ni * 64);
         const s16x4_t hi = tr_read(sb, fragB + pc * XH * SB + ni * 64 + 4 * SB);
-        fb[pc][ni] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        fb[pc][ni] = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
       }
     }
 #pragma unroll
-    for (int t = (P == 3 ? 0 : 5); t < 6; ++t)
+    for (int t = 0; t < Products<P>::N; ++t)
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < C::NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[P == 3 ? kPA[t] : 0][mi], fb[P == 3 ? kPB[t] : 0][ni],
-                                                                acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = mfma_piece<P>(fa[Products<P>::A[t]][mi], fb[Products<P>::B[t]][ni], acc[mi][ni]);
   };
   const int nsteps = (mend > mbeg) ? (mend - mbeg + WBK - 1) / WBK : 0;
   const int last = nsteps - 1;
@@ -880,7 +879,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgradParams p) {
 #pragma unroll
       for (int ni = 0; ni < C::NI; ++ni) {
         const int nn = nn0 + wn * C::WN + ni * 32 + col_l;
-        if (nn < p.KK) slab[(size_t)co * p.KK + nn] = acc[mi][ni][reg];
+        if (nn < p.KK) slab[(size_t)co * p.KK + nn] = P == 2 ? acc[mi][ni][reg] * f16_desc : acc[mi][ni][reg];
       }
     }
 }
@@ -924,6 +923,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6t_kernel(WgradParams p) {
   const int np_total = p.M >> 7;
   const int pbeg = split * p.pps, pend = min(np_total, pbeg + p.pps);
   if (pbeg >= pend) return;
+  float f16_sd = 1.f, f16_desc = 1.f;                  // P == 2: scale of dy (from its maximum), scale of the result
+  if (P == 2) { float inv; f16_sd = f16_grad_scale(p.a_amax, &inv); f16_desc = inv * (1.f / kF16AScale); }
 
   const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((long)p.N * H * W * p.Cin * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)((long)p.M * p.Cout * 4), 0x00020000);
@@ -956,12 +957,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6t_kernel(WgradParams p) {
       const int item = tid + 256 * j, pix = item >> 3, q = item & 7;
       if (pix < npix) {
         float4 r = rx[j];
+        if (P == 2) { r.x *= kF16AScale; r.y *= kF16AScale; r.z *= kF16AScale; r.w *= kF16AScale; }
         unsigned char* d = SX + pix * XPB + q * 8;
 #pragma unroll
         for (int pc = 0; pc < P; ++pc) {
-          const uint2 v = pack_bf16x4(r);
+          const uint2 v = pack_piece4<P>(r);
           *reinterpret_cast<uint2*>(d + pc * xplane) = v;
-          if (pc + 1 < P) r = sub_bf16x4(r, v);
+          if (pc + 1 < P) r = sub_piece4<P>(r, v);
         }
       }
     }
@@ -990,11 +992,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6t_kernel(WgradParams p) {
       const int item = tid + 256 * j, apix = item / DQ, aq = item - apix * DQ;
       if (item < XH * DQ) {
         float4 r = rd[j];
+        if (P == 2) { r.x *= f16_sd; r.y *= f16_sd; r.z *= f16_sd; r.w *= f16_sd; }
 #pragma unroll
         for (int pc = 0; pc < P; ++pc) {
-          const uint2 v = pack_bf16x4(r);
+          const uint2 v = pack_piece4<P>(r);
           *reinterpret_cast<uint2*>(sb + pc * XH * SA + apix * SA + aq * 8) = v;
-          if (pc + 1 < P) r = sub_bf16x4(r, v);
+          if (pc + 1 < P) r = sub_piece4<P>(r, v);
         }
       }
     }
@@ -1015,12 +1018,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6t_kernel(WgradParams p) {
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
   auto compute = [&](int buf, int ks) {
     const unsigned char* sb = S + buf * DYB;
-    bf16x8_t fa[P];
+    uint4 fa[P];
 #pragma unroll
     for (int pc = P - 1; pc >= 0; --pc) {
       const s16x4_t lo = tr_read(sb, fragA + pc * XH * SA);
       const s16x4_t hi = tr_read(sb, fragA + pc * XH * SA + 4 * SA);
-      fa[pc] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      fa[pc] = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     }
     // halo pixel of the slice's first pixel for tap (0, 0) offset: row ks (two rows 2 (ks & 3) of image ks >> 2 when 8-wide)
     const int wbase = tw == 16 ? (ks + 1) * hw + 1 : (ks >> 2) * npix_img + (2 * (ks & 3) + 1) * hw + 1;
@@ -1030,16 +1033,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6t_kernel(WgradParams p) {
       if (t < 9) {
         const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
         const unsigned xo = (unsigned)((wbase + dy * hw + dx) * XPB) + fragX;
-        bf16x8_t fb[P];
+        uint4 fb[P];
 #pragma unroll
         for (int pc = P - 1; pc >= 0; --pc) {
           const s16x4_t lo = tr_read(SX, xo + pc * xplane);
           const s16x4_t hi = tr_read(SX, xo + pc * xplane + 4 * XPB);
-          fb[pc] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          fb[pc] = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
 #pragma unroll
-        for (int k = (P == 3 ? 0 : 5); k < 6; ++k)
-          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[P == 3 ? kPA[k] : 0], fb[P == 3 ? kPB[k] : 0], acc[ti], 0, 0, 0);
+        for (int k = 0; k < Products<P>::N; ++k)
+          acc[ti] = mfma_piece<P>(fa[Products<P>::A[k]], fb[Products<P>::B[k]], acc[ti]);
       }
     }
   };
@@ -1070,7 +1073,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6t_kernel(WgradParams p) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int co = co0 + cb * 32 + (reg & 3) + 8 * (reg >> 2) + rsub;
-        if (co < p.Cout) slab[(size_t)co * p.KK + t * p.Cin + c0 + col_l] = acc[ti][reg];
+        if (co < p.Cout) slab[(size_t)co * p.KK + t * p.Cin + c0 + col_l] = P == 2 ? acc[ti][reg] * f16_desc : acc[ti][reg];
       }
     }
   }
@@ -1119,6 +1122,12 @@ static int launch_wgrad_x6t_t(const WgradParams& p, int splits, int pps, hipStre
 }
 
 int launch_wgrad_x6t(const WgradParams& p, int bm, int splits, int pps, int pieces, hipStream_t st) {
+  if (pieces == 2) {                                   // f16x3: x at the fixed activation scale, dy at the scale of p.a_amax
+    XAS_REQUIRE(p.a_amax, "conv_wgrad: the f16x3 weight gradient needs the maximum of dy (xas_conv_shape.grad_amax)");
+    if (bm == 128) return launch_wgrad_x6t_t<128, 2>(p, splits, pps, st);
+    if (bm == 64) return launch_wgrad_x6t_t<64, 2>(p, splits, pps, st);
+    return launch_wgrad_x6t_t<32, 2>(p, splits, pps, st);
+  }
   if (pieces == 3) {
     if (bm == 128) return launch_wgrad_x6t_t<128, 3>(p, splits, pps, st);
     if (bm == 64) return launch_wgrad_x6t_t<64, 3>(p, splits, pps, st);
@@ -1151,6 +1160,12 @@ void wgrad_x6_tile(int Cout, long KK, int* bm, int* bn) {
 }
 
 int launch_wgrad_x6(const WgradParams& p, int bm, int bn, int splits, int pieces, hipStream_t st) {
+  if (pieces == 2) {
+    XAS_REQUIRE(p.a_amax, "conv_wgrad: the f16x3 weight gradient needs the maximum of dy (xas_conv_shape.grad_amax)");
+    if (bm == 32) return launch_wgrad_x6_t<32, 128, 2>(p, splits, st);
+    if (bm == 128) return bn == 128 ? launch_wgrad_x6_t<128, 128, 2>(p, splits, st) : launch_wgrad_x6_t<128, 64, 2>(p, splits, st);
+    return bn == 128 ? launch_wgrad_x6_t<64, 128, 2>(p, splits, st) : launch_wgrad_x6_t<64, 64, 2>(p, splits, st);
+  }
   if (bm == 32) return pieces == 3 ? launch_wgrad_x6_t<32, 128, 3>(p, splits, st) : launch_wgrad_x6_t<32, 128, 1>(p, splits, st);
   if (pieces == 3) {
     if (bm == 128) return bn == 128 ? launch_wgrad_x6_t<128, 128, 3>(p, splits, st) : launch_wgrad_x6_t<128, 64, 3>(p, splits, st);

@@ -294,11 +294,13 @@ class _PackCache:
         if key != self.key:
             self.key, self.packed = key, {}
 
-    def get(self, w, transposed, shp=None):
+    def get(self, w, transposed, shp=None, planes=None):
         """Weight buffer for the forward-type (transposed = 0) / data-gradient-type (1) entry points.  shp: the call's
-        ConvShape - the library says which format that (shape, precision) wants; None: fp32 packed."""
+        ConvShape - the library says which format that (shape, precision) wants; None: fp32 packed.  planes: build
+        this format regardless (prepack)."""
         self._fresh(w)
-        planes = query('xas_conv_weight_planes', shp, int(transposed)) if shp is not None else 0
+        if planes is None:
+            planes = query('xas_conv_weight_planes', shp, int(transposed)) if shp is not None else 0
         k = (transposed, planes)
         if k in self.packed:
             return self.packed[k]
@@ -1004,12 +1006,14 @@ def prepack(module):
     entries = _conv_entries(module)
     if not entries:
         return
+    prec = query('xas_get_precision')
     if not BATCH_PREP:
         for _, cache, w, shp in entries:
             cache.get(w, 0, shp)
             cache.get(w, 1, shp)
+            if (prec == _lib.PREC_F16X3 and GRAD_F16 and shp.mode == 0 and query('xas_conv_weight_planes', shp, 1) == 3):
+                cache.get(w, 1, shp, planes=2)         # the data gradient's second format (dy with its maximum)
         return
-    prec = query('xas_get_precision')
     key = (prec, tuple(w.data_ptr() for _, _, w, _ in entries))
     tab = getattr(module, '_xas_prep', None)
     if tab is None or tab['key'] != key:
