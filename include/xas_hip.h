@@ -78,6 +78,11 @@ int xas_head_softargmax_fwd(const float* logits, int B, int K, int D, int num_hy
 int xas_head_softargmax_bwd(const float* logits, const float* stats, const int64_t* z_idx,
                             const float* grad_kps, int B, int K, int D, int num_hypo, int neighbor,
                             float* grad_logits, float* coef, void* stream);
+/* Same, and max |grad_logits| is merged into *amax_out (device float, zeroed by the caller; NULL: none): the scale of the
+ * gradient operand of the final 1x1 convolution's f16x3 gradient launches (xas_conv_shape.grad_amax). */
+int xas_head_softargmax_bwd_amax(const float* logits, const float* stats, const int64_t* z_idx,
+                                 const float* grad_kps, int B, int K, int D, int num_hypo, int neighbor,
+                                 float* grad_logits, float* coef, float* amax_out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Patch -> world geometry, all hypotheses in one launch.

@@ -210,7 +210,11 @@ __global__ void head_bwd_coef_kernel(const float* __restrict__ stats, const int6
 }
 
 __global__ void head_bwd_kernel(const float4* __restrict__ logits, const float* __restrict__ coef, HeadGeom g,
-                                float4* __restrict__ grad) {
+                                float4* __restrict__ grad, float* __restrict__ amax_out) {
+  __shared__ unsigned s_amax;                          // amax_out != null: max |grad| of the block (bit pattern), then of the launch
+  if (threadIdx.x == 0) s_amax = 0u;
+  if (amax_out) __syncthreads();
+  float amx = 0.f;
   const int tid = threadIdx.x;
   const int c4 = tid % g.C4, slot = tid / g.C4;
   const int k = c4 / g.G, dq = c4 % g.G;
@@ -231,7 +235,13 @@ __global__ void head_bwd_kernel(const float4* __restrict__ logits, const float* 
     o.y = __expf(v.y - lse) * (lin + gz.y);
     o.z = __expf(v.z - lse) * (lin + gz.z);
     o.w = __expf(v.w - lse) * (lin + gz.w);
+    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     stream_store(grad + off + (size_t)p * g.C4, o);
+  }
+  if (amax_out) {                                      // (the block is not a whole number of waves: reduce through LDS)
+    if (amx > 0.f) atomicMax(&s_amax, __float_as_uint(amx));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_amax) atomicMax(reinterpret_cast<unsigned*>(amax_out), s_amax);
   }
 }
 
@@ -270,6 +280,12 @@ extern "C" int xas_head_softargmax_fwd(const float* logits, int B, int K, int D,
 extern "C" int xas_head_softargmax_bwd(const float* logits, const float* stats, const int64_t* z_idx,
                                        const float* grad_kps, int B, int K, int D, int num_hypo, int neighbor,
                                        float* grad_logits, float* coef, void* stream) {
+  return xas_head_softargmax_bwd_amax(logits, stats, z_idx, grad_kps, B, K, D, num_hypo, neighbor, grad_logits, coef, nullptr, stream);
+}
+
+extern "C" int xas_head_softargmax_bwd_amax(const float* logits, const float* stats, const int64_t* z_idx,
+                                            const float* grad_kps, int B, int K, int D, int num_hypo, int neighbor,
+                                            float* grad_logits, float* coef, float* amax_out, void* stream) {
   HeadGeom g;
   if (make_geom(B, K, D, &g)) return 1;
   XAS_REQUIRE(logits && stats && grad_kps && grad_logits && coef, "head bwd: null buffer");
@@ -280,7 +296,7 @@ extern "C" int xas_head_softargmax_bwd(const float* logits, const float* stats, 
                      num_hypo, neighbor, coef);
   XAS_LAUNCH_CHECK();
   hipLaunchKernelGGL(head_bwd_kernel, dim3(g.nchunk, B), dim3(g.C4 * g.R), 0, as_stream(stream),
-                     reinterpret_cast<const float4*>(logits), coef, g, reinterpret_cast<float4*>(grad_logits));
+                     reinterpret_cast<const float4*>(logits), coef, g, reinterpret_cast<float4*>(grad_logits), amax_out);
   XAS_LAUNCH_CHECK();
   return 0;
 }

@@ -38,6 +38,7 @@ SIGNATURES = {
     'xas_head_workspace_floats': ('iii', 'z'),
     'xas_head_softargmax_fwd': ('piiiiipppippp', 'i'),
     'xas_head_softargmax_bwd': ('ppppiiiiippp', 'i'),
+    'xas_head_softargmax_bwd_amax': ('ppppiiiiipppp', 'i'),
     'xas_patch_to_world_fwd': ('ppppppiiiffipp', 'i'),
     'xas_patch_to_world_bwd': ('pppppppiiiffipp', 'i'),
     'xas_lines_nblk': ('i', 'i'),

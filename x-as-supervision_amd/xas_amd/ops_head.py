@@ -46,8 +46,12 @@ class _SoftArgmax(torch.autograd.Function):
         g_kps = g_kps.contiguous()
         grad = torch.empty_like(logits)          # keeps the channels_last strides
         coef = torch.empty(B * K * (4 + D), device=logits.device, dtype=torch.float32)
-        call('xas_head_softargmax_bwd', ptr(logits), ptr(stats), ptr(z_idx), ptr(g_kps), B, K, D, Hy, nb,
-             ptr(grad), ptr(coef))
+        from . import ops_nn
+        slot = ops_nn.grad_amax_slot(logits.device)          # max |grad|: the final conv's f16x3 gradient launches scale dy with it
+        call('xas_head_softargmax_bwd_amax', ptr(logits), ptr(stats), ptr(z_idx), ptr(g_kps), B, K, D, Hy, nb,
+             ptr(grad), ptr(coef), ptr(slot))
+        if slot is not None:
+            grad._xas_amax = slot
         return grad, None, None, None, None
 
 

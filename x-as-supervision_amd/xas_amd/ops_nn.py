@@ -259,6 +259,25 @@ def _amax_slot(device):
     return a[i:i + 1]
 
 
+def grad_amax_slot(device):
+    """A zeroed float for a kernel that writes a gradient tensor to merge max |g| into; None outside XAS_PREC_F16X3."""
+    if not GRAD_F16 or query('xas_get_precision') != _lib.PREC_F16X3:
+        return None
+    return _amax_slot(device)
+
+
+_act_amax = {}
+
+
+def activation_amax(device):
+    """Pointer-able constant for a DATA-GRADIENT-type launch whose gathered operand is an ACTIVATION (the forward of a
+    ConvTranspose2d): 2^10 selects the fixed activation scale 2^4 of the f16x3 kernels (conv_shared.h kF16AScale)."""
+    t = _act_amax.get(device)
+    if t is None:
+        t = _act_amax[device] = torch.full((1,), 1024.0, device=device, dtype=torch.float32)
+    return t
+
+
 def with_grad_amax(shp, dy):
     """ConvShape of a gradient launch that reads `dy`: with the pointer to max |dy| when its producer recorded one."""
     slot = getattr(dy, '_xas_amax', None)
@@ -627,7 +646,11 @@ class _ConvTranspose2d(torch.autograd.Function):
         # equivalent conv: big side (hb,wb,cot) -> small side (h,w,cit)
         shp = _shape(n, hb, wb, cot, cit, r, s, stride, pad, h, w)
         y = empty_cl(n, cot, hb, wb, x)
-        call('xas_conv_dgrad', ptr(x), ptr(cache.get(weight, 1, shp)), ptr(y), shp)
+        shp_f = shp
+        if x.is_cuda and GRAD_F16 and query('xas_get_precision') == _lib.PREC_F16X3:
+            # the gathered operand of this data-gradient-type launch is an activation: fixed scale (see activation_amax)
+            shp_f = ConvShape(n, hb, wb, cot, cit, r, s, stride, pad, h, w, 0, activation_amax(x.device).data_ptr())
+        call('xas_conv_dgrad', ptr(x), ptr(cache.get(weight, 1, shp_f)), ptr(y), shp_f)
         ctx.save_for_backward(x, weight)
         ctx.shp, ctx.cache = shp, cache
         if ctx.needs_input_grad[1]:
@@ -638,11 +661,14 @@ class _ConvTranspose2d(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         shp = ctx.shp
+        dy_in = dy
         dy = to_cl(dy)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            shp_g = grad_operand_shape(shp)
+            shp_g = with_grad_amax(shp, dy_in)             # dy with its maximum: f16x3 at that scale; else pinned to bf16x6
+            if shp_g is shp:
+                shp_g = grad_operand_shape(shp)
             call('xas_conv_fwd', ptr(dy), ptr(ctx.cache.get(weight, 0, shp_g)), None, ptr(dx), shp_g)
         if ctx.needs_input_grad[1] and not _wgrad_into_grad(dy, x, shp, weight):
             dw = _wgrad(dy, x, shp, weight.shape)
@@ -869,7 +895,7 @@ def _bn_backward(saved, cfg, gamma, beta, dy, want_param_grads, want_dres=True):
         dist.all_reduce(sums, group=group)                # one coalesced message per layer (all groups)
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if (has_res and (want_dres or not masked)) else None
-    slot = _amax_slot(dev) if (GRAD_F16 and query('xas_get_precision') == _lib.PREC_F16X3) else None
+    slot = grad_amax_slot(dev)
     call('xas_bn_bwd_apply_amax', px, py, ptr(dy), ptr(mean), ptr(var), ptr(gamma),
          ptr(beta), ptr(sums), eps, act, M, c, G, float(count), ptr(dx), ptr(dres), ptr(mask), ptr(slot))
     if slot is not None:
@@ -988,7 +1014,7 @@ def _conv_entries(module):
             if type(m).__name__ == 'ConvTranspose2d':          # weight [Cin_t, Cout_t, R, S]: the equivalent conv is Cout_t -> Cin_t
                 hs = 8
                 hb = (hs - 1) * stride - 2 * pad + r
-                shp = grad_operand_shape(_shape(1, hb, hb, b, a, r, s, stride, pad, hs, hs))   # (its forward-type launch is a backward)
+                shp = _shape(1, hb, hb, b, a, r, s, stride, pad, hs, hs)
             else:
                 hi = 16
                 ho = (hi + 2 * pad - r) // stride + 1
