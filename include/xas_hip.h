@@ -49,6 +49,7 @@ int xas_set_tuning(int flags);
  * xas_set_precision sets the process default; a call overrides it with xas_conv_shape.mode = 1 + XAS_PREC_* (0 = default).
  * In the bf16 modes forward / data gradient take PRE-SPLIT weights: see xas_conv_weight_planes / xas_split_weight. */
 enum { XAS_PREC_F32 = 0, XAS_PREC_BF16 = 1, XAS_PREC_BF16X6 = 2, XAS_PREC_F16X3 = 3 };
+enum { XAS_GRAD_IS_X = 0x100 };      /* flag of xas_conv_shape.mode */
 int xas_set_precision(int mode);
 int xas_get_precision(void);
 int xas_abi_version(void);
@@ -140,7 +141,9 @@ typedef struct {
   int Cout, R, S;
   int stride, pad;
   int Ho, Wo;
-  int mode;          /* 0: process default precision (xas_set_precision); otherwise 1 + XAS_PREC_* for this call */
+  int mode;          /* low byte: 0 = process default precision (xas_set_precision), otherwise 1 + XAS_PREC_* for this call;
+                      * | XAS_GRAD_IS_X: in a weight-gradient call the gradient tensor is the `x` argument, not `dy`
+                      *   (the weight gradient of a ConvTranspose2d) - tells grad_amax which operand it describes */
   const float* grad_amax;   /* NULL, or a DEVICE pointer to max |g| over the gradient tensor this call reads (dy of a data /
                               * weight gradient; the input of a forward launch that is itself a backward, e.g. the data gradient of
                               * a ConvTranspose2d), complete on the call's stream.  XAS_PREC_F16X3 then splits that tensor into two

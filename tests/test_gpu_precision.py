@@ -167,6 +167,32 @@ def test_f16x3_gradients_with_amax(n, cin, h, w, cout, k, stride, pad, scale):
     assert rel(dw, wref) < 3e-6, rel(dw, wref)
 
 
+@pytest.mark.parametrize('scale', [1e-6, 1.0, 1e3])
+def test_f16x3_conv_transpose_with_norm(scale):
+    """ConvTranspose2d -> BatchNorm -> ReLU (deconv_head.py:27-32) in the default mode: the forward is a data-gradient-type
+    launch on an ACTIVATION (fixed scale), its backward a forward-type launch and a weight gradient whose gradient tensor
+    is the `x` argument (XAS_GRAD_IS_X), both scaled by the maximum the norm's backward recorded.  Against float64 autograd."""
+    from xas_amd import layers as L
+    from xas_amd._lib import query
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 64, 8, 8, generator=g) + 0.2
+    ct = L.ConvTranspose2d(64, 96, 4, 2, 1).cuda()
+    bn = L.BatchNorm2d(96).cuda().train()
+    gy = (torch.randn(4, 96, 16, 16, generator=g) * scale)
+    xg = x.cuda().requires_grad_(True)
+    y = torch.relu(bn(ct(xg)))
+    (y * gy.cuda()).sum().backward()
+    assert query('xas_get_precision') == 3
+    wd = ct.weight.detach().double().cpu().requires_grad_(True)
+    xd = x.double().requires_grad_(True)
+    gd, bd = bn.weight.detach().double().cpu(), bn.bias.detach().double().cpu()
+    yd = torch.relu(TF.batch_norm(TF.conv_transpose2d(xd, wd, None, 2, 1), None, None, gd, bd, True, 0.1, bn.eps))
+    (yd * gy.double()).sum().backward()
+    assert rel(y, yd) < 3e-6
+    assert rel(xg.grad, xd.grad) < 2e-5, rel(xg.grad, xd.grad)            # (through the norm's backward: cancellation)
+    assert rel(ct.weight.grad, wd.grad) < 2e-5, rel(ct.weight.grad, wd.grad)
+
+
 def _split_mode_case(n, cin, h, w, cout, k, stride, pad):
     from xas_amd import layers as L
     g = torch.Generator().manual_seed(cin + cout + k + n)

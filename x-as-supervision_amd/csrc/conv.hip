@@ -1460,7 +1460,7 @@ static int launch_tile(const IgemmParams& p, int Mrows_max, int phases, hipStrea
 
 static int g_precision = XAS_PREC_F16X3;     // process default (xas_set_precision); a call overrides it with xas_conv_shape.mode
 
-static inline int precision_of(const xas_conv_shape* s) { return s->mode > 0 ? s->mode - 1 : g_precision; }
+static inline int precision_of(const xas_conv_shape* s) { return (s->mode & 0xff) > 0 ? (s->mode & 0xff) - 1 : g_precision; }
 // operand planes of a pass in a precision mode (pass 0: forward-type launch, 1 data gradient, 2 weight gradient):
 // XAS_PREC_F16X3 runs on two fp16 planes where the scale of the split operands is known - forward-type launches
 // (activations: fixed scale) and gradient launches that come with the maximum of their gradient tensor
@@ -2029,7 +2029,9 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
   wgrad_plan(s, x6, &bm, &bn, &splits, &mps);
   WgradParams p{};
   p.x = x; p.dy = dy; p.out = (splits == 1 && !oihw) ? dw_packed : workspace;
-  p.a_amax = s->grad_amax;
+  // which argument is the gradient tensor: dy (a conv's weight gradient) or x (XAS_GRAD_IS_X: a ConvTranspose2d's)
+  p.a_amax = (s->mode & XAS_GRAD_IS_X) ? nullptr : s->grad_amax;
+  p.b_amax = (s->mode & XAS_GRAD_IS_X) ? s->grad_amax : nullptr;
   p.N = s->N; p.Hi = s->Hi; p.Wi = s->Wi; p.Cin = s->Cin; p.Cout = s->Cout; p.R = s->R; p.S = s->S;
   p.stride = s->stride; p.pad = s->pad; p.Ho = s->Ho; p.Wo = s->Wo;
   p.KK = s->R * s->S * s->Cin; p.M = s->N * s->Ho * s->Wo; p.m_per_split = mps;

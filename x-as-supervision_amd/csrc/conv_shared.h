@@ -425,7 +425,8 @@ struct WgradParams {
   int nct, ntiles, nsplits;                           // Cout tiles, tiles per split, pixel splits
   int tune;
   int t2d_tw, pps;                                    // wgrad_x6t_kernel: patch width (16 / 8), pixel patches per split
-  const float* a_amax;                                // f16x3 kernels: device pointer to max |dy| (scale of dy's fp16 pieces)
+  const float* a_amax; const float* b_amax;           // f16x3 kernels: device pointers to max |dy| / max |x| when that operand is a
+                                                      // gradient tensor (scale of its fp16 pieces); null: an activation (fixed scale)
   FastDiv div_hw, div_w, div_cin, div_s;
 };
 

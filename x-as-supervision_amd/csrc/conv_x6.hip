@@ -707,8 +707,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgradParams p) {
 #ifdef XAS_WGRAD_PRIO
   __builtin_amdgcn_s_setprio(XAS_WGRAD_PRIO);
 #endif
-  float f16_sd = 1.f, f16_desc = 1.f;                  // P == 2: scale of dy (from its maximum), scale of the result
-  if (P == 2) { float inv; f16_sd = f16_grad_scale(p.a_amax, &inv); f16_desc = inv * (1.f / kF16AScale); }
+  float f16_sd = kF16AScale, f16_sx = kF16AScale, f16_desc = 1.f;      // P == 2: scales of dy and of x, scale of the result
+  if (P == 2) {                                        // (the gradient operand from its maximum, the activation fixed)
+    float id = 1.f / kF16AScale, ix = 1.f / kF16AScale;
+    if (p.a_amax) f16_sd = f16_grad_scale(p.a_amax, &id);
+    if (p.b_amax) f16_sx = f16_grad_scale(p.b_amax, &ix);
+    f16_desc = id * ix;
+  }
 
   // ---- dy operand: per-lane offset fixed, rows of a half-step from a scalar offset, split end = buffer range
   const int aq = tid % AQ, apix = tid / AQ;
@@ -791,7 +796,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgradParams p) {
 #pragma unroll
     for (int q4 = 0; q4 < BPQ; ++q4) {
       float4 r = rb[h * BPQ + q4];
-      if (P == 2) { r.x *= kF16AScale; r.y *= kF16AScale; r.z *= kF16AScale; r.w *= kF16AScale; }
+      if (P == 2) { r.x *= f16_sx; r.y *= f16_sx; r.z *= f16_sx; r.w *= f16_sx; }
 #pragma unroll
       for (int pc = 0; pc < P; ++pc) {
         const uint2 q = pack_piece4<P>(r);
@@ -923,8 +928,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6t_kernel(WgradParams p) {
   const int np_total = p.M >> 7;
   const int pbeg = split * p.pps, pend = min(np_total, pbeg + p.pps);
   if (pbeg >= pend) return;
-  float f16_sd = 1.f, f16_desc = 1.f;                  // P == 2: scale of dy (from its maximum), scale of the result
-  if (P == 2) { float inv; f16_sd = f16_grad_scale(p.a_amax, &inv); f16_desc = inv * (1.f / kF16AScale); }
+  float f16_sd = kF16AScale, f16_sx = kF16AScale, f16_desc = 1.f;      // P == 2: scales of dy and of x, scale of the result
+  if (P == 2) {                                        // (the gradient operand from its maximum, the activation fixed)
+    float id = 1.f / kF16AScale, ix = 1.f / kF16AScale;
+    if (p.a_amax) f16_sd = f16_grad_scale(p.a_amax, &id);
+    if (p.b_amax) f16_sx = f16_grad_scale(p.b_amax, &ix);
+    f16_desc = id * ix;
+  }
 
   const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((long)p.N * H * W * p.Cin * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)((long)p.M * p.Cout * 4), 0x00020000);
@@ -957,7 +967,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6t_kernel(WgradParams p) {
       const int item = tid + 256 * j, pix = item >> 3, q = item & 7;
       if (pix < npix) {
         float4 r = rx[j];
-        if (P == 2) { r.x *= kF16AScale; r.y *= kF16AScale; r.z *= kF16AScale; r.w *= kF16AScale; }
+        if (P == 2) { r.x *= f16_sx; r.y *= f16_sx; r.z *= f16_sx; r.w *= f16_sx; }
         unsigned char* d = SX + pix * XPB + q * 8;
 #pragma unroll
         for (int pc = 0; pc < P; ++pc) {
@@ -1123,7 +1133,7 @@ static int launch_wgrad_x6t_t(const WgradParams& p, int splits, int pps, hipStre
 
 int launch_wgrad_x6t(const WgradParams& p, int bm, int splits, int pps, int pieces, hipStream_t st) {
   if (pieces == 2) {                                   // f16x3: x at the fixed activation scale, dy at the scale of p.a_amax
-    XAS_REQUIRE(p.a_amax, "conv_wgrad: the f16x3 weight gradient needs the maximum of dy (xas_conv_shape.grad_amax)");
+    XAS_REQUIRE(p.a_amax || p.b_amax, "conv_wgrad: the f16x3 weight gradient needs the maximum of its gradient operand (xas_conv_shape.grad_amax)");
     if (bm == 128) return launch_wgrad_x6t_t<128, 2>(p, splits, pps, st);
     if (bm == 64) return launch_wgrad_x6t_t<64, 2>(p, splits, pps, st);
     return launch_wgrad_x6t_t<32, 2>(p, splits, pps, st);
@@ -1161,7 +1171,7 @@ void wgrad_x6_tile(int Cout, long KK, int* bm, int* bn) {
 
 int launch_wgrad_x6(const WgradParams& p, int bm, int bn, int splits, int pieces, hipStream_t st) {
   if (pieces == 2) {
-    XAS_REQUIRE(p.a_amax, "conv_wgrad: the f16x3 weight gradient needs the maximum of dy (xas_conv_shape.grad_amax)");
+    XAS_REQUIRE(p.a_amax || p.b_amax, "conv_wgrad: the f16x3 weight gradient needs the maximum of its gradient operand (xas_conv_shape.grad_amax)");
     if (bm == 32) return launch_wgrad_x6_t<32, 128, 2>(p, splits, st);
     if (bm == 128) return bn == 128 ? launch_wgrad_x6_t<128, 128, 2>(p, splits, st) : launch_wgrad_x6_t<128, 64, 2>(p, splits, st);
     return bn == 128 ? launch_wgrad_x6_t<64, 128, 2>(p, splits, st) : launch_wgrad_x6_t<64, 64, 2>(p, splits, st);

@@ -226,6 +226,7 @@ def _shape(n, hi, wi, cin, cout, r, s, stride, pad, ho, wo, mode=0):
 
 
 MODE_F32 = 1 + _lib.PREC_F32          # ConvShape.mode of a call that must run on the exact-fp32 kernels
+GRAD_IS_X = 0x100                     # xas_hip.h XAS_GRAD_IS_X
 
 
 # ---- maxima of gradient tensors (XAS_PREC_F16X3) -----------------------------------------------------------------
@@ -670,8 +671,11 @@ class _ConvTranspose2d(torch.autograd.Function):
             if shp_g is shp:
                 shp_g = grad_operand_shape(shp)
             call('xas_conv_fwd', ptr(dy), ptr(ctx.cache.get(weight, 0, shp_g)), None, ptr(dx), shp_g)
-        if ctx.needs_input_grad[1] and not _wgrad_into_grad(dy, x, shp, weight):
-            dw = _wgrad(dy, x, shp, weight.shape)
+        shp_w = with_grad_amax(shp, dy_in)
+        if shp_w is not shp:
+            shp_w.mode = GRAD_IS_X                          # the gradient tensor is the weight gradient's `x` argument here
+        if ctx.needs_input_grad[1] and not _wgrad_into_grad(dy, x, shp_w, weight):
+            dw = _wgrad(dy, x, shp_w, weight.shape)
         return dx, dw, None, None, None
 
 
