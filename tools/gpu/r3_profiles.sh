@@ -8,4 +8,5 @@ timeout -k 10 600 python bench.py --shape-report $OUT/shapes.txt > $OUT/bench_b3
 for w in MPI_Multi_SurS1 HM36_Multi_SurS2; do timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline --f32-steps 0 > $OUT/bench_$w.json 2> $OUT/bench_$w.err; echo "$w: $(grep timed $OUT/bench_$w.err)"; done
 timeout -k 10 300 python bench.py --workload HM36_Multi_SynthS2 --batch 64 --no-cpu-baseline --f32-steps 0 > $OUT/bench_synth_b64.json 2> $OUT/bench_synth_b64.err; echo "synth b64: $(grep timed $OUT/bench_synth_b64.err)"
 timeout -k 10 300 python bench.py --precision f32 --no-cpu-baseline > $OUT/bench_b32_f32.json 2> $OUT/bench_b32_f32.err; echo "f32: $(grep timed $OUT/bench_b32_f32.err)"
+timeout -k 10 300 python bench.py --precision bf16x6 --no-cpu-baseline --f32-steps 0 > $OUT/bench_b32_bf16x6.json 2> $OUT/bench_b32_bf16x6.err; echo "bf16x6: $(grep timed $OUT/bench_b32_bf16x6.err)"
 timeout -k 10 300 python bench.py --precision bf16 --no-cpu-baseline --f32-steps 0 > $OUT/bench_b32_bf16.json 2> $OUT/bench_b32_bf16.err; echo "bf16: $(grep timed $OUT/bench_b32_bf16.err)"

@@ -17,7 +17,8 @@ import re
 import sys
 
 SIMDS = 256 * 4
-CONV = ('igemm_kernel', 'igemm_buf_kernel', 'wgrad_kernel', 'wgrad_buf_kernel', 'stem_fwd_kernel', 'igemm_x6_kernel', 'wgrad_x6_kernel')
+CONV = ('igemm_kernel', 'igemm_buf_kernel', 'wgrad_kernel', 'wgrad_buf_kernel', 'stem_fwd_kernel', 'stem_wgrad_kernel', 'igemm_x6_kernel', 'wgrad_x6_kernel',
+        'igemm_x6t_kernel', 'wgrad_x6t_kernel')
 
 
 def short(name):
