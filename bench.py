@@ -174,7 +174,7 @@ def main():
     # HIP events bracket every conv-family launch of the LAST timed step (1 818 launches): bracketing all K steps cost
     # ~4 % of the headline (two event packets per launch on the queue), one step costs < 1 %.
     from xas_amd.prof import CONV_ENTRIES
-    HEAD = ('xas_head_softargmax_fwd', 'xas_head_softargmax_bwd')
+    HEAD = ('xas_head_softargmax_fwd', 'xas_head_softargmax_bwd', 'xas_head_softargmax_bwd_amax')
     timer = KernelTimer(CONV_ENTRIES + HEAD)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -304,11 +304,12 @@ def main():
                          'by_kernel_class': {k.lstrip(':'): {kk: d[kk] for kk in ('launches', 'ms', 'achieved', 'peak', 'frac')} for k, d in cl.items()},
                          'conv_family_frac_of_mixed_peak': mix_frac,
                          'sustained_mfma_ceiling': {
-                             'bf16_TFLOPs': 1892.0, 'bf16x6_equivalent_TFLOPs': 315.3,
+                             'bf16_TFLOPs': 1892.0, 'bf16x6_equivalent_TFLOPs': 315.3, 'f16x3_equivalent_TFLOPs': 630.7,
                              'what': 'static constant, NOT measured in this run: a register-only v_mfma_f32_32x32x16_bf16 loop '
                                      'with random (non-zero) operands sustains 1 892 TFLOP/s on this part (2 486 with zero '
                                      'operands: the clock drops under the power limit), tools/micro/mfma_bf16_peak.hip, '
-                                     'profiles/r03_mfma_bf16_sustained_peak.txt; frac above is against the nominal 419.5'},
+                                     'profiles/r03_mfma_bf16_sustained_peak.txt (the fp16 instruction has the same rate; / 3 and / 6 for '
+                                     'the split modes); frac above is against the NOMINAL peak of the class'},
                          'conv_family_tflops': fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
                          'algorithmic_bytes_per_launch': timer.bytes_total / max(1, n_launch),
                          'note': 'weight-gradient kernels run on a side stream concurrently with the main chain, so '
@@ -333,7 +334,7 @@ def main():
         for k, v in head.items():
             if v['ms'] > 0:
                 tbs = v['flops'] / (v['ms'] * 1e-3) / 1e12
-                hd[k.replace('xas_head_softargmax_', '').replace(':direct', '')] = {
+                hd[k.replace('xas_head_softargmax_', '').replace(':direct', '').replace('_amax', '')] = {
                     'launches': v['launches'], 'us_per_launch': v['ms'] * 1e3 / v['launches'],
                     'algorithmic_MB_per_launch': v['flops'] / v['launches'] / 1e6, 'achieved_TBps': tbs, 'frac_of_8TBps': tbs / 8.0}
         line['roofline']['head'] = dict(hd, kernel='head_partial_kernel + head_finalize_kernel (fwd), head_bwd_coef_kernel + '

@@ -54,7 +54,7 @@ class KernelTimer:
         if name == 'xas_head_softargmax_fwd':          # (logits, B, K, D, ...): the logits are read once
             B, K, D = args[1], args[2], args[3]
             work, sig = 4.0 * B * K * D * D * D, (B, K, D)
-        elif name == 'xas_head_softargmax_bwd':        # (logits, stats, z_idx, grad_kps, B, K, D, ...): read + write
+        elif name in ('xas_head_softargmax_bwd', 'xas_head_softargmax_bwd_amax'):        # (logits, stats, z_idx, grad_kps, B, K, D, ...): read + write
             B, K, D = args[4], args[5], args[6]
             work, sig = 8.0 * B * K * D * D * D, (B, K, D)
         self.records.append((name, a, b, work, mfma, sig))
