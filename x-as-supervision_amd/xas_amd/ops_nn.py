@@ -252,7 +252,7 @@ def _amax_slot(device):
     a = _amax['arena']
     if a is None or a.device != device or _amax['next'] >= _AMAX_SLOTS:
         if a is not None:
-            _amax['retired'].append(a)          # kernels in flight may still read it
+            _amax['retired'] = (_amax['retired'] + [a])[-4:]      # kernels in flight may still read the last few
         a = _amax['arena'] = torch.zeros(_AMAX_SLOTS, device=device, dtype=torch.float32)
         _amax['next'] = 0
     i = _amax['next']
