@@ -101,9 +101,9 @@ def main():
     ap.add_argument('--tune', type=int, default=0, help='kernel tuning experiment flags (xas_set_tuning)')
     ap.add_argument('--precision', default='f16x3', choices=['bf16x6', 'f16x3', 'f32', 'bf16'],
                     help='arithmetic of the MFMA convolutions (xas_hip.h XAS_PREC_*).  f16x3 (default, the headline; the '
-                         'whole parity suite runs in this mode): forward launches split every fp32 operand into two fp16 '
-                         'pieces (22 bits) and accumulate three partial products in fp32 (peak 2516.8 / 3 = 838.9 TFLOP/s fp32-'
-                         'equivalent), gradient launches run as bf16x6.  bf16x6: every pass with fp32 '
+                         'whole parity suite runs in this mode): every fp32 operand is split into two fp16 '
+                         'pieces (22 bits, power-of-two scaled) and three partial products are accumulated in fp32 (peak 2516.8 / 3 = '
+                         '838.9 TFLOP/s fp32-equivalent).  bf16x6: every pass with fp32 '
                          'operands split exactly into three bf16 pieces, six exact partial products accumulated in fp32 - '
                          'fp32-accurate, peak 2516.8 / 6 = 419.5 TFLOP/s fp32-'
                          'equivalent.  f32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32, peak 157.3).  bf16: operands rounded '
@@ -275,7 +275,7 @@ def main():
             variant_check = {'max_abs_joint_diff_vs_exact_fp32_mfma': float((kv - k32).abs().max()),
                              'what': 'detector forward (eval-mode norms) on 8 images, this precision mode vs the exact-fp32 MFMA kernels; parity bar 1e-4'}
         kernel_names = {':bf16x6': 'igemm_x6_kernel<.,.,.,3> (fwd / dgrad) + wgrad_x6_kernel<.,.,3>: bf16x6 MFMA implicit-GEMM conv family',
-                        ':f16x3': 'igemm_x6_kernel<.,.,0,2> / igemm_x6t_kernel<.,0,2> (fwd): f16x3 MFMA implicit-GEMM conv family',
+                        ':f16x3': 'igemm_x6_kernel<.,.,.,2> / igemm_x6t_kernel<.,.,2> (fwd / dgrad) + wgrad_x6_kernel<.,.,2> / wgrad_x6t_kernel<.,2>: f16x3 MFMA implicit-GEMM conv family',
                         ':bf16': 'igemm_x6_kernel<.,.,.,1> + wgrad_x6_kernel<.,.,1>: bf16 MFMA implicit-GEMM conv family',
                         ':f32': 'igemm_buf_kernel + wgrad_buf_kernel (+ stem_fwd_kernel): exact-fp32 MFMA implicit-GEMM conv family'}
         line = {
@@ -284,7 +284,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'f32': 'f32 (exact fp32 MFMA)', 'bf16x6': 'f32 (bf16x6 split, f32 accumulate)',
-                      'f16x3': 'f32 (forward: f16x3 split, gradients: bf16x6 split; f32 accumulate)',
+                      'f16x3': 'f32 (f16x3 split: every fp32 operand as two fp16 pieces, three products; f32 accumulate)',
                       'bf16': 'bf16 products, f32 accumulate (variant: NOT fp32 accurate, not the headline)'}[args.precision],
             'data': 'synthetic',
             'config': {'workload': args.workload, 'batch_per_gpu': args.batch, 'cameras': len(cams),

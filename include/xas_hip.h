@@ -39,15 +39,25 @@ const char* xas_last_error(void);
  *   8388608 (bit 23)  no 64 x 256 tiles for layers whose output channels are a multiple of 256
  *   16777216 (bit 24) the general weight-gradient kernel for the 7x7 stem instead of stem_wgrad_kernel */
 int xas_set_tuning(int flags);
-/* Arithmetic of the MFMA convolutions (forward, data gradient, weight gradient).  All three keep fp32 activations, fp32
+/* Arithmetic of the MFMA convolutions (forward, data gradient, weight gradient).  All modes keep fp32 activations, fp32
  * master weights and fp32 accumulation; they differ in how a product of two fp32 operands is formed:
- *   XAS_PREC_BF16X6 (default)  every fp32 operand is split exactly into three bf16 pieces and six exact partial products
+ *   XAS_PREC_F16X3 (default)  every fp32 operand is split into two fp16 pieces x = h1 + h2 + e, |e| <= 2^-22 |x| (round to
+ *                   nearest twice), after an exact power-of-two scaling that keeps both pieces inside fp16's normal
+ *                   range: weights as 2^10 w (|w| < 64), activations as 2^4 x (full accuracy for |x| in [2^-10, 2^11]: images,
+ *                   masks, normalised activations), gradient tensors at the scale that puts their maximum in [2^14, 2^15)
+ *                   (xas_conv_shape.grad_amax, produced by the kernel that wrote the gradient).  Three partial products
+ *                   h1 g1 + h1 g2 + h2 g1, each exact in fp32, accumulated by v_mfma_f32_32x32x16_f16: 3 instead of 6 matrix
+ *                   instructions per K = 16.  Measured distance to a float64 convolution: the same as the exact-fp32 MFMA
+ *                   path's (its own accumulation error dominates: 5e-7 relative at K = 576).  A gradient launch WITHOUT
+ *                   grad_amax runs as bf16x6;
+ *   XAS_PREC_BF16X6  every fp32 operand is split exactly into three bf16 pieces and six exact partial products
  *                   are accumulated in fp32 by v_mfma_f32_32x32x16_bf16: per-product error below one fp32 rounding
- *                   (1.09e-7 relative against float64 at K = 64, exact-fp32 MFMA 1.06e-7), 2.67x the fp32-MFMA math rate;
+ *                   (1.09e-7 relative against float64 at K = 64, exact-fp32 MFMA 1.06e-7), 2.67x the fp32-MFMA math rate; no
+ *                   assumption on operand ranges;
  *   XAS_PREC_F32    v_mfma_f32_32x32x2_f32, bit for bit a k-ordered fmaf chain;
  *   XAS_PREC_BF16   operands rounded to bf16 once (NOT fp32 accurate; a variant that is reported separately).
  * xas_set_precision sets the process default; a call overrides it with xas_conv_shape.mode = 1 + XAS_PREC_* (0 = default).
- * In the bf16 modes forward / data gradient take PRE-SPLIT weights: see xas_conv_weight_planes / xas_split_weight. */
+ * In the split modes forward / data gradient take PRE-SPLIT weights: see xas_conv_weight_planes / xas_split_weight. */
 enum { XAS_PREC_F32 = 0, XAS_PREC_BF16 = 1, XAS_PREC_BF16X6 = 2, XAS_PREC_F16X3 = 3 };
 enum { XAS_GRAD_IS_X = 0x100 };      /* flag of xas_conv_shape.mode */
 int xas_set_precision(int mode);
@@ -152,14 +162,14 @@ typedef struct {
 } xas_conv_shape;
 
 /* Which weight buffer xas_conv_fwd* (pass 0) / xas_conv_dgrad* (pass 1) expect for this shape in its precision mode:
- * 0 = fp32 packed weights (xas_pack_weight); 1 or 3 = that many bf16 planes: xas_split_weight of the packed weights
+ * 0 = fp32 packed weights (xas_pack_weight); 1 or 3 = that many bf16 planes, 2 = two fp16 planes of 2^10 w: xas_split_weight of the packed weights
  * [rows][K] with K = R*S*Cin (pass 0, rows = Cout) or R*S*Cout (pass 1, rows = Cin).  The split layout is the MFMA operand
  * image [rows / 32][K / 16][planes][64 lanes][8 bf16] (rows zero-padded to a multiple of 32): the kernels load it straight
  * into operand registers.  Shapes outside the MFMA tiles (stem, one-channel layers) always take fp32 weights.  Built once
  * per optimizer step and weight. */
 int xas_conv_weight_planes(const xas_conv_shape* s, int pass);
 /* Kernel family a pass of this shape runs on (0 forward-type, 1 data-gradient-type, 2 weight gradient): 0 no MFMA (direct /
- * one-channel kernels), 1 exact-fp32 MFMA, 2 bf16 MFMA, 3 bf16x6 MFMA.  For measurement (bench.py prices a launch against
+ * one-channel kernels), 1 exact-fp32 MFMA, 2 bf16 MFMA, 3 bf16x6 MFMA, 4 f16x3 MFMA.  For measurement (bench.py prices a launch against
  * the peak of the pipe it uses). */
 int xas_conv_kernel_class(const xas_conv_shape* s, int pass);
 size_t xas_split_weight_bytes(long rows, long K, int pieces);
@@ -170,7 +180,7 @@ int xas_split_weight(const float* w_packed, void* w_split, long rows, long K, in
  * after every optimizer step).  descs: device array of n entries of 12 int64 each:
  *   { src (OIHW fp32, device), dst (device, xas_split_weight_bytes(rows, K, planes) bytes), Cout, Cin, R, S,
  *     transposed (0: rows = Cout, K = (r, s, ci); 1: rows = Cin, K = (r, s, co), as xas_pack_weight),
- *     planes (3 or 1), rows, K, first block of the entry (prefix sum of ceil(ceil(rows / 32) * (K / 16) * 64 / 256)), 0 }
+ *     planes (3, 2 or 1), rows, K, first block of the entry (prefix sum of ceil(ceil(rows / 32) * (K / 16) * 64 / 256)), 0 }
  * blocks: total number of blocks.  Results are bit-identical to xas_pack_weight followed by xas_split_weight. */
 int xas_prepare_weights(const void* descs, int n, long blocks, void* stream);
 

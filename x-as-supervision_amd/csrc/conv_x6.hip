@@ -1,15 +1,27 @@
-// fp32-ACCURATE convolutions on the bf16 matrix pipe of gfx950 ("bf16x6"): forward, data gradient (== ConvTranspose2d
-// forward) and weight gradient, the default precision of the library since round 3 (xas_hip.h: XAS_PREC_BF16X6).
+// fp32-ACCURATE convolutions on the 16-bit matrix pipe of gfx950: forward, data gradient (== ConvTranspose2d forward) and
+// weight gradient, in two piece formats (xas_hip.h: XAS_PREC_F16X3, the library default, and XAS_PREC_BF16X6).
 //
-// Every fp32 operand x is split EXACTLY into three bf16 pieces x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1),
-// x3 = bf16(x - x1 - x2): 3 x 8 significant bits = the 24 of fp32).  Of the nine partial products of x * y the six
-//     x3 y1, x1 y3, x2 y2, x2 y1, x1 y2, x1 y1
-// are kept; each is exact in fp32 (8 x 8 bits) and the MFMA accumulates them in fp32, smallest first; the three dropped
-// ones are below 2^-25 |x y|, under the rounding error of ONE fp32 product.  Measured against float64 (r02):
-// 1.09e-7 relative at K = 64 (exact-fp32 MFMA: 1.06e-7), 1.0e-6 at K = 4608 (8.1e-7).  6 x 32 cycles per K = 16 of
-// v_mfma_f32_32x32x16_bf16 against 8 x 64 cycles of v_mfma_f32_32x32x2_f32: 2.67x the math rate, peak 2.5 PFLOP/s / 6 =
-// 419 TFLOP/s of fp32-equivalent work.  PIECES = 1 is the plain bf16 variant (operands rounded once; NOT fp32 accurate;
-// xas_hip.h: XAS_PREC_BF16), kept as the reported-separately variant of SURVEY 8 f-3.
+// bf16x6 (P = 3 planes).  Every fp32 operand x is split EXACTLY into three bf16 pieces x = x1 + x2 + x3 (x1 = bf16(x),
+// x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 3 x 8 significant bits = the 24 of fp32).  Of the nine partial products of
+// x * y the six  x3 y1, x1 y3, x2 y2, x2 y1, x1 y2, x1 y1  are kept; each is exact in fp32 (8 x 8 bits) and the MFMA
+// accumulates them in fp32, smallest first; the three dropped ones are below 2^-25 |x y|.  Measured against float64 (r02,
+// DESIGN 7b): 1.09e-7 relative at K = 64 (exact-fp32 MFMA: 1.06e-7), 1.0e-6 at K = 4608 (8.1e-7).  6 x 32 cycles per
+// K = 16 of v_mfma_f32_32x32x16_bf16 against 8 x 64 cycles of v_mfma_f32_32x32x2_f32: peak 2.5 PFLOP/s / 6 = 419 TFLOP/s
+// of fp32-equivalent work.  No assumption on operand ranges (bf16 has fp32's exponent).
+//
+// f16x3 (P = 2 planes, r03).  fp16 carries 11 significant bits: TWO pieces h1 = fp16(s x), h2 = fp16(s x - h1) leave
+// |s x - h1 - h2| <= 2^-22 |s x|, and THREE partial products h2 g1, h1 g2, h1 g1 (each exact in fp32) per product: half
+// the matrix instructions, two thirds of the LDS traffic and of the conversion work of bf16x6.  The representation
+// error (7e-8 relative on a dot product) stays under the fp32 accumulation error every MFMA mode shares (1-3e-7): the
+// distance to float64 is the exact-fp32 path's.  fp16's narrow exponent is handled by EXACT power-of-two scales s, undone
+// on the fp32 accumulators: weights 2^10 (pre-split once per optimizer step; |w| < 64), activations 2^4 (images, masks,
+// normalised activations: full accuracy for |x| in [2^-10, 2^11], absolute floor 2^-29 below), and gradient tensors by
+// the power of two that puts their MAXIMUM in [2^14, 2^15) - the kernel that writes a gradient tensor (batch-norm
+// backward, soft-argmax backward) merges max |g| into a device float, the consumer reads it through
+// xas_conv_shape.grad_amax (IgemmParams::a_amax / WgradParams::a_amax, b_amax).  Elements 2^-15 and more below the
+// maximum lose relative (not absolute) accuracy: error floor 2^-39 max|g| per element, invisible next to the fp32
+// rounding of the large terms of the same sum.  A gradient launch without a maximum runs as bf16x6.  PIECES = 1 is the
+// plain bf16 variant (operands rounded once; NOT fp32 accurate; XAS_PREC_BF16), kept as the reported-separately variant.
 //
 // Kernel structure (both kernels): 256 threads = 4 waves, tile BM x BN, K-step of 32 (channels of a tap / pixels) loaded
 // two K-steps ahead into two register sets by buffer loads (hardware zero-fill for padding and ragged edges), processed as
@@ -89,8 +101,14 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
 // traffic, no conversion work, no LDS stores for that operand (the VGPR -> LDS store path, ~80 B/clk per CU, is what
 // bounded the first version of this kernel: 24 KB of stores per half-step and block).
 // ------------------------------------------------------------------------------------
+#ifndef XAS_X6_WAVES2
+#define XAS_X6_WAVES2 2            // waves per SIMD the two-piece (f16x3) builds of igemm_x6_kernel / wgrad_x6_kernel are compiled for
+#endif
+#ifndef XAS_WX6_WAVES2
+#define XAS_WX6_WAVES2 2
+#endif
 template <int BM, int BN, int MODE, int P, bool BNB = false>
-__global__ __launch_bounds__(256, 2) void igemm_x6_kernel(IgemmParams p) {
+__global__ __launch_bounds__(256, (P == 2 ? XAS_X6_WAVES2 : 2)) void igemm_x6_kernel(IgemmParams p) {
   using C = TileCfg<BM, BN>;
   constexpr int PLANE = BM * XLDH;              // halfwords
   constexpr int HBUF = P * PLANE;               // halfwords per half-buffer
@@ -670,7 +688,7 @@ template <int BMN>
 struct XStride { static constexpr int value = BMN * 2 + (BMN == 128 ? 64 : (BMN == 64 ? 64 : 0)); };   // 320 / 192 / 64 bytes
 
 template <int BM, int BN, int P>
-__global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgradParams p) {
+__global__ __launch_bounds__(256, (P == 2 ? XAS_WX6_WAVES2 : 2)) void wgrad_x6_kernel(WgradParams p) {
   using C = TileCfg<BM, BN>;
   constexpr int SA = XStride<BM>::value, SB = XStride<BN>::value;      // bytes per pixel row of a plane
   constexpr int ASZ = P * XH * SA, BSZ = P * XH * SB, HBUF = ASZ + BSZ; // bytes per half-buffer
