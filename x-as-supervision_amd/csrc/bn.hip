@@ -98,6 +98,13 @@ __device__ __forceinline__ float4 load_wt(__amdgpu_buffer_rsrc_t r, unsigned byt
   return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
 }
 
+// loads of the reduction passes: non-temporal like every streamed operand (XAS_BN_REDUCE_NT=0: plain loads, so that the
+// apply pass that re-reads the same tensors right afterwards may find them in the Infinity Cache - measured, see DESIGN)
+#ifndef XAS_BN_REDUCE_NT
+#define XAS_BN_REDUCE_NT 1
+#endif
+__device__ __forceinline__ float4 red_load(const float4* p) { return XAS_BN_REDUCE_NT ? stream_load(p) : *p; }
+
 template <int MODE, int UNR = 4, int FL = 4>   // 0: stats of x around pivot ; 1: bn backward sums ; 2: plain column sums of x ;
                       // 3: bn backward sums WITHOUT x: xhat = (z - beta)/gamma with z recovered from y (act != 0)
                       // 4: bn backward sums WITHOUT y: the activation mask is re-derived from x (`y` carries gamma,
@@ -147,8 +154,8 @@ __device__ __forceinline__ void col_reduce_body(const ColArgs& a) {
 #pragma unroll UNR
   for (long r = r0 + ty; r < r1; r += g.TY) {
     if (MODE == 3) {
-      float4 g4 = stream_load(reinterpret_cast<const float4*>(dy + r * C + c));
-      const float4 yv = stream_load(reinterpret_cast<const float4*>(y + r * C + c));
+      float4 g4 = red_load(reinterpret_cast<const float4*>(dy + r * C + c));
+      const float4 yv = red_load(reinterpret_cast<const float4*>(y + r * C + c));
       const float neg = act == 1 ? 0.f : 0.01f, up = act == 1 ? 0.f : 100.f;
       float4 z;                                            // pre-activation value
       z.x = yv.x > 0.f ? yv.x : yv.x * up; z.y = yv.y > 0.f ? yv.y : yv.y * up;
@@ -160,9 +167,9 @@ __device__ __forceinline__ void col_reduce_body(const ColArgs& a) {
       s2.z = fmaf(g4.z, (z.z - p0.z) * p1.z, s2.z); s2.w = fmaf(g4.w, (z.w - p0.w) * p1.w, s2.w);
       continue;
     }
-    const float4 xv = stream_load(reinterpret_cast<const float4*>(x + r * C + c));
+    const float4 xv = red_load(reinterpret_cast<const float4*>(x + r * C + c));
     if (MODE == 4) {
-      float4 g4 = stream_load(reinterpret_cast<const float4*>(dy + r * C + c));
+      float4 g4 = red_load(reinterpret_cast<const float4*>(dy + r * C + c));
       const float neg = act == 1 ? 0.f : 0.01f;
       g4.x *= bn_affine(xv.x, p0.x, rsg.x, bt.x) > 0.f ? 1.f : neg; g4.y *= bn_affine(xv.y, p0.y, rsg.y, bt.y) > 0.f ? 1.f : neg;
       g4.z *= bn_affine(xv.z, p0.z, rsg.z, bt.z) > 0.f ? 1.f : neg; g4.w *= bn_affine(xv.w, p0.w, rsg.w, bt.w) > 0.f ? 1.f : neg;
@@ -178,14 +185,14 @@ __device__ __forceinline__ void col_reduce_body(const ColArgs& a) {
       s1.x += a0; s1.y += b; s1.z += cc; s1.w += d;
       s2.x = fmaf(a0, a0, s2.x); s2.y = fmaf(b, b, s2.y); s2.z = fmaf(cc, cc, s2.z); s2.w = fmaf(d, d, s2.w);
     } else {
-      float4 g4 = stream_load(reinterpret_cast<const float4*>(dy + r * C + c));
+      float4 g4 = red_load(reinterpret_cast<const float4*>(dy + r * C + c));
       if (act && a.mask) {
         const unsigned mb = a.mask[(r * C + c) >> 2];
         const float neg = act == 1 ? 0.f : 0.01f;
         g4.x *= (mb & 1u) ? 1.f : neg; g4.y *= (mb & 2u) ? 1.f : neg;
         g4.z *= (mb & 4u) ? 1.f : neg; g4.w *= (mb & 8u) ? 1.f : neg;
       } else if (act) {
-        const float4 yv = stream_load(reinterpret_cast<const float4*>(y + r * C + c));
+        const float4 yv = red_load(reinterpret_cast<const float4*>(y + r * C + c));
         const float neg = act == 1 ? 0.f : 0.01f;
         g4.x *= yv.x > 0.f ? 1.f : neg; g4.y *= yv.y > 0.f ? 1.f : neg;
         g4.z *= yv.z > 0.f ? 1.f : neg; g4.w *= yv.w > 0.f ? 1.f : neg;
