@@ -569,6 +569,9 @@ static bool x6t_takes(const IgemmParams& p, int bm, int phases) {
 //   producers end before the epilogue.  Parity-green; 154 TFLOP/s with 4 producers (one block per CU: a lone MFMA wave
 //   per SIMD has nobody to cover its barrier and weight-load waits), 138 with 2 producers and two blocks per CU, against
 //   179 for this kernel at three blocks per CU.
+// * (r03, f16x3) whole K-steps between barriers for the two-piece format, whose half-step is only 12 MFMAs per wave
+//   (four half-buffers, one barrier per 24 MFMAs, weight fragments requested a K-step ahead): parity-green, 249 against
+//   254 TFLOP/s on ten forward shapes and +0.9 ms per step - the barrier count is not what the short half-steps cost.
 // * an L2 warm-up of the activation rows four K-steps ahead (one buffer_load_dword ... lds per row and K-step into a
 //   scratch strip): 163 against 169.5 TFLOP/s with the warm-up switched off in the same build - the activation-load
 //   stalls of the ablation are not HBM latency that a warmer L2 removes.
