@@ -104,11 +104,14 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
 #ifndef XAS_X6_WAVES2
 #define XAS_X6_WAVES2 2            // waves per SIMD the two-piece (f16x3) builds of igemm_x6_kernel / wgrad_x6_kernel are compiled for
 #endif
+#ifndef XAS_X6_WAVES2_WIDE
+#define XAS_X6_WAVES2_WIDE 2       // the same for the 64 x 256 tile (132 registers: 4 would cap it at 128)
+#endif
 #ifndef XAS_WX6_WAVES2
 #define XAS_WX6_WAVES2 2
 #endif
 template <int BM, int BN, int MODE, int P, bool BNB = false>
-__global__ __launch_bounds__(256, (P == 2 ? XAS_X6_WAVES2 : 2)) void igemm_x6_kernel(IgemmParams p) {
+__global__ __launch_bounds__(256, (P == 2 ? (BM == 64 && BN == 256 ? XAS_X6_WAVES2_WIDE : XAS_X6_WAVES2) : 2)) void igemm_x6_kernel(IgemmParams p) {
   using C = TileCfg<BM, BN>;
   constexpr int PLANE = BM * XLDH;              // halfwords
   constexpr int HBUF = P * PLANE;               // halfwords per half-buffer
