@@ -193,6 +193,30 @@ def test_f16x3_conv_transpose_with_norm(scale):
     assert rel(ct.weight.grad, wd.grad) < 2e-5, rel(ct.weight.grad, wd.grad)
 
 
+def test_f16x3_gradient_with_two_consumers_falls_back():
+    """A conv output with TWO consumers: autograd sums the two gradients (possibly in place into the tensor that carries a
+    recorded maximum).  The conv backward must not trust a maximum recorded before the accumulation: result against
+    float64 autograd at the usual bar, with the second gradient 1e4 times larger than the first."""
+    from xas_amd import layers as L
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(4, 64, 16, 16, generator=g)
+    conv = L.Conv2d(64, 64, 3, 1, 1, bias=False).cuda()
+    bn = L.BatchNorm2d(64).cuda().train()
+    gy = torch.randn(4, 64, 16, 16, generator=g) * 1e-3
+    xg = x.cuda().requires_grad_(True)
+    y = conv(xg)
+    out = (torch.relu(bn(y)) * gy.cuda()).sum() + (y * 10.0 * gy.cuda()).sum()          # norm branch + a direct branch
+    out.backward()
+    wd = conv.weight.detach().double().cpu().requires_grad_(True)
+    xd = x.double().requires_grad_(True)
+    yd = TF.conv2d(xd, wd, None, 1, 1)
+    od = (torch.relu(TF.batch_norm(yd, None, None, bn.weight.detach().double().cpu(), bn.bias.detach().double().cpu(), True, 0.1, bn.eps))
+          * gy.double()).sum() + (yd * 10.0 * gy.double()).sum()
+    od.backward()
+    assert rel(xg.grad, xd.grad) < 1e-5, rel(xg.grad, xd.grad)
+    assert rel(conv.weight.grad, wd.grad) < 1e-5, rel(conv.weight.grad, wd.grad)
+
+
 def _split_mode_case(n, cin, h, w, cout, k, stride, pad):
     from xas_amd import layers as L
     g = torch.Generator().manual_seed(cin + cout + k + n)

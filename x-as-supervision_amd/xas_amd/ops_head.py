@@ -51,7 +51,7 @@ class _SoftArgmax(torch.autograd.Function):
         call('xas_head_softargmax_bwd_amax', ptr(logits), ptr(stats), ptr(z_idx), ptr(g_kps), B, K, D, Hy, nb,
              ptr(grad), ptr(coef), ptr(slot))
         if slot is not None:
-            grad._xas_amax = slot
+            ops_nn.tag_grad_amax(grad, slot)
         return grad, None, None, None, None
 
 

@@ -279,11 +279,19 @@ def activation_amax(device):
     return t
 
 
+def tag_grad_amax(t, slot):
+    """Attach the slot that holds max |t| to the gradient tensor t (read by with_grad_amax)."""
+    t._xas_amax = (slot, t._version)
+
+
 def with_grad_amax(shp, dy):
     """ConvShape of a gradient launch that reads `dy`: with the pointer to max |dy| when its producer recorded one."""
-    slot = getattr(dy, '_xas_amax', None)
-    if slot is None or shp.mode != 0 or not GRAD_F16 or query('xas_get_precision') != _lib.PREC_F16X3:
+    tag = getattr(dy, '_xas_amax', None)
+    # (the tag holds the tensor's version counter at the time the maximum was recorded: a gradient that autograd has since
+    # accumulated into IN PLACE - a conv output with two consumers - no longer matches its maximum and runs as bf16x6)
+    if tag is None or tag[1] != dy._version or shp.mode != 0 or not GRAD_F16 or query('xas_get_precision') != _lib.PREC_F16X3:
         return shp
+    slot = tag[0]
     return ConvShape(shp.N, shp.Hi, shp.Wi, shp.Cin, shp.Cout, shp.R, shp.S, shp.stride, shp.pad, shp.Ho, shp.Wo, 0,
                      slot.data_ptr())
 
@@ -903,7 +911,7 @@ def _bn_backward(saved, cfg, gamma, beta, dy, want_param_grads, want_dres=True):
     call('xas_bn_bwd_apply_amax', px, py, ptr(dy), ptr(mean), ptr(var), ptr(gamma),
          ptr(beta), ptr(sums), eps, act, M, c, G, float(count), ptr(dx), ptr(dres), ptr(mask), ptr(slot))
     if slot is not None:
-        dx._xas_amax = slot                      # max |dx|: the conv backward that reads dx scales its fp16 pieces with it
+        tag_grad_amax(dx, slot)                  # max |dx|: the conv backward that reads dx scales its fp16 pieces with it
     return dx, dgamma, dbeta, dres
 
 
