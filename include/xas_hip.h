@@ -37,7 +37,8 @@ const char* xas_last_error(void);
  * and two that concern the bf16-split kernels (tests/test_gpu_tap_kernels.py compares both settings):
  *   4194304 (bit 22)  no tap re-use kernels: stride-1 3x3 layers on the implicit-GEMM kernels (forward, data and weight gradient)
  *   8388608 (bit 23)  no 64 x 256 tiles for layers whose output channels are a multiple of 256
- *   16777216 (bit 24) the general weight-gradient kernel for the 7x7 stem instead of stem_wgrad_kernel */
+ *   16777216 (bit 24) the general weight-gradient kernel for the 7x7 stem instead of stem_wgrad_kernel
+ *   33554432 (bit 25) the exact-fp32 stem forward kernel in the f16x3 mode too */
 int xas_set_tuning(int flags);
 /* Arithmetic of the MFMA convolutions (forward, data gradient, weight gradient).  All modes keep fp32 activations, fp32
  * master weights and fp32 accumulation; they differ in how a product of two fp32 operands is formed:

@@ -131,3 +131,29 @@ def test_stem_weight_gradient_kernel_equals_the_general_kernel():
             query('xas_set_tuning', 0)
     assert rel(res[0], wc.grad) < 3e-6 and rel(res[1 << 24], wc.grad) < 3e-6
     assert rel(res[0], res[1 << 24]) < 2e-6
+
+
+def test_stem_forward_f16x3_kernel_against_float64_and_the_fp32_kernel():
+    """stem_fwd_f16_kernel (default mode: two fp16 planes of patch and weights, K laid out as 7 filter rows x 24) against a
+    float64 convolution and against stem_fwd_kernel (tune bit 25), on an image size with ragged tiles."""
+    from xas_amd import layers as L
+    from xas_amd._lib import query
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(5, 3, 72, 104, generator=g) * 1.5 + 0.2
+    wt = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    ref = TF.conv2d(x.double(), wt.double(), None, 2, 3)
+    m = L.Conv2d(3, 64, 7, 2, 3, bias=False).cuda()
+    with torch.no_grad():
+        m.weight.copy_(wt)
+    res = {}
+    for tune in (0, 1 << 25):
+        query('xas_set_tuning', tune)
+        try:
+            with torch.no_grad():
+                res[tune] = m(x.cuda()).double().cpu()
+        finally:
+            query('xas_set_tuning', 0)
+    for tune, y in res.items():
+        e = float((y - ref).norm() / ref.norm())
+        assert e < 1e-6, (tune, e)
+    assert float((res[0] - res[1 << 25]).abs().max()) < 2e-5

@@ -1014,6 +1014,120 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------
+// The same forward in the f16x3 arithmetic (XAS_PREC_F16X3; conv_x6.hip for the scheme): image patch and weights are split
+// into two fp16 planes when they are staged (2^4 x, 2^10 w), the K axis is laid out as 7 filter rows x 24 (21 taps*channels
+// of a row + 3 zero weights) so that the 8 consecutive k of an MFMA operand are 8 consecutive halfwords of ONE patch row:
+// 11 K-steps of v_mfma_f32_32x32x16_f16 x 3 products instead of 74 K-steps of v_mfma_f32_32x32x2_f32.
+// ------------------------------------------------------------------------------------
+constexpr int STH_KR = 24, STH_K = 7 * STH_KR, STH_KS = 11;       // k per filter row, real k (168), K-steps of 16 (176)
+constexpr int STH_WROW = STH_KS * 16 + 8;                          // halfwords per weight row (184: rows 368 B apart)
+constexpr int STH_PROW = 120;                                      // halfwords per patch row (111 used)
+#ifndef XAS_STH_TPB
+#define XAS_STH_TPB 16
+#endif
+constexpr int STH_TPB = XAS_STH_TPB;                               // output tiles per block (one split of the weights)
+
+__global__ __launch_bounds__(256) void stem_fwd_f16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           float* __restrict__ y, int N, int H, int W, int Ho, int Wo) {
+  __shared__ __align__(16) unsigned short wsh[2 * ST_CO * STH_WROW];        // [plane][co][k']
+  __shared__ __align__(16) unsigned short ph[2 * ST_PH * STH_PROW];         // [plane][patch row][px * 3 + c]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_w = (Wo + ST_TW - 1) / ST_TW, tiles = tiles_w * ((Ho + ST_TH - 1) / ST_TH);
+  const int n = blockIdx.y;
+  for (int e = tid; e < ST_CO * STH_WROW; e += 256) {
+    const int co = e / STH_WROW, k = e - co * STH_WROW;
+    const int r = k / STH_KR, j = k - r * STH_KR;
+    float v = (k < STH_K && j < 21) ? w[co * ST_K + r * 21 + j] * kF16WScale : 0.f;
+    const _Float16 h1 = (_Float16)v, h2 = (_Float16)(v - (float)h1);
+    wsh[e] = __builtin_bit_cast(unsigned short, h1);
+    wsh[ST_CO * STH_WROW + e] = __builtin_bit_cast(unsigned short, h2);
+  }
+  for (int e = tid; e < 2 * ST_PH * STH_PROW; e += 256) ph[e] = 0;           // (row tails stay zero: read against zero weights)
+  const int i = lane & 31, hh = lane >> 5;
+  const int ly = wave * 2 + (i >> 4), lx = i & 15;                           // pixel of this lane inside the tile
+  unsigned aoff[STH_KS];                                                     // halfword offset of this lane's 8 k of every K-step
+#pragma unroll
+  for (int ks = 0; ks < STH_KS; ++ks) {
+    const int kb = ks * 16 + hh * 8;
+    const int r = kb < STH_K ? kb / STH_KR : 0, j = kb < STH_K ? kb - r * STH_KR : 0;
+    aoff[ks] = (unsigned)((ly * 2 + r) * STH_PROW + lx * 6 + j);
+  }
+  // patch element e = tid + 256 j -> (patch row, column * 3 + channel): fixed per thread; the NEXT tile's values are fetched
+  // into registers before the MFMAs of the current one (the loads of a tile were exposed between two barriers)
+  constexpr int NPV = (ST_PH * ST_PW * 3 + 255) / 256;                       // 10
+  int ppy[NPV], pq[NPV];
+#pragma unroll
+  for (int j = 0; j < NPV; ++j) {
+    const int e = tid + 256 * j;
+    ppy[j] = e < ST_PH * ST_PW * 3 ? e / (3 * ST_PW) : -1;
+    pq[j] = e - (e / (3 * ST_PW)) * (3 * ST_PW);
+  }
+  float pv[NPV];
+  auto load_patch = [&](int tile) {
+    const int ty = tile / tiles_w, tx = tile - ty * tiles_w;
+    const int iy0 = ty * ST_TH * 2 - 3, ix0 = tx * ST_TW * 2 - 3;
+#pragma unroll
+    for (int j = 0; j < NPV; ++j) {
+      const int iy = iy0 + ppy[j], ix = ix0 + pq[j] / 3;
+      const bool ok = ppy[j] >= 0 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      pv[j] = ok ? x[(((size_t)n * H + iy) * W + ix0) * 3 + pq[j]] : 0.f;
+    }
+  };
+  const int tile0 = blockIdx.x * STH_TPB;
+  if (tile0 < tiles) load_patch(tile0);
+  for (int tt = 0; tt < STH_TPB; ++tt) {
+    const int tile = tile0 + tt;
+    if (tile >= tiles) break;
+    const int ty = tile / tiles_w, tx = tile % tiles_w;
+    const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+    __syncthreads();                                   // the previous tile's patch has been consumed (weights, zero fill complete)
+#pragma unroll
+    for (int j = 0; j < NPV; ++j) {
+      if (ppy[j] >= 0) {
+        const float v = pv[j] * kF16AScale;
+        const _Float16 h1 = (_Float16)v, h2 = (_Float16)(v - (float)h1);
+        ph[ppy[j] * STH_PROW + pq[j]] = __builtin_bit_cast(unsigned short, h1);
+        ph[ST_PH * STH_PROW + ppy[j] * STH_PROW + pq[j]] = __builtin_bit_cast(unsigned short, h2);
+      }
+    }
+    __syncthreads();
+    if (tt + 1 < STH_TPB && tile + 1 < tiles) load_patch(tile + 1);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < STH_KS; ++ks) {
+      uint4 a[2], b0[2], b1[2];
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) {
+        const unsigned* ap = reinterpret_cast<const unsigned*>(ph + pc * ST_PH * STH_PROW + aoff[ks]);   // 4-byte aligned
+        a[pc] = make_uint4(ap[0], ap[1], ap[2], ap[3]);
+        const unsigned short* wp = wsh + pc * ST_CO * STH_WROW + ks * 16 + hh * 8;
+        b0[pc] = *reinterpret_cast<const uint4*>(wp + i * STH_WROW);
+        b1[pc] = *reinterpret_cast<const uint4*>(wp + (32 + i) * STH_WROW);
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {                    // a2 b1, a1 b2, a1 b1 (smallest first)
+        const int pa = t == 0 ? 1 : 0, pb = t == 1 ? 1 : 0;
+        acc0 = mfma_piece<2>(a[pa], b0[pb], acc0);
+        acc1 = mfma_piece<2>(a[pa], b1[pb], acc1);
+      }
+    }
+    const int col = lane & 31, rsub = 4 * (lane >> 5);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int pi = (reg & 3) + 8 * (reg >> 2) + rsub;        // pixel index within the wave's 2 x 16 strip
+      const int oy = oy0 + wave * 2 + (pi >> 4), ox = ox0 + (pi & 15);
+      if (oy < Ho && ox < Wo) {
+        float* o = y + (((size_t)n * Ho + oy) * Wo + ox) * ST_CO;
+        o[col] = acc0[reg] * kF16Descale;
+        o[32 + col] = acc1[reg] * kF16Descale;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // Stem weight gradient: dW[co][k] = sum over pixels dy[p][co] * x[tap k of p], k = (r * 7 + s) * 3 + c, K = pixels.
 // It is the LAST weight gradient of a backward pass (its dy is the last gradient the pass produces), so it runs alone at the
 // tail of every step: the general global-load kernel took 2.03 ms there (38.9 TFLOP/s: three-channel scalar gathers).
@@ -1565,6 +1679,10 @@ static int conv_fwd_impl(const float* x, const float* w_packed, const float* bia
   hipStream_t st = as_stream(stream);
   if (s->Cin == 3 && s->R == 7 && s->S == 7 && s->stride == 2 && s->pad == 3 && s->Cout == ST_CO && bias == nullptr) {
     const int tiles = (int)(cdiv(s->Ho, ST_TH) * cdiv(s->Wo, ST_TW));
+    if (precision_of(s) == XAS_PREC_F16X3 && !(g_tune & (1 << 25)))       // (tune bit 25: the exact-fp32 stem kernel)
+      hipLaunchKernelGGL(stem_fwd_f16_kernel, dim3((unsigned)cdiv(tiles, STH_TPB), s->N), dim3(256), 0, st, x, w_packed, y, s->N, s->Hi,
+                         s->Wi, s->Ho, s->Wo);
+    else
     hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)cdiv(tiles, ST_TPB), s->N), dim3(256), 0, st, x, w_packed, y, s->N, s->Hi,
                        s->Wi, s->Ho, s->Wo);
     XAS_LAUNCH_CHECK();
@@ -1628,7 +1746,8 @@ extern "C" int xas_conv_kernel_class(const xas_conv_shape* s, int pass) {
   const bool thin = (s->Cout == 1 && thin_ok(s, s->Cin)) || (s->Cin == 1 && thin_ok(s, s->Cout));
   if (thin) return 0;
   if (pass == 0) {
-    if (s->Cin == 3 && s->R == 7 && s->S == 7 && s->stride == 2 && s->pad == 3 && s->Cout == ST_CO) return 1;     // stem kernel
+    if (s->Cin == 3 && s->R == 7 && s->S == 7 && s->stride == 2 && s->pad == 3 && s->Cout == ST_CO)              // stem kernels
+      return (prec == XAS_PREC_F16X3 && !(g_tune & (1 << 25))) ? 4 : 1;
     return (s->Cin % BK == 0 && s->Cout >= 16) ? split : 0;
   }
   if (pass == 1) return (s->Cout % BK == 0 && s->Cin >= 16) ? split : 0;
