@@ -70,6 +70,14 @@ __device__ __forceinline__ void grad_add4(float* p, float4 v) {
   unsafeAtomicAdd(p + 0, v.x); unsafeAtomicAdd(p + 1, v.y); unsafeAtomicAdd(p + 2, v.z); unsafeAtomicAdd(p + 3, v.w);
 }
 
+// The norm kernels sit on the critical chain of the step and share the CUs with the weight-gradient kernels of the side
+// stream: like the chain's convolutions (conv_x6.hip XAS_X6_PRIO) they win the issue arbitration.  r02 / early r03: no
+// effect (the chain was MFMA-bound); with the f16x3 convolutions the norms are half of the chain: -1.0 ms per step
+// (in-box A/B against no priority, 117.5 vs 118.5).
+#ifndef XAS_BN_PRIO
+#define XAS_BN_PRIO 3
+#endif
+
 struct ColArgs {
   const float* x; const float* y; const float* dy; const float* mean; const float* var; const float* aux;
   float eps; int act; long M; int C; ColGeom g;
