@@ -1,5 +1,12 @@
-import sys, os, torch
-sys.path[:0] = ['/root/repo', '/root/repo/x-as-supervision_amd']
+"""Micro-benchmark of the 7x7 stride-2 stem forward at 256 images: the f16x3 kernel against the exact-fp32 kernel (tune
+bit 25) and a float64 convolution.  usage: python tools/bench_stem.py"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'x-as-supervision_amd')]
 from xas_amd import _lib
 from xas_amd._lib import ConvShape, call, ptr, query
 import torch.nn.functional as TF
