@@ -167,6 +167,14 @@ def test_f16x3_gradients_with_amax(n, cin, h, w, cout, k, stride, pad, scale):
     assert rel(dw, wref) < 3e-6, rel(dw, wref)
 
 
+@pytest.mark.parametrize('n,cin,h,w,cout,k', [(16, 64, 64, 64, 64, 3), (64, 32, 32, 32, 128, 3), (4, 32, 128, 128, 32, 3),
+                                             (160, 32, 8, 8, 512, 3), (16, 64, 64, 64, 256, 1), (16, 256, 64, 64, 64, 1)])
+def test_f16x3_gradients_with_amax_large_problem_kernels(n, cin, h, w, cout, k):
+    """The same at sizes where the dispatch selects the tap re-use kernels (igemm_x6t / wgrad_x6t) and the 64 x 256 tiles
+    (cases of test_gpu_tap_kernels.py), gradient magnitude 1e-4."""
+    test_f16x3_gradients_with_amax(n, cin, h, w, cout, k, 1, k // 2, 1e-4)
+
+
 @pytest.mark.parametrize('scale', [1e-6, 1.0, 1e3])
 def test_f16x3_conv_transpose_with_norm(scale):
     """ConvTranspose2d -> BatchNorm -> ReLU (deconv_head.py:27-32) in the default mode: the forward is a data-gradient-type
