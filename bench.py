@@ -303,6 +303,9 @@ def main():
                                  'fp32-equivalent (MI355X_MICROARCH.md)',
                          'by_kernel_class': {k.lstrip(':'): {kk: d[kk] for kk in ('launches', 'ms', 'achieved', 'peak', 'frac')} for k, d in cl.items()},
                          'conv_family_frac_of_mixed_peak': mix_frac,
+                         # the same rate against the peak of the round's previous fp32-accurate scheme (bf16x6: six products per fp32
+                         # product, 419.5): how the fp32-equivalent throughput moved across the change of scheme, NOT the roofline fraction
+                         'achieved_over_bf16x6_peak': cl[dom]['achieved'] / (PEAK_BF16_MFMA_TFLOPS / 6.0),
                          'sustained_mfma_ceiling': {
                              'bf16_TFLOPs': 1892.0, 'bf16x6_equivalent_TFLOPs': 315.3, 'f16x3_equivalent_TFLOPs': 630.7,
                              'what': 'static constant, NOT measured in this run: a register-only v_mfma_f32_32x32x16_bf16 loop '
