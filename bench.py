@@ -175,7 +175,8 @@ def main():
     # ~4 % of the headline (two event packets per launch on the queue), one step costs < 1 %.
     from xas_amd.prof import CONV_ENTRIES
     HEAD = ('xas_head_softargmax_fwd', 'xas_head_softargmax_bwd', 'xas_head_softargmax_bwd_amax')
-    timer = KernelTimer(CONV_ENTRIES + HEAD)
+    from xas_amd.prof import BN_ENTRIES
+    timer = KernelTimer(CONV_ENTRIES + HEAD + BN_ENTRIES)
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == args.steps - 1:
@@ -223,6 +224,7 @@ def main():
     if rank == 0:
         summ = timer.summary()
         head = {k: summ.pop(k) for k in list(summ) if k.startswith('xas_head_')}
+        bnfam = {k: summ.pop(k) for k in list(summ) if k.startswith('xas_bn_')}
 
         def classes(sm):
             """per kernel class (':f32', ':bf16', ':bf16x6'): launches, ms, flops, achieved TFLOP/s, peak, fraction"""
@@ -344,6 +346,19 @@ def main():
                                         'head_bwd_kernel (bwd)', bound='hbm', peak_TBps=8.0,
                                         note='logits of one camera-batched pass (%d images x 18.87 MB): read once forward, read + '
                                              'written backward' % (args.batch * len(cams)))
+        # batch-norm family (HBM bound; the second-largest family of the step): algorithmic bytes of every call of the event-timed
+        # step / its HIP-event time on its stream (statistics that ride in a conv epilogue are not in here: they are conv time)
+        bn_ms = sum(v['ms'] for v in bnfam.values())
+        bn_by = sum(v['flops'] for v in bnfam.values())
+        if bn_ms > 0:
+            line['roofline']['batch_norm'] = {
+                'bound': 'hbm', 'launches': sum(v['launches'] for v in bnfam.values()), 'ms_per_step': bn_ms / timed_steps,
+                'algorithmic_GB_per_step': bn_by / timed_steps / 1e9, 'achieved_TBps': bn_by / (bn_ms * 1e-3) / 1e12,
+                'peak_TBps': 8.0, 'frac': bn_by / (bn_ms * 1e-3) / 1e12 / 8.0,
+                'by_entry': {k: {'launches': v['launches'], 'ms': v['ms'], 'TBps': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 else 0.0}
+                             for k, v in bnfam.items()},
+                'kernel': 'col_reduce(_lean)_kernel, bn_apply_stream_kernel, bn_bwd_apply_stream_kernel (bn.hip)',
+                'note': 'per-call times include sharing the chip with the weight-gradient stream'}
         if traffic is not None:
             line['roofline']['mfma_busy_pct_pmc'] = pmc.get('mfma_busy_pct')      # same static source as `traffic`
         if args.shape_report:

@@ -10,6 +10,26 @@ CONV_ENTRIES = ('xas_conv_fwd', 'xas_conv_fwd_bnstats', 'xas_conv_dgrad', 'xas_c
                 'xas_conv_wgrad_oihw', 'xas_conv_wgrad_acc')
 
 
+# batch-norm entry points (HBM bound): the `flops` field of their records carries the algorithmic HBM BYTES of the call
+BN_ENTRIES = ('xas_bn_stats', 'xas_bn_apply', 'xas_bn_bwd_reduce', 'xas_bn_bwd_apply', 'xas_bn_bwd_apply_amax')
+
+
+def bn_bytes(name, a):
+    """Algorithmic bytes of a batch-norm call from its arguments (every activation-sized tensor it must read or write once;
+    sign masks are one byte per float4)."""
+    if name == 'xas_bn_stats':                      # (x, M, C, ...)
+        return 4.0 * a[1] * a[2]
+    if name == 'xas_bn_apply':                      # (x, mean, var, gamma, beta, residual, eps, act, M, C, groups, y, mask_out)
+        t = 4.0 * a[8] * a[9]
+        return t * (2 + (1 if a[5] else 0)) + (t / 16 if a[12] else 0.0)
+    if name == 'xas_bn_bwd_reduce':                 # (x, y, dy, mean, var, gamma, beta, eps, act, M, C, groups, sums, ws, db, dg, mask)
+        t = 4.0 * a[9] * a[10]
+        return t * (1 + (1 if a[0] else 0) + (1 if a[1] else 0)) + (t / 16 if a[16] else 0.0)
+    # xas_bn_bwd_apply(_amax): (x, y, dy, mean, var, gamma, beta, sums, eps, act, M, C, groups, count, dx, dres, mask[, amax])
+    t = 4.0 * a[10] * a[11]
+    return t * (2 + (1 if a[0] else 0) + (1 if a[1] else 0) + (1 if a[15] else 0)) + (t / 16 if a[16] else 0.0)
+
+
 def conv_flops(shape):
     """2 * MACs of the convolution described by an xas_conv_shape (same count for fwd / dgrad / wgrad)."""
     return 2.0 * shape.N * shape.Ho * shape.Wo * shape.Cout * shape.R * shape.S * shape.Cin
@@ -54,6 +74,8 @@ class KernelTimer:
         if name == 'xas_head_softargmax_fwd':          # (logits, B, K, D, ...): the logits are read once
             B, K, D = args[1], args[2], args[3]
             work, sig = 4.0 * B * K * D * D * D, (B, K, D)
+        elif name in BN_ENTRIES:
+            work, sig = bn_bytes(name, args), None
         elif name in ('xas_head_softargmax_bwd', 'xas_head_softargmax_bwd_amax'):        # (logits, stats, z_idx, grad_kps, B, K, D, ...): read + write
             B, K, D = args[4], args[5], args[6]
             work, sig = 8.0 * B * K * D * D * D, (B, K, D)
