@@ -173,6 +173,11 @@ int xas_conv_weight_planes(const xas_conv_shape* s, int pass);
  * one-channel kernels), 1 exact-fp32 MFMA, 2 bf16 MFMA, 3 bf16x6 MFMA, 4 f16x3 MFMA.  For measurement (bench.py prices a launch against
  * the peak of the pipe it uses). */
 int xas_conv_kernel_class(const xas_conv_shape* s, int pass);
+/* f16x3: 1 if a weight of magnitude >= 64 (or a NaN) has gone through xas_split_weight / xas_prepare_weights since the flag
+ * was last cleared - such a weight does not fit the 2^10 w scaling of the fp16 pieces and the results of its layer are
+ * inf / NaN; 0 otherwise; -1 on a HIP error.  SYNCHRONISES the device (call it rarely: engine.TrainStep every 64 steps).
+ * reset != 0 clears the flag.  Remedy: XAS_PREC_BF16X6. */
+int xas_f16_weight_overflow(int reset);
 size_t xas_split_weight_bytes(long rows, long K, int pieces);
 int xas_split_weight(const float* w_packed, void* w_split, long rows, long K, int pieces, void* stream);
 

@@ -377,3 +377,24 @@ def test_free_running_steps_split_modes_vs_exact_fp32():
         errs[mode] = float(rel_e.max())
         print(mode, 'vs f32 over 3 free-running steps: relative loss differences per step\n', rel_e)
         assert float(rel_e[0].max()) < 5e-6 and float(rel_e[1].max()) < 5e-3, (mode, rel_e)
+
+
+def test_f16x3_weight_range_is_checked():
+    """Weights are split as 2^10 w: a weight of magnitude 64 or more cannot be represented.  The preparation kernels raise a
+    device flag (xas_f16_weight_overflow; engine.TrainStep polls it) instead of producing inf / NaN silently."""
+    from xas_amd import layers as L
+    from xas_amd._lib import query
+    query('xas_f16_weight_overflow', 1)
+    m = L.Conv2d(64, 64, 3, 1, 1, bias=False).cuda()
+    x = torch.randn(2, 64, 16, 16).cuda()
+    with precision_mode('f16x3'), torch.no_grad():
+        m(x)
+        torch.cuda.synchronize()
+        assert query('xas_f16_weight_overflow', 1) == 0
+        m.weight[3, 5, 1, 1] = 100.0
+        from xas_amd import ops_nn
+        ops_nn.bump_weights_epoch()
+        m(x)
+        torch.cuda.synchronize()
+        assert query('xas_f16_weight_overflow', 1) == 1
+        assert query('xas_f16_weight_overflow', 0) == 0          # cleared by the previous call

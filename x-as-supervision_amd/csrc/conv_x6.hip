@@ -64,6 +64,15 @@ __device__ __forceinline__ int xswz(int row, int half) { return (half ^ ((row >>
 // with ONE fully coalesced 16-byte-per-lane load straight into the operand registers - the weights never pass through
 // LDS (rows beyond the matrix are zero).
 // ------------------------------------------------------------------------------------
+// f16x3 weights are split as 2^10 w: a weight of magnitude 64 or more leaves fp16's range.  The preparation kernels raise
+// this flag instead of failing silently into inf / NaN results; xas_f16_weight_overflow reads (and clears) it.
+__device__ unsigned g_f16_weight_overflow = 0u;
+__device__ __forceinline__ void f16_weight_check(float4 a, float4 b) {
+  const float m = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                        fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+  if (!(m < 65504.f)) atomicOr(&g_f16_weight_overflow, 1u);        // (NaN weights raise it too)
+}
+
 template <int P>
 __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
                                                            int rows, int K, long total /* 8-element pieces */) {
@@ -83,6 +92,7 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
   if (P == 2) {                                              // fp16 pieces of 2^10 w (exact scaling)
     r0.x *= kF16WScale; r0.y *= kF16WScale; r0.z *= kF16WScale; r0.w *= kF16WScale;
     r1.x *= kF16WScale; r1.y *= kF16WScale; r1.z *= kF16WScale; r1.w *= kF16WScale;
+    f16_weight_check(r0, r1);
   }
 #pragma unroll
   for (int pc = 0; pc < P; ++pc) {
@@ -1256,6 +1266,7 @@ __global__ __launch_bounds__(256) void prepare_weights_kernel(const long* __rest
   if (P == 2) {                                        // two fp16 pieces of 2^10 w (split_weight_kernel<2>)
     r0.x *= kF16WScale; r0.y *= kF16WScale; r0.z *= kF16WScale; r0.w *= kF16WScale;
     r1.x *= kF16WScale; r1.y *= kF16WScale; r1.z *= kF16WScale; r1.w *= kF16WScale;
+    f16_weight_check(r0, r1);
     const uint2 q0 = pack_f16x4(r0), q1 = pack_f16x4(r1);
     *reinterpret_cast<uint4*>(o) = make_uint4(q0.x, q0.y, q1.x, q1.y);
     r0 = sub_f16x4(r0, q0); r1 = sub_f16x4(r1, q1);
@@ -1275,6 +1286,16 @@ extern "C" int xas_prepare_weights(const void* descs, int n, long blocks, void* 
   hipLaunchKernelGGL(prepare_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), reinterpret_cast<const long*>(descs), n);
   XAS_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int xas_f16_weight_overflow(int reset) {
+  unsigned v = 0u;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_f16_weight_overflow), sizeof(v)) != hipSuccess) return -1;     // (synchronises)
+  if (v && reset) {
+    const unsigned z = 0u;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_f16_weight_overflow), &z, sizeof(z));
+  }
+  return v ? 1 : 0;
 }
 
 extern "C" size_t xas_split_weight_bytes(long rows, long K, int pieces) {

@@ -32,6 +32,7 @@ SIGNATURES = {
     'xas_get_precision': ('', 'i'),
     'xas_conv_weight_planes': ('si', 'i'),
     'xas_conv_kernel_class': ('si', 'i'),
+    'xas_f16_weight_overflow': ('i', 'i'),
     'xas_split_weight_bytes': ('lli', 'z'),
     'xas_split_weight': ('ppllip', 'i'),
     'xas_prepare_weights': ('pilp', 'i'),

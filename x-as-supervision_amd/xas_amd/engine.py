@@ -188,4 +188,10 @@ class TrainStep:
         if aux is not None:
             torch.cuda.current_stream().wait_stream(aux)     # (already joined when the adversarial term is part of the losses)
         self.cur_step += 1
+        if self.cur_step % 64 == 1 and next(self.model.regressor.parameters()).is_cuda:
+            # the f16x3 weight format holds |w| < 64: the preparation kernels flag anything larger (one device
+            # synchronisation after the first step and then every 64 steps) instead of letting a layer turn into inf / NaN unnoticed
+            if ops_nn.query('xas_get_precision') == 3 and ops_nn.query('xas_f16_weight_overflow', 1) == 1:
+                raise RuntimeError('a convolution weight has left the range of the f16x3 arithmetic (|w| >= 64 or NaN): '
+                                   'run with XAS_PRECISION=2 (bf16x6)')
         return loss_disc, loss_kp, total, out
