@@ -10,8 +10,44 @@ for p in (ROOT, PKG, os.path.join(ROOT, 'tests', 'golden')):
         sys.path.insert(0, p)
 
 
+TEST_LIMIT_S = 180      # no single test may run longer (marker `limit(seconds)` raises it for a named test)
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'multiproc: starts worker processes (collected LAST, so that `-x` reaches them only '
+                                       'after every single-process parity test has been recorded)')
+    config.addinivalue_line('markers', 'limit(seconds): per-test time limit other than the default %d s' % TEST_LIMIT_S)
+
+
+def pytest_collection_modifyitems(config, items):
+    """Single-process oracle / golden parity tests first, everything that starts processes last (stable within each half)."""
+    items.sort(key=lambda it: 1 if it.get_closest_marker('multiproc') is not None else 0)
+
+
+@pytest.fixture(autouse=True)
+def _time_limit(request):
+    """SIGALRM after the limit -> the test FAILS (with the stack of where it was) and the run goes on.  A test blocked
+    inside a C call that never returns to the interpreter is not interrupted by this - the multi-process harness
+    (tests/_ranks.py) bounds its workers by itself, and subprocess calls carry their own timeout."""
+    import signal
+    import threading
+    m = request.node.get_closest_marker('limit')
+    limit = int(m.args[0]) if m is not None else TEST_LIMIT_S
+    if threading.current_thread() is not threading.main_thread() or not hasattr(signal, 'SIGALRM'):
+        yield
+        return
+
+    def on_alarm(signum, frame):
+        pytest.fail('test exceeded its %d s limit' % limit, pytrace=True)
+
+    old = signal.signal(signal.SIGALRM, on_alarm)
+    signal.alarm(limit)
+    try:
+        yield
+    finally:
+        signal.alarm(0)
+        signal.signal(signal.SIGALRM, old)
 
 
 def golden(name):

@@ -3,49 +3,28 @@ exactly like a single process on the concatenated batch, SyncBatchNorm statistic
 global-batch statistics, buffers are broadcast from rank 0.  (No GPU, no HIP kernels: the reducer and the
 statistic exchange are backend-agnostic torch.distributed code.)"""
 import os
-import socket
 import sys
 
 import pytest
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
 
+from _ranks import init_group, run_ranks
+
+pytestmark = pytest.mark.multiproc
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def _worker(rank, world, port, fn, ret):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    for p in (ROOT, os.path.join(ROOT, 'x-as-supervision_amd')):
-        if p not in sys.path:
-            sys.path.insert(0, p)
+def _worker(rank, world, fn):
     torch.set_num_threads(2)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    try:
-        ret[rank] = fn(rank, world)
-    finally:
-        dist.destroy_process_group()
+    init_group('gloo', rank, world)
+    res = fn(rank, world)
+    dist.destroy_process_group()
+    return res
 
 
 def _run(fn, world=2):
-    ctx = mp.get_context('spawn')
-    ret = ctx.Manager().dict()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, fn, ret)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0, 'worker failed'
-    return dict(ret)
+    return run_ranks(_worker, world, (fn,), limit=100)
 
 
 def _reducer_case(rank, world):

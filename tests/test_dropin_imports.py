@@ -93,7 +93,7 @@ print('RESULT ' + json.dumps(out))
 @pytest.mark.skipif(not os.path.isdir(REF), reason='needs the reference checkout (build container only)')
 def test_mirror_in_front_of_reference_resolves_both():
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1', PYTHONPATH='')
-    r = subprocess.run([sys.executable, '-c', CHILD, PKG, REF], capture_output=True, text=True, env=env, cwd='/tmp', timeout=300)
+    r = subprocess.run([sys.executable, '-c', CHILD, PKG, REF], capture_output=True, text=True, env=env, cwd='/tmp', timeout=150)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('RESULT ')][-1]
     out = json.loads(line[len('RESULT '):])
@@ -124,7 +124,7 @@ def test_mirror_alone_names_the_missing_reference():
     code = ("import sys; sys.path.insert(0, %r)\n"
             "try:\n    from train_util import basic_data\n    print('resolved')\n"
             "except ImportError as e:\n    print('ImportError', e)\n") % PKG
-    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd='/tmp', timeout=300,
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd='/tmp', timeout=150,
                        env=dict(os.environ, PYTHONPATH='', PYTHONDONTWRITEBYTECODE='1'))
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.startswith('ImportError'), r.stdout

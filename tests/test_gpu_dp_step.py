@@ -2,72 +2,58 @@
 side-stream bucketed gradient averaging, SyncBatchNorm statistic exchange, parameter broadcast.  After the
 step the replicas must hold identical parameters and identical synchronised running statistics."""
 import os
-import socket
-import sys
 
 import pytest
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
 
-pytestmark = pytest.mark.gpu
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+from _ranks import init_group, run_ranks
+
+pytestmark = [pytest.mark.gpu, pytest.mark.multiproc]
 
 
-def _worker(rank, world, port, ret, opts=None):
+def _worker(rank, world, opts=None):
     opts = opts or {}
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK='0', XAS_DP_NOTIFY=str(opts.get('notify', 1)), XAS_CAM_BATCH=str(opts.get('cam_batch', 1)))
-    for p in (ROOT, os.path.join(ROOT, 'x-as-supervision_amd')):
-        if p not in sys.path:
-            sys.path.insert(0, p)
+    os.environ.update(XAS_DP_NOTIFY=str(opts.get('notify', 1)), XAS_CAM_BATCH=str(opts.get('cam_batch', 1)),
+                      XAS_DISC_BESIDE_GEN=str(opts.get('beside', 1)))
     torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    try:
-        from xas_amd import engine
-        from xas_amd.synthetic import model_config, synthetic_batch
-        cfg = model_config('HM36_Multi_SurS2')
-        cfg['model_params']['cam_id_list'] = opts.get('cams', [0])
-        torch.manual_seed(100 + rank)                         # different init per rank: the broadcast must fix it
-        model, disc, od, odisc = engine.prepare_model(cfg)
-        model.cuda().train(), disc.cuda().train()
-        disc.smpl_discriminator.header.p = 0.0
-        step = engine.TrainStep(cfg, model, disc, od, odisc, num_buckets=3, dedupe=bool(opts.get('dedupe', False)))
-        assert step.red_det is not None and len(step.red_det.buckets) >= 2
-        early = []
-        orig_launch = step.red_det._launch
-        step.red_det._launch = lambda b: (early.append(step.red_det._armed), orig_launch(b))[1]
-        x = synthetic_batch(2, opts.get('cams', [0]), torch.device('cuda'), seed=10 + rank)   # different data per rank
-        ld, lk, tot, _ = step(x)
-        torch.cuda.synchronize()
-        p = od.param_arena
-        sd = model.state_dict()
-        ret[rank] = (float(p.double().sum()), float(p.double().abs().sum()), float(odisc.param_arena.double().sum()),
-                     float(sd['regressor.net.backbone.bn1.running_mean'].double().sum()),
-                     float(sd['regressor.net.backbone.layer1.0.bn1.running_mean'].double().sum()),
-                     bool(torch.isfinite(tot)), int(sum(early)))
-    finally:
-        dist.destroy_process_group()
+    init_group('gloo', rank, world)
+    from xas_amd import engine
+    from xas_amd.synthetic import model_config, synthetic_batch
+    cfg = model_config('HM36_Multi_SurS2')
+    cfg['model_params']['cam_id_list'] = opts.get('cams', [0])
+    torch.manual_seed(100 + rank)                         # different init per rank: the broadcast must fix it
+    model, disc, od, odisc = engine.prepare_model(cfg)
+    model.cuda().train(), disc.cuda().train()
+    disc.smpl_discriminator.header.p = 0.0
+    step = engine.TrainStep(cfg, model, disc, od, odisc, num_buckets=3, dedupe=bool(opts.get('dedupe', False)))
+    assert step.red_det is not None and len(step.red_det.buckets) >= 2
+    early = []
+    orig_launch = step.red_det._launch
+    step.red_det._launch = lambda b: (early.append(step.red_det._armed), orig_launch(b))[1]
+    x = synthetic_batch(2, opts.get('cams', [0]), torch.device('cuda'), seed=10 + rank)   # different data per rank
+    ld, lk, tot, _ = step(x)
+    torch.cuda.synchronize()
+    p = od.param_arena
+    sd = model.state_dict()
+    res = (float(p.double().sum()), float(p.double().abs().sum()), float(odisc.param_arena.double().sum()),
+                 float(sd['regressor.net.backbone.bn1.running_mean'].double().sum()),
+                 float(sd['regressor.net.backbone.layer1.0.bn1.running_mean'].double().sum()),
+                 bool(torch.isfinite(tot)), int(sum(early)))
+    dist.destroy_process_group()          # (on an exception the harness exits the rank without waiting for its peers)
+    return res
 
 
 def _run2(opts=None):
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context('spawn')
-    ret = ctx.Manager().dict()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret, opts)) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(600)
-        assert p.exitcode == 0
+    ret = run_ranks(_worker, 2, (opts,))
     return ret[0], ret[1]
 
 
-def test_two_rank_step_keeps_replicas_identical():
-    a, b = _run2()
+@pytest.mark.parametrize('beside', [1, 0])
+def test_two_rank_step_keeps_replicas_identical(beside):
+    """beside = XAS_DISC_BESIDE_GEN: the discriminator update on the second stream next to the generator's detector passes
+    (1, the single-GPU default) or on the main stream in program order (0)."""
+    a, b = _run2(dict(beside=beside))
     assert a[5] and b[5]
     assert a[0] == b[0] and a[1] == b[1]          # generator parameters bit-identical after the averaged step
     assert a[2] == b[2]                           # discriminator parameters too

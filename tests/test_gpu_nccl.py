@@ -4,28 +4,21 @@ all-gather + merge kernel, backward all-reduce, bucketed gradient all-reduce on 
 communicator, launched from the readiness hooks during backward).  With one rank the exchange must be the identity:
 the step must equal the step without a process group."""
 import os
-import socket
-import sys
 
 import pytest
 import torch
-import torch.multiprocessing as mp
 
-pytestmark = pytest.mark.gpu
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+from _ranks import init_group, run_ranks
+
+pytestmark = [pytest.mark.gpu, pytest.mark.multiproc]
 
 
-def _worker(mode, port, ret):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
-                      HSA_ENABLE_IPC_MODE_LEGACY='0')
-    for p in (ROOT, os.path.join(ROOT, 'x-as-supervision_amd'), os.path.join(ROOT, 'tests', 'golden')):
-        if p not in sys.path:
-            sys.path.insert(0, p)
+def _worker(rank, world, mode):
     import torch.distributed as dist
     torch.cuda.set_device(0)
     if mode == 'nccl':
         os.environ['XAS_FORCE_DP'] = '1'
-        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+        init_group('nccl', 0, 1, device_id=torch.device('cuda', 0))
     from xas_amd import engine
     from xas_amd.synthetic import model_config, synthetic_batch
     cfg = model_config('HM36_Multi_SurS2')
@@ -48,27 +41,18 @@ def _worker(mode, port, ret):
         losses.append((float(ld.detach()), float(tot.detach())))
     torch.cuda.synchronize()
     sd = model.state_dict()
-    ret[mode] = (losses, od.param_arena.double().sum().item(), od.param_arena.double().abs().sum().item(),
+    res = (losses, od.param_arena.double().sum().item(), od.param_arena.double().abs().sum().item(),
                  odisc.param_arena.double().sum().item(), sd['regressor.net.backbone.bn1.running_mean'].double().sum().item(),
                  sd['regressor.net.backbone.bn1.running_var'].double().sum().item(),
                  (sum(launched), len(launched)) if mode == 'nccl' else None)
     if mode == 'nccl':
         dist.destroy_process_group()
+    return res
 
 
 def test_nccl_world1_step_equals_plain_step():
-    ctx = mp.get_context('spawn')
-    ret = ctx.Manager().dict()
-    for mode in ('plain', 'nccl'):
-        s = socket.socket()
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-        s.close()
-        p = ctx.Process(target=_worker, args=(mode, port, ret))
-        p.start()
-        p.join(600)
-        assert p.exitcode == 0, mode
-    a, b = ret['plain'], ret['nccl']
+    a = run_ranks(_worker, 1, ('plain',))[0]
+    b = run_ranks(_worker, 1, ('nccl',))[0]
     early, total = b[6]
     assert total == 2 * 3 and early >= 1                     # 3 buckets per generator step; some launched from the hooks
     for (la, ta), (lb, tb) in zip(a[0], b[0]):

@@ -7,7 +7,7 @@ import sys
 import pytest
 import yaml
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.multiproc, pytest.mark.limit(400)]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, 'x-as-supervision_amd')
 
@@ -24,7 +24,7 @@ def test_train_entry_synthetic(tmp_path):
     base = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
             '--master-port', '29541', os.path.join(PKG, 'train.py'), '--config', str(cfg_path), '--synthetic', '2',
             '--log_dir', str(tmp_path / 'log'), '--seed', '3']
-    r = subprocess.run(base, env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(base, env=env, capture_output=True, text=True, timeout=150)
     assert r.returncode == 0, r.stderr[-3000:]
     runs = os.listdir(tmp_path / 'log')
     assert len(runs) == 1
@@ -38,13 +38,13 @@ def test_train_entry_synthetic(tmp_path):
     assert 'smpl_discriminator.joint_gcn.0.gc1.lin_l.weight' in sd['unsup_disc']
     assert set(sd['optimizer_detector']['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}
     # resume (finetune mode restarts at epoch 0 in a new directory)
-    r = subprocess.run(base + ['--checkpoint', str(ckpt), '--finetune'], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(base + ['--checkpoint', str(ckpt), '--finetune'], env=env, capture_output=True, text=True, timeout=150)
     assert r.returncode == 0, r.stderr[-3000:]
     # evaluate the checkpoint with the mirrored eval entry (synthetic consistent scene): result file as the reference's
     ev = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
           '--master-port', '29542', os.path.join(PKG, 'eval.py'), '--config', str(cfg_path), '--checkpoint', str(ckpt),
           '--synthetic', '2', '--batch_size', '2', '--multi_hypo', 'best']
-    r = subprocess.run(ev, env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(ev, env=env, capture_output=True, text=True, timeout=150)
     assert r.returncode == 0, r.stderr[-3000:]
     res = (tmp_path / 'log' / runs[0] / 'eval' / 'eval_result.txt').read_text().split('\n')
     assert res[0].startswith('2D MSE: ') and any(l.startswith('TRI P-MPJPE: ') for l in res)
