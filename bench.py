@@ -75,6 +75,62 @@ def cpu_baseline(workload, threads):
                       % (workload, B, times[0], ' '.join('%.1f' % t for t in times[1:]))}
 
 
+def train_step_variant_check(step, x, model, disc, opt_det, opt_disc, xl, precision):
+    """One full TRAIN-MODE step at the benchmark size in `precision` and one on the exact-fp32 MFMA kernels, both from the SAME
+    state (parameters, Adam moments, running statistics snapshot / restored): relative difference of every loss term and of
+    the two gradient arenas as the optimizers would consume them (condition c)."""
+    import torch
+    f_det, f_disc = opt_det._flat, (opt_disc._flat if opt_disc is not None else None)
+    bufs = [b for m in (model, disc) for b in m.buffers()]
+
+    def snapshot():
+        return ([t.clone() for f in (f_det, f_disc) if f is not None for t in (f['p'], f['m'], f['v'])],
+                [b.clone() for b in bufs], opt_det._steps, opt_disc._steps if opt_disc is not None else 0, step.cur_step)
+
+    def restore(sn):
+        ts, bs, s_det, s_disc, cur = sn
+        it = iter(ts)
+        with torch.no_grad():
+            for f in (f_det, f_disc):
+                if f is not None:
+                    for k in ('p', 'm', 'v'):
+                        f[k].copy_(next(it))
+            for b, v in zip(bufs, bs):
+                b.copy_(v)
+        opt_det._steps = s_det
+        opt_det._epoch[0] += 1                       # packed weight copies are stale
+        if opt_disc is not None:
+            opt_disc._steps = s_disc
+            opt_disc._epoch[0] += 1
+        step.cur_step = cur
+
+    def run(prec):
+        xl.query('xas_set_precision', prec)
+        torch.manual_seed(4242)                      # the discriminator's dropout mask: the same in both runs
+        grads = {}
+        step.grad_probe = lambda which, arena: grads.__setitem__(which, arena.clone())
+        ld, lk, tot, _ = step(x)
+        step.grad_probe = None
+        torch.cuda.synchronize()
+        losses = {'disc': float(ld.detach()) if ld is not None else 0.0, 'total': float(tot.detach())}
+        losses.update({k: float(v.detach().mean()) for k, v in lk.items()})
+        return losses, grads
+
+    sn = snapshot()
+    la, ga = run(xl.PREC_NAMES[precision])
+    restore(sn)
+    lb, gb = run(xl.PREC_F32)
+    restore(sn)
+    xl.query('xas_set_precision', xl.PREC_NAMES[precision])
+    rel = {k: abs(la[k] - lb[k]) / max(abs(lb[k]), 1e-30) for k in lb if lb[k] != 0.0 or la[k] != 0.0}
+    gr = {k: float((ga[k] - gb[k]).double().norm() / gb[k].double().norm().clamp_min(1e-300)) for k in gb}
+    return {'what': 'ONE train-mode step (disc + gen, B as timed) in this precision mode vs the exact-fp32 MFMA kernels from the same '
+                    'state: |loss_mode - loss_f32| / |loss_f32| per loss term, ||g_mode - g_f32|| / ||g_f32|| over each gradient arena '
+                    'as handed to Adam',
+            'loss_rel_diff': rel, 'max_loss_rel_diff': max(rel.values()) if rel else 0.0,
+            'grad_arena_rel_diff': gr, 'grad_arena_norm_f32': {k: float(v.double().norm()) for k, v in gb.items()}}
+
+
 def launch_ranks(n):
     """Run this script as n ranks of a single-node torchrun job (child process; no exec, no GPU use here)."""
     import socket
@@ -109,7 +165,7 @@ def main():
                          'equivalent.  f32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32, peak 157.3).  bf16: operands rounded '
                          'once - NOT fp32 accurate (misses the 1e-4 joint bar), a variant that is reported separately, never '
                          'the headline; peak 2516.8')
-    ap.add_argument('--f32-steps', type=int, default=2,
+    ap.add_argument('--f32-steps', type=int, default=5,
                     help='extra UNTIMED-by-the-headline steps on the exact-fp32 MFMA kernels after the timed region, to print '
                          'that figure beside the bf16x6 headline (0 = skip)')
     ap.add_argument('--dedupe', action='store_true',
@@ -276,6 +332,8 @@ def main():
             reg.train(was)
             variant_check = {'max_abs_joint_diff_vs_exact_fp32_mfma': float((kv - k32).abs().max()),
                              'what': 'detector forward (eval-mode norms) on 8 images, this precision mode vs the exact-fp32 MFMA kernels; parity bar 1e-4'}
+            if world == 1:
+                variant_check['train_step'] = train_step_variant_check(step, x, model, disc, opt_det, opt_disc, _xl, args.precision)
         kernel_names = {':bf16x6': 'igemm_x6_kernel<.,.,.,3> (fwd / dgrad) + wgrad_x6_kernel<.,.,3>: bf16x6 MFMA implicit-GEMM conv family',
                         ':f16x3': 'igemm_x6_kernel<.,.,.,2> / igemm_x6t_kernel<.,.,2> (fwd / dgrad) + wgrad_x6_kernel<.,.,2> / wgrad_x6t_kernel<.,2>: f16x3 MFMA implicit-GEMM conv family',
                         ':bf16': 'igemm_x6_kernel<.,.,.,1> + wgrad_x6_kernel<.,.,1>: bf16 MFMA implicit-GEMM conv family',

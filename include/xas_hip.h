@@ -44,13 +44,15 @@ int xas_set_tuning(int flags);
  * master weights and fp32 accumulation; they differ in how a product of two fp32 operands is formed:
  *   XAS_PREC_F16X3 (default)  every fp32 operand is split into two fp16 pieces x = h1 + h2 + e, |e| <= 2^-22 |x| (round to
  *                   nearest twice), after an exact power-of-two scaling that keeps both pieces inside fp16's normal
- *                   range: weights as 2^10 w (|w| < 64), activations as 2^4 x (full accuracy for |x| in [2^-10, 2^11]: images,
- *                   masks, normalised activations), gradient tensors at the scale that puts their maximum in [2^14, 2^15)
- *                   (xas_conv_shape.grad_amax, produced by the kernel that wrote the gradient).  Three partial products
+ *                   range: weights as 2^10 w (|w| < 64; anything larger raises xas_f16_weight_overflow), and EVERY tensor
+ *                   operand - activation or gradient - at the scale that puts its maximum in [2^14, 2^15): the maximum comes
+ *                   with the call (xas_conv_shape.grad_amax / x_amax), recorded by the kernel that wrote the tensor
+ *                   (xas_bn_apply_amax, xas_bn_bwd_apply_amax, xas_head_softargmax_bwd_amax) or by xas_abs_max.  There is
+ *                   no fixed activation scale, hence no range activations must stay in (r04).  Three partial products
  *                   h1 g1 + h1 g2 + h2 g1, each exact in fp32, accumulated by v_mfma_f32_32x32x16_f16: 3 instead of 6 matrix
  *                   instructions per K = 16.  Measured distance to a float64 convolution: the same as the exact-fp32 MFMA
- *                   path's (its own accumulation error dominates: 5e-7 relative at K = 576).  A gradient launch WITHOUT
- *                   grad_amax runs as bf16x6;
+ *                   path's (its own accumulation error dominates: 5e-7 relative at K = 576).  A launch that comes WITHOUT
+ *                   the maxima of its tensor operands runs as bf16x6 (range-free by construction);
  *   XAS_PREC_BF16X6  every fp32 operand is split exactly into three bf16 pieces and six exact partial products
  *                   are accumulated in fp32 by v_mfma_f32_32x32x16_bf16: per-product error below one fp32 rounding
  *                   (1.09e-7 relative against float64 at K = 64, exact-fp32 MFMA 1.06e-7), 2.67x the fp32-MFMA math rate; no
@@ -136,8 +138,8 @@ int xas_draw_lines_max_bwd(const float* kps, long kp_stride_b, long kp_stride_j,
                            float* grad_kps_xy /* [B][K][2] */, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * Convolution family: MFMA implicit GEMM on NHWC fp32 activations (fp32-accurate bf16x6 by default, exact fp32 MFMA
- * on request: XAS_PREC_*).
+ * Convolution family: MFMA implicit GEMM on NHWC fp32 activations (fp32-accurate f16x3 by default - bf16x6 for launches
+ * without operand maxima -, exact fp32 MFMA on request: XAS_PREC_*).
  * Replaces the cuDNN calls behind nn.Conv2d / nn.ConvTranspose2d / nn.Linear in
  * integral_base_modules/resnet.py:16-47, deconv_head.py:24-35, physique_network.py:15-50,
  * discriminator.py:8-21 and torchvision's Bottleneck.
@@ -153,13 +155,16 @@ typedef struct {
   int stride, pad;
   int Ho, Wo;
   int mode;          /* low byte: 0 = process default precision (xas_set_precision), otherwise 1 + XAS_PREC_* for this call;
-                      * | XAS_GRAD_IS_X: in a weight-gradient call the gradient tensor is the `x` argument, not `dy`
-                      *   (the weight gradient of a ConvTranspose2d) - tells grad_amax which operand it describes */
-  const float* grad_amax;   /* NULL, or a DEVICE pointer to max |g| over the gradient tensor this call reads (dy of a data /
-                              * weight gradient; the input of a forward launch that is itself a backward, e.g. the data gradient of
-                              * a ConvTranspose2d), complete on the call's stream.  XAS_PREC_F16X3 then splits that tensor into two
-                              * fp16 pieces at the power-of-two scale that puts the maximum just below 2^15 (f16x3 for the gradient
-                              * pass); without it gradient passes run as bf16x6.  xas_bn_bwd_apply_amax produces it. */
+                      * | XAS_GRAD_IS_X: in a weight-gradient call grad_amax describes the `x` argument and x_amax the `dy`
+                      *   argument (the weight gradient of a ConvTranspose2d, whose gradient tensor is passed as `x`) */
+  const float* grad_amax;   /* NULL, or a DEVICE pointer to max |v| over the tensor operand of the call, complete on the call's
+                              * stream: the input x of a forward-type launch (xas_conv_fwd*), dy of a data-gradient-type launch
+                              * (xas_conv_dgrad*; for a ConvTranspose2d forward that is its input activation), dy of a weight
+                              * gradient.  An upper bound is as good as the maximum.  XAS_PREC_F16X3 splits that tensor into two fp16
+                              * pieces at the power-of-two scale that puts the maximum just below 2^15; without it the launch runs
+                              * as bf16x6.  Producers: xas_bn_apply_amax, xas_bn_bwd_apply_amax, xas_head_softargmax_bwd_amax,
+                              * xas_abs_max. */
+  const float* x_amax;      /* weight gradient only: the same for its `x` argument (both maxima -> f16x3, else bf16x6) */
 } xas_conv_shape;
 
 /* Which weight buffer xas_conv_fwd* (pass 0) / xas_conv_dgrad* (pass 1) expect for this shape in its precision mode:
@@ -208,7 +213,9 @@ int xas_conv_fwd_bnstats(const float* x, const float* w_packed, float* y, const 
  * Outputs: dx = gradient wrt xb; sums [groups][2][Cin] (sum dz | sum dz * xhat); dbeta_acc / dgamma_acc (both or neither
  * NULL) += local parameter gradients; dz: scratch of xb's size.  workspace:
  * xas_conv_dgrad_bn_bwd_workspace_floats(s, groups).  The reductions ride in the data gradient's epilogue when its tile
- * grid lines up with the groups (stride 1), otherwise the call is xas_conv_dgrad + xas_bn_bwd_reduce + xas_bn_bwd_apply. */
+ * grid lines up with the groups (stride 1), otherwise the call is xas_conv_dgrad + xas_bn_bwd_reduce + xas_bn_bwd_apply.
+ * Operand maxima in `s` are IGNORED: w_packed_t is always the format xas_conv_weight_planes(s, 1) names for the shape with
+ * grad_amax == NULL (three bf16 planes in both split modes - the fused epilogue exists for that format only). */
 size_t xas_conv_dgrad_bn_bwd_workspace_floats(const xas_conv_shape* s, int groups);
 int xas_conv_dgrad_bn_bwd(const float* dy, const float* w_packed_t, const xas_conv_shape* s, const float* xb,
                           const float* mean, const float* var_biased, const float* gamma, const float* beta, float eps,
@@ -300,6 +307,15 @@ int xas_col_sum_acc(const float* x, long M, int C, float* acc, float* workspace,
 int xas_bn_apply(const float* x, const float* mean, const float* var_biased, const float* gamma,
                  const float* beta, const float* residual, float eps, int act, long M, int C, int groups,
                  float* y, uint8_t* mask_out, void* stream);
+/* Same, and max |y| over the whole result is merged into *amax_out (device float, zeroed by the caller; atomic maximum on
+ * the bit pattern): the scale of y as the input of the next convolution's f16x3 launches (xas_conv_shape.grad_amax; x_amax of
+ * its weight gradient).  amax_out == NULL: xas_bn_apply. */
+int xas_bn_apply_amax(const float* x, const float* mean, const float* var_biased, const float* gamma,
+                      const float* beta, const float* residual, float eps, int act, long M, int C, int groups,
+                      float* y, uint8_t* mask_out, float* amax_out, void* stream);
+/* max |x| over n floats merged into *amax_out (as above): for convolution inputs that no kernel of this library wrote
+ * (images, rendered masks).  One streaming read. */
+int xas_abs_max(const float* x, long n, float* amax_out, void* stream);
 /* running = (1-momentum)*running + momentum*stat_g for g = 0..groups-1; var uses the unbiased estimate n/(n-1). */
 int xas_bn_update_running(const float* mean, const float* var_biased, float* running_mean,
                           float* running_var, float momentum, long count, int C, int groups, void* stream);

@@ -62,7 +62,7 @@ def test_exports_and_signatures():
         assert name in _lib.SIGNATURES, 'no ctypes signature for %s' % name
         assert _lib.SIGNATURES[name] == (codes, ret), '%s: table %r vs header %r' % (name, _lib.SIGNATURES[name], (codes, ret))
     assert set(_lib.SIGNATURES) <= set(protos)
-    assert ctypes.sizeof(_lib.ConvShape) == 12 * 4 + 8 and _lib.ConvShape.grad_amax.offset == 48      # 12 ints + the gradient-maximum pointer
+    assert ctypes.sizeof(_lib.ConvShape) == 12 * 4 + 16 and _lib.ConvShape.grad_amax.offset == 48 and _lib.ConvShape.x_amax.offset == 56      # 12 ints + the two operand-maximum pointers
     assert lib.xas_abi_version() == 2
 
 

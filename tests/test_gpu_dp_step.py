@@ -14,8 +14,10 @@ pytestmark = [pytest.mark.gpu, pytest.mark.multiproc]
 
 def _worker(rank, world, opts=None):
     opts = opts or {}
-    os.environ.update(XAS_DP_NOTIFY=str(opts.get('notify', 1)), XAS_CAM_BATCH=str(opts.get('cam_batch', 1)),
-                      XAS_DISC_BESIDE_GEN=str(opts.get('beside', 1)))
+    os.environ.update(XAS_DP_NOTIFY=str(opts.get('notify', 1)), XAS_CAM_BATCH=str(opts.get('cam_batch', 1)))
+    os.environ.pop('XAS_DISC_BESIDE_GEN', None)               # unset = the data-parallel default (main stream, engine.py)
+    if opts.get('beside') is not None:
+        os.environ['XAS_DISC_BESIDE_GEN'] = str(opts['beside'])
     torch.cuda.set_device(0)
     init_group('gloo', rank, world)
     from xas_amd import engine
@@ -49,10 +51,11 @@ def _run2(opts=None):
     return ret[0], ret[1]
 
 
-@pytest.mark.parametrize('beside', [1, 0])
+@pytest.mark.parametrize('beside', [None, 1, 0])
 def test_two_rank_step_keeps_replicas_identical(beside):
     """beside = XAS_DISC_BESIDE_GEN: the discriminator update on the second stream next to the generator's detector passes
-    (1, the single-GPU default) or on the main stream in program order (0)."""
+    (1, the single-GPU default) or on the main stream in program order (0; also what an unset variable means under data
+    parallelism: None)."""
     a, b = _run2(dict(beside=beside))
     assert a[5] and b[5]
     assert a[0] == b[0] and a[1] == b[1]          # generator parameters bit-identical after the averaged step

@@ -215,12 +215,13 @@ def test_conv_beyond_2gib_splits_over_images():
     shp = F._shape(n, h, w, cin, cout, 1, 1, 1, 0, h, w)
     cache = F._PackCache()
     dx = torch.empty_like(x)
-    call('xas_conv_dgrad', ptr(dy), ptr(cache.get(wt, 1, shp)), ptr(dx), shp)
+    shp_g, shp_f = F.shape_with_maxima(shp, dy, x), F.shape_with_maxima(shp, x)      # f16x3 kernels in the default mode
+    call('xas_conv_dgrad', ptr(dy), ptr(cache.get(wt, 1, shp_g)), ptr(dx), shp_g)
     dw = torch.zeros(cout, cin, 1, 1, device='cuda')
-    ws = torch.empty(max(1, query('xas_conv_wgrad_workspace_floats', shp)), device='cuda')
-    call('xas_conv_wgrad_acc', ptr(x), ptr(dy), ptr(dw), ptr(ws), shp)
+    ws = torch.empty(max(1, query('xas_conv_wgrad_workspace_floats', shp_g)), device='cuda')
+    call('xas_conv_wgrad_acc', ptr(x), ptr(dy), ptr(dw), ptr(ws), shp_g)
     y = torch.empty_like(dy)
-    call('xas_conv_fwd', ptr(x), ptr(cache.get(wt, 0, shp)), None, ptr(y), shp)
+    call('xas_conv_fwd', ptr(x), ptr(cache.get(wt, 0, shp_f)), None, ptr(y), shp_f)
     torch.cuda.synchronize()
     # reference per image range with plain matmuls (fp32 on the GPU: an independent code path)
     w2 = wt.view(cout, cin)

@@ -115,3 +115,51 @@ def test_geodesic_full_size_properties():
             assert float(out[b].max()) <= float(np.exp(2.0)) + 24.0 + 1e-3
         else:
             assert (out[b] == 1).all()
+
+
+class _GeoDataset(torch.utils.data.Dataset):
+    """What the reference loader's __getitem__ does with the mask (dataloader.py:80): one per-sample call."""
+
+    def __init__(self, masks):
+        self.masks = masks
+
+    def __len__(self):
+        return len(self.masks)
+
+    def __getitem__(self, i):
+        from human_utils.common.utility.geodesic import compute_geodesic_dis
+        out, cen = compute_geodesic_dis(self.masks[i], 'img_%d' % i, [2, 1, 3, 20, 0.0])
+        return torch.as_tensor(np.asarray(out, dtype=np.float32)), int(torch.utils.data.get_worker_info() is not None)
+
+
+def test_geodesic_reference_entry_never_touches_gpu_in_loader_workers(tmp_path, monkeypatch):
+    """train.py:278 builds DataLoader(num_workers=10) by FORK after the parent initialised the GPU: the mirrored
+    `compute_geodesic_dis` (reference signature) must hand a worker's call to the reference module behind it on the path -
+    a device call in a forked child raises 'Cannot re-initialize CUDA in forked subprocess' - and use the kernel in the parent."""
+    import sys
+    from xas_amd import _next
+    ref_pkg = tmp_path / 'human_utils' / 'common' / 'utility'
+    ref_pkg.mkdir(parents=True)
+    (ref_pkg / 'geodesic.py').write_text(
+        'import numpy as np\n'
+        'def compute_geodesic_dis(img, img_path, geodesic_param_list, centers=None, is_norm=True):\n'
+        '    return np.full_like(img, -7.0, dtype=np.float32), np.zeros((1, 2), np.int16)\n')
+    import human_utils.common.utility as util_pkg
+    import human_utils.common.utility.geodesic as geo
+    monkeypatch.setattr(util_pkg, '__path__', list(util_pkg.__path__) + [str(ref_pkg)])
+    monkeypatch.delitem(sys.modules, geo.__name__ + '.__ref__', raising=False)
+    assert _next.next_module(geo.__name__, geo.__file__).__file__ == str(ref_pkg / 'geodesic.py')
+    masks = gi.blob_mask(4, 64, seed=5).astype(np.float32)                      # [4,1,64,64]
+    torch.zeros(1, device='cuda').add_(1)                                       # the parent HAS initialised the GPU
+    # parent process: the HIP kernel (batch of one), also with a centre that carries a depth column ([1,3], geodesic.py:19-24)
+    out, cen = geo.compute_geodesic_dis(masks[0], 'p', [2, 1, 3, 20, 0.0])
+    assert out.shape == (1, 64, 64) and out.min() >= 1.0 and cen.shape == (1, 2) and cen.dtype == np.int16
+    out3, cen3 = geo.compute_geodesic_dis(masks[0], 'p', [2, 1, 3, 20, 0.0], centers=np.array([[cen[0, 0], cen[0, 1], 123]]))
+    assert np.array_equal(out3, out) and np.array_equal(cen3, cen)
+    # forked workers: the reference module's answer, no device call
+    loader = torch.utils.data.DataLoader(_GeoDataset(masks), batch_size=2, num_workers=2, multiprocessing_context='fork')
+    got = [(o, w) for o, w in loader]
+    assert len(got) == 2
+    for o, w in got:
+        assert bool((w == 1).all()) and bool((o == -7.0).all())
+    monkeypatch.delitem(sys.modules, geo.__name__ + '.__ref__', raising=False)

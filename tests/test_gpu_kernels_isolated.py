@@ -89,6 +89,7 @@ def test_conv_dgrad_acc(n, cin, h, w, cout, k, stride, pad):
     wg = wt.cuda()
     buf = skip.cuda().contiguous(memory_format=torch.channels_last)
     dyg = dy.cuda().contiguous(memory_format=torch.channels_last)
+    shp = F.shape_with_maxima(shp, dyg)               # with max |dy|: the f16x3 kernels (without: bf16x6, test_gpu_precision.py)
     call('xas_conv_dgrad_acc', ptr(dyg), ptr(cache.get(wg, 1, shp)), ptr(buf), shp)
     assert rel(buf, ref) < 3e-6
     # and the plain form writes exactly the difference
@@ -111,6 +112,7 @@ def test_conv_wgrad_acc(n, cin, h, w, cout, k, stride, pad):
     ws = torch.empty(max(1, query('xas_conv_wgrad_workspace_floats', shp)), device='cuda')
     xg = x.cuda().contiguous(memory_format=torch.channels_last)          # named: a temporary could be freed (and its
     dyg = dy.cuda().contiguous(memory_format=torch.channels_last)        # memory re-used) before the launch reads it
+    shp = F.shape_with_maxima(shp, dyg, xg)           # both maxima: the f16x3 weight-gradient kernels
     call('xas_conv_wgrad_acc', ptr(xg), ptr(dyg), ptr(buf), ptr(ws), shp)
     assert rel(buf, ref) < 3e-6
 
@@ -161,6 +163,7 @@ def test_conv_dgrad_acc_masked(n, cin, h, w, cout, k, stride, pad):
     dyg = dy.cuda().contiguous(memory_format=torch.channels_last)
     dpg = dprev.cuda().contiguous(memory_format=torch.channels_last)
     out = torch.full_like(dpg, float('nan'))
+    shp = F.shape_with_maxima(shp, dyg)
     call('xas_conv_dgrad_acc_masked', ptr(dyg), ptr(cache.get(wg, 1, shp)), ptr(out), shp, ptr(dpg), ptr(mask))
     assert rel(out, ref) < 3e-6
 
@@ -218,6 +221,7 @@ def test_conv_fwd_bnstats(n, cin, h, w, cout, k, stride, pad, G, form):
     cache = F._PackCache()
     wg = wt.cuda()
     xg = x.cuda().contiguous(memory_format=torch.channels_last)
+    shp = F.shape_with_maxima(shp, xg)
     M, Mg = n * ho * wo, n * ho * wo // G
     y0 = torch.empty(n, cout, ho, wo, device='cuda').contiguous(memory_format=torch.channels_last)
     call('xas_conv_fwd', ptr(xg), ptr(cache.get(wg, 0, shp)), None, ptr(y0), shp)

@@ -1,7 +1,8 @@
 """Arithmetic modes of the MFMA convolutions (xas_hip.h XAS_PREC_*).
 
-The library default is f16x3 (forward launches: every fp32 operand as two fp16 pieces, three partial products; gradient
-launches: bf16x6, three bf16 pieces, six partial products; fp32 accumulation everywhere - both fp32 ACCURATE): every other
+The library default is f16x3 (every fp32 operand as two fp16 pieces at a scale taken from the recorded maximum of its
+tensor, three partial products; launches that come without those maxima: bf16x6, three bf16 pieces, six partial products;
+fp32 accumulation everywhere - both fp32 ACCURATE): every other
 GPU test therefore exercises that mode, including every oracle / reference-golden parity test, with tolerances unchanged
 from the rounds in which exact-fp32 MFMA was the default.  This file
 
@@ -111,23 +112,124 @@ def test_conv_split_modes_are_fp32_accurate(n, cin, h, w, cout, k, stride, pad, 
         _split_mode_case(n, cin, h, w, cout, k, stride, pad)
 
 
-def test_conv_f16x3_small_and_large_operands():
-    """The fp16 pieces have a fixed scale (conv_shared.h: 2^4 x, 2^10 w): activations of 1e-2 .. 3e2 and weights of 3e-5 .. 1
-    stay within the 3e-6 bar; below that range the second piece reaches fp16's subnormals (absolute error floor 2^-29 for
-    activations), above it the first piece overflows - every conv input of this network is an image, a mask or a normalised
-    activation."""
+def test_conv_f16x3_any_operand_magnitude():
+    """r04: no fixed activation scale.  Every tensor operand of an f16x3 launch is split at the power-of-two scale its
+    recorded maximum selects (ops_nn.act_amax: the producer's slot, else xas_abs_max), so activations of ANY magnitude -
+    1e-12 .. 1e8, far outside the old 2^4 window (inf above 2^11, precision loss below 2^-10) - meet the 3e-6 bar of the
+    other fp32-accurate modes in all three passes, including a heavy-tailed input (elements down to 1e-6 of the maximum).
+    Weights keep their 2^10 scale (|w| < 64, flagged otherwise: test_f16x3_weight_range_is_flagged)."""
     from xas_amd import layers as L
-    for xs, ws in ((1e-2, 1.0), (3e2, 1.0), (1.0, 1e-3), (1.0, 30.0), (30.0, 1e-2)):
+    from xas_amd import ops_nn as O
+    from xas_amd._lib import query
+    for xs, ws in ((1e-12, 1.0), (1e-5, 1.0), (1e-2, 1.0), (3e2, 1.0), (5e3, 1.0), (1e8, 1.0), (1.0, 1e-3), (1.0, 30.0), (5e3, 1e-2)):
         g = torch.Generator().manual_seed(7)
-        x = torch.randn(2, 128, 16, 16, generator=g) * xs
+        x = torch.randn(2, 128, 16, 16, generator=g) * torch.exp(torch.randn(2, 128, 16, 16, generator=g) * 2.0) * xs
         wt = torch.randn(64, 128, 3, 3, generator=g) * ws / 34.0
+        gy = torch.randn(2, 64, 16, 16, generator=g)
         m = L.Conv2d(128, 64, 3, 1, 1, bias=False).cuda()
         with torch.no_grad():
             m.weight.copy_(wt)
         with precision_mode('f16x3'):
-            y = m(x.cuda())
-        exact = TF.conv2d(x.double(), wt.double(), None, 1, 1)
-        assert rel(y, exact) < 3e-6, (xs, ws, rel(y, exact))
+            xg = x.cuda().requires_grad_(True)
+            y = m(xg)
+            # dy with its maximum, as a norm's backward would hand it over
+            dy = gy.cuda().contiguous(memory_format=torch.channels_last)
+            O.tag_grad_amax(dy, dy.abs().max().reshape(1).contiguous())
+            y.backward(dy)
+            torch.cuda.synchronize()
+        xd, wd = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+        yd = TF.conv2d(xd, wd, None, 1, 1)
+        yd.backward(gy.double())
+        assert torch.isfinite(y).all()
+        assert rel(y, yd) < 3e-6, (xs, ws, rel(y, yd))
+        assert rel(xg.grad, xd.grad) < 3e-6, (xs, ws)
+        assert rel(m.weight.grad, wd.grad) < 3e-6, (xs, ws, rel(m.weight.grad, wd.grad))
+
+
+def test_f16x3_launch_without_maxima_runs_as_bf16x6():
+    """A call that does not come with the maximum of its tensor operand (a maintainer binding the C ABI without the amax
+    protocol) never meets fp16's range: it runs on the bf16x6 kernels (kernel class 3, three-plane weights) - |x| = 5e3 and
+    1e-5, which the r03 fixed scale turned into inf / lost bits, are exact to the bar; with the maximum the same call is
+    class 4 (f16x3)."""
+    from xas_amd import ops_nn as O
+    from xas_amd._lib import call, ptr, query
+    n, cin, h, w, cout = 2, 64, 16, 16, 64
+    g = torch.Generator().manual_seed(3)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / 24.0
+    with precision_mode('f16x3'):
+        for xs in (5e3, 1e-5):
+            x = torch.randn(n, cin, h, w, generator=g) * xs
+            xg = O.to_cl(x.cuda())
+            shp = O._shape(n, h, w, cin, cout, 3, 3, 1, 1, h, w)
+            assert query('xas_conv_kernel_class', shp, 0) == 3 and query('xas_conv_weight_planes', shp, 0) == 3
+            assert query('xas_conv_kernel_class', shp, 1) == 3 and query('xas_conv_kernel_class', shp, 2) == 3
+            cache = O._PackCache()
+            wg = wt.cuda()
+            y = O.empty_cl(n, cout, h, w, xg)
+            call('xas_conv_fwd', ptr(xg), ptr(cache.get(wg, 0, shp)), None, ptr(y), shp)
+            ref = TF.conv2d(x.double(), wt.double(), None, 1, 1)
+            assert torch.isfinite(y).all() and rel(y, ref) < 3e-6, (xs, rel(y, ref))
+            shp_m = O.shape_with_maxima(shp, xg)
+            assert query('xas_conv_kernel_class', shp_m, 0) == 4 and query('xas_conv_weight_planes', shp_m, 0) == 2
+            y2 = O.empty_cl(n, cout, h, w, xg)
+            call('xas_conv_fwd', ptr(xg), ptr(cache.get(wg, 0, shp_m)), None, ptr(y2), shp_m)
+            assert torch.isfinite(y2).all() and rel(y2, ref) < 3e-6, (xs, rel(y2, ref))
+            # a weight gradient needs BOTH maxima for f16x3
+            dy = O.to_cl(torch.randn(n, cout, h, w, generator=g).cuda())
+            only_dy = O.shape_with_maxima(shp, dy)
+            assert query('xas_conv_kernel_class', only_dy, 2) == 3
+            both = O.shape_with_maxima(shp, dy, xg)
+            assert query('xas_conv_kernel_class', both, 2) == 4
+
+
+def test_maxima_travel_with_the_tensors_on_the_hot_path():
+    """The detector's convolutions find the maximum of their input on the tensor (recorded by the norm / pooling kernel that
+    wrote it): one xas_abs_max per pass - for the images - and none in the backward.  A stale tag (a tensor that outlived its
+    step: the slot arena has been rewound) is not used."""
+    from modules.keypoint_detector_integral_multi import KPDetector3DMulti
+    from xas_amd import ops_nn as O
+    from xas_amd.synthetic import model_config
+    cfg = model_config('HM36_Multi_SurS1')['model_params']['detector_params']
+    torch.manual_seed(0)
+    det = KPDetector3DMulti(**cfg).cuda().train()
+    img = torch.rand(2, 3, 256, 256, device='cuda')
+    with precision_mode('f16x3'):
+        O.reset_grad_amax()
+        before = O.amax_stats['abs_max']
+        kps = det(img)[0]
+        assert O.amax_stats['abs_max'] - before == 1
+        kps.square().sum().backward()
+        assert O.amax_stats['abs_max'] - before == 1
+        # stale tags: after the arena is rewound the image is measured again
+        xin = O.to_cl(torch.randn(2, 64, 8, 8, device='cuda'))
+        s1 = O.act_amax(xin)
+        assert O.amax_of(xin) is s1
+        O.reset_grad_amax()
+        assert O.amax_of(xin) is None
+        xin.mul_(2.0)
+        s2 = O.act_amax(xin)
+        torch.cuda.synchronize()
+        assert abs(float(s2) - float(xin.abs().max())) == 0.0
+        xin.add_(1.0)                                   # modified in place: the recorded maximum no longer describes it
+        assert O.amax_of(xin) is None
+
+
+def test_f16x3_stem_weight_range_is_flagged():
+    """The stem kernel splits its 9 408 weights itself (2^10 w): |w| >= 64 raises the same device flag as the
+    weight-preparation kernels (test_f16x3_weight_range_is_checked), read and cleared by xas_f16_weight_overflow."""
+    from xas_amd import layers as L
+    from xas_amd._lib import query
+    with precision_mode('f16x3'), torch.no_grad():
+        query('xas_f16_weight_overflow', 1)
+        stem = L.Conv2d(3, 64, 7, 2, 3, bias=False).cuda()
+        img = torch.rand(2, 3, 64, 64, device='cuda')
+        y = stem(img)
+        ref = TF.conv2d(img.double().cpu(), stem.weight.detach().double().cpu(), None, 2, 3)
+        assert rel(y, ref) < 3e-6
+        assert query('xas_f16_weight_overflow', 1) == 0
+        stem.weight[10, 1, 3, 3] = -65.0
+        stem(img)
+        assert query('xas_f16_weight_overflow', 1) == 1 and query('xas_f16_weight_overflow', 0) == 0      # read-and-clear
 
 
 @pytest.mark.parametrize('scale', [1e-9, 1e-5, 1.0, 1e4])
@@ -154,9 +256,11 @@ def test_f16x3_gradients_with_amax(n, cin, h, w, cout, k, stride, pad, scale):
         wc = wt.cuda()
         dx = O.empty_cl(n, cin, h, w, dyc)
         call('xas_conv_dgrad', ptr(dyc), ptr(cache.get(wc, 1, shp)), ptr(dx), shp)
-        # weight gradient: x at the fixed activation scale, dy at the scale of its maximum
+        # weight gradient: x and dy each at the scale of its maximum
         x = torch.randn(n, cin, h, w, generator=g) * 2.0 + 0.3
         xc = O.to_cl(x.cuda())
+        xmax = xc.abs().max().reshape(1).contiguous()
+        shp = ConvShape(n, h, w, cin, cout, k, k, stride, pad, ho, wo, 0, amax.data_ptr(), xmax.data_ptr())
         assert query('xas_conv_kernel_class', shp, 2) in (4, 1)          # (shapes outside the split kernels: exact fp32)
         dw = torch.empty(cout, cin, k, k, device='cuda')
         ws = torch.empty(max(1, query('xas_conv_wgrad_workspace_floats', shp)), device='cuda')

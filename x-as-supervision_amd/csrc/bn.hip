@@ -436,11 +436,25 @@ __device__ __forceinline__ float act_fwd(float v, int act) {
   return act == 0 ? v : (act == 1 ? fmaxf(v, 0.f) : (v > 0.f ? v : 0.01f * v));
 }
 
+// max |v| of a launch -> *out (zeroed by the caller before the launch): non-negative floats order like their bit patterns, and
+// +inf sorts above every finite value (the consumer then keeps scale 1: the inf reaches its fp16 pieces and the result, as it
+// would in fp32).  NaN elements do NOT enter the maximum (fmaxf drops them): they travel in the data itself.
+__device__ __forceinline__ void publish_amax(float* out, float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(v));
+}
+__device__ __forceinline__ float amax4(float a, float4 o) {
+  return fmaxf(fmaxf(a, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+}
+
 // grid.y = group: the rows of group g use mean / var row g ([G][C]); n4g = float4 elements per group
 __global__ void bn_apply_kernel(const float4* __restrict__ x, const float* __restrict__ mean,
                                 const float* __restrict__ var, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, const float4* __restrict__ res, float eps, int act,
-                                long n4g, int C4, float4* __restrict__ y, uint8_t* __restrict__ mask_out) {
+                                long n4g, int C4, float4* __restrict__ y, uint8_t* __restrict__ mask_out,
+                                float* __restrict__ amax_out) {
+  float amx = 0.f;
   const long goff = (long)blockIdx.y * n4g;
   mean += (size_t)blockIdx.y * C4 * 4; var += (size_t)blockIdx.y * C4 * 4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4g; i += (long)gridDim.x * blockDim.x) {
@@ -457,16 +471,10 @@ __global__ void bn_apply_kernel(const float4* __restrict__ x, const float* __res
     if (mask_out)          // sign bits of the pre-activation value: what the backward needs of y (1/16 of its bytes)
       mask_out[goff + i] = (uint8_t)((o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u));
     o.x = act_fwd(o.x, act); o.y = act_fwd(o.y, act); o.z = act_fwd(o.z, act); o.w = act_fwd(o.w, act);
+    amx = amax4(amx, o);
     y[goff + i] = o;
   }
-}
-
-// max |v| of a launch -> *out (zeroed by the caller before the launch): non-negative floats order like their bit patterns;
-// NaN / inf sort above every finite value, so a poisoned gradient stays visible downstream
-__device__ __forceinline__ void publish_amax(float* out, float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(v));
+  if (amax_out) publish_amax(amax_out, amx);
 }
 
 // grid.y = group; sums: [G][2][C] = sum_dz | sum_dz_xhat of each group
@@ -543,7 +551,8 @@ __global__ __launch_bounds__(256) void bn_apply_stream_kernel(const float4* __re
                                                              const float* __restrict__ var, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float4* __restrict__ res,
                                                              float eps, long n4g, int C4, float4* __restrict__ y,
-                                                             uint8_t* __restrict__ mask_out) {
+                                                             uint8_t* __restrict__ mask_out, float* __restrict__ amax_out) {
+  float amx = 0.f;                                     // max |y| of this thread (amax_out != null: xas_bn_apply_amax)
 #ifdef XAS_BN_PRIO
   __builtin_amdgcn_s_setprio(XAS_BN_PRIO);
 #endif
@@ -564,6 +573,7 @@ __global__ __launch_bounds__(256) void bn_apply_stream_kernel(const float4* __re
     if (MASKOUT)
       mask_out[goff + k] = (uint8_t)((o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u));
     o.x = act_fwd(o.x, ACT); o.y = act_fwd(o.y, ACT); o.z = act_fwd(o.z, ACT); o.w = act_fwd(o.w, ACT);
+    amx = amax4(amx, o);
     stream_store(y + goff + k, o);
   };
   const float4 z4 = make_float4(0, 0, 0, 0);
@@ -575,6 +585,7 @@ __global__ __launch_bounds__(256) void bn_apply_stream_kernel(const float4* __re
     for (int u = 0; u < 4; ++u) one(i + u * stride, xv[u], rv[u]);
   }
   for (; i < n4g; i += stride) one(i, x[goff + i], RES ? res[goff + i] : z4);
+  if (amax_out) publish_amax(amax_out, amx);
 }
 
 // SIGN: where the activation sign comes from: 0 no activation, 1 y, 2 x (re-derived, no residual), 3 mask bytes
@@ -954,6 +965,12 @@ extern "C" int xas_col_sum(const float* x, long M, int C, float* out, float* wor
 extern "C" int xas_bn_apply(const float* x, const float* mean, const float* var_biased, const float* gamma,
                             const float* beta, const float* residual, float eps, int act, long M, int C, int groups,
                             float* y, uint8_t* mask_out, void* stream) {
+  return xas_bn_apply_amax(x, mean, var_biased, gamma, beta, residual, eps, act, M, C, groups, y, mask_out, nullptr, stream);
+}
+
+extern "C" int xas_bn_apply_amax(const float* x, const float* mean, const float* var_biased, const float* gamma,
+                                 const float* beta, const float* residual, float eps, int act, long M, int C, int groups,
+                                 float* y, uint8_t* mask_out, float* amax_out, void* stream) {
   XAS_REQUIRE(x && mean && var_biased && gamma && beta && y, "bn_apply: null buffer");
   XAS_REQUIRE(M > 0 && C >= 4 && C % 4 == 0 && act >= 0 && act <= 2 && groups >= 1 && M % groups == 0,
               "bn_apply: bad shape M=%ld C=%d act=%d groups=%d", M, C, act, groups);
@@ -971,7 +988,7 @@ extern "C" int xas_bn_apply(const float* x, const float* mean, const float* var_
       float4* y4 = reinterpret_cast<float4*>(y);
 #define XAS_BN_FWD(ACT, RES, MK)                                                                                         \
   hipLaunchKernelGGL((bn_apply_stream_kernel<ACT, RES, MK>), grid, dim3(256), 0, as_stream(stream), x4, mean, var_biased, \
-                     gamma, beta, r4, eps, n4g, C4, y4, mask_out)
+                     gamma, beta, r4, eps, n4g, C4, y4, mask_out, amax_out)
       if (residual && mask_out) { if (act == 1) XAS_BN_FWD(1, true, true); else if (act == 2) XAS_BN_FWD(2, true, true); else XAS_BN_FWD(0, true, true); }
       else if (residual) { if (act == 1) XAS_BN_FWD(1, true, false); else if (act == 2) XAS_BN_FWD(2, true, false); else XAS_BN_FWD(0, true, false); }
       else { if (act == 1) XAS_BN_FWD(1, false, false); else if (act == 2) XAS_BN_FWD(2, false, false); else XAS_BN_FWD(0, false, false); }
@@ -982,7 +999,8 @@ extern "C" int xas_bn_apply(const float* x, const float* mean, const float* var_
   }
   hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid_g(n4g, groups), groups), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float4*>(x), mean, var_biased, gamma, beta,
-                     reinterpret_cast<const float4*>(residual), eps, act, n4g, C / 4, reinterpret_cast<float4*>(y), mask_out);
+                     reinterpret_cast<const float4*>(residual), eps, act, n4g, C / 4, reinterpret_cast<float4*>(y), mask_out,
+                     amax_out);
   XAS_LAUNCH_CHECK();
   return 0;
 }
@@ -1112,6 +1130,32 @@ extern "C" int xas_bn_bwd_apply_amax(const float* x, const float* y, const float
                      reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(y),
                      reinterpret_cast<const float4*>(dy), mean, var_biased, gamma, beta, sums, eps, act, n4g,
                      C / 4, (float)(1.0 / count), reinterpret_cast<float4*>(dx), reinterpret_cast<float4*>(dresidual), mask, amax_out);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+// max |x| over a tensor -> *amax_out (merged with atomicMax: the caller zeroes it once).  For conv inputs that no kernel of
+// this library wrote (images, rendered masks, tensors handed in from outside): one streaming read, HBM bound.
+__global__ __launch_bounds__(256) void abs_max_kernel(const float* __restrict__ x, long n, float* __restrict__ amax_out) {
+  float amx = 0.f;
+  const long n4 = n / 4, stride = (long)gridDim.x * blockDim.x;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = stream_load(x4 + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) amx = amax4(amx, v[u]);
+  }
+  for (; i < n4; i += stride) amx = amax4(amx, x4[i]);
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) amx = fmaxf(amx, fabsf(x[n4 * 4 + threadIdx.x]));
+  publish_amax(amax_out, amx);
+}
+
+extern "C" int xas_abs_max(const float* x, long n, float* amax_out, void* stream) {
+  XAS_REQUIRE(x && amax_out && n > 0 && (((uintptr_t)x) & 15) == 0, "abs_max: need a 16-byte aligned tensor and an output float");
+  hipLaunchKernelGGL(abs_max_kernel, dim3(ew_grid(cdiv(n, 4))), dim3(256), 0, as_stream(stream), x, n, amax_out);
   XAS_LAUNCH_CHECK();
   return 0;
 }

@@ -1027,9 +1027,15 @@ constexpr int STH_PROW = 120;                                      // halfwords 
 #endif
 constexpr int STH_TPB = XAS_STH_TPB;                               // output tiles per block (one split of the weights)
 
+__device__ unsigned g_f16_weight_overflow_stem = 0u;      // (the stem splits its 9 408 weights in the kernel: its own flag, read by
+                                                          // xas_f16_weight_overflow together with the preparation kernels' one)
 __global__ __launch_bounds__(256) void stem_fwd_f16_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           float* __restrict__ y, int N, int H, int W, int Ho, int Wo) {
+                                                           float* __restrict__ y, int N, int H, int W, int Ho, int Wo,
+                                                           const float* __restrict__ x_amax) {
   __shared__ __align__(16) unsigned short wsh[2 * ST_CO * STH_WROW];        // [plane][co][k']
+  float inv_sx;
+  const float f16_sx = f16_grad_scale(x_amax, &inv_sx);                      // image scale from max |x| (wave-uniform)
+  const float f16_desc = inv_sx * (1.f / kF16WScale);
   __shared__ __align__(16) unsigned short ph[2 * ST_PH * STH_PROW];         // [plane][patch row][px * 3 + c]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_w = (Wo + ST_TW - 1) / ST_TW, tiles = tiles_w * ((Ho + ST_TH - 1) / ST_TH);
@@ -1038,6 +1044,7 @@ __global__ __launch_bounds__(256) void stem_fwd_f16_kernel(const float* __restri
     const int co = e / STH_WROW, k = e - co * STH_WROW;
     const int r = k / STH_KR, j = k - r * STH_KR;
     float v = (k < STH_K && j < 21) ? w[co * ST_K + r * 21 + j] * kF16WScale : 0.f;
+    if (!(fabsf(v) < 65504.f)) atomicOr(&g_f16_weight_overflow_stem, 1u);      // |w| >= 64 or NaN: flagged, like the pre-split weights
     const _Float16 h1 = (_Float16)v, h2 = (_Float16)(v - (float)h1);
     wsh[e] = __builtin_bit_cast(unsigned short, h1);
     wsh[ST_CO * STH_WROW + e] = __builtin_bit_cast(unsigned short, h2);
@@ -1084,7 +1091,7 @@ __global__ __launch_bounds__(256) void stem_fwd_f16_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < NPV; ++j) {
       if (ppy[j] >= 0) {
-        const float v = pv[j] * kF16AScale;
+        const float v = pv[j] * f16_sx;
         const _Float16 h1 = (_Float16)v, h2 = (_Float16)(v - (float)h1);
         ph[ppy[j] * STH_PROW + pq[j]] = __builtin_bit_cast(unsigned short, h1);
         ph[ST_PH * STH_PROW + ppy[j] * STH_PROW + pq[j]] = __builtin_bit_cast(unsigned short, h2);
@@ -1120,8 +1127,8 @@ __global__ __launch_bounds__(256) void stem_fwd_f16_kernel(const float* __restri
       const int oy = oy0 + wave * 2 + (pi >> 4), ox = ox0 + (pi & 15);
       if (oy < Ho && ox < Wo) {
         float* o = y + (((size_t)n * Ho + oy) * Wo + ox) * ST_CO;
-        o[col] = acc0[reg] * kF16Descale;
-        o[32 + col] = acc1[reg] * kF16Descale;
+        o[col] = acc0[reg] * f16_desc;
+        o[32 + col] = acc1[reg] * f16_desc;
       }
     }
   }
@@ -1576,13 +1583,18 @@ static int g_precision = XAS_PREC_F16X3;     // process default (xas_set_precisi
 
 static inline int precision_of(const xas_conv_shape* s) { return (s->mode & 0xff) > 0 ? (s->mode & 0xff) - 1 : g_precision; }
 // operand planes of a pass in a precision mode (pass 0: forward-type launch, 1 data gradient, 2 weight gradient):
-// XAS_PREC_F16X3 runs on two fp16 planes where the scale of the split operands is known - forward-type launches
-// (activations: fixed scale) and gradient launches that come with the maximum of their gradient tensor
-// (xas_conv_shape.grad_amax) - and as bf16x6 otherwise
+// XAS_PREC_F16X3 runs on two fp16 planes when the maximum of EVERY tensor operand of the launch came with the call
+// (xas_conv_shape.grad_amax; a weight gradient also needs x_amax) - the scale of each split is derived from it, there is no
+// fixed scale and therefore no range the operands must stay in (r04) - and as bf16x6 otherwise
 static inline int planes_of(int prec, int pass, bool has_amax) {
+  (void)pass;
   if (prec == XAS_PREC_F32) return 0;
   if (prec == XAS_PREC_BF16) return 1;
-  return (prec == XAS_PREC_F16X3 && (pass == 0 || has_amax)) ? 2 : 3;
+  return (prec == XAS_PREC_F16X3 && has_amax) ? 2 : 3;
+}
+// do the maxima a pass needs come with the call?
+static inline bool has_amax_for(const xas_conv_shape* s, int pass) {
+  return pass == 2 ? (s->grad_amax != nullptr && s->x_amax != nullptr) : s->grad_amax != nullptr;
 }
 
 // prec: XAS_PREC_*.  The bf16-split kernels (conv_x6.hip) take PRE-SPLIT weights (xas_split_weight); the exact-fp32 kernels
@@ -1623,8 +1635,8 @@ static int images_per_launch(int N, long elems_per_image_a, long elems_per_image
 
 extern "C" int xas_set_tuning(int flags) { g_tune = flags; return 0; }
 extern "C" int xas_set_precision(int mode) {
-  XAS_REQUIRE(mode >= 0 && mode <= 3, "set_precision: 0 = exact fp32 MFMA, 1 = bf16 MFMA (not fp32 accurate), 2 = bf16x6 (fp32-accurate, default), "
-              "3 = f16x3 forward passes + bf16x6 gradient passes");
+  XAS_REQUIRE(mode >= 0 && mode <= 3, "set_precision: 0 = exact fp32 MFMA, 1 = bf16 MFMA (not fp32 accurate), 2 = bf16x6 (fp32-accurate, no "
+              "operand maxima needed), 3 = f16x3 (default; fp32-accurate; launches that come without the maxima of their operands run as bf16x6)");
   g_precision = mode;
   return 0;
 }
@@ -1632,6 +1644,18 @@ extern "C" int xas_get_precision(void) { return g_precision; }
 
 static int conv_fwd_impl(const float* x, const float* w_packed, const float* bias, float* y, const xas_conv_shape* s,
                          void* stream, float* stat_partial, const float* stat_pivot);
+
+namespace xas {
+int stem_weight_overflow(int reset) {
+  unsigned v = 0u;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_f16_weight_overflow_stem), sizeof(v)) != hipSuccess) return -1;
+  if (v && reset) {
+    const unsigned z = 0u;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_f16_weight_overflow_stem), &z, sizeof(z));
+  }
+  return v ? 1 : 0;
+}
+}  // namespace xas
 
 extern "C" int xas_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
                             const xas_conv_shape* s, void* stream) {
@@ -1679,9 +1703,10 @@ static int conv_fwd_impl(const float* x, const float* w_packed, const float* bia
   hipStream_t st = as_stream(stream);
   if (s->Cin == 3 && s->R == 7 && s->S == 7 && s->stride == 2 && s->pad == 3 && s->Cout == ST_CO && bias == nullptr) {
     const int tiles = (int)(cdiv(s->Ho, ST_TH) * cdiv(s->Wo, ST_TW));
-    if (precision_of(s) == XAS_PREC_F16X3 && !(g_tune & (1 << 25)))       // (tune bit 25: the exact-fp32 stem kernel)
+    // f16x3 needs max |image| (the scale of the split); without it - and under tune bit 25 - the exact-fp32 stem kernel
+    if (precision_of(s) == XAS_PREC_F16X3 && s->grad_amax && !(g_tune & (1 << 25)))
       hipLaunchKernelGGL(stem_fwd_f16_kernel, dim3((unsigned)cdiv(tiles, STH_TPB), s->N), dim3(256), 0, st, x, w_packed, y, s->N, s->Hi,
-                         s->Wi, s->Ho, s->Wo);
+                         s->Wi, s->Ho, s->Wo, s->grad_amax);
     else
     hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)cdiv(tiles, ST_TPB), s->N), dim3(256), 0, st, x, w_packed, y, s->N, s->Hi,
                        s->Wi, s->Ho, s->Wo);
@@ -1733,7 +1758,7 @@ extern "C" int xas_conv_weight_planes(const xas_conv_shape* s, int pass) {
   bool mfma;
   if (pass == 0) mfma = !thin && !(s->Cin == 3 && s->R == 7) && s->Cin % BK == 0 && s->Cout >= 16;
   else mfma = !thin && s->Cout % BK == 0 && s->Cin >= 16;
-  return mfma ? planes_of(prec, pass, s->grad_amax != nullptr) : 0;
+  return mfma ? planes_of(prec, pass, has_amax_for(s, pass)) : 0;
 }
 
 // Which kernel family a pass of this shape runs on (for measurement: bench.py prices every launch against the peak of the
@@ -1742,12 +1767,12 @@ extern "C" int xas_conv_weight_planes(const xas_conv_shape* s, int pass) {
 extern "C" int xas_conv_kernel_class(const xas_conv_shape* s, int pass) {
   if (!s) return 0;
   const int prec = precision_of(s);
-  const int split = prec == XAS_PREC_F32 ? 1 : (prec == XAS_PREC_BF16 ? 2 : (planes_of(prec, pass, s->grad_amax != nullptr) == 2 ? 4 : 3));
+  const int split = prec == XAS_PREC_F32 ? 1 : (prec == XAS_PREC_BF16 ? 2 : (planes_of(prec, pass, has_amax_for(s, pass)) == 2 ? 4 : 3));
   const bool thin = (s->Cout == 1 && thin_ok(s, s->Cin)) || (s->Cin == 1 && thin_ok(s, s->Cout));
   if (thin) return 0;
   if (pass == 0) {
     if (s->Cin == 3 && s->R == 7 && s->S == 7 && s->stride == 2 && s->pad == 3 && s->Cout == ST_CO)              // stem kernels
-      return (prec == XAS_PREC_F16X3 && !(g_tune & (1 << 25))) ? 4 : 1;
+      return (prec == XAS_PREC_F16X3 && s->grad_amax && !(g_tune & (1 << 25))) ? 4 : 1;
     return (s->Cin % BK == 0 && s->Cout >= 16) ? split : 0;
   }
   if (pass == 1) return (s->Cout % BK == 0 && s->Cin >= 16) ? split : 0;
@@ -1908,6 +1933,11 @@ extern "C" int xas_conv_dgrad_bn_bwd(const float* dy, const float* w_packed_t, c
                                      float* workspace, float* dbeta_acc, float* dgamma_acc, void* stream) {
   XAS_REQUIRE(s && groups >= 1 && s->N % groups == 0, "conv_dgrad_bn_bwd: the batch does not split into %d groups", groups);
   XAS_REQUIRE(xb && mean && var_biased && gamma && beta && dz && dx && sums && workspace, "conv_dgrad_bn_bwd: null buffer");
+  // this entry always takes the weight format of the shape WITHOUT operand maxima (bf16x6 planes in the split modes: the fused
+  // epilogue exists for three planes only): a grad_amax that came with the shape is ignored, for both of its code paths
+  xas_conv_shape local = *s;
+  local.grad_amax = nullptr; local.x_amax = nullptr;
+  s = &local;
   const long M = (long)s->N * s->Hi * s->Wi;
   const int C = s->Cin;
   const int bm = dgrad_bnb_tile_rows(s, groups);
@@ -2149,8 +2179,8 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
   WgradParams p{};
   p.x = x; p.dy = dy; p.out = (splits == 1 && !oihw) ? dw_packed : workspace;
   // which argument is the gradient tensor: dy (a conv's weight gradient) or x (XAS_GRAD_IS_X: a ConvTranspose2d's)
-  p.a_amax = (s->mode & XAS_GRAD_IS_X) ? nullptr : s->grad_amax;
-  p.b_amax = (s->mode & XAS_GRAD_IS_X) ? s->grad_amax : nullptr;
+  p.a_amax = (s->mode & XAS_GRAD_IS_X) ? s->x_amax : s->grad_amax;      // max |dy argument|
+  p.b_amax = (s->mode & XAS_GRAD_IS_X) ? s->grad_amax : s->x_amax;      // max |x argument|
   p.N = s->N; p.Hi = s->Hi; p.Wi = s->Wi; p.Cin = s->Cin; p.Cout = s->Cout; p.R = s->R; p.S = s->S;
   p.stride = s->stride; p.pad = s->pad; p.Ho = s->Ho; p.Wo = s->Wo;
   p.KK = s->R * s->S * s->Cin; p.M = s->N * s->Ho * s->Wo; p.m_per_split = mps;
@@ -2169,9 +2199,9 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw_packed, fl
       wgrad_x6t_plan(s->N, s->Hi, s->Wi, s->Cin, s->Cout, s->R, s->S, s->stride, s->pad, s->Ho, s->Wo, &tbm, &tsplits, &tpps)) {
     splits = tsplits;
     p.out = (splits == 1 && !oihw) ? dw_packed : workspace;
-    rc = launch_wgrad_x6t(p, tbm, tsplits, tpps, planes_of(precision_of(s), 2, s->grad_amax != nullptr), st);
+    rc = launch_wgrad_x6t(p, tbm, tsplits, tpps, planes_of(precision_of(s), 2, has_amax_for(s, 2)), st);
   } else
-  if (x6) rc = launch_wgrad_x6(p, bm, bn, splits, planes_of(precision_of(s), 2, s->grad_amax != nullptr), st);
+  if (x6) rc = launch_wgrad_x6(p, bm, bn, splits, planes_of(precision_of(s), 2, has_amax_for(s, 2)), st);
   else if (buf_ok) {
     if (bm == 32) rc = launch_wgrad_buf<32, 128>(p, splits, st);
     else if (bn == 64) rc = bm == 128 ? launch_wgrad_buf<128, 64>(p, splits, st) : launch_wgrad_buf<64, 64>(p, splits, st);

@@ -61,8 +61,8 @@ struct IgemmParams {
   float bnb_eps;
   int bnb_rows_per_group;
   float* bnb_partial;
-  // f16x3 launches: null -> the gathered tensor is an activation (fixed scale kF16AScale); else device pointer to
-  // max |v| over the gathered (gradient) tensor: scale = the power of two that puts the maximum just below 2^15
+  // f16x3 launches: device pointer to max |v| over the gathered tensor (activation or gradient): scale = the power of two
+  // that puts the maximum just below 2^15 (required: a launch without it runs as bf16x6)
   const float* a_amax;
 };
 
@@ -117,8 +117,9 @@ typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 constexpr float kF16WScale = 1024.f;           // weights are split as 2^10 w: their second pieces stay clear of fp16's subnormals
                                                // (|w| < 64 assumed - larger weights become inf, loudly); results are scaled back
-constexpr float kF16AScale = 16.f;             // activations (images, normalised activations, masks) as 2^4 x: full 22-bit
-                                               // accuracy for |x| in [2^-10, 2^11], an absolute floor of 2^-29 below, inf above
+constexpr float kF16AScale = 16.f;             // (initial value of the per-launch tensor scale only: every f16x3 launch derives
+                                               // its scales from the recorded maxima of its operands, f16_grad_scale below)
+int stem_weight_overflow(int reset);           // conv.hip: flag of the stem kernel's in-kernel weight split (-1: read failed)
 constexpr float kF16Descale = 1.f / (kF16WScale * kF16AScale);
 // scale of a gradient operand from its maximum magnitude (wave-uniform): amax in [2^(e-127), 2^(e-126)) -> 2^(141 - e), i.e.
 // amax * scale in [2^14, 2^15).  Zero / denormal-range maxima: 1 (nothing to resolve).  *inv = 1 / scale (exact).

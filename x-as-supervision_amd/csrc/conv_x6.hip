@@ -14,13 +14,13 @@
 // the matrix instructions, two thirds of the LDS traffic and of the conversion work of bf16x6.  The representation
 // error (7e-8 relative on a dot product) stays under the fp32 accumulation error every MFMA mode shares (1-3e-7): the
 // distance to float64 is the exact-fp32 path's.  fp16's narrow exponent is handled by EXACT power-of-two scales s, undone
-// on the fp32 accumulators: weights 2^10 (pre-split once per optimizer step; |w| < 64), activations 2^4 (images, masks,
-// normalised activations: full accuracy for |x| in [2^-10, 2^11], absolute floor 2^-29 below), and gradient tensors by
-// the power of two that puts their MAXIMUM in [2^14, 2^15) - the kernel that writes a gradient tensor (batch-norm
-// backward, soft-argmax backward) merges max |g| into a device float, the consumer reads it through
-// xas_conv_shape.grad_amax (IgemmParams::a_amax / WgradParams::a_amax, b_amax).  Elements 2^-15 and more below the
-// maximum lose relative (not absolute) accuracy: error floor 2^-39 max|g| per element, invisible next to the fp32
-// rounding of the large terms of the same sum.  A gradient launch without a maximum runs as bf16x6.  PIECES = 1 is the
+// on the fp32 accumulators: weights 2^10 (pre-split once per optimizer step; |w| < 64, flagged otherwise), and EVERY tensor
+// operand - activations and gradients alike (r04: no fixed activation scale, hence no activation range) - by the power of
+// two that puts its MAXIMUM in [2^14, 2^15): the kernel that writes a tensor (batch-norm apply / backward, soft-argmax
+// backward; xas_abs_max for anything else) merges max |v| into a device float, the consumer reads it through
+// xas_conv_shape.grad_amax / x_amax (IgemmParams::a_amax / WgradParams::a_amax, b_amax).  Elements 2^-15 and more below the
+// maximum lose relative (not absolute) accuracy: error floor 2^-39 max|v| per element, invisible next to the fp32
+// rounding of the large terms of the same sum.  A launch without the maxima of its operands runs as bf16x6.  PIECES = 1 is the
 // plain bf16 variant (operands rounded once; NOT fp32 accurate; XAS_PREC_BF16), kept as the reported-separately variant.
 //
 // Kernel structure (both kernels): 256 threads = 4 waves, tile BM x BN, K-step of 32 (channels of a tap / pixels) loaded
@@ -683,7 +683,10 @@ static int launch_igemm_x6_p(const IgemmParams& p, int Mrows_max, int phases, hi
 // derived from IgemmParams::a_amax when it is a gradient)
 int launch_igemm_x6(const IgemmParams& p, int mode, int Mrows_max, int phases, int pieces, hipStream_t st) {
   if (mode == 0) {
-    if (pieces == 2) return launch_igemm_x6_p<0, 2>(p, Mrows_max, phases, st);
+    if (pieces == 2) {
+      XAS_REQUIRE(p.a_amax, "conv: an f16x3 forward launch needs the maximum of its input tensor (xas_conv_shape.grad_amax)");
+      return launch_igemm_x6_p<0, 2>(p, Mrows_max, phases, st);
+    }
     return pieces == 3 ? launch_igemm_x6_p<0, 3>(p, Mrows_max, phases, st) : launch_igemm_x6_p<0, 1>(p, Mrows_max, phases, st);
   }
   if (pieces == 2) {
@@ -742,7 +745,7 @@ __global__ __launch_bounds__(256, (P == 2 ? XAS_WX6_WAVES2 : 2)) void wgrad_x6_k
   __builtin_amdgcn_s_setprio(XAS_WGRAD_PRIO);
 #endif
   float f16_sd = kF16AScale, f16_sx = kF16AScale, f16_desc = 1.f;      // P == 2: scales of dy and of x, scale of the result
-  if (P == 2) {                                        // (the gradient operand from its maximum, the activation fixed)
+  if (P == 2) {                                        // (each operand from its maximum; the launchers insist on both)
     float id = 1.f / kF16AScale, ix = 1.f / kF16AScale;
     if (p.a_amax) f16_sd = f16_grad_scale(p.a_amax, &id);
     if (p.b_amax) f16_sx = f16_grad_scale(p.b_amax, &ix);
@@ -963,7 +966,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6t_kernel(WgradParams p) {
   const int pbeg = split * p.pps, pend = min(np_total, pbeg + p.pps);
   if (pbeg >= pend) return;
   float f16_sd = kF16AScale, f16_sx = kF16AScale, f16_desc = 1.f;      // P == 2: scales of dy and of x, scale of the result
-  if (P == 2) {                                        // (the gradient operand from its maximum, the activation fixed)
+  if (P == 2) {                                        // (each operand from its maximum; the launchers insist on both)
     float id = 1.f / kF16AScale, ix = 1.f / kF16AScale;
     if (p.a_amax) f16_sd = f16_grad_scale(p.a_amax, &id);
     if (p.b_amax) f16_sx = f16_grad_scale(p.b_amax, &ix);
@@ -1166,8 +1169,8 @@ static int launch_wgrad_x6t_t(const WgradParams& p, int splits, int pps, hipStre
 }
 
 int launch_wgrad_x6t(const WgradParams& p, int bm, int splits, int pps, int pieces, hipStream_t st) {
-  if (pieces == 2) {                                   // f16x3: x at the fixed activation scale, dy at the scale of p.a_amax
-    XAS_REQUIRE(p.a_amax || p.b_amax, "conv_wgrad: the f16x3 weight gradient needs the maximum of its gradient operand (xas_conv_shape.grad_amax)");
+  if (pieces == 2) {                                   // f16x3: dy at the scale of p.a_amax, x at the scale of p.b_amax
+    XAS_REQUIRE(p.a_amax && p.b_amax, "conv_wgrad: the f16x3 weight gradient needs the maxima of both tensor operands (xas_conv_shape.grad_amax, x_amax)");
     if (bm == 128) return launch_wgrad_x6t_t<128, 2>(p, splits, pps, st);
     if (bm == 64) return launch_wgrad_x6t_t<64, 2>(p, splits, pps, st);
     return launch_wgrad_x6t_t<32, 2>(p, splits, pps, st);
@@ -1205,7 +1208,7 @@ void wgrad_x6_tile(int Cout, long KK, int* bm, int* bn) {
 
 int launch_wgrad_x6(const WgradParams& p, int bm, int bn, int splits, int pieces, hipStream_t st) {
   if (pieces == 2) {
-    XAS_REQUIRE(p.a_amax || p.b_amax, "conv_wgrad: the f16x3 weight gradient needs the maximum of its gradient operand (xas_conv_shape.grad_amax)");
+    XAS_REQUIRE(p.a_amax && p.b_amax, "conv_wgrad: the f16x3 weight gradient needs the maxima of both tensor operands (xas_conv_shape.grad_amax, x_amax)");
     if (bm == 32) return launch_wgrad_x6_t<32, 128, 2>(p, splits, st);
     if (bm == 128) return bn == 128 ? launch_wgrad_x6_t<128, 128, 2>(p, splits, st) : launch_wgrad_x6_t<128, 64, 2>(p, splits, st);
     return bn == 128 ? launch_wgrad_x6_t<64, 128, 2>(p, splits, st) : launch_wgrad_x6_t<64, 64, 2>(p, splits, st);
@@ -1295,7 +1298,9 @@ extern "C" int xas_f16_weight_overflow(int reset) {
     const unsigned z = 0u;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_f16_weight_overflow), &z, sizeof(z));
   }
-  return v ? 1 : 0;
+  const int stem = stem_weight_overflow(reset);        // the stem kernel splits its weights itself (conv.hip)
+  if (stem < 0) return -1;
+  return (v || stem) ? 1 : 0;
 }
 
 extern "C" size_t xas_split_weight_bytes(long rows, long K, int pieces) {

@@ -6,7 +6,11 @@ two fast-marching solves per sample and camera).
 (`img [1,H,W]` numpy, `img_path`, parameter list, optional centres, `is_norm`) and return types, so that the reference's
 own loader (`human_utils/dataloader/dataloader.py:13,80`) keeps working with the mirror in front of it on PYTHONPATH: it
 runs the batch kernel on a batch of one.  `is_norm=False` (raw distances; no shipped config) and anything else this
-module does not define fall through to the reference module.
+module does not define fall through to the reference module.  So does every call from a DataLoader WORKER process
+(train.py:278 starts `--worker 10` of them by fork after the parent has initialised the GPU: a forked child must never touch
+the device - "Cannot re-initialize CUDA in forked subprocess") and every call in a process without a usable GPU: there the
+reference's scikit-fmm implementation runs, exactly as without the mirror.  The GPU maps of a training run come from
+`gpu_patch` on whole device batches, not from this per-sample entry.
 """
 import ctypes
 
@@ -39,13 +43,21 @@ def compute_centroid(mask):
     return np.array([np.sum(grid[1] * mask) / np.sum(mask), np.sum(grid[0] * mask) / np.sum(mask)]).astype(np.int16)
 
 
+def _in_loader_worker():
+    """True in a DataLoader worker process or in any forked child of a process that had initialised the GPU."""
+    import torch.utils.data
+    return torch.utils.data.get_worker_info() is not None or torch.cuda._is_in_bad_fork()
+
+
 def compute_geodesic_dis(img, img_path, geodesic_param_list, centers=None, is_norm=True):
     """Reference signature (geodesic.py:14): img [1,H,W] numpy mask -> (weight map [1,H,W], centres [n,2] int16)."""
-    if not is_norm or img.shape[-1] != img.shape[-2] or (centers is not None and len(centers) != 1):
+    if (not is_norm or img.shape[-1] != img.shape[-2] or (centers is not None and len(centers) != 1) or _in_loader_worker()
+            or not torch.cuda.is_available()):
         return __getattr__('compute_geodesic_dis')(img, img_path, geodesic_param_list, centers, is_norm)
     dev = torch.device('cuda', torch.cuda.current_device())
     m = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32)).to(dev)[None]
-    c = None if centers is None else torch.as_tensor(np.asarray(centers, dtype=np.int32).reshape(1, 2))
+    # (a centre may carry a depth column - the reference indexes center[0], center[1] only, geodesic.py:23-24,30-31)
+    c = None if centers is None else torch.as_tensor(np.ascontiguousarray(np.asarray(centers)[:, :2], dtype=np.int32))
     out, cen = compute_geodesic_dis_batch(m, geodesic_param_list, c)
     return out[0].cpu().numpy(), cen.cpu().numpy().astype(np.int16).reshape(-1, 2)
 

@@ -15,7 +15,9 @@ _T = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c
 class ConvShape(ctypes.Structure):
     """xas_conv_shape"""
     _fields_ = [(n, ctypes.c_int) for n in ('N', 'Hi', 'Wi', 'Cin', 'Cout', 'R', 'S', 'stride', 'pad', 'Ho', 'Wo', 'mode')] + [
-        ('grad_amax', ctypes.c_void_p)]      # device pointer to max |g| of the call's gradient operand, or None
+        ('grad_amax', ctypes.c_void_p),      # device pointer to max |v| of the call's tensor operand (x of forward-type, dy of
+                                             # gradient launches), or None
+        ('x_amax', ctypes.c_void_p)]         # weight gradient: the same for its x argument
 
 
 # xas_hip.h XAS_PREC_*: arithmetic of the MFMA convolutions.  ConvShape.mode = 0 (process default) or 1 + one of these.
@@ -67,6 +69,8 @@ SIGNATURES = {
     'xas_col_sum': ('plippp', 'i'),
     'xas_col_sum_acc': ('plippp', 'i'),
     'xas_bn_apply': ('ppppppfiliippp', 'i'),
+    'xas_bn_apply_amax': ('ppppppfiliipppp', 'i'),
+    'xas_abs_max': ('plpp', 'i'),
     'xas_bn_update_running': ('ppppfliip', 'i'),
     'xas_bn_bwd_reduce': ('pppppppfiliipppppp', 'i'),
     'xas_bn_bwd_apply': ('ppppppppfiliidpppp', 'i'),
@@ -118,7 +122,7 @@ def load():
     lib.xas_last_error.restype = ctypes.c_char_p
     lib.xas_last_error.argtypes = []
     _lib = lib
-    mode = os.environ.get('XAS_PRECISION', '')          # '' = library default (2, bf16x6); '0' = exact fp32 MFMA; '1' = bf16
+    mode = os.environ.get('XAS_PRECISION', '')          # '' = library default (3, f16x3: launches without operand maxima run as bf16x6); '2' = bf16x6; '0' = exact fp32 MFMA; '1' = bf16
     if mode != '':
         lib.xas_set_precision.argtypes = [ctypes.c_int]
         lib.xas_set_precision.restype = ctypes.c_int

@@ -23,8 +23,21 @@ from .optim import FusedAdam
 
 # The discriminator's own forward / backward / Adam (a few hundred small launches, ~4 ms of an otherwise idle GPU) runs on a
 # second stream beside the generator step's detector passes, which do not depend on it (only the generator LOSSES do).
-DISC_BESIDE_GEN = os.environ.get('XAS_DISC_BESIDE_GEN', '1') != '0'
+# Single process: on by default.  Under data parallelism: OFF unless XAS_DISC_BESIDE_GEN=1 asks for it - the update then runs on
+# the main stream in program order.  Reasons: (i) its gradient exchange (`red_disc.finish()`) blocks the HOST on backends whose
+# collectives are host-synchronous (gloo), so nothing of the generator step is enqueued beside it anyway; (ii) r03's driver run
+# lost a two-rank gloo step to a hang that 92 repetitions on MI355X did not reproduce (profiles/r04_dp_step_loop.txt) - the
+# second stream was the one r03 addition on that path, and a multi-rank run must not depend on it until it has run on RCCL
+# with N > 1.  tests/test_gpu_dp_step.py runs the two-rank step both ways.
+_BESIDE_ENV = os.environ.get('XAS_DISC_BESIDE_GEN')
+DISC_BESIDE_GEN = _BESIDE_ENV != '0'          # (kept for tools that read it: the single-process setting)
 _aux = {}
+
+
+def disc_beside_gen():
+    if _BESIDE_ENV is not None:
+        return _BESIDE_ENV != '0'
+    return not dp_active()
 
 
 def _aux_stream():
@@ -92,6 +105,8 @@ class TrainStep:
         self.disc_every = interval if interval >= 1 else 1
         self.gen_every = 1 if interval >= 1 else int(1.0 / interval)
         self.cur_step = 0
+        self.grad_probe = None      # measurement hook: called as grad_probe('disc' | 'det', gradient arena) just before the
+                                    # optimizer consumes it (bench.py's variant check); None on the training path
         self.red_det = self.red_disc = None
         opt_det.grad_arena                       # materialise the gradient arenas: conv weight gradients are
         if opt_disc is not None:                 # accumulated straight into them on a side stream
@@ -108,6 +123,17 @@ class TrainStep:
             dist.broadcast(opt_det.param_arena, src=0)
             if opt_disc is not None:
                 dist.broadcast(opt_disc.param_arena, src=0)
+
+    def _check_weight_range(self):
+        """The f16x3 weight format holds |w| < 64 (2^10 w in fp16): the weight-preparation kernels and the stem kernel flag
+        anything larger instead of letting a layer turn into inf / NaN unnoticed.  Tensor operands need no such check: their
+        scales come from recorded maxima (ops_nn).  Polled before the FIRST optimizer step - a checkpoint that does not fit
+        must not be trained on - and every 64 steps after; one device synchronisation each."""
+        if not next(self.model.regressor.parameters()).is_cuda:
+            return
+        if ops_nn.query('xas_get_precision') == 3 and ops_nn.query('xas_f16_weight_overflow', 1) == 1:
+            raise RuntimeError('a convolution weight has left the range of the f16x3 arithmetic (|w| >= 64 or NaN): '
+                               'run with XAS_PRECISION=2 (bf16x6)')
 
     def __call__(self, x):
         out = {}
@@ -137,6 +163,8 @@ class TrainStep:
             ops_nn.join_side_stream()
             if self.red_disc:
                 self.red_disc.finish()
+            if self.grad_probe is not None:
+                self.grad_probe('disc', self.opt_disc.grad_arena)
             self.opt_disc.step()
             self.opt_disc.zero_grad()
             return ld, info
@@ -145,7 +173,7 @@ class TrainStep:
         if do_disc:
             if shared is not None:
                 loss_disc, _ = disc_update({k: v['kps'] for k, v in shared[0].items()})
-            elif DISC_BESIDE_GEN and do_gen and next(self.model.regressor.parameters()).is_cuda:
+            elif disc_beside_gen() and do_gen and next(self.model.regressor.parameters()).is_cuda:
                 preds = self.disc.detector_pass(x, self.model.regressor)      # the detector pass stays on the main chain
                 main, aux = torch.cuda.current_stream(), _aux_stream()
                 aux.wait_stream(main)
@@ -183,15 +211,15 @@ class TrainStep:
             ops_nn.join_side_stream()
             if self.red_det:
                 self.red_det.finish()
+            if self.cur_step == 0:
+                self._check_weight_range()           # BEFORE the first update: weights as loaded (a checkpoint) must fit
+            if self.grad_probe is not None:
+                self.grad_probe('det', self.opt_det.grad_arena)
             self.opt_det.step()
             self.opt_det.zero_grad()
         if aux is not None:
             torch.cuda.current_stream().wait_stream(aux)     # (already joined when the adversarial term is part of the losses)
         self.cur_step += 1
-        if self.cur_step % 64 == 1 and next(self.model.regressor.parameters()).is_cuda:
-            # the f16x3 weight format holds |w| < 64: the preparation kernels flag anything larger (one device
-            # synchronisation after the first step and then every 64 steps) instead of letting a layer turn into inf / NaN unnoticed
-            if ops_nn.query('xas_get_precision') == 3 and ops_nn.query('xas_f16_weight_overflow', 1) == 1:
-                raise RuntimeError('a convolution weight has left the range of the f16x3 arithmetic (|w| >= 64 or NaN): '
-                                   'run with XAS_PRECISION=2 (bf16x6)')
+        if self.cur_step % 64 == 0:
+            self._check_weight_range()               # then every 64 steps (weights drift slowly; one device synchronisation)
         return loss_disc, loss_kp, total, out

@@ -229,16 +229,22 @@ MODE_F32 = 1 + _lib.PREC_F32          # ConvShape.mode of a call that must run o
 GRAD_IS_X = 0x100                     # xas_hip.h XAS_GRAD_IS_X
 
 
-# ---- maxima of gradient tensors (XAS_PREC_F16X3) -----------------------------------------------------------------
-# The f16x3 gradient kernels split dy into two fp16 pieces at a power-of-two scale taken from max |dy|.  The kernel that
-# WRITES a gradient tensor merges that maximum into a float of this arena (xas_bn_bwd_apply_amax: every conv of the
-# detector and of the physique net is followed by a norm, so its dy is a norm's dx); the tensor object carries the slot
-# (`_xas_amax`) to the conv backward that reads it, which passes the pointer on in its ConvShape.  A gradient that
-# arrives without a slot runs on the bf16x6 kernels.  Slots are handed out in order from a zeroed arena;
-# reset_grad_amax() (engine.TrainStep, once per step, after the streams have joined) rewinds and re-zeroes it.
-_amax = {'arena': None, 'next': 0, 'retired': []}
+# ---- maxima of tensor operands (XAS_PREC_F16X3) ------------------------------------------------------------------
+# The f16x3 kernels split EVERY tensor operand - activations and gradients - into two fp16 pieces at a power-of-two scale
+# taken from max |tensor| (r04: no fixed activation scale, hence no range an activation has to stay in).  The kernel that
+# WRITES a tensor merges that maximum into a float of this arena (xas_bn_apply_amax for activations - every conv input of
+# both networks except the images and the rendered masks is a norm's output; xas_bn_bwd_apply_amax / the soft-argmax
+# backward for gradients); the tensor object carries the slot (`_xas_amax`) to the conv that reads it, which passes the
+# pointer on in its ConvShape.  A conv INPUT that arrives without a slot gets one from xas_abs_max (one streaming read: the
+# images of a pass, 40 us at B = 32 x 8); a GRADIENT that arrives without a slot runs on the bf16x6 kernels.  Max pooling
+# and bilinear up-sampling hand their input's slot on (max |y| <= max |x|: an upper bound serves as well).  Slots are handed
+# out in order from a zeroed arena; reset_grad_amax() (engine.TrainStep, once per step, after the streams have joined)
+# rewinds and re-zeroes it and starts a new EPOCH: a tag from an earlier epoch (a tensor that outlived its step, e.g. a
+# resident input batch) is void.
+_amax = {'arena': None, 'next': 0, 'retired': [], 'epoch': 0}
 _AMAX_SLOTS = 4096
 GRAD_F16 = os.environ.get('XAS_GRAD_F16', '1') == '1'
+amax_stats = {'abs_max': 0}        # launches of xas_abs_max (tests: the hot path needs one per pass, for the images)
 
 
 def reset_grad_amax():
@@ -246,6 +252,7 @@ def reset_grad_amax():
         _amax['arena'].zero_()
     _amax['next'] = 0
     _amax['retired'] = []
+    _amax['epoch'] += 1
 
 
 def _amax_slot(device):
@@ -260,49 +267,106 @@ def _amax_slot(device):
     return a[i:i + 1]
 
 
+def f16x3_on():
+    return GRAD_F16 and query('xas_get_precision') == _lib.PREC_F16X3
+
+
 def grad_amax_slot(device):
-    """A zeroed float for a kernel that writes a gradient tensor to merge max |g| into; None outside XAS_PREC_F16X3."""
-    if not GRAD_F16 or query('xas_get_precision') != _lib.PREC_F16X3:
+    """A zeroed float for a kernel that writes a tensor to merge max |v| into; None outside XAS_PREC_F16X3."""
+    if not f16x3_on():
         return None
     return _amax_slot(device)
 
 
-_act_amax = {}
-
-
-def activation_amax(device):
-    """Pointer-able constant for a DATA-GRADIENT-type launch whose gathered operand is an ACTIVATION (the forward of a
-    ConvTranspose2d): 2^10 selects the fixed activation scale 2^4 of the f16x3 kernels (conv_shared.h kF16AScale)."""
-    t = _act_amax.get(device)
-    if t is None:
-        t = _act_amax[device] = torch.full((1,), 1024.0, device=device, dtype=torch.float32)
-    return t
-
-
 def tag_grad_amax(t, slot):
-    """Attach the slot that holds max |t| to the gradient tensor t (read by with_grad_amax)."""
-    t._xas_amax = (slot, t._version)
+    """Attach the slot that holds max |t| (or an upper bound) to the tensor t (read by amax_of / with_grad_amax)."""
+    t._xas_amax = (slot, t._version, _amax['epoch'])
 
 
-def with_grad_amax(shp, dy):
-    """ConvShape of a gradient launch that reads `dy`: with the pointer to max |dy| when its producer recorded one."""
-    tag = getattr(dy, '_xas_amax', None)
-    # (the tag holds the tensor's version counter at the time the maximum was recorded: a gradient that autograd has since
-    # accumulated into IN PLACE - a conv output with two consumers - no longer matches its maximum and runs as bf16x6)
-    if tag is None or tag[1] != dy._version or shp.mode != 0 or not GRAD_F16 or query('xas_get_precision') != _lib.PREC_F16X3:
+tag_amax = tag_grad_amax
+
+
+def amax_of(t):
+    """The slot recorded for tensor t, or None.  The tag holds the tensor's version counter at the time the maximum was
+    recorded - a tensor modified IN PLACE since (a gradient autograd accumulated into: a conv output with two consumers)
+    no longer matches its maximum - and the epoch of the slot arena (reset_grad_amax)."""
+    tag = getattr(t, '_xas_amax', None)
+    if tag is None or tag[1] != t._version or tag[2] != _amax['epoch']:
+        return None
+    return tag[0]
+
+
+def act_amax(x):
+    """Slot holding max |x| for the conv INPUT x (dense fp32 device tensor): the producer's, else measured now.  None
+    outside XAS_PREC_F16X3."""
+    if not x.is_cuda or x.dtype != torch.float32 or not f16x3_on():
+        return None
+    slot = amax_of(x)
+    if slot is None:
+        slot = _amax_slot(x.device)
+        call('xas_abs_max', ptr(x), x.numel(), ptr(slot))
+        tag_grad_amax(x, slot)
+        amax_stats['abs_max'] += 1
+    return slot
+
+
+def pass_amax(y, x):
+    """y = f(x) with max |y| <= max |x| (max pooling, bilinear interpolation): y inherits x's slot."""
+    slot = amax_of(x)
+    if slot is not None:
+        tag_grad_amax(y, slot)
+
+
+def _with_ptrs(shp, grad, x, mode=None):
+    return ConvShape(shp.N, shp.Hi, shp.Wi, shp.Cin, shp.Cout, shp.R, shp.S, shp.stride, shp.pad, shp.Ho, shp.Wo,
+                     shp.mode if mode is None else mode, grad.data_ptr() if grad is not None else None,
+                     x.data_ptr() if x is not None else None)
+
+
+def with_act_amax(shp, x):
+    """(ConvShape of a launch whose tensor operand is the ACTIVATION x, slot): with the pointer to max |x| in f16x3 mode
+    (shape unchanged and None otherwise)."""
+    if shp.mode != 0:
+        return shp, None
+    slot = act_amax(x)
+    if slot is None:
+        return shp, None
+    shp = _with_ptrs(shp, slot, None)
+    shp._slots = (slot,)                          # (the ctypes struct holds a raw pointer: keep the slot tensor alive with it)
+    return shp, slot
+
+
+def with_grad_amax(shp, dy, x_slot=None):
+    """ConvShape of a gradient launch that reads `dy`: grad_amax -> max |dy| when its producer recorded one, x_amax -> the
+    slot of the forward's input (weight gradient).  `shp` may be the forward's shape (its own pointers are dropped).
+    No valid maximum of dy: no pointers at all - every pass of the call runs as bf16x6."""
+    if shp.mode != 0:
         return shp
-    slot = tag[0]
-    return ConvShape(shp.N, shp.Hi, shp.Wi, shp.Cin, shp.Cout, shp.R, shp.S, shp.stride, shp.pad, shp.Ho, shp.Wo, 0,
-                     slot.data_ptr())
+    slot = amax_of(dy) if f16x3_on() else None
+    if slot is None:
+        return _with_ptrs(shp, None, None) if (shp.grad_amax or shp.x_amax) else shp
+    out = _with_ptrs(shp, slot, x_slot)
+    out._slots = (slot, x_slot)
+    return out
+
+
+def shape_with_maxima(shp, t, x=None):
+    """For callers outside the autograd layers (tests, tools/): the shape with the MEASURED maximum of the launch's tensor
+    operand t (x of a forward, dy of a gradient launch) and, for a weight gradient, of its x argument."""
+    a = act_amax(t)
+    b = act_amax(x) if x is not None else None
+    if a is None or shp.mode != 0:
+        return shp
+    out = _with_ptrs(shp, a, b)
+    out._slots = (a, b)
+    return out
 
 
 def grad_operand_shape(shp):
-    """ConvShape for a FORWARD-type launch whose input is a gradient tensor (the data gradient of a ConvTranspose2d is a
-    forward convolution of dy).  XAS_PREC_F16X3 splits the inputs of forward launches into fp16 pieces at a fixed scale
-    that suits activations, not gradients: such a call is pinned to the bf16x6 kernels."""
+    """ConvShape for a FORWARD-type launch whose input is a gradient tensor WITHOUT a recorded maximum (the data gradient of
+    a ConvTranspose2d is a forward convolution of dy): pinned to the bf16x6 kernels."""
     if shp.mode == 0 and query('xas_get_precision') == _lib.PREC_F16X3:
-        return ConvShape(shp.N, shp.Hi, shp.Wi, shp.Cin, shp.Cout, shp.R, shp.S, shp.stride, shp.pad, shp.Ho, shp.Wo,
-                         1 + _lib.PREC_BF16X6)
+        return _with_ptrs(shp, None, None, mode=1 + _lib.PREC_BF16X6)
     return shp
 
 
@@ -383,11 +447,11 @@ class _Conv2d(torch.autograd.Function):
         if ci != ci2:
             raise RuntimeError('conv2d: input has %d channels, weight expects %d' % (ci, ci2))
         ho, wo = (hi + 2 * pad - r) // stride + 1, (wi + 2 * pad - s) // stride + 1
-        shp = _shape(n, hi, wi, ci, co, r, s, stride, pad, ho, wo)
+        shp, x_slot = with_act_amax(_shape(n, hi, wi, ci, co, r, s, stride, pad, ho, wo), x)
         y = empty_cl(n, co, ho, wo, x)
         call('xas_conv_fwd', ptr(x), ptr(cache.get(weight, 0, shp)), ptr(bias), ptr(y), shp)
         ctx.save_for_backward(x, weight, *([bias] if bias is not None else []))
-        ctx.shp, ctx.cache, ctx.has_bias = shp, cache, bias is not None
+        ctx.shp, ctx.cache, ctx.has_bias, ctx.x_slot = shp, cache, bias is not None, x_slot
         if ctx.needs_input_grad[1]:
             note_use(weight)
         if bias is not None and ctx.needs_input_grad[2]:
@@ -397,7 +461,7 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight, *rest = ctx.saved_tensors
-        shp = with_grad_amax(ctx.shp, dy)
+        shp = with_grad_amax(ctx.shp, dy, ctx.x_slot)
         dy = to_cl(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -423,7 +487,7 @@ def _conv_forward(x, weight, stride, pad, cache):
     if ci != ci2:
         raise RuntimeError('conv2d: input has %d channels, weight expects %d' % (ci, ci2))
     ho, wo = (hi + 2 * pad - r) // stride + 1, (wi + 2 * pad - s) // stride + 1
-    shp = _shape(n, hi, wi, ci, co, r, s, stride, pad, ho, wo)
+    shp, _ = with_act_amax(_shape(n, hi, wi, ci, co, r, s, stride, pad, ho, wo), x)      # (the shape keeps the input's slot)
     y = empty_cl(n, co, ho, wo, x)
     call('xas_conv_fwd', ptr(x), ptr(cache.get(weight, 0, shp)), None, ptr(y), shp)
     return y, shp
@@ -448,7 +512,7 @@ def _conv_bn_forward(x, conv, bn, residual, group):
         raise RuntimeError('conv2d: input has %d channels, weight expects %d' % (ci, ci2))
     stride, pad = conv.stride, conv.padding
     ho, wo = (hi + 2 * pad - r) // stride + 1, (wi + 2 * pad - s) // stride + 1
-    shp = _shape(n, hi, wi, ci, co, r, s, stride, pad, ho, wo)
+    shp, _ = with_act_amax(_shape(n, hi, wi, ci, co, r, s, stride, pad, ho, wo), x)
     y = empty_cl(n, co, ho, wo, x)
     wp = conv._cache.get(weight, 0, shp)
     G = _groups[0]
@@ -494,7 +558,8 @@ def _conv_dgrad_bn_bwd(dy, conv, shp, saved, cfg, bn, want_param_grads):
               and gg.dtype == torch.float32 and gb.dtype == torch.float32)
     dz = torch.empty_like(xb)
     dx = torch.empty_like(xb)
-    call('xas_conv_dgrad_bn_bwd', ptr(dy), ptr(conv._cache.get(conv.weight, 1, shp)), shp, ptr(xb), ptr(mean), ptr(var),
+    shp_n = _with_ptrs(shp, None, None)          # this entry takes the weight format of the shape without maxima (xas_hip.h)
+    call('xas_conv_dgrad_bn_bwd', ptr(dy), ptr(conv._cache.get(conv.weight, 1, shp_n)), shp_n, ptr(xb), ptr(mean), ptr(var),
          ptr(gamma), ptr(beta), float(eps), G, float(count), ptr(dz), ptr(dx), ptr(sums), ptr(ws),
          ptr(gb) if direct else None, ptr(gg) if direct else None)
     if direct:
@@ -506,11 +571,17 @@ def _conv_dgrad_bn_bwd(dy, conv, shp, saved, cfg, bn, want_param_grads):
     return dx, None
 
 
+def _x_slot_of(fwd_shp):
+    """The input's slot a forward shape carries (with_act_amax), for the weight gradient of the same layer."""
+    sl = getattr(fwd_shp, '_slots', None)
+    return sl[0] if sl else None
+
+
 def _conv_backward(x, weight, dy, shp, cache, need_dx, need_dw, acc_into=None):
     """-> (dx, dw).  acc_into: a gradient buffer of x's shape that already holds the other branch's gradient; the
     data gradient is added to it in the kernel epilogue.  dw is None when it went straight into weight.grad."""
     dx = dw = None
-    shp = with_grad_amax(shp, dy)
+    shp = with_grad_amax(shp, dy, _x_slot_of(shp))
     if need_dx:
         if acc_into is not None:
             dx = acc_into
@@ -596,9 +667,10 @@ class _Bottleneck(torch.autograd.Function):
             if FUSE_DGRAD_BN and _bn_bwd_fusable(cf) and (want_bn or (id(bn.weight) not in need and id(bn.bias) not in need)):
                 # conv_i's data gradient with bn_{i-1}'s backward reductions in its epilogue
                 dyc = g
-                g, dgb = _conv_dgrad_bn_bwd(dyc, convs[i], shps[o + i], saved[o + i - 1], cf, bn, want_bn)
-                if id(convs[i].weight) in need and not _wgrad_into_grad(ins[i], dyc, shps[o + i], convs[i].weight):
-                    pgrads[id(convs[i].weight)] = _wgrad(ins[i], dyc, shps[o + i], convs[i].weight.shape)
+                shp_b = with_grad_amax(shps[o + i], dyc, _x_slot_of(shps[o + i]))      # (the fused data gradient ignores the maxima)
+                g, dgb = _conv_dgrad_bn_bwd(dyc, convs[i], shp_b, saved[o + i - 1], cf, bn, want_bn)
+                if id(convs[i].weight) in need and not _wgrad_into_grad(ins[i], dyc, shp_b, convs[i].weight):
+                    pgrads[id(convs[i].weight)] = _wgrad(ins[i], dyc, shp_b, convs[i].weight.shape)
                 if dgb is not None:
                     pgrads[id(bn.weight)], pgrads[id(bn.bias)] = dgb
                 continue
@@ -608,7 +680,7 @@ class _Bottleneck(torch.autograd.Function):
             g, _ = bn_b(o + i - 1, bns[i - 1], g)
         if fuse_skip:
             dx = torch.empty_like(x)
-            shp0 = with_grad_amax(shps[o], g)
+            shp0 = with_grad_amax(shps[o], g, _x_slot_of(shps[o]))
             call('xas_conv_dgrad_acc_masked', ptr(g), ptr(convs[0]._cache.get(convs[0].weight, 1, shp0)), ptr(dx), shp0,
                  ptr(dout), ptr(saved[o + 2][1]))
             if id(convs[0].weight) in need and not _wgrad_into_grad(x, g, shp0, convs[0].weight):
@@ -655,13 +727,11 @@ class _ConvTranspose2d(torch.autograd.Function):
         # equivalent conv: big side (hb,wb,cot) -> small side (h,w,cit)
         shp = _shape(n, hb, wb, cot, cit, r, s, stride, pad, h, w)
         y = empty_cl(n, cot, hb, wb, x)
-        shp_f = shp
-        if x.is_cuda and GRAD_F16 and query('xas_get_precision') == _lib.PREC_F16X3:
-            # the gathered operand of this data-gradient-type launch is an activation: fixed scale (see activation_amax)
-            shp_f = ConvShape(n, hb, wb, cot, cit, r, s, stride, pad, h, w, 0, activation_amax(x.device).data_ptr())
+        # the gathered operand of this data-gradient-type launch is the activation x: its maximum selects the scale
+        shp_f, x_slot = with_act_amax(shp, x)
         call('xas_conv_dgrad', ptr(x), ptr(cache.get(weight, 1, shp_f)), ptr(y), shp_f)
         ctx.save_for_backward(x, weight)
-        ctx.shp, ctx.cache = shp, cache
+        ctx.shp, ctx.cache, ctx.x_slot = shp, cache, x_slot
         if ctx.needs_input_grad[1]:
             note_use(weight)
         return y
@@ -679,9 +749,9 @@ class _ConvTranspose2d(torch.autograd.Function):
             if shp_g is shp:
                 shp_g = grad_operand_shape(shp)
             call('xas_conv_fwd', ptr(dy), ptr(ctx.cache.get(weight, 0, shp_g)), None, ptr(dx), shp_g)
-        shp_w = with_grad_amax(shp, dy_in)
+        shp_w = with_grad_amax(shp, dy_in, ctx.x_slot)      # grad_amax: max |dy|, x_amax: max |x| ...
         if shp_w is not shp:
-            shp_w.mode = GRAD_IS_X                          # the gradient tensor is the weight gradient's `x` argument here
+            shp_w.mode = GRAD_IS_X                          # ... and the gradient tensor is the weight gradient's `x` argument here
         if ctx.needs_input_grad[1] and not _wgrad_into_grad(dy, x, shp_w, weight):
             dw = _wgrad(dy, x, shp_w, weight.shape)
         return dx, dw, None, None, None
@@ -847,7 +917,11 @@ def _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, m
     # byte per float4 (1/16 of y's bytes) - neither backward pass reads y
     masked = training and residual is not None and act != ACT_NONE and os.environ.get('XAS_BN_MASK', '1') == '1'
     mask = torch.empty(M * c // 4, device=dev, dtype=torch.uint8) if masked else None
-    call('xas_bn_apply', ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(res), float(eps), act, M, c, G, ptr(y), ptr(mask))
+    slot = grad_amax_slot(dev) if x.is_cuda else None
+    call('xas_bn_apply_amax', ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(res), float(eps), act, M, c, G, ptr(y), ptr(mask),
+         ptr(slot))
+    if slot is not None:
+        tag_grad_amax(y, slot)                   # max |y|: the next conv scales its fp16 pieces with it
     # Backward traffic: which of x / y the backward passes need
     #   leaky ReLU, no residual : neither pass reads x (xhat recovered from the invertible output y);
     #   ReLU, no residual       : neither pass reads y (the mask is re-derived from x: 2 reads + 1 write in the apply
@@ -948,6 +1022,7 @@ class _MaxPool(torch.autograd.Function):
         y = empty_cl(n, c, ho, wo, x)
         idx = torch.empty(n * ho * wo * c, device=x.device, dtype=torch.int8)
         call('xas_maxpool3x3s2_fwd', ptr(x), n, h, w, c, ptr(y), ptr(idx))
+        pass_amax(y, x)
         ctx.save_for_backward(idx)
         ctx.shape = (n, c, h, w)
         return y
@@ -973,6 +1048,7 @@ class _Upsample2x(torch.autograd.Function):
         n, c, h, w = x.shape
         y = empty_cl(n, c, 2 * h, 2 * w, x)
         call('xas_upsample2x_fwd', ptr(x), n, h, w, c, ptr(y))
+        pass_amax(y, x)
         ctx.shape = (n, c, h, w)
         return y
 
@@ -1050,7 +1126,8 @@ def prepack(module):
             cache.get(w, 0, shp)
             cache.get(w, 1, shp)
             if (prec == _lib.PREC_F16X3 and GRAD_F16 and shp.mode == 0 and query('xas_conv_weight_planes', shp, 1) == 3):
-                cache.get(w, 1, shp, planes=2)         # the data gradient's second format (dy with its maximum)
+                cache.get(w, 0, shp, planes=2)         # the formats of launches that come with their operand maxima
+                cache.get(w, 1, shp, planes=2)
         return
     key = (prec, tuple(w.data_ptr() for _, _, w, _ in entries))
     tab = getattr(module, '_xas_prep', None)
@@ -1058,12 +1135,15 @@ def prepack(module):
         rows_of, views, desc, blk, off = [], [], [], 0, 0
         sizes = []
         for idx, (_, cache, w, shp) in enumerate(entries):
-            for t, extra in ((0, False), (1, False), (1, True)):
-                planes = query('xas_conv_weight_planes', shp, t)
-                if extra:                      # f16x3: the data gradient also runs on two fp16 planes when its dy comes with
-                    if not (planes == 3 and prec == _lib.PREC_F16X3 and GRAD_F16 and shp.mode == 0):   # its maximum
-                        continue
+            f16 = prec == _lib.PREC_F16X3 and GRAD_F16 and shp.mode == 0
+            for t, extra in ((0, False), (1, False), (0, True), (1, True)):
+                planes = query('xas_conv_weight_planes', shp, t)      # (dummy shape without operand maxima)
+                if extra:                      # f16x3: launches that come with the maxima of their operands run on two fp16
+                    if not (planes == 3 and f16):                      # planes - every forward, every data gradient whose
+                        continue                                       # dy was tagged
                     planes = 2
+                elif t == 0 and planes == 3 and f16:
+                    continue                   # forward launches always come with max |x| (act_amax): three planes only on demand
                 if not planes or not w.is_contiguous():
                     continue
                 co, ci, r, s = w.shape
