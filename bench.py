@@ -75,7 +75,7 @@ def cpu_baseline(workload, threads):
                       % (workload, B, times[0], ' '.join('%.1f' % t for t in times[1:]))}
 
 
-def train_step_variant_check(step, x, model, disc, opt_det, opt_disc, xl, precision):
+def train_step_variant_check(step, x, model, disc, opt_det, opt_disc, xl, precision, base_tune=0):
     """One full TRAIN-MODE step at the benchmark size in `precision` and one on the exact-fp32 MFMA kernels, both from the SAME
     state (parameters, Adam moments, running statistics snapshot / restored): relative difference of every loss term and of
     the two gradient arenas as the optimizers would consume them (condition c)."""
@@ -84,7 +84,9 @@ def train_step_variant_check(step, x, model, disc, opt_det, opt_disc, xl, precis
     bufs = [b for m in (model, disc) for b in m.buffers()]
 
     def snapshot():
-        return ([t.clone() for f in (f_det, f_disc) if f is not None for t in (f['p'], f['m'], f['v'])],
+        # (the gradient arenas too: the generator's backward leaves gradients in the DISCRIMINATOR's arena that the next
+        # discriminator update consumes - train.py:160-190 never zeroes them in between, and neither does the mirror)
+        return ([t.clone() for f in (f_det, f_disc) if f is not None for t in (f['p'], f['m'], f['v'], f['g'])],
                 [b.clone() for b in bufs], opt_det._steps, opt_disc._steps if opt_disc is not None else 0, step.cur_step)
 
     def restore(sn):
@@ -93,7 +95,7 @@ def train_step_variant_check(step, x, model, disc, opt_det, opt_disc, xl, precis
         with torch.no_grad():
             for f in (f_det, f_disc):
                 if f is not None:
-                    for k in ('p', 'm', 'v'):
+                    for k in ('p', 'm', 'v', 'g'):
                         f[k].copy_(next(it))
             for b, v in zip(bufs, bs):
                 b.copy_(v)
@@ -104,14 +106,17 @@ def train_step_variant_check(step, x, model, disc, opt_det, opt_disc, xl, precis
             opt_disc._epoch[0] += 1
         step.cur_step = cur
 
-    def run(prec):
+    def run(prec, tune=None):
+        tune = base_tune if tune is None else tune
         xl.query('xas_set_precision', prec)
+        xl.query('xas_set_tuning', tune)
         torch.manual_seed(4242)                      # the discriminator's dropout mask: the same in both runs
         grads = {}
         step.grad_probe = lambda which, arena: grads.__setitem__(which, arena.clone())
         ld, lk, tot, _ = step(x)
         step.grad_probe = None
         torch.cuda.synchronize()
+        xl.query('xas_set_tuning', base_tune)
         losses = {'disc': float(ld.detach()) if ld is not None else 0.0, 'total': float(tot.detach())}
         losses.update({k: float(v.detach().mean()) for k, v in lk.items()})
         return losses, grads
@@ -121,10 +126,23 @@ def train_step_variant_check(step, x, model, disc, opt_det, opt_disc, xl, precis
     restore(sn)
     lb, gb = run(xl.PREC_F32)
     restore(sn)
+    ref = None
+    if precision != 'bf16x6':                        # the range-free six-product mode against the same exact-fp32 run: the yardstick
+        lc, gc = run(xl.PREC_BF16X6)
+        restore(sn)
+        ref = {'max_loss_rel_diff': max([abs(lc[k] - lb[k]) / max(abs(lb[k]), 1e-30) for k in lb if lb[k] != 0.0 or lc[k] != 0.0] or [0.0]),
+               'grad_arena_rel_diff': {k: float((gc[k] - gb[k]).double().norm() / gb[k].double().norm().clamp_min(1e-300)) for k in gb}}
+    # ... and the exact-fp32 kernels against THEMSELVES with another summation order (tuning bits 32 | 524288: plain K loops in
+    # forward / data gradient / weight gradient): how far two exact-fp32 evaluations of this step's gradient are apart
+    ld_, gd_ = run(xl.PREC_F32, tune=32 | 524288)
+    restore(sn)
+    reorder = {'max_loss_rel_diff': max([abs(ld_[k] - lb[k]) / max(abs(lb[k]), 1e-30) for k in lb if lb[k] != 0.0 or ld_[k] != 0.0] or [0.0]),
+               'grad_arena_rel_diff': {k: float((gd_[k] - gb[k]).double().norm() / gb[k].double().norm().clamp_min(1e-300)) for k in gb}}
     xl.query('xas_set_precision', xl.PREC_NAMES[precision])
     rel = {k: abs(la[k] - lb[k]) / max(abs(lb[k]), 1e-30) for k in lb if lb[k] != 0.0 or la[k] != 0.0}
     gr = {k: float((ga[k] - gb[k]).double().norm() / gb[k].double().norm().clamp_min(1e-300)) for k in gb}
-    return {'what': 'ONE train-mode step (disc + gen, B as timed) in this precision mode vs the exact-fp32 MFMA kernels from the same '
+    return {**({'bf16x6_vs_exact_fp32_same_state': ref} if ref else {}),
+            'exact_fp32_other_summation_order_vs_exact_fp32_same_state': reorder,'what': 'ONE train-mode step (disc + gen, B as timed) in this precision mode vs the exact-fp32 MFMA kernels from the same '
                     'state: |loss_mode - loss_f32| / |loss_f32| per loss term, ||g_mode - g_f32|| / ||g_f32|| over each gradient arena '
                     'as handed to Adam',
             'loss_rel_diff': rel, 'max_loss_rel_diff': max(rel.values()) if rel else 0.0,
@@ -168,6 +186,8 @@ def main():
     ap.add_argument('--f32-steps', type=int, default=5,
                     help='extra UNTIMED-by-the-headline steps on the exact-fp32 MFMA kernels after the timed region, to print '
                          'that figure beside the bf16x6 headline (0 = skip)')
+    ap.add_argument('--no-variant-check', action='store_true',
+                    help='skip the untimed precision cross-checks after the timed region (profiling runs: keeps other modes out of the trace)')
     ap.add_argument('--dedupe', action='store_true',
                     help='NOT the headline: share the real-image detector forward between the discriminator and the '
                          'generator update (engine.TrainStep(dedupe=True)); the JSON line is marked config.dedupe')
@@ -318,7 +338,7 @@ def main():
                             'measured in this run' % (tname, pmc.get('collected', 'see file')))
                 break
         variant_check = None
-        if args.precision != 'f32':
+        if args.precision != 'f32' and not args.no_variant_check:
             # this mode's distance to the exact-fp32 MFMA path, measured here (untimed): joints of one detector pass on 8 images
             reg = model.regressor
             was = reg.training
@@ -333,7 +353,7 @@ def main():
             variant_check = {'max_abs_joint_diff_vs_exact_fp32_mfma': float((kv - k32).abs().max()),
                              'what': 'detector forward (eval-mode norms) on 8 images, this precision mode vs the exact-fp32 MFMA kernels; parity bar 1e-4'}
             if world == 1:
-                variant_check['train_step'] = train_step_variant_check(step, x, model, disc, opt_det, opt_disc, _xl, args.precision)
+                variant_check['train_step'] = train_step_variant_check(step, x, model, disc, opt_det, opt_disc, _xl, args.precision, args.tune)
         kernel_names = {':bf16x6': 'igemm_x6_kernel<.,.,.,3> (fwd / dgrad) + wgrad_x6_kernel<.,.,3>: bf16x6 MFMA implicit-GEMM conv family',
                         ':f16x3': 'igemm_x6_kernel<.,.,.,2> / igemm_x6t_kernel<.,.,2> (fwd / dgrad) + wgrad_x6_kernel<.,.,2> / wgrad_x6t_kernel<.,2>: f16x3 MFMA implicit-GEMM conv family',
                         ':bf16': 'igemm_x6_kernel<.,.,.,1> + wgrad_x6_kernel<.,.,1>: bf16 MFMA implicit-GEMM conv family',

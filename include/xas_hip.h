@@ -62,6 +62,15 @@ int xas_set_tuning(int flags);
  * xas_set_precision sets the process default; a call overrides it with xas_conv_shape.mode = 1 + XAS_PREC_* (0 = default).
  * In the split modes forward / data gradient take PRE-SPLIT weights: see xas_conv_weight_planes / xas_split_weight. */
 enum { XAS_PREC_F32 = 0, XAS_PREC_BF16 = 1, XAS_PREC_BF16X6 = 2, XAS_PREC_F16X3 = 3 };
+/* A RECORDED MAXIMUM ("amax slot": xas_conv_shape.grad_amax / x_amax, the amax_out arguments) is an array of
+ * XAS_AMAX_SLOT_FLOATS floats in device memory, 16-byte aligned: XAS_AMAX_SUB sub-maxima XAS_AMAX_STRIDE floats (128 bytes)
+ * apart; the value is the maximum over the sub-maxima (the other floats are not touched).  Producers merge with one atomic
+ * per block into the sub-maximum the block index selects - one address per tensor serialised 16 384 atomics per launch, 190 us.
+ * ZERO the whole array before the first producer merges into it.  To hand over a maximum computed elsewhere, write it to
+ * element 0 of a zeroed array. */
+#define XAS_AMAX_SUB 32
+#define XAS_AMAX_STRIDE 32
+#define XAS_AMAX_SLOT_FLOATS (XAS_AMAX_SUB * XAS_AMAX_STRIDE)
 enum { XAS_GRAD_IS_X = 0x100 };      /* flag of xas_conv_shape.mode */
 int xas_set_precision(int mode);
 int xas_get_precision(void);
@@ -307,13 +316,13 @@ int xas_col_sum_acc(const float* x, long M, int C, float* acc, float* workspace,
 int xas_bn_apply(const float* x, const float* mean, const float* var_biased, const float* gamma,
                  const float* beta, const float* residual, float eps, int act, long M, int C, int groups,
                  float* y, uint8_t* mask_out, void* stream);
-/* Same, and max |y| over the whole result is merged into *amax_out (device float, zeroed by the caller; atomic maximum on
- * the bit pattern): the scale of y as the input of the next convolution's f16x3 launches (xas_conv_shape.grad_amax; x_amax of
+/* Same, and max |y| over the whole result is merged into the amax slot amax_out (XAS_AMAX_SLOT_FLOATS floats, zeroed by the
+ * caller; atomic maximum on the bit pattern): the scale of y as the input of the next convolution's f16x3 launches (xas_conv_shape.grad_amax; x_amax of
  * its weight gradient).  amax_out == NULL: xas_bn_apply. */
 int xas_bn_apply_amax(const float* x, const float* mean, const float* var_biased, const float* gamma,
                       const float* beta, const float* residual, float eps, int act, long M, int C, int groups,
                       float* y, uint8_t* mask_out, float* amax_out, void* stream);
-/* max |x| over n floats merged into *amax_out (as above): for convolution inputs that no kernel of this library wrote
+/* max |x| over n floats merged into the amax slot amax_out (as above): for convolution inputs that no kernel of this library wrote
  * (images, rendered masks).  One streaming read. */
 int xas_abs_max(const float* x, long n, float* amax_out, void* stream);
 /* running = (1-momentum)*running + momentum*stat_g for g = 0..groups-1; var uses the unbiased estimate n/(n-1). */
@@ -337,8 +346,8 @@ int xas_bn_bwd_apply(const float* x, const float* y, const float* dy, const floa
                      const float* var_biased, const float* gamma, const float* beta, const float* sums,
                      float eps, int act, long M, int C, int groups, double count,
                      float* dx, float* dresidual, const uint8_t* mask, void* stream);
-/* Same, and max |dx| over the whole result is merged into *amax_out (device float, zeroed by the caller before the first
- * launch that merges into it; atomic maximum on the bit pattern): the scale of dx as the gradient operand of the f16x3
+/* Same, and max |dx| over the whole result is merged into the amax slot amax_out (XAS_AMAX_SLOT_FLOATS device floats, zeroed
+ * by the caller before the first launch that merges into it; atomic maximum on the bit pattern): the scale of dx as the gradient operand of the f16x3
  * data / weight gradients (xas_conv_shape.grad_amax).  amax_out == NULL: xas_bn_bwd_apply. */
 int xas_bn_bwd_apply_amax(const float* x, const float* y, const float* dy, const float* mean,
                           const float* var_biased, const float* gamma, const float* beta, const float* sums,

@@ -155,7 +155,16 @@ def test_physique_forward_groups_equals_separate_calls():
     yb.pow(2).sum().backward()
     assert maxabs(yb, torch.cat(ya)) < 5e-6
     assert rel(xb.grad, torch.cat([m.grad for m in xa])) < 2e-4
+    ga = dict(a.named_parameters())
     for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if n.endswith('.bias') and n[:-5] + '.weight' in ga and ga[n[:-5] + '.weight'].dim() == 4 and not n.startswith('decoder.4'):
+            # the bias of a convolution that feeds a batch norm has NO gradient in exact arithmetic (the norm removes the mean):
+            # what both evaluations hold is rounding noise of the column sums, compared against the scale of the layer's
+            # weight gradient instead of against itself (the two evaluations split their operands at different maxima - one
+            # slot per call - so their noise is not bit-identical)
+            scale = float(ga[n[:-5] + '.weight'].grad.norm())
+            assert float((pb.grad - pa.grad).norm()) < 2e-4 * scale, n
+            continue
         assert rel(pb.grad, pa.grad) < 2e-4, n
     for k, v in a.state_dict().items():
         if 'running' in k:

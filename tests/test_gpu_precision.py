@@ -134,7 +134,7 @@ def test_conv_f16x3_any_operand_magnitude():
             y = m(xg)
             # dy with its maximum, as a norm's backward would hand it over
             dy = gy.cuda().contiguous(memory_format=torch.channels_last)
-            O.tag_grad_amax(dy, dy.abs().max().reshape(1).contiguous())
+            O.tag_grad_amax(dy, O.amax_slot_from_value(dy.abs().max()))
             y.backward(dy)
             torch.cuda.synchronize()
         xd, wd = x.double().requires_grad_(True), wt.double().requires_grad_(True)
@@ -209,7 +209,7 @@ def test_maxima_travel_with_the_tensors_on_the_hot_path():
         xin.mul_(2.0)
         s2 = O.act_amax(xin)
         torch.cuda.synchronize()
-        assert abs(float(s2) - float(xin.abs().max())) == 0.0
+        assert float(s2.max()) == float(xin.abs().max()) and int((s2 != 0).sum()) <= 32
         xin.add_(1.0)                                   # modified in place: the recorded maximum no longer describes it
         assert O.amax_of(xin) is None
 
@@ -249,7 +249,7 @@ def test_f16x3_gradients_with_amax(n, cin, h, w, cout, k, stride, pad, scale):
     dref = torch.nn.grad.conv2d_input((n, cin, h, w), wt.double(), dy.double(), stride, pad)
     with precision_mode('f16x3'):
         dyc = O.to_cl(dy.cuda())
-        amax = dyc.abs().max().reshape(1).contiguous()
+        amax = O.amax_slot_from_value(dyc.abs().max())
         shp = ConvShape(n, h, w, cin, cout, k, k, stride, pad, ho, wo, 0, amax.data_ptr())
         assert query('xas_conv_weight_planes', shp, 1) == 2
         cache = O._PackCache()
@@ -259,7 +259,7 @@ def test_f16x3_gradients_with_amax(n, cin, h, w, cout, k, stride, pad, scale):
         # weight gradient: x and dy each at the scale of its maximum
         x = torch.randn(n, cin, h, w, generator=g) * 2.0 + 0.3
         xc = O.to_cl(x.cuda())
-        xmax = xc.abs().max().reshape(1).contiguous()
+        xmax = O.amax_slot_from_value(xc.abs().max())
         shp = ConvShape(n, h, w, cin, cout, k, k, stride, pad, ho, wo, 0, amax.data_ptr(), xmax.data_ptr())
         assert query('xas_conv_kernel_class', shp, 2) in (4, 1)          # (shapes outside the split kernels: exact fp32)
         dw = torch.empty(cout, cin, k, k, device='cuda')

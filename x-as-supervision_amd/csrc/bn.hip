@@ -436,18 +436,6 @@ __device__ __forceinline__ float act_fwd(float v, int act) {
   return act == 0 ? v : (act == 1 ? fmaxf(v, 0.f) : (v > 0.f ? v : 0.01f * v));
 }
 
-// max |v| of a launch -> *out (zeroed by the caller before the launch): non-negative floats order like their bit patterns, and
-// +inf sorts above every finite value (the consumer then keeps scale 1: the inf reaches its fp16 pieces and the result, as it
-// would in fp32).  NaN elements do NOT enter the maximum (fmaxf drops them): they travel in the data itself.
-__device__ __forceinline__ void publish_amax(float* out, float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(v));
-}
-__device__ __forceinline__ float amax4(float a, float4 o) {
-  return fmaxf(fmaxf(a, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
-}
-
 // grid.y = group: the rows of group g use mean / var row g ([G][C]); n4g = float4 elements per group
 __global__ void bn_apply_kernel(const float4* __restrict__ x, const float* __restrict__ mean,
                                 const float* __restrict__ var, const float* __restrict__ gamma,

@@ -84,6 +84,43 @@ __device__ __forceinline__ float4 stream_load(const float4* p) {
 #endif
 }
 
+// ---- recorded maxima (the scales of the f16x3 tensor operands) ---------------------------------------------------------
+// A maximum is kept as kAmaxSub sub-maxima kAmaxStride floats (128 bytes) apart - XAS_AMAX_SLOT_FLOATS floats in all; its value
+// is the max over the sub-maxima.  One address per tensor serialised EVERY finishing wave of a producer at the L2 atomic unit:
+// 16 384 same-address atomics = 190 us flat per launch (r04 trace: a 10 us norm kernel took 190 us with the maximum switched
+// on; the backward apply kernels had carried that cost since r03).  Now a block reduces through LDS and issues ONE atomic to
+// the sub-maximum its index selects: <= 128 atomics per address and launch.
+constexpr int kAmaxSub = XAS_AMAX_SUB, kAmaxStride = XAS_AMAX_STRIDE;
+static_assert(kAmaxSub == 32 && kAmaxSub * kAmaxStride == XAS_AMAX_SLOT_FLOATS, "amax slot layout");
+
+// max |v| of a launch -> out (zeroed by the caller before the first launch that merges into it): non-negative floats order
+// like their bit patterns, and +inf sorts above every finite value (the consumer then keeps scale 1: the inf reaches its fp16
+// pieces and the result, as it would in fp32).  NaN elements do NOT enter the maximum (fmaxf drops them): they travel in the
+// data itself.  EVERY thread of the block must call (block-wide barrier inside).
+__device__ __forceinline__ void publish_amax(float* out, float v) {
+  __shared__ float s_amx[16];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  const int nw = ((int)blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) s_amx[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < nw; ++w) v = fmaxf(v, s_amx[w]);
+    const unsigned sub = (blockIdx.x + blockIdx.y * gridDim.x) % (unsigned)kAmaxSub;
+    if (v > 0.f) atomicMax(reinterpret_cast<unsigned*>(out + sub * kAmaxStride), __float_as_uint(v));
+  }
+}
+__device__ __forceinline__ float amax4(float a, float4 o) {
+  return fmaxf(fmaxf(a, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+}
+// the value of a recorded maximum (wave-uniform): lane l reads sub-maximum l mod 32, butterfly over the wave
+__device__ __forceinline__ float read_amax(const float* amax) {
+  float v = amax[(threadIdx.x & (kAmaxSub - 1)) * kAmaxStride];
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 

@@ -124,7 +124,7 @@ constexpr float kF16Descale = 1.f / (kF16WScale * kF16AScale);
 // scale of a gradient operand from its maximum magnitude (wave-uniform): amax in [2^(e-127), 2^(e-126)) -> 2^(141 - e), i.e.
 // amax * scale in [2^14, 2^15).  Zero / denormal-range maxima: 1 (nothing to resolve).  *inv = 1 / scale (exact).
 __device__ __forceinline__ float f16_grad_scale(const float* amax, float* inv) {
-  const unsigned bits = __builtin_amdgcn_readfirstlane(__float_as_uint(*amax));
+  const unsigned bits = __builtin_amdgcn_readfirstlane(__float_as_uint(read_amax(amax)));
   const int e = (int)((bits >> 23) & 0xffu);
   if (e < 40 || e > 250) { *inv = 1.f; return 1.f; }
   *inv = __uint_as_float((unsigned)(e - 14) << 23);           // 2^(e - 141)

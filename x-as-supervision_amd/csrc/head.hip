@@ -241,7 +241,9 @@ __global__ void head_bwd_kernel(const float4* __restrict__ logits, const float* 
   if (amax_out) {                                      // (the block is not a whole number of waves: reduce through LDS)
     if (amx > 0.f) atomicMax(&s_amax, __float_as_uint(amx));
     __syncthreads();
-    if (threadIdx.x == 0 && s_amax) atomicMax(reinterpret_cast<unsigned*>(amax_out), s_amax);
+    // one atomic per block, to the sub-maximum the block index selects (common.h: recorded maxima)
+    const unsigned sub = (blockIdx.x + blockIdx.y * gridDim.x) % (unsigned)kAmaxSub;
+    if (threadIdx.x == 0 && s_amax) atomicMax(reinterpret_cast<unsigned*>(amax_out + sub * kAmaxStride), s_amax);
   }
 }
 

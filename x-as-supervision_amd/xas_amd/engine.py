@@ -208,7 +208,7 @@ class TrainStep:
             if self.red_det:
                 self.red_det.arm()
             total.backward()
-            ops_nn.join_side_stream()
+            ops_nn.join_side_stream(reset_chains=True)
             if self.red_det:
                 self.red_det.finish()
             if self.cur_step == 0:

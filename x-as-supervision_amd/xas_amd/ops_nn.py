@@ -75,16 +75,20 @@ def _keep_for_side(*tensors):
         owner.wait_event(old_ev)
 
 
-def join_side_stream():
+def join_side_stream(reset_chains=False):
     """Make the current stream wait for every weight gradient launched on the side stream, and for the pass chains of the
-    step (streams.chains: their backward kernels add norm-parameter gradients to the arena on their own streams)."""
+    step (streams.chains: their backward kernels add norm-parameter gradients to the arena on their own streams).
+    reset_chains=True forgets the chains afterwards: ONLY the join that follows the generator backward does that
+    (engine.TrainStep) - the discriminator update, its reducer and its optimizer join from their own stream in the middle of a
+    step, and the generator's chains, recorded before, must still be known to the join after the generator backward."""
     cur = torch.cuda.current_stream()
     if _side['dirty'] and _side['stream'] is not None:
         cur.wait_stream(_side['stream'])
         _side['dirty'] = False
     for s in streams.chain_streams_in_use():
         cur.wait_stream(s)
-    streams.reset_chain_use()
+    if reset_chains:
+        streams.reset_chain_use()
     if _side.get('keep'):
         _side['keep'] = []
 
@@ -242,14 +246,15 @@ GRAD_IS_X = 0x100                     # xas_hip.h XAS_GRAD_IS_X
 # rewinds and re-zeroes it and starts a new EPOCH: a tag from an earlier epoch (a tensor that outlived its step, e.g. a
 # resident input batch) is void.
 _amax = {'arena': None, 'next': 0, 'retired': [], 'epoch': 0}
-_AMAX_SLOTS = 4096
+_AMAX_SLOTS = 2048
+AMAX_SLOT_FLOATS = 1024            # xas_hip.h XAS_AMAX_SLOT_FLOATS: 32 sub-maxima 128 bytes apart (one atomic per block, spread)
 GRAD_F16 = os.environ.get('XAS_GRAD_F16', '1') == '1'
 amax_stats = {'abs_max': 0}        # launches of xas_abs_max (tests: the hot path needs one per pass, for the images)
 
 
 def reset_grad_amax():
     if _amax['arena'] is not None and _amax['next'] > 0:
-        _amax['arena'].zero_()
+        _amax['arena'][:_amax['next'] * AMAX_SLOT_FLOATS].zero_()          # (only the slots that were handed out)
     _amax['next'] = 0
     _amax['retired'] = []
     _amax['epoch'] += 1
@@ -260,11 +265,18 @@ def _amax_slot(device):
     if a is None or a.device != device or _amax['next'] >= _AMAX_SLOTS:
         if a is not None:
             _amax['retired'] = (_amax['retired'] + [a])[-4:]      # kernels in flight may still read the last few
-        a = _amax['arena'] = torch.zeros(_AMAX_SLOTS, device=device, dtype=torch.float32)
+        a = _amax['arena'] = torch.zeros(_AMAX_SLOTS * AMAX_SLOT_FLOATS, device=device, dtype=torch.float32)
         _amax['next'] = 0
     i = _amax['next']
     _amax['next'] = i + 1
-    return a[i:i + 1]
+    return a[i * AMAX_SLOT_FLOATS:(i + 1) * AMAX_SLOT_FLOATS]
+
+
+def amax_slot_from_value(v):
+    """An amax slot holding the maximum `v` (0-dim or 1-element device tensor) computed elsewhere - tests, tools."""
+    s = torch.zeros(AMAX_SLOT_FLOATS, device=v.device, dtype=torch.float32)
+    s[0] = v.reshape(())
+    return s
 
 
 def f16x3_on():

@@ -11,7 +11,7 @@ CONV_ENTRIES = ('xas_conv_fwd', 'xas_conv_fwd_bnstats', 'xas_conv_dgrad', 'xas_c
 
 
 # batch-norm entry points (HBM bound): the `flops` field of their records carries the algorithmic HBM BYTES of the call
-BN_ENTRIES = ('xas_bn_stats', 'xas_bn_apply', 'xas_bn_bwd_reduce', 'xas_bn_bwd_apply', 'xas_bn_bwd_apply_amax')
+BN_ENTRIES = ('xas_bn_stats', 'xas_bn_apply', 'xas_bn_apply_amax', 'xas_bn_bwd_reduce', 'xas_bn_bwd_apply', 'xas_bn_bwd_apply_amax')
 
 
 def bn_bytes(name, a):
@@ -19,7 +19,7 @@ def bn_bytes(name, a):
     sign masks are one byte per float4)."""
     if name == 'xas_bn_stats':                      # (x, M, C, ...)
         return 4.0 * a[1] * a[2]
-    if name == 'xas_bn_apply':                      # (x, mean, var, gamma, beta, residual, eps, act, M, C, groups, y, mask_out)
+    if name in ('xas_bn_apply', 'xas_bn_apply_amax'):      # (x, mean, var, gamma, beta, residual, eps, act, M, C, groups, y, mask_out[, amax])
         t = 4.0 * a[8] * a[9]
         return t * (2 + (1 if a[5] else 0)) + (t / 16 if a[12] else 0.0)
     if name == 'xas_bn_bwd_reduce':                 # (x, y, dy, mean, var, gamma, beta, eps, act, M, C, groups, sums, ws, db, dg, mask)

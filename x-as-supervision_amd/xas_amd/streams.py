@@ -149,7 +149,7 @@ class chains:
 
     def __enter__(self):
         self.main = torch.cuda.current_stream()
-        self.was = _active[0]
+        self.was, self.was_main = _active[0], _main[0]
         self.used = []
         if self.num > 1:
             _active[0] = True
@@ -182,4 +182,4 @@ class chains:
                 self.main.wait_stream(s)
             self.main.wait_stream(book_stream())
             _active[0] = self.was
-            _main[0] = None
+            _main[0] = self.was_main              # (nested inside an active camera-stream fork: the outer context keeps its main stream)
