@@ -132,9 +132,10 @@ def train_step_variant_check(step, x, model, disc, opt_det, opt_disc, xl, precis
         restore(sn)
         ref = {'max_loss_rel_diff': max([abs(lc[k] - lb[k]) / max(abs(lb[k]), 1e-30) for k in lb if lb[k] != 0.0 or lc[k] != 0.0] or [0.0]),
                'grad_arena_rel_diff': {k: float((gc[k] - gb[k]).double().norm() / gb[k].double().norm().clamp_min(1e-300)) for k in gb}}
-    # ... and the exact-fp32 kernels against THEMSELVES with another summation order (tuning bits 32 | 524288: plain K loops in
-    # forward / data gradient / weight gradient): how far two exact-fp32 evaluations of this step's gradient are apart
-    ld_, gd_ = run(xl.PREC_F32, tune=32 | 524288)
+    # ... and the exact-fp32 kernels against THEMSELVES with another summation order in the batch-norm column reductions
+    # (tuning value 65536: 128 instead of 256 row slabs per reduction - statistics of 17 layers, the two backward sums of every
+    # layer): how far two exact-fp32 evaluations of this step's gradient are apart
+    ld_, gd_ = run(xl.PREC_F32, tune=65536)
     restore(sn)
     reorder = {'max_loss_rel_diff': max([abs(ld_[k] - lb[k]) / max(abs(lb[k]), 1e-30) for k in lb if lb[k] != 0.0 or ld_[k] != 0.0] or [0.0]),
                'grad_arena_rel_diff': {k: float((gd_[k] - gb[k]).double().norm() / gb[k].double().norm().clamp_min(1e-300)) for k in gb}}
@@ -211,10 +212,12 @@ def main():
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        import datetime
+        limit = datetime.timedelta(minutes=10)       # a rank that never arrives fails the job instead of hanging it
         if args.backend == 'nccl':
-            dist.init_process_group(backend='nccl', device_id=dev)
+            dist.init_process_group(backend='nccl', device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(backend=args.backend)
+            dist.init_process_group(backend=args.backend, timeout=limit)
 
     from xas_amd import engine
     from xas_amd.prof import KernelTimer
@@ -297,6 +300,14 @@ def main():
 
     per_sample = IMAGES_PER_SAMPLE['MPI' if args.workload.startswith('MPI') else 'HM36']
     samples = world * args.batch * args.steps
+    checksums = None
+    if world > 1:
+        # replicas must hold identical parameters after the averaged steps: one float64 checksum per rank and optimizer
+        mine = torch.tensor([float(opt_det.param_arena.double().sum()),
+                             float(opt_disc.param_arena.double().sum()) if opt_disc is not None else 0.0], device=dev, dtype=torch.float64)
+        allc = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine)
+        checksums = [[float(v) for v in c.tolist()] for c in allc]
     if rank == 0:
         summ = timer.summary()
         head = {k: summ.pop(k) for k in list(summ) if k.startswith('xas_head_')}
@@ -370,6 +381,8 @@ def main():
             'config': {'workload': args.workload, 'batch_per_gpu': args.batch, 'cameras': len(cams),
                        'image': '256x256', 'images_per_sample': per_sample, 'parallelism': 'dp%d' % world,
                        'samples_per_s': samples / dt, 'ranks': world,
+                       **({'param_checksum_per_rank': checksums, 'replicas_identical': all(c == checksums[0] for c in checksums)}
+                          if checksums else {}),
                        'samples_per_s_per_rank': samples / dt / world,
                        'detector_forwards_per_s': samples * (2 if args.dedupe else 3) * len(cams) / dt,
                        'precision': args.precision,

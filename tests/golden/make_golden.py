@@ -588,6 +588,76 @@ def g_disc_gcn():
 
 
 # ----------------------------------------------------------------- 9. dense -> sparse known answer
+def _allgrads(build, run):
+    """names / norms / strided samples of every parameter gradient of the reference module in fp32, and `dev` = its own
+    fp32-vs-fp64 distance per tensor (format of detector_allgrads: tests/conftest.check_all_grads)."""
+    res = {}
+    for dtype in (torch.float32, torch.float64):
+        ref = build().to(dtype).train()
+        y = run(ref, dtype)
+        res[dtype] = (y.detach(), [(n, p.grad.detach()) for n, p in ref.named_parameters()])
+    y32, g32 = res[torch.float32]
+    y64, g64 = res[torch.float64]
+    names = [n for n, _ in g32]
+    norms = np.array([float(g.double().norm()) for _, g in g32])
+    dev = np.array([float((a.double() - b).norm() / (b.norm() + 1e-30)) for (_, a), (_, b) in zip(g32, g64)])
+    samples = np.zeros((len(g32), 32), np.float32)
+    for i, (_, g) in enumerate(g32):
+        flat = g.reshape(-1)
+        step = max(1, flat.numel() // 32)
+        v = flat[::step][:32].numpy()
+        samples[i, :len(v)] = v
+    return dict(names=np.array(names), y=y32, y_f64=y64.float(), norms=norms, dev=dev, samples=samples)
+
+
+def g_physique_allgrads():
+    """Gradient of EVERY parameter of the reference's PhysiqueMaskGenerator (r03 VERDICT item 9): B = 4 blob masks, train-mode
+    norms, loss = sum(y * gw)."""
+    x = T(gi.blob_mask(4, 64, seed=152)) * 0.9
+    gw = T(np.random.Generator(np.random.PCG64(153)).standard_normal((4, 1, 64, 64)).astype(np.float32))
+
+    def build():
+        ref = PhysiqueMaskGenerator([32, 64, 128])
+        ref.load_state_dict(gi.seeded_fill_(onets.PhysiqueNet([32, 64, 128]), seed=151).state_dict(), strict=True)
+        return ref
+
+    def run(ref, dtype):
+        y = ref(x.to(dtype))
+        (y * gw.to(dtype)).sum().backward()
+        return y
+    save('physique_allgrads', x=x, grad_out=gw, **_allgrads(build, run))
+
+
+def g_disc_allgrads():
+    """Gradient of EVERY parameter of the reference's GCNDiscriminatorDecouple (modules/discriminator.py + modules/gcn.py
+    imported unchanged, the two PyG primitives restated), train mode with dropout 0, B = 6 poses, loss = sum(y * gw)."""
+    _install_pyg_shims()
+    from modules.discriminator import GCNDiscriminatorDecouple
+    cfg = yaml.load(open(os.path.join(REF, 'config', 'HM36_Multi_SurS2.yaml')), Loader=yaml.FullLoader)['model_params']
+    p17, c17 = ref_model.cal_links(cfg['parent_ids'], cfg['line_select_ids'], use_root=False, extension=False)
+    rng = np.random.Generator(np.random.PCG64(191))
+    kp = T((0.4 * rng.standard_normal((6, 18, 3))).astype(np.float32))
+    gw = T(rng.standard_normal((6, 1)).astype(np.float32))
+    shapes = {}
+
+    def build():
+        ref = GCNDiscriminatorDecouple(cfg['smpl_disc_params'])
+        gi.seeded_fill_(ref, seed=192)
+        ref.parent_ids, ref.child_ids = p17, c17
+        if hasattr(ref.header, 'dropout'):
+            ref.header.dropout.p = 0.0
+        shapes.update({k: list(v.shape) for k, v in ref.state_dict().items()})
+        return ref
+
+    def run(ref, dtype):
+        y = ref(kp.to(dtype))
+        (y * gw.to(dtype).reshape(y.shape)).sum().backward()
+        return y
+    out = _allgrads(build, run)
+    save('disc_decouple_allgrads', kp=kp, grad_out=gw, keys=np.array(list(shapes.keys())),
+         shapes=np.array([str(v) for v in shapes.values()]), **out)
+
+
 def g_sparse():
     src = open(os.path.join(REF, 'modules', 'gcn.py')).read()
     fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == 'my_batched_dense_to_sparse'][0]
@@ -749,7 +819,7 @@ def g_tbvis():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['head', 'lines', 'geometry', 'losses', 'physique', 'detector', 'detector_allgrads', 'smpl', 'model', 'model2', 'model3',
-                             'model4', 'configs',
+                             'model4', 'configs', 'physique_allgrads', 'disc_allgrads',
                              'disc', 'disc_gcn', 'sparse', 'evalpath', 'input', 'tbvis']
     for w in which:
         globals()['g_' + w]()

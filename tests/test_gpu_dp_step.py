@@ -77,3 +77,24 @@ def test_early_bucket_launch_equals_launch_at_finish(dedupe, cam_batch):
     assert a1[5] and a0[5]
     assert a1[:3] == b1[:3] and a0[:3] == b0[:3]               # replicas agree within each mode
     assert a1[:3] == a0[:3], (a1, a0)                          # and early launches change nothing
+
+
+@pytest.mark.limit(240)
+def test_bench_two_rank_rehearsal():
+    """`python bench.py --gpus 2 --backend gloo` on ONE card: the launcher path the driver uses for N > 1 (a parent that never
+    touches the GPU starts the ranks as a child torchrun job), the barrier / MAX-over-ranks timing, the whole-job line of rank 0:
+    n_gpus == ranks == 2, value = both ranks' images, and the replicas' parameter checksums identical after the averaged steps."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('XAS_DISC_BESIDE_GEN', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--batch', '4', '--steps', '2',
+                        '--warmup', '1', '--f32-steps', '0', '--no-cpu-baseline'], capture_output=True, text=True, timeout=200, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['config']['ranks'] == 2 and line['config']['parallelism'] == 'dp2'
+    assert line['scaling'] == 'weak' and line['steps'] == 2 and line['warmup'] == 1
+    assert abs(line['value'] - 2 * 4 * 8 * 2 / (line['ms_per_step'] * 2e-3)) < 1e-6 * line['value']      # whole-job images / time
+    assert line['config']['replicas_identical'] is True, line['config']['param_checksum_per_rank']

@@ -45,6 +45,51 @@ def test_physique_net_vs_golden():
     assert maxabs(sd['encoder.0.1.running_var'], T(g['run_var_enc0'])) < 1e-6
 
 
+def test_physique_net_all_parameter_gradients():
+    """EVERY parameter gradient of the physique net against the reference's (golden physique_allgrads: norms + strided samples
+    of its fp32 run, and its own fp32-vs-fp64 distance per tensor): per-tensor tolerance max(2e-4, 4 x that distance).  The
+    biases of the nine convolutions that feed a norm have no gradient in exact arithmetic (fp64: 1e-14): noise only."""
+    from conftest import check_all_grads
+    from modules.physique_network import PhysiqueMaskGenerator
+    from oracle.nets import PhysiqueNet
+    g = golden('physique_allgrads')
+    net = PhysiqueMaskGenerator([32, 64, 128])
+    net.load_state_dict(gi.seeded_fill_(PhysiqueNet([32, 64, 128]), seed=151).state_dict(), strict=True)
+    net.cuda().train()
+    y = net(T(g['x']).cuda())
+    assert maxabs(y, T(g['y'])) < 5e-6
+    (y * T(g['grad_out']).cuda()).sum().backward()
+    names = g['names'].tolist()
+    noise = {n for n, d in zip(names, g['dev']) if float(d) > 1.0}
+    assert len(noise) == 9 and all(n.endswith('.bias') for n in noise)
+    worst = check_all_grads([(n, p.grad) for n, p in net.named_parameters()], g, 2e-4, 4.0, 'physique', noise_only=noise)
+    print('physique net: worst error / tolerance over %d tensors: %.2f' % (len(names) - len(noise), worst))
+
+
+def test_decouple_discriminator_all_parameter_gradients():
+    """EVERY parameter gradient of GCNDiscriminatorDecouple against the reference's own module (golden
+    disc_decouple_allgrads, train mode, dropout 0): per-tensor tolerance max(1e-4, 4 x the reference's fp32-vs-fp64 distance)."""
+    import ast
+    from conftest import check_all_grads
+    from modules.discriminator import GCNDiscriminatorDecouple
+    from modules.model import cal_links
+    g = golden('disc_decouple_allgrads')
+    hip = GCNDiscriminatorDecouple(gi.model_params('S2')['smpl_disc_params'])
+    keys = g['keys'].tolist()
+    shapes = [ast.literal_eval(s) for s in g['shapes'].tolist()]
+    hip.load_state_dict(gi.seeded_state_dict(keys, shapes, 192), strict=True)
+    hip.parent_ids, hip.child_ids = cal_links(gi.HM36_PARENTS, gi.LINE_SELECT, use_root=False, extension=False)
+    hip.cuda().train()
+    hip.header.p = 0.0
+    y = hip(T(g['kp']).cuda())
+    ref = T(g['y'])
+    assert maxabs(y, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
+    (y * T(g['grad_out']).cuda().reshape(y.shape)).sum().backward()
+    named = dict(hip.named_parameters())
+    worst = check_all_grads([(n, named[n].grad) for n in g['names'].tolist()], g, 1e-4, 4.0, 'decouple discriminator')
+    print('decouple discriminator: worst error / tolerance over %d tensors: %.2f' % (len(named), worst))
+
+
 def _discs(seed=7):
     from modules.discriminator import GCNDiscriminatorDecouple
     from modules.model import cal_links

@@ -153,3 +153,46 @@ def test_full_size_step_b32_four_cameras(monkeypatch):
         assert abs(a[2][k] - b[2][k]) <= 1e-5 * abs(b[2][k]) + 1e-7, (k, a[2][k], b[2][k])
     # Adam's first step moves a weight by lr * sign(g): only ~zero gradients may flip
     assert float(((a[3] - b[3]).abs() > 1e-5).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize('name,batch', [('HM36_Multi_SurS2', 32), ('HM36_Multi_SynthS2', 64)])
+def test_full_size_step_other_baseline_configs(name, batch, monkeypatch):
+    """BASELINE configs 3 and 5 at the size BASELINE.json names (SurS2 finetune: symmetry + adversarial terms active,
+    B = 32; SynthS2: B = 64 per GPU), one disc + gen step: the camera-batched step must give the loss terms of the step that
+    calls the networks once per camera (<= 1e-5 relative; the adversarial term, which sees the UPDATED discriminator, 1e-4),
+    every loss and parameter finite, parameters after the step in agreement, and the f16x3 default must sit on the
+    exact-fp32 MFMA kernels' losses (<= 2e-5 relative)."""
+    import modules.model as mm
+    from conftest import precision_mode
+    from xas_amd import engine
+    from xas_amd.synthetic import model_config, synthetic_batch
+    cfg = model_config(name)
+    cams = cfg['model_params']['cam_id_list']
+    x = synthetic_batch(batch, cams, torch.device('cuda'), seed=100)
+
+    def one(batched, mode):
+        monkeypatch.setattr(mm, 'CAM_BATCH', batched)
+        monkeypatch.setattr(mm, 'JOIN_PSEUDO', batched)
+        torch.manual_seed(1234)
+        model, disc, od, odisc = engine.prepare_model(cfg)
+        model.cuda().train(), disc.cuda().train()
+        disc.smpl_discriminator.header.p = 0.0
+        step = engine.TrainStep(cfg, model, disc, od, odisc)
+        with precision_mode(mode):
+            ld, lk, tot, out = step(x)
+            torch.cuda.synchronize()
+        assert bool(torch.isfinite(ld)) and bool(torch.isfinite(tot))
+        assert bool(torch.isfinite(od.param_arena).all()) and bool(torch.isfinite(odisc.param_arena).all())
+        r = (float(ld), float(tot), {k: float(v.mean()) for k, v in lk.items()}, od.param_arena.clone())
+        del model, disc, od, odisc, step
+        torch.cuda.empty_cache()
+        return r
+
+    a, b, c = one(True, 'f16x3'), one(False, 'f16x3'), one(True, 'f32')
+    for other, tol in ((b, 1e-5), (c, 2e-5)):
+        assert abs(a[0] - other[0]) <= tol * abs(other[0]) + 1e-7, (a[0], other[0])
+        for k in other[2]:
+            t = 10 * tol if k == 'smpl_gen' else tol
+            assert abs(a[2][k] - other[2][k]) <= t * abs(other[2][k]) + 1e-7, (k, a[2][k], other[2][k])
+    assert any(v != 0.0 for k, v in a[2].items() if k in ('symmetry', 'smpl_gen'))          # the S2 terms are live
+    assert float(((a[3] - b[3]).abs() > 1e-5).float().mean()) < 0.02
