@@ -210,6 +210,49 @@ def test_camera_batched_step_equals_per_camera_step(monkeypatch):
             assert rel(b[4][k], a[4][k]) < 1e-4, k
 
 
+@pytest.mark.parametrize('name,cams,batch', [('HM36_Multi_SurS2', [0, 1, 2], 2), ('HM36_Multi_SurS1', [0, 1, 2, 3], 8)])
+def test_joint_prefix_pass_step_equals_separate_passes(name, cams, batch, monkeypatch):
+    """r04: the discriminator step's detector pass as a no-grad PREFIX of the generator step's grouped pass (ops_nn prefix
+    pass, model.joint_detector_pass; default) against a pass of its own (XAS_JOINT_DISC=0): same losses, same discriminator
+    inputs, same parameters and running statistics after the step (up to fp32 summation order), and the backward must not
+    have touched the prefix: the batch counters count 3 calls per camera either way."""
+    import modules.model as mm
+    from xas_amd import engine
+    from xas_amd.synthetic import model_config, synthetic_batch
+    cfg = model_config(name)
+    cfg['model_params']['cam_id_list'] = cams
+    x = synthetic_batch(batch, cams, torch.device('cuda'), seed=97)
+    res = []
+    for joint in (False, True):
+        monkeypatch.setattr(mm, 'JOINT_DISC', joint)
+        torch.manual_seed(11)
+        model, disc, od, odisc = engine.prepare_model(cfg)
+        model.cuda().train(), disc.cuda().train()
+        disc.smpl_discriminator.header.p = 0.0
+        step = engine.TrainStep(cfg, model, disc, od, odisc)
+        assert model.joint_pass_possible(x) == joint
+        ld, lk, tot, out = step(x)
+        torch.cuda.synchronize()
+        res.append((float(ld), {k: float(v.mean()) for k, v in lk.items()}, od.param_arena.clone(), odisc.param_arena.clone(),
+                    {k: v.clone() for k, v in model.state_dict().items() if 'running' in k or 'num_batches' in k}, sorted(out),
+                    {k: v.clone() for k, v in out.items() if isinstance(v, torch.Tensor) and v.is_floating_point()}))
+    a, b = res
+    assert abs(a[0] - b[0]) < 1e-6 + 1e-5 * abs(a[0]), (a[0], b[0])
+    for k in a[1]:
+        assert abs(a[1][k] - b[1][k]) < 1e-6 + 2e-5 * abs(a[1][k]), (k, a[1][k], b[1][k])
+    assert a[5] == b[5]
+    for k in a[6]:
+        assert maxabs(a[6][k], b[6][k]) < 1e-4 * max(1.0, float(a[6][k].abs().max())), k
+    assert float((a[2] - b[2]).abs().max()) < 2.5e-4            # Adam's first step: 2 * lr at worst (sign flip of a ~zero gradient)
+    assert float(((a[2] - b[2]).abs() > 1e-5).float().mean()) < 0.02
+    assert float(((a[3] - b[3]).abs() > 1e-5).float().mean()) < 0.02
+    for k in a[4]:
+        if 'num_batches' in k:
+            assert int(a[4][k]) == int(b[4][k]) == 3 * len(cams), k
+        else:
+            assert rel(b[4][k], a[4][k]) < 1e-4, k
+
+
 def test_conv_beyond_2gib_splits_over_images():
     """A gathered operand of >= 2 GiB (the logits gradient of a camera-batched pass) is processed as several launches
     over image ranges: same result as the per-range reference."""

@@ -30,13 +30,25 @@ class KPDetector3DMulti(nn.Module):
         self.last_peak_indices = idx
         return kps, depth_prob_map
 
-    def forward_groups(self, x, groups):
+    def forward_groups(self, x, groups, prefix_groups=0):
         """The reference's `groups` consecutive calls forward(x[0:B]), forward(x[B:2B]), ... as ONE pass over the
         concatenated batch: convolutions see G*B images, every batch-norm layer keeps per-call statistics and applies
-        its running-statistic updates in call order (ops_nn.bn_groups).  -> kps [G*B, Hy, K, 3], depth maps [G, K, D]."""
-        with ops_nn.bn_groups(groups):
+        its running-statistic updates in call order (ops_nn.bn_groups).  -> kps [G*B, Hy, K, 3], depth maps [G, K, D].
+        prefix_groups = P > 0 (ops_nn: prefix pass): the first P calls record no graph (the discriminator step's
+        detector pass, model.py:231).  `x` is then the TAIL view [(G-P)*B, ...] of one image buffer [G*B, ...] whose
+        first P*B images are those calls' inputs; -> (kps of the G-P graph calls, depth maps [G, K, D], kps of the prefix
+        calls [P*B, Hy, K, 3], no graph)."""
+        if not prefix_groups:
+            with ops_nn.bn_groups(groups):
+                heatmap = self.net(x)
+            kps, depth_prob_map, idx = ops_head.softargmax_multi(heatmap, self.num_kp, self.num_hypo, self.neighbor_size,
+                                                                groups=groups)
+            self.last_peak_indices = idx
+            return kps, depth_prob_map
+        per_group = x.shape[0] // (groups - prefix_groups)
+        with ops_nn.bn_groups(groups, prefix_groups, per_group):
             heatmap = self.net(x)
-        kps, depth_prob_map, idx = ops_head.softargmax_multi(heatmap, self.num_kp, self.num_hypo, self.neighbor_size,
-                                                            groups=groups)
+            kps, depth_prob_map, idx = ops_head.softargmax_multi(heatmap, self.num_kp, self.num_hypo, self.neighbor_size,
+                                                                groups=groups)
         self.last_peak_indices = idx
-        return kps, depth_prob_map
+        return kps, depth_prob_map, ops_head._last_prefix[0]

@@ -55,6 +55,10 @@ def _to_world(kps, x, key, mono):
 CAM_BATCH = os.environ.get('XAS_CAM_BATCH', '1') == '1'
 CAM_BATCH_MAX = max(1, int(os.environ.get('XAS_CAM_BATCH_MAX', '8')))
 JOIN_PSEUDO = os.environ.get('XAS_CAM_BATCH_PSEUDO', '1') == '1'
+# r04: the discriminator step's detector pass (real images, no graph) rides in front of the generator step's pass (real +
+# pseudo images) as a no-grad PREFIX of one grouped pass (ops_nn: prefix pass).  Every one of the reference's 3 * cameras
+# detector calls is still computed, in the reference's order; only the launches are shared.  XAS_JOINT_DISC=0: a pass of its own.
+JOINT_DISC = os.environ.get('XAS_JOINT_DISC', '1') == '1'
 
 
 def _grouped(net, tensors):
@@ -97,9 +101,41 @@ class Counter3DModel(torch.nn.Module):
     def forward(self, x, smpl_discriminator):
         return self.finish(x, smpl_discriminator, *self.camera_passes(x))
 
-    def camera_passes(self, x, pseudo=True, after_geometry=None):
+    def joint_pass_possible(self, x):
+        """Can the discriminator step's detector pass join the generator step's as a no-grad prefix?  One stream, camera
+        batching with the pseudo images joined, a multi-hypothesis detector in training mode on the GPU, and all 3 * cameras
+        groups within the image budget of one pass (the logits stay below 2^31 elements)."""
+        keys = ['cam_{}'.format(c) for c in _cams(x, self.cam_id_list)]
+        img = x[keys[0] + '_img']
+        groups = 3 * len(keys)
+        return (JOINT_DISC and CAM_BATCH and JOIN_PSEUDO and CAM_BATCH_MAX >= 8 and streams.CHAINS <= 1 and img.is_cuda
+                and 'smpl_pseudo_img_loss' in self.loss_config and self.regressor.training
+                and type(self.regressor).__name__ == 'KPDetector3DMulti' and groups * img.shape[0] <= 384
+                and all(x[k + '_img'].shape == img.shape and x[k + '_pseudo_img'].shape == img.shape for k in keys))
+
+    def joint_detector_pass(self, x):
+        """ONE grouped detector pass for the step: [real images of every camera (the discriminator step's calls, model.py:231:
+        no graph) | the same real images | the pseudo images (the generator step's calls, model.py:64,147)], in the order of
+        the reference's calls - which fixes the order of the batch-norm running-statistic updates.
+        -> ({cam_key: kps, no graph} for Counter3DDisc.forward(preds=...), [(kps, depth map)] * 2 cameras for camera_passes(dets=...))."""
+        keys = ['cam_{}'.format(c) for c in _cams(x, self.cam_id_list)]
+        ops_nn.prepack(self.regressor)
+        real = [x[k + '_img'] for k in keys]
+        imgs = real + real + [x[k + '_pseudo_img'] for k in keys]
+        B, P, G = real[0].shape[0], len(keys), len(imgs)
+        buf = ops_nn.stack_nchw(imgs)
+        if not buf.is_contiguous(memory_format=torch.channels_last):
+            buf = ops_nn.from_nchw(buf)
+        kps, dmap, kps_prefix = self.regressor.forward_groups(buf[P * B:], G, prefix_groups=P)
+        dmap = dmap.reshape(G, *dmap.shape[-2:])
+        preds = {k: kps_prefix[g * B:(g + 1) * B] for g, k in enumerate(keys)}
+        dets = [(kps[g * B:(g + 1) * B], dmap[P + g]) for g in range(G - P)]
+        return preds, dets
+
+    def camera_passes(self, x, pseudo=True, after_geometry=None, dets=None):
         """Detector / geometry / mask part of the step for every camera (everything that does not involve the
-        discriminator).  `pseudo=False` leaves the pseudo-image branch to a later `pseudo_passes` call."""
+        discriminator).  `pseudo=False` leaves the pseudo-image branch to a later `pseudo_passes` call.  `dets`: the detector
+        outputs of joint_detector_pass (real + pseudo images of every camera) - the detector is then not run here."""
         cams = _cams(x, self.cam_id_list)
         lc = self.loss_config
         out = {}
@@ -119,8 +155,11 @@ class Counter3DModel(torch.nn.Module):
         per_cam = {}
         with streams.chains(2 if two_chains else 1) as ch:
             with ch.run(0):
-                imgs = [x[k + '_img'] for k in keys] + ([x[k + '_pseudo_img'] for k in keys] if fuse_pseudo else [])
-                dets = _grouped(self.regressor, imgs)
+                if dets is None:
+                    imgs = [x[k + '_img'] for k in keys] + ([x[k + '_pseudo_img'] for k in keys] if fuse_pseudo else [])
+                    dets = _grouped(self.regressor, imgs)
+                elif not (fuse_pseudo and len(dets) == 2 * len(keys)):
+                    raise RuntimeError('camera_passes(dets=...): expects the joined real + pseudo detector outputs')
                 pseudo_dets = dets[len(keys):] if fuse_pseudo else None
                 for cam, key, (kps, depth_map) in zip(cams, keys, dets):
                     assert kps.dim() == 4, "use aligned multi-hypothesis settings"

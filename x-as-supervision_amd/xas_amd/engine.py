@@ -170,11 +170,18 @@ class TrainStep:
             return ld, info
 
         aux = None
+        # r04: the discriminator step's detector pass as a no-grad prefix of the generator step's pass (modules/model.py:
+        # joint_detector_pass) - one grouped pass of 3 * cameras groups; all of the reference's detector calls, its order
+        dets = None
+        joint = shared is None and do_disc and do_gen and self.model.joint_pass_possible(x)
+        if joint:
+            joint_preds, dets = self.model.joint_detector_pass(x)
         if do_disc:
             if shared is not None:
                 loss_disc, _ = disc_update({k: v['kps'] for k, v in shared[0].items()})
             elif disc_beside_gen() and do_gen and next(self.model.regressor.parameters()).is_cuda:
-                preds = self.disc.detector_pass(x, self.model.regressor)      # the detector pass stays on the main chain
+                # (without the joint pass: the detector pass stays on the main chain)
+                preds = joint_preds if joint else self.disc.detector_pass(x, self.model.regressor)
                 main, aux = torch.cuda.current_stream(), _aux_stream()
                 aux.wait_stream(main)
                 with torch.cuda.stream(aux):
@@ -185,7 +192,7 @@ class TrainStep:
                     if isinstance(t, torch.Tensor) and t.is_cuda:
                         t.record_stream(main)
             else:
-                loss_disc, _ = disc_update(None)
+                loss_disc, _ = disc_update(joint_preds if joint else None)
         if do_gen:
             if shared is not None:
                 self.model.pseudo_passes(x, *shared)
@@ -199,8 +206,10 @@ class TrainStep:
                     if 'smpl_gen_loss' in self.model.loss_config:
                         early['v'] = self.model.adversarial_on(aux, x, self.disc.smpl_discriminator,
                                                                {k: v['world'] for k, v in per_cam.items()})
-                cams = self.model.camera_passes(x, after_geometry=after_geometry)   # beside the discriminator update
+                cams = self.model.camera_passes(x, after_geometry=after_geometry, dets=dets)   # beside the discriminator update
                 loss_kp, info = self.model.finish(x, self.disc.smpl_discriminator, *cams, aux=aux, gen_val_early=early.get('v'))
+            elif dets is not None:
+                loss_kp, info = self.model.finish(x, self.disc.smpl_discriminator, *self.model.camera_passes(x, dets=dets))
             else:
                 loss_kp, info = self.model(x, self.disc.smpl_discriminator)
             out.update(info)

@@ -20,7 +20,9 @@ def _nhwc_storage(logits):
 class _SoftArgmax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, num_kp, num_hypo, neighbor, groups):
-        logits = _nhwc_storage(logits)
+        from . import ops_nn
+        logits_tail = _nhwc_storage(logits)
+        logits = ops_nn._full(logits_tail)               # prefix pass (ops_nn): prefix + graph images in one launch
         B, C, H, W = logits.shape
         D = C // num_kp
         if not (C == num_kp * D and D == H == W):
@@ -33,13 +35,16 @@ class _SoftArgmax(torch.autograd.Function):
         ws = torch.empty(query('xas_head_workspace_floats', B, num_kp, D), device=dev, dtype=torch.float32)
         call('xas_head_softargmax_fwd', ptr(logits), B, num_kp, D, num_hypo, neighbor, ptr(kps), ptr(z_idx),
              ptr(dmap), groups, ptr(stats), ptr(ws))
-        ctx.save_for_backward(logits, stats, z_idx)
+        s = B - logits_tail.shape[0]                     # images of the no-grad prefix (0 outside a prefix pass)
+        kps_prefix = kps[:s] if s else kps[:0]
+        kps, z_idx_all = (kps[s:], z_idx) if s else (kps, z_idx)
+        ctx.save_for_backward(logits_tail, stats[s:] if s else stats, z_idx[s:] if s else z_idx)
         ctx.cfg = (num_kp, D, num_hypo, neighbor)
-        ctx.mark_non_differentiable(z_idx, dmap)
-        return kps, dmap, z_idx
+        ctx.mark_non_differentiable(z_idx_all, dmap, kps_prefix)
+        return kps, dmap, z_idx_all, kps_prefix
 
     @staticmethod
-    def backward(ctx, g_kps, _g_dmap, _g_idx):
+    def backward(ctx, g_kps, _g_dmap, _g_idx, _g_prefix=None):
         logits, stats, z_idx = ctx.saved_tensors
         K, D, Hy, nb = ctx.cfg
         B = logits.shape[0]
@@ -58,13 +63,18 @@ class _SoftArgmax(torch.autograd.Function):
 def softargmax_multi(logits, num_kp, num_hypo, neighbor_size, groups=1):
     """-> kps [B,num_hypo,K,3], depth_prob_map [K,D] ([groups,K,D] for groups > 1: first sample of each sub-batch),
     z_idx [B,K,num_hypo] int64  (keypoint_detector_integral_multi.py:66-88)."""
-    kps, dmap, idx = _SoftArgmax.apply(logits, num_kp, num_hypo, neighbor_size, groups)
+    kps, dmap, idx, prefix = _SoftArgmax.apply(logits, num_kp, num_hypo, neighbor_size, groups)
+    _last_prefix[0] = prefix
     return kps, (dmap[0] if groups == 1 else dmap), idx
+
+
+_last_prefix = [None]          # joints of the no-grad prefix images of the latest call (prefix pass: KPDetector3DMulti.forward_groups)
 
 
 def softargmax_single(logits, num_kp, groups=1):
     """-> kps [B,1,K,3], depth_prob_map [K,D] ([groups,K,D] for groups > 1)  (keypoint_detector_integral.py:45-65)."""
-    kps, dmap, _ = _SoftArgmax.apply(logits, num_kp, 1, 0, groups)
+    kps, dmap, _, prefix = _SoftArgmax.apply(logits, num_kp, 1, 0, groups)
+    _last_prefix[0] = prefix
     return kps, (dmap[0] if groups == 1 else dmap)
 
 

@@ -18,17 +18,56 @@ _weights_epoch = [0]          # bumped by the fused optimizer (raw-pointer updat
 # calls (model.py:64,147,231).  `bn_groups(G)` is entered by the grouped forward of the detector / physique net.
 _groups = [1]
 
+# Prefix pass (r04).  The discriminator update needs the detector's outputs on the real images WITHOUT a graph (model.py:231,
+# detached at :243); the generator step then runs the detector on the same images (with a graph) and on the pseudo images.
+# Nothing between those passes changes the detector, so all of them can travel as ONE grouped pass of 3 * cameras groups -
+# 4x / 1.5x larger launches for the late layers - provided the backward leaves the no-grad groups alone.  That is done by
+# MEMORY LAYOUT, not by the backward kernels: every activation of the pass is one buffer [prefix images | graph images];
+# the tensor that travels through autograd is the TAIL view, the prefix sits in front of it in the same storage.  A forward
+# function recovers the whole buffer (`_full`), runs its kernels over all images and groups, and returns / saves tail views
+# only: autograd and every backward function see the graph images alone, with their own group count, exactly as if the
+# prefix had never been there.
+_prefix = [0, 0]            # images, groups of the no-grad prefix of the current pass
+
 
 class bn_groups:
-    def __init__(self, groups):
+    def __init__(self, groups, prefix_groups=0, images_per_group=0):
         self.groups = int(groups)
+        self.prefix = [int(prefix_groups) * int(images_per_group), int(prefix_groups)]
+        if self.prefix[1] and not (0 < self.prefix[1] < self.groups and images_per_group > 0):
+            raise RuntimeError('bn_groups: the no-grad prefix must be a proper, non-empty subset of the groups')
 
     def __enter__(self):
         self.prev, _groups[0] = _groups[0], self.groups
+        self.prev_prefix = list(_prefix)
+        _prefix[0], _prefix[1] = self.prefix
         return self
 
     def __exit__(self, *exc):
         _groups[0] = self.prev
+        _prefix[0], _prefix[1] = self.prev_prefix
+
+
+def _full(x):
+    """The whole buffer of a prefix pass (prefix images + x) from its tail view x; x itself outside a prefix pass."""
+    s = _prefix[0]
+    if not s or x is None:
+        return x
+    per = x.stride(0)
+    off = x.storage_offset() - s * per
+    if (x.dim() != 4 or not x.is_contiguous(memory_format=CL) or off < 0
+            or (x.storage_offset() + x.numel()) * 4 > x.untyped_storage().nbytes()):
+        raise RuntimeError('prefix pass: an activation arrived without its %d prefix images in front of it' % s)
+    return torch.as_strided(x, (x.shape[0] + s,) + tuple(x.shape[1:]), x.stride(), off)
+
+
+def _tail(tf, per_image=None):
+    """The graph images of a full buffer of the current pass (the buffer itself outside a prefix pass).  per_image: the
+    tensor is flat, that many elements per image."""
+    s = _prefix[0]
+    if not s:
+        return tf
+    return tf[s * per_image:] if per_image is not None else tf[s:]
 
 
 def current_groups():
@@ -316,7 +355,8 @@ def act_amax(x):
     slot = amax_of(x)
     if slot is None:
         slot = _amax_slot(x.device)
-        call('xas_abs_max', ptr(x), x.numel(), ptr(slot))
+        xm = _full(x) if (x.dim() == 4 and _prefix[0]) else x          # (a prefix pass: the kernels read the whole buffer)
+        call('xas_abs_max', ptr(xm), xm.numel(), ptr(slot))
         tag_grad_amax(x, slot)
         amax_stats['abs_max'] += 1
     return slot
@@ -333,6 +373,17 @@ def _with_ptrs(shp, grad, x, mode=None):
     return ConvShape(shp.N, shp.Hi, shp.Wi, shp.Cin, shp.Cout, shp.R, shp.S, shp.stride, shp.pad, shp.Ho, shp.Wo,
                      shp.mode if mode is None else mode, grad.data_ptr() if grad is not None else None,
                      x.data_ptr() if x is not None else None)
+
+
+def _with_n(shp, n):
+    """The same convolution over n images (keeps mode and operand-maximum pointers)."""
+    if n == shp.N:
+        return shp
+    out = ConvShape(n, shp.Hi, shp.Wi, shp.Cin, shp.Cout, shp.R, shp.S, shp.stride, shp.pad, shp.Ho, shp.Wo, shp.mode,
+                    shp.grad_amax, shp.x_amax)
+    if hasattr(shp, '_slots'):
+        out._slots = shp._slots
+    return out
 
 
 def with_act_amax(shp, x):
@@ -460,8 +511,11 @@ class _Conv2d(torch.autograd.Function):
             raise RuntimeError('conv2d: input has %d channels, weight expects %d' % (ci, ci2))
         ho, wo = (hi + 2 * pad - r) // stride + 1, (wi + 2 * pad - s) // stride + 1
         shp, x_slot = with_act_amax(_shape(n, hi, wi, ci, co, r, s, stride, pad, ho, wo), x)
-        y = empty_cl(n, co, ho, wo, x)
-        call('xas_conv_fwd', ptr(x), ptr(cache.get(weight, 0, shp)), ptr(bias), ptr(y), shp)
+        xf = _full(x)                                     # (prefix pass: the kernel runs over prefix + graph images)
+        yf = empty_cl(xf.shape[0], co, ho, wo, x)
+        shp_f = _with_n(shp, xf.shape[0])
+        call('xas_conv_fwd', ptr(xf), ptr(cache.get(weight, 0, shp_f)), ptr(bias), ptr(yf), shp_f)
+        y = _tail(yf)
         ctx.save_for_backward(x, weight, *([bias] if bias is not None else []))
         ctx.shp, ctx.cache, ctx.has_bias, ctx.x_slot = shp, cache, bias is not None, x_slot
         if ctx.needs_input_grad[1]:
@@ -500,9 +554,11 @@ def _conv_forward(x, weight, stride, pad, cache):
         raise RuntimeError('conv2d: input has %d channels, weight expects %d' % (ci, ci2))
     ho, wo = (hi + 2 * pad - r) // stride + 1, (wi + 2 * pad - s) // stride + 1
     shp, _ = with_act_amax(_shape(n, hi, wi, ci, co, r, s, stride, pad, ho, wo), x)      # (the shape keeps the input's slot)
-    y = empty_cl(n, co, ho, wo, x)
-    call('xas_conv_fwd', ptr(x), ptr(cache.get(weight, 0, shp)), None, ptr(y), shp)
-    return y, shp
+    xf = _full(x)
+    yf = empty_cl(xf.shape[0], co, ho, wo, x)
+    shp_f = _with_n(shp, xf.shape[0])
+    call('xas_conv_fwd', ptr(xf), ptr(cache.get(weight, 0, shp_f)), None, ptr(yf), shp_f)
+    return _tail(yf), shp
 
 
 FUSE_CONV_STATS = os.environ.get('XAS_CONV_STATS', '1') == '1'
@@ -525,8 +581,11 @@ def _conv_bn_forward(x, conv, bn, residual, group):
     stride, pad = conv.stride, conv.padding
     ho, wo = (hi + 2 * pad - r) // stride + 1, (wi + 2 * pad - s) // stride + 1
     shp, _ = with_act_amax(_shape(n, hi, wi, ci, co, r, s, stride, pad, ho, wo), x)
-    y = empty_cl(n, co, ho, wo, x)
-    wp = conv._cache.get(weight, 0, shp)
+    xf = _full(x)                                         # (prefix pass: prefix + graph images, all groups)
+    shp_f = _with_n(shp, xf.shape[0])
+    yf = empty_cl(xf.shape[0], co, ho, wo, x)
+    y = _tail(yf)
+    wp = conv._cache.get(weight, 0, shp_f)
     G = _groups[0]
     # sums are taken around 0: a pivot taken from the running mean would make the last bits of the statistics depend on
     # optimisation state (a detector pass computed once and re-used - TrainStep(dedupe=True) - must equal the recomputed
@@ -534,8 +593,8 @@ def _conv_bn_forward(x, conv, bn, residual, group):
     pivot = None
 
     def stats(mean_p, var_p, out_stride, count_p, rm_p, rv_p, momentum):
-        ws = torch.empty(query('xas_conv_fwd_bnstats_workspace_floats', shp, G), device=x.device, dtype=torch.float32)
-        call('xas_conv_fwd_bnstats', ptr(x), ptr(wp), ptr(y), shp, G, ptr(pivot), mean_p, var_p, out_stride, count_p,
+        ws = torch.empty(query('xas_conv_fwd_bnstats_workspace_floats', shp_f, G), device=x.device, dtype=torch.float32)
+        call('xas_conv_fwd_bnstats', ptr(xf), ptr(wp), ptr(yf), shp_f, G, ptr(pivot), mean_p, var_p, out_stride, count_p,
              ptr(ws), rm_p, rv_p, float(momentum))
 
     out, sv, cf = _bn_forward(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, True, bn.momentum,
@@ -738,10 +797,13 @@ class _ConvTranspose2d(torch.autograd.Function):
         hb, wb = (h - 1) * stride - 2 * pad + r, (w - 1) * stride - 2 * pad + s
         # equivalent conv: big side (hb,wb,cot) -> small side (h,w,cit)
         shp = _shape(n, hb, wb, cot, cit, r, s, stride, pad, h, w)
-        y = empty_cl(n, cot, hb, wb, x)
         # the gathered operand of this data-gradient-type launch is the activation x: its maximum selects the scale
         shp_f, x_slot = with_act_amax(shp, x)
-        call('xas_conv_dgrad', ptr(x), ptr(cache.get(weight, 1, shp_f)), ptr(y), shp_f)
+        xf = _full(x)                                     # (prefix pass: prefix + graph images)
+        shp_f = _with_n(shp_f, xf.shape[0])
+        yf = empty_cl(xf.shape[0], cot, hb, wb, x)
+        call('xas_conv_dgrad', ptr(xf), ptr(cache.get(weight, 1, shp_f)), ptr(yf), shp_f)
+        y = _tail(yf)
         ctx.save_for_backward(x, weight)
         ctx.shp, ctx.cache, ctx.x_slot = shp, cache, x_slot
         if ctx.needs_input_grad[1]:
@@ -860,8 +922,12 @@ def _sync_stats(mean, var, count, group):
 
 def _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, group, stats_fn=None):
     """-> (y, saved tensors (x|y, y|x, mean, var), cfg) - the body of _BatchNorm.forward, also used by _Bottleneck.
-    The batch is `current_groups()` independent sub-batches (cameras): statistics are [G, C]."""
-    x = to_cl(x)
+    The batch is `current_groups()` independent sub-batches (cameras): statistics are [G, C].  Prefix pass: the kernels run
+    over the whole buffer (all groups); what is returned and saved are the tail views / the graph groups' statistic rows."""
+    x_tail = to_cl(x)
+    x = _full(x_tail)
+    if x is not x_tail and not training:
+        raise RuntimeError('prefix pass: training-mode norms only')
     n, c, h, w = x.shape
     G = _groups[0]
     if n % G:
@@ -923,7 +989,7 @@ def _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, m
     else:
         mean = running_mean.reshape(1, c).expand(G, c).contiguous() if G > 1 else running_mean
         var = running_var.reshape(1, c).expand(G, c).contiguous() if G > 1 else running_var
-    res = to_cl(residual) if residual is not None else None
+    res = _full(to_cl(residual)) if residual is not None else None
     y = torch.empty_like(x)
     # layers with a residual (block outputs): the backward needs only the SIGN of the pre-activation value, saved as one
     # byte per float4 (1/16 of y's bytes) - neither backward pass reads y
@@ -941,6 +1007,16 @@ def _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, m
     #   otherwise               : both.
     xfree = training and act == ACT_LEAKY and residual is None
     yfree = training and act == ACT_RELU and residual is None and os.environ.get('XAS_BN_YFREE', '1') == '1'
+    if x is not x_tail:
+        # hand on / keep the graph images only: tail views of the buffers, the statistic rows of the graph groups
+        k = _prefix[1]
+        y = _tail(y)
+        if slot is not None:
+            tag_grad_amax(y, slot)               # (the maximum over the whole buffer bounds the tail's)
+        mask = _tail(mask, per_image=h * w * c // 4) if masked else None
+        M, G = M - _prefix[0] * h * w, G - k
+        mean, var = mean[k:], var[k:]
+        x = x_tail
     saved = (y if xfree else x, mask if masked else (x if yfree else y), mean, var)
     cfg = (M, c, float(eps), act, count, group, training, residual is not None, xfree, yfree, G, masked)
     return y, saved, cfg
@@ -1031,9 +1107,12 @@ class _MaxPool(torch.autograd.Function):
         x = to_cl(x)
         n, c, h, w = x.shape
         ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-        y = empty_cl(n, c, ho, wo, x)
-        idx = torch.empty(n * ho * wo * c, device=x.device, dtype=torch.int8)
-        call('xas_maxpool3x3s2_fwd', ptr(x), n, h, w, c, ptr(y), ptr(idx))
+        xf = _full(x)
+        nf = xf.shape[0]
+        yf = empty_cl(nf, c, ho, wo, x)
+        idxf = torch.empty(nf * ho * wo * c, device=x.device, dtype=torch.int8)
+        call('xas_maxpool3x3s2_fwd', ptr(xf), nf, h, w, c, ptr(yf), ptr(idxf))
+        y, idx = _tail(yf), _tail(idxf, per_image=ho * wo * c)
         pass_amax(y, x)
         ctx.save_for_backward(idx)
         ctx.shape = (n, c, h, w)
@@ -1056,6 +1135,8 @@ def maxpool3x3s2(x):
 class _Upsample2x(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
+        if _prefix[0]:
+            raise RuntimeError('prefix pass: up-sampling is not on the detector path')
         x = to_cl(x)
         n, c, h, w = x.shape
         y = empty_cl(n, c, 2 * h, 2 * w, x)
