@@ -243,12 +243,13 @@ def test_joint_prefix_pass_step_equals_separate_passes(name, cams, batch, monkey
     assert a[5] == b[5]
     for k in a[6]:
         assert maxabs(a[6][k], b[6][k]) < 1e-4 * max(1.0, float(a[6][k].abs().max())), k
-    assert float((a[2] - b[2]).abs().max()) < 2.5e-4            # Adam's first step: 2 * lr at worst (sign flip of a ~zero gradient)
+    lr = cfg['train_params']['lr_kp_detector']
+    assert float((a[2] - b[2]).abs().max()) < 2.5 * lr          # Adam's first step: 2 * lr at worst (sign flip of a ~zero gradient)
     assert float(((a[2] - b[2]).abs() > 1e-5).float().mean()) < 0.02
     assert float(((a[3] - b[3]).abs() > 1e-5).float().mean()) < 0.02
     for k in a[4]:
         if 'num_batches' in k:
-            assert int(a[4][k]) == int(b[4][k]) == 3 * len(cams), k
+            assert int(a[4][k]) == int(b[4][k]) == (3 * len(cams) if k.startswith('regressor.') else len(cams)), k
         else:
             assert rel(b[4][k], a[4][k]) < 1e-4, k
 
