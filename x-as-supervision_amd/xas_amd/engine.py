@@ -23,12 +23,13 @@ from .optim import FusedAdam
 
 # The discriminator's own forward / backward / Adam (a few hundred small launches, ~4 ms of an otherwise idle GPU) runs on a
 # second stream beside the generator step's detector passes, which do not depend on it (only the generator LOSSES do).
-# Single process: on by default.  Under data parallelism: OFF unless XAS_DISC_BESIDE_GEN=1 asks for it - the update then runs on
-# the main stream in program order.  Reasons: (i) its gradient exchange (`red_disc.finish()`) blocks the HOST on backends whose
-# collectives are host-synchronous (gloo), so nothing of the generator step is enqueued beside it anyway; (ii) r03's driver run
-# lost a two-rank gloo step to a hang that 92 repetitions on MI355X did not reproduce (profiles/r04_dp_step_loop.txt) - the
-# second stream was the one r03 addition on that path, and a multi-rank run must not depend on it until it has run on RCCL
-# with N > 1.  tests/test_gpu_dp_step.py runs the two-rank step both ways.
+# Single process: on.  Data parallelism over RCCL (`nccl`): on - collectives are stream-ordered there, the update's gradient
+# exchange is enqueued on the second stream like its kernels (tests/test_gpu_nccl.py drives exactly this through a world-size-1
+# RCCL group).  Data parallelism over a backend whose collectives block the HOST (gloo: rehearsals, tests): OFF - the update runs
+# on the main stream in program order: `red_disc.finish()` would hold the host inside the second-stream context, so nothing of
+# the generator step could be enqueued beside it anyway, and r03's driver run lost a two-rank gloo step to a hang on exactly
+# this path that 95 repetitions on MI355X did not reproduce (profiles/r04_dp_step_loop.txt).  XAS_DISC_BESIDE_GEN=0/1 forces
+# either; tests/test_gpu_dp_step.py runs the two-rank gloo step all three ways.
 _BESIDE_ENV = os.environ.get('XAS_DISC_BESIDE_GEN')
 DISC_BESIDE_GEN = _BESIDE_ENV != '0'          # (kept for tools that read it: the single-process setting)
 _aux = {}
@@ -37,7 +38,9 @@ _aux = {}
 def disc_beside_gen():
     if _BESIDE_ENV is not None:
         return _BESIDE_ENV != '0'
-    return not dp_active()
+    if not dp_active():
+        return True
+    return dist.get_backend() == 'nccl'
 
 
 def _aux_stream():
