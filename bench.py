@@ -435,8 +435,9 @@ def main():
                     'algorithmic_MB_per_launch': v['flops'] / v['launches'] / 1e6, 'achieved_TBps': tbs, 'frac_of_8TBps': tbs / 8.0}
         line['roofline']['head'] = dict(hd, kernel='head_partial_kernel + head_finalize_kernel (fwd), head_bwd_coef_kernel + '
                                         'head_bwd_kernel (bwd)', bound='hbm', peak_TBps=8.0,
-                                        note='logits of one camera-batched pass (%d images x 18.87 MB): read once forward, read + '
-                                             'written backward' % (args.batch * len(cams)))
+                                        note='logits of one grouped detector pass (18.87 MB per image; forward: every image of the pass - with the '
+                                             'joint prefix pass 3 x cameras x B = %d, else 2 x cameras x B -, read once; backward: the 2 x cameras x B = %d '
+                                             'graph images, read + written)' % (3 * args.batch * len(cams), 2 * args.batch * len(cams)))
         # batch-norm family (HBM bound; the second-largest family of the step): algorithmic bytes of every call of the event-timed
         # step / its HIP-event time on its stream (statistics that ride in a conv epilogue are not in here: they are conv time)
         bn_ms = sum(v['ms'] for v in bnfam.values())

@@ -1265,6 +1265,7 @@ def prepack(module):
         _, cache, w, _ = entries[idx]
         cache._fresh(w)
         cache.packed[(t, planes)] = view
-    for _, cache, w, shp in entries:                   # whatever the table does not cover (fp32-packed formats)
-        cache.get(w, 0, shp)
-        cache.get(w, 1, shp)
+    for _, cache, w, shp in entries:                   # whatever the table does not cover: the fp32-packed formats (a split
+        for t in (0, 1):                               # format the table leaves out - f16x3: three-plane forward weights, only
+            if query('xas_conv_weight_planes', shp, t) == 0 or not w.is_contiguous():      # wanted by a launch that comes
+                cache.get(w, t, shp)                   # without the maximum of its input - is built on demand)
