@@ -58,9 +58,10 @@ class Linear(nn.Module):
         if bias:
             bound = 1 / math.sqrt(cin)
             nn.init.uniform_(self.bias, -bound, bound)
+        self._cache = F._PackCache()
 
     def forward(self, x):
-        return F.linear(x, self.weight, self.bias)
+        return F.linear(x, self.weight, self.bias, self._cache)
 
 
 class BatchNorm2d(nn.Module):

@@ -841,19 +841,40 @@ def conv_transpose2d(x, weight, stride, pad, cache):
 LINEAR_SIDE = os.environ.get('XAS_LINEAR_SIDE', '1') == '1'
 
 
+# r04: linear layers wide enough for the MFMA tiles run on the convolution kernels of the process's precision mode (default:
+# the split-arithmetic kernels - without operand maxima that is bf16x6, fp32-accurate and range-free) instead of always on
+# the exact-fp32 pipe: their rows are presented as ONE image of H x W pixels (a 1x1 convolution does not care how its pixels
+# are arranged), which is what the split kernels' pixel decode wants.  The discriminator's 128 -> 128 layers over
+# B * 18 * 12 rows: 132 -> ~25 us per weight gradient, 50 -> ~12 us forward.  XAS_LINEAR_MFMA=0: as before.
+LINEAR_MFMA = os.environ.get('XAS_LINEAR_MFMA', '1') == '1'
+
+
+def _row_map(rows):
+    """rows = H * W with a width the split kernels' pixel decode accepts (W >= 32 or few carries), or None."""
+    for w in (96, 64, 128, 72, 48, 32, 80, 112, 56, 40, 36, 24, 16):
+        if rows % w == 0 and rows // w >= 2 and 31 // w + 1 <= rows // w:
+            return rows // w, w
+    return None
+
+
 class _Linear(torch.autograd.Function):
-    """y = x @ W^T + b as a 1x1 'convolution' over rows (discriminator.py:8-21, 186-191)."""
+    """y = x @ W^T + b as a 1x1 'convolution' over rows (discriminator.py:8-21, 186-191).  wf / wt: kernel-side copies of the
+    weight for the forward / data-gradient launch (None: the raw fp32 weight on the exact-fp32 kernels); hw: the row map."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, wf, wt, hw):
         x = x.contiguous()
         rows, ci = x.shape
         co = weight.shape[0]
-        shp = _shape(rows, 1, 1, ci, co, 1, 1, 1, 0, 1, 1, MODE_F32)      # raw fp32 weights: the exact-fp32 kernels
+        if wf is not None:
+            shp = _shape(1, hw[0], hw[1], ci, co, 1, 1, 1, 0, hw[0], hw[1])         # process precision mode, no operand maxima
+        else:
+            shp = _shape(rows, 1, 1, ci, co, 1, 1, 1, 0, 1, 1, MODE_F32)      # raw fp32 weights: the exact-fp32 kernels
+            wf = weight.detach().contiguous()
         y = torch.empty(rows, co, device=x.device, dtype=torch.float32)
-        call('xas_conv_fwd', ptr(x), ptr(weight.detach().contiguous()), ptr(bias), ptr(y), shp)
-        ctx.save_for_backward(x, weight)
-        ctx.shp, ctx.has_bias = shp, bias is not None
+        call('xas_conv_fwd', ptr(x), ptr(wf), ptr(bias), ptr(y), shp)
+        ctx.save_for_backward(x, weight, *([wt] if wt is not None else []))
+        ctx.shp, ctx.has_bias, ctx.rows = shp, bias is not None, rows
         # the parameters whose .grad take the sums directly (leaves only: a derived tensor has no gradient buffer)
         ctx.bias_ref = bias if (bias is not None and bias.is_leaf) else None
         ctx.weight_ref = weight if weight.is_leaf else None
@@ -861,28 +882,40 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, *rest = ctx.saved_tensors
         shp = ctx.shp
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wt = weight.detach().t().contiguous()            # [Cin][Cout]
+            wt = rest[0] if rest else weight.detach().t().contiguous()            # [Cin][Cout] (kernel-side format)
             dx = torch.empty_like(x)
             call('xas_conv_dgrad', ptr(dy), ptr(wt), ptr(dx), shp)
         wref = ctx.weight_ref
         if ctx.needs_input_grad[1] and not (LINEAR_SIDE and dy.is_cuda and wref is not None and _wgrad_into_grad(x, dy, shp, wref)):
             dw = torch.empty_like(weight)
             ws = torch.empty(max(1, query('xas_conv_wgrad_workspace_floats', shp)), device=x.device, dtype=torch.float32)
-            call('xas_conv_wgrad', ptr(x), ptr(dy), ptr(dw), ptr(ws), shp)
+            call('xas_conv_wgrad_oihw' if rest else 'xas_conv_wgrad', ptr(x), ptr(dy), ptr(dw), ptr(ws), shp)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             bias = ctx.bias_ref
-            if not (LINEAR_SIDE and dy.is_cuda and bias is not None and _bias_into_grad(dy, shp.N, shp.Cout, bias, force=True)):
-                db = _bias_grad(dy, shp.N, shp.Cout)
-        return dx, dw, db
+            if not (LINEAR_SIDE and dy.is_cuda and bias is not None and _bias_into_grad(dy, ctx.rows, shp.Cout, bias, force=True)):
+                db = _bias_grad(dy, ctx.rows, shp.Cout)
+        return dx, dw, db, None, None, None
 
 
-def linear(x, weight, bias):
-    return _Linear.apply(x, weight, bias)
+def linear(x, weight, bias, cache=None):
+    """cache: the layer's _PackCache (layers.Linear) - with it, a layer wide enough for the MFMA tiles runs on the kernels of
+    the process's precision mode (see LINEAR_MFMA); called with the PARAMETER object, whose optimizer epoch keys the cache."""
+    wf = wt = hw = None
+    if (cache is not None and LINEAR_MFMA and x.is_cuda and x.dim() == 2 and weight.is_contiguous() and weight.shape[1] % 32 == 0
+            and weight.shape[0] >= 16 and weight.shape[0] % 4 == 0 and x.shape[0] >= 64):
+        hw = _row_map(x.shape[0])
+        if hw is not None:
+            co, ci = weight.shape
+            w4 = weight.detach().view(co, ci, 1, 1)
+            w4._xas_epoch = getattr(weight, '_xas_epoch', _weights_epoch)
+            shp = _shape(1, hw[0], hw[1], ci, co, 1, 1, 1, 0, hw[0], hw[1])
+            wf, wt = cache.get(w4, 0, shp), cache.get(w4, 1, shp)
+    return _Linear.apply(x, weight, bias, wf, wt, hw)
 
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
