@@ -69,6 +69,8 @@ def _grouped(net, tensors):
     res = []
     B = tensors[0].shape[0]
     per_pass = max(1, min(CAM_BATCH_MAX, 384 // max(1, B)))     # logits of a pass: G*B*64*64*1152 elements < 2^31
+    n_pass = -(-len(tensors) // per_pass)
+    per_pass = -(-len(tensors) // n_pass)                        # equal passes (8 groups at B = 64: 4 + 4, not 6 + 2)
     for lo in range(0, len(tensors), per_pass):
         part = tensors[lo:lo + per_pass]
         G = len(part)
