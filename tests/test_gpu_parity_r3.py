@@ -134,6 +134,8 @@ def test_full_size_step_b32_four_cameras(monkeypatch):
     for batched in (True, False):
         monkeypatch.setattr(mm, 'CAM_BATCH', batched)
         monkeypatch.setattr(mm, 'JOIN_PSEUDO', batched)
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
         torch.manual_seed(1234)
         model, disc, od, odisc = engine.prepare_model(cfg)
         model.cuda().train(), disc.cuda().train()
@@ -144,6 +146,9 @@ def test_full_size_step_b32_four_cameras(monkeypatch):
         assert bool(torch.isfinite(ld)) and bool(torch.isfinite(tot))
         assert bool(torch.isfinite(od.param_arena).all()) and bool(torch.isfinite(odisc.param_arena).all())
         res.append((float(ld), float(tot), {k: float(v.mean()) for k, v in lk.items()}, od.param_arena.clone()))
+        # memory bound of the benchmark configuration: activations of the joint 12-group pass, both
+        # weight-plane formats, gradient arenas and maxima - measured 67 GB batched (50 GB per camera); the part has 288
+        assert torch.cuda.max_memory_allocated() < (80 if batched else 60) * 2**30, torch.cuda.max_memory_allocated() / 2**30
         del model, disc, od, odisc, step
         torch.cuda.empty_cache()
     a, b = res

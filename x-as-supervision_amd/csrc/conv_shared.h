@@ -139,9 +139,55 @@ __device__ __forceinline__ float4 sub_f16x4(float4 v, uint2 q) {
   const f16x2_t lo = __builtin_bit_cast(f16x2_t, q.x), hi = __builtin_bit_cast(f16x2_t, q.y);
   return make_float4(v.x - (float)lo.x, v.y - (float)lo.y, v.z - (float)hi.x, v.w - (float)hi.y);
 }
+// Both fp16 pieces of four fp32 values at scale s in EIGHT vector-ALU instructions: h1 = fp16(s v) by v_fma_mixlo/hi_f16 (the
+// scale folded into the conversion, the pair packed by the instruction), h2 = fp16(s v - h1) by the same instruction reading
+// h1 as an fp16 source (op_sel picks the half).  s v is exact (s is a power of two) and s v - h1 is exactly representable in
+// fp32, so every result is rounded once: bit-identical to pack_f16x4 / sub_f16x4 up to the sign of a zero piece (fma(-0, s, +0)
+// = +0; a zero piece contributes nothing either way) - tools/micro/split_f16_check.hip, 50 M values incl. inf / NaN / denormals.  What the
+// compiler makes of the generic formulation is 14 instructions per float4 (it computes h1 twice: once unpacked as the fp16
+// source of h2, once by v_mul + v_cvt_pk for the packed store) - and the conversion work, not the matrix pipe, is what the
+// weight-gradient kernels wait for (both operands are split in the kernel: ~1 400 vector-ALU cycles against 768 MFMA cycles
+// per K-step and wave before this change).
+__device__ __forceinline__ void split_f16x4(float4 v, float s, uint2& h1, uint2& h2) {
+  unsigned a, b, c, d;
+  asm("v_fma_mixlo_f16 %0, %2, %3, 0\n\t"
+      "v_fma_mixlo_f16 %1, %2, %5, 0\n\t"
+      "v_fma_mixhi_f16 %0, %2, %4, 0\n\t"
+      "v_fma_mixhi_f16 %1, %2, %6, 0"
+      : "=&v"(a), "=&v"(b) : "v"(s), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+  asm("v_fma_mixlo_f16 %0, %2, %3, -%7 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %1, %2, %5, -%8 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %2, %4, -%7 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %1, %2, %6, -%8 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(c), "=&v"(d) : "v"(s), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(a), "v"(b));
+  h1 = make_uint2(a, b);
+  h2 = make_uint2(c, d);
+}
+// the pieces of four values, smallest plane index first (P = 2: fp16 at scale s; P = 3 / 1: bf16, s unused)
+template <int P> struct Pieces { uint2 q[P]; };
+template <int P> __device__ __forceinline__ Pieces<P> split_pieces(float4 r, float s);
 // piece formats by plane count: 3 / 1 planes = bf16 pieces, 2 planes = fp16 pieces
 template <int P> __device__ __forceinline__ uint2 pack_piece4(float4 v) { return P == 2 ? pack_f16x4(v) : pack_bf16x4(v); }
 template <int P> __device__ __forceinline__ float4 sub_piece4(float4 v, uint2 q) { return P == 2 ? sub_f16x4(v, q) : sub_bf16x4(v, q); }
+template <int P> __device__ __forceinline__ Pieces<P> split_pieces(float4 r, float s) {
+  Pieces<P> o;
+  if constexpr (P == 2) {
+#ifdef XAS_F16_SPLIT_GENERIC                       // (A/B builds: the compiler's 14-instruction form)
+    r.x *= s; r.y *= s; r.z *= s; r.w *= s;
+    o.q[0] = pack_f16x4(r);
+    o.q[1] = pack_f16x4(sub_f16x4(r, o.q[0]));
+#else
+    split_f16x4(r, s, o.q[0], o.q[1]);
+#endif
+  } else {
+#pragma unroll
+    for (int pc = 0; pc < P; ++pc) {
+      o.q[pc] = pack_bf16x4(r);
+      if (pc + 1 < P) r = sub_bf16x4(r, o.q[pc]);
+    }
+  }
+  return o;
+}
 // kept partial products (a piece, b piece), smallest first
 template <int P> struct Products;
 template <> struct Products<3> { static constexpr int N = 6; static constexpr int A[6] = {2, 0, 1, 1, 0, 0}; static constexpr int B[6] = {0, 2, 1, 0, 1, 0}; };

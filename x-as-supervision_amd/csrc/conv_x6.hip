@@ -266,6 +266,12 @@ __global__ __launch_bounds__(256, (P == 2 ? (BM == 64 && BN == 256 ? XAS_X6_WAVE
 #pragma unroll
     for (int j = 0; j < AP; ++j) {
       float4 r = ra[h * AP + j];
+#if !(XAS_X6_ABL & (32 | 64))
+      const Pieces<P> pcs = split_pieces<P>(r, f16_sa);       // (P = 2: both fp16 pieces in eight instructions, conv_shared.h)
+#pragma unroll
+      for (int pc = 0; pc < P; ++pc)
+        *reinterpret_cast<uint2*>(sb + pc * PLANE + (arow + 64 * j) * XLDH + xswz(arow, kq4 >> 1) + (kq4 & 1) * 4) = pcs.q[pc];
+#else
       if (P == 2) { r.x *= f16_sa; r.y *= f16_sa; r.z *= f16_sa; r.w *= f16_sa; }
 #pragma unroll
       for (int pc = 0; pc < P; ++pc) {
@@ -282,6 +288,7 @@ __global__ __launch_bounds__(256, (P == 2 ? (BM == 64 && BN == 256 ? XAS_X6_WAVE
         *reinterpret_cast<uint2*>(sb + pc * PLANE + (arow + 64 * j) * XLDH + xswz(arow, kq4 >> 1) + (kq4 & 1) * 4) = q;
         if (pc + 1 < P && !(XAS_X6_ABL & 32)) r = sub_piece4<P>(r, q);
       }
+#endif
     }
   };
   const int i = lane & 31, hh = lane >> 5;
@@ -443,15 +450,10 @@ __global__ __launch_bounds__(256, XAS_X6T_WAVES) void igemm_x6t_kernel(IgemmPara
     for (int j = 0; j < XT_NJ; ++j) {
       const int item = tid + 256 * j, pix = item >> 3, q = item & 7;
       if (pix < npix) {
-        float4 r = ra[j];
-        if (P == 2) { r.x *= f16_sa; r.y *= f16_sa; r.z *= f16_sa; r.w *= f16_sa; }
+        const Pieces<P> pcs = split_pieces<P>(ra[j], f16_sa);
         unsigned char* d = S + pix * XT_PIXB + q * 8;
 #pragma unroll
-        for (int pc = 0; pc < P; ++pc) {
-          const uint2 v = pack_piece4<P>(r);
-          *reinterpret_cast<uint2*>(d + pc * plane_b) = v;
-          if (pc + 1 < P) r = sub_piece4<P>(r, v);
-        }
+        for (int pc = 0; pc < P; ++pc) *reinterpret_cast<uint2*>(d + pc * plane_b) = pcs.q[pc];
       }
     }
   };
@@ -821,25 +823,15 @@ __global__ __launch_bounds__(256, (P == 2 ? XAS_WX6_WAVES2 : 2)) void wgrad_x6_k
 #pragma unroll
     for (int j = 0; j < APH; ++j) {
       if (AHALF && ahalf != h) continue;               // (wave-uniform) this wave's dy rows belong to the other half
-      float4 r = ra[AHALF ? 0 : h * APH + j];
-      if (P == 2) { r.x *= f16_sd; r.y *= f16_sd; r.z *= f16_sd; r.w *= f16_sd; }
+      const Pieces<P> pcs = split_pieces<P>(ra[AHALF ? 0 : h * APH + j], f16_sd);
 #pragma unroll
-      for (int pc = 0; pc < P; ++pc) {
-        const uint2 q = pack_piece4<P>(r);
-        *reinterpret_cast<uint2*>(sb + pc * XH * SA + AROWS * j * SA + dstA) = q;
-        if (pc + 1 < P) r = sub_piece4<P>(r, q);
-      }
+      for (int pc = 0; pc < P; ++pc) *reinterpret_cast<uint2*>(sb + pc * XH * SA + AROWS * j * SA + dstA) = pcs.q[pc];
     }
 #pragma unroll
     for (int q4 = 0; q4 < BPQ; ++q4) {
-      float4 r = rb[h * BPQ + q4];
-      if (P == 2) { r.x *= f16_sx; r.y *= f16_sx; r.z *= f16_sx; r.w *= f16_sx; }
+      const Pieces<P> pcs = split_pieces<P>(rb[h * BPQ + q4], f16_sx);
 #pragma unroll
-      for (int pc = 0; pc < P; ++pc) {
-        const uint2 q = pack_piece4<P>(r);
-        *reinterpret_cast<uint2*>(sb + pc * XH * SB + q4 * 128 + dstB) = q;
-        if (pc + 1 < P) r = sub_piece4<P>(r, q);
-      }
+      for (int pc = 0; pc < P; ++pc) *reinterpret_cast<uint2*>(sb + pc * XH * SB + q4 * 128 + dstB) = pcs.q[pc];
     }
   };
   // transposing fragment read: lane (l16 = lane & 15 -> row qd = l16 >> 2, column quad pp = l16 & 3; g1 = channel half;
@@ -1003,15 +995,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6t_kernel(WgradParams p) {
     for (int j = 0; j < XT_NJ; ++j) {
       const int item = tid + 256 * j, pix = item >> 3, q = item & 7;
       if (pix < npix) {
-        float4 r = rx[j];
-        if (P == 2) { r.x *= f16_sx; r.y *= f16_sx; r.z *= f16_sx; r.w *= f16_sx; }
+        const Pieces<P> pcs = split_pieces<P>(rx[j], f16_sx);
         unsigned char* d = SX + pix * XPB + q * 8;
 #pragma unroll
-        for (int pc = 0; pc < P; ++pc) {
-          const uint2 v = pack_piece4<P>(r);
-          *reinterpret_cast<uint2*>(d + pc * xplane) = v;
-          if (pc + 1 < P) r = sub_piece4<P>(r, v);
-        }
+        for (int pc = 0; pc < P; ++pc) *reinterpret_cast<uint2*>(d + pc * xplane) = pcs.q[pc];
       }
     }
   };
@@ -1038,14 +1025,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6t_kernel(WgradParams p) {
     for (int j = 0; j < DJ; ++j) {
       const int item = tid + 256 * j, apix = item / DQ, aq = item - apix * DQ;
       if (item < XH * DQ) {
-        float4 r = rd[j];
-        if (P == 2) { r.x *= f16_sd; r.y *= f16_sd; r.z *= f16_sd; r.w *= f16_sd; }
+        const Pieces<P> pcs = split_pieces<P>(rd[j], f16_sd);
 #pragma unroll
-        for (int pc = 0; pc < P; ++pc) {
-          const uint2 v = pack_piece4<P>(r);
-          *reinterpret_cast<uint2*>(sb + pc * XH * SA + apix * SA + aq * 8) = v;
-          if (pc + 1 < P) r = sub_piece4<P>(r, v);
-        }
+        for (int pc = 0; pc < P; ++pc) *reinterpret_cast<uint2*>(sb + pc * XH * SA + apix * SA + aq * 8) = pcs.q[pc];
       }
     }
   };

@@ -1249,9 +1249,11 @@ def prepack(module):
     prec = query('xas_get_precision')
     if not BATCH_PREP:
         for _, cache, w, shp in entries:
-            cache.get(w, 0, shp)
+            f16 = (prec == _lib.PREC_F16X3 and GRAD_F16 and shp.mode == 0 and query('xas_conv_weight_planes', shp, 1) == 3)
+            if not (f16 and query('xas_conv_weight_planes', shp, 0) == 3):
+                cache.get(w, 0, shp)                   # (f16x3: the three-plane forward format is built on demand only)
             cache.get(w, 1, shp)
-            if (prec == _lib.PREC_F16X3 and GRAD_F16 and shp.mode == 0 and query('xas_conv_weight_planes', shp, 1) == 3):
+            if f16:
                 cache.get(w, 0, shp, planes=2)         # the formats of launches that come with their operand maxima
                 cache.get(w, 1, shp, planes=2)
         return
