@@ -28,7 +28,7 @@ from .optim import FusedAdam
 # RCCL group).  Data parallelism over a backend whose collectives block the HOST (gloo: rehearsals, tests): OFF - the update runs
 # on the main stream in program order: `red_disc.finish()` would hold the host inside the second-stream context, so nothing of
 # the generator step could be enqueued beside it anyway, and r03's driver run lost a two-rank gloo step to a hang on exactly
-# this path that 95 repetitions on MI355X did not reproduce (profiles/r04_dp_step_loop.txt).  XAS_DISC_BESIDE_GEN=0/1 forces
+# this path that 107 repetitions on MI355X did not reproduce (profiles/r04_dp_step_loop.txt).  XAS_DISC_BESIDE_GEN=0/1 forces
 # either; tests/test_gpu_dp_step.py runs the two-rank gloo step all three ways.
 _BESIDE_ENV = os.environ.get('XAS_DISC_BESIDE_GEN')
 DISC_BESIDE_GEN = _BESIDE_ENV != '0'          # (kept for tools that read it: the single-process setting)
