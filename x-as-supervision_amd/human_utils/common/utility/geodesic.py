@@ -46,7 +46,8 @@ def compute_centroid(mask):
 def _in_loader_worker():
     """True in a DataLoader worker process or in any forked child of a process that had initialised the GPU."""
     import torch.utils.data
-    return torch.utils.data.get_worker_info() is not None or torch.cuda._is_in_bad_fork()
+    bad_fork = getattr(torch.cuda, '_is_in_bad_fork', None)          # (private helper of torch.cuda: present in 2.x)
+    return torch.utils.data.get_worker_info() is not None or bool(bad_fork and bad_fork())
 
 
 def compute_geodesic_dis(img, img_path, geodesic_param_list, centers=None, is_norm=True):
