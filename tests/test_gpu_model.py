@@ -398,6 +398,12 @@ def _check_wiring(gname, cfg, cams, seed, tol_loss=3e-4, rng_seed=None):
     assert maxabs(out['kp_gt_world'], T(g['kp_gt_world'])) < 0.05
     assert maxabs(out['mask_heatmap_line_' + cl][:, :, ::4, ::4], T(g['mask_line_sub'])) < 2e-4
     p = dict(reg.named_parameters())
+    # (gradient slices of the PLANTED-PEAK fixture: a smoke check of the wiring - which loss reaches which network at which
+    # scale - not the accuracy instrument.  The reference's own fp32 evaluation of this graph sits ~1e-2 from any other
+    # evaluation order, and a float64 run of the reference takes other depth peaks altogether (r04: tried as a yardstick - its
+    # loss differs by 3 %), so no data-driven bar exists for it; every parameter gradient of the three networks is held to
+    # max(floor, 4 x the reference's fp32-vs-fp64 distance) on well-conditioned fixtures instead: detector_allgrads,
+    # physique_allgrads, disc_decouple_allgrads)
     assert rel(p['net.head.features.9.bias'].grad, T(g['g_fin_b'])) < 3e-2
     assert rel(p['net.backbone.conv1.weight'].grad, T(g['g_conv1'])) < 5e-2
     if float(T(g['g_phys_dec4_w']).norm()) > 0:
