@@ -63,7 +63,13 @@ def test_exports_and_signatures():
         assert _lib.SIGNATURES[name] == (codes, ret), '%s: table %r vs header %r' % (name, _lib.SIGNATURES[name], (codes, ret))
     assert set(_lib.SIGNATURES) <= set(protos)
     assert ctypes.sizeof(_lib.ConvShape) == 12 * 4 + 16 and _lib.ConvShape.grad_amax.offset == 48 and _lib.ConvShape.x_amax.offset == 56      # 12 ints + the two operand-maximum pointers
-    assert lib.xas_abi_version() == 2
+    assert lib.xas_abi_version() == 3
+    # recorded maxima: the slot layout of the header is the one the Python side allocates
+    import re
+    from xas_amd import ops_nn
+    src = open(os.path.join(ROOT, 'include', 'xas_hip.h')).read()
+    sub, stride = (int(re.search(r'#define %s (\d+)' % n, src).group(1)) for n in ('XAS_AMAX_SUB', 'XAS_AMAX_STRIDE'))
+    assert sub * stride == ops_nn.AMAX_SLOT_FLOATS and stride * 4 == 128
 
 
 def test_no_cpu_fallback():

@@ -15,4 +15,5 @@ void set_error(const char* fmt, ...) {
 }  // namespace xas
 
 extern "C" const char* xas_last_error(void) { return xas::g_err; }
-extern "C" int xas_abi_version(void) { return 2; }   // 2: xas_conv_shape.mode, pre-split weights (round 3)
+extern "C" int xas_abi_version(void) { return 3; }   // 2: xas_conv_shape.mode, pre-split weights (round 3); 3: xas_conv_shape.x_amax,
+                                                     // recorded maxima as slots of XAS_AMAX_SLOT_FLOATS floats (round 4)
