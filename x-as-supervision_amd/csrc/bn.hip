@@ -664,68 +664,74 @@ __global__ void bn_running_kernel(const float* mean, const float* var, float* rm
 }
 
 // ---------------------------------------------------------------- max pool 3x3 s2 p1
-__global__ void maxpool_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, int Ho, int Wo,
-                                   float* __restrict__ y, int8_t* __restrict__ idx) {
-  const int C4 = C / 4;
-  const long total = (long)N * Ho * Wo * C4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    long t = i / C4;
-    const int wo = t % Wo; t /= Wo;
-    const int ho = t % Ho; const int n = t / Ho;
-    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-    bool first = true;
-    for (int r = 0; r < 3; ++r) {
-      const int hi = ho * 2 - 1 + r;
-      if ((unsigned)hi >= (unsigned)H) continue;
-      for (int s = 0; s < 3; ++s) {
-        const int wi = wo * 2 - 1 + s;
-        if ((unsigned)wi >= (unsigned)W) continue;
-        const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + hi) * W + wi) * C + c);
-        const int tap = r * 3 + s;
-        if (first || v.x > best.x) { best.x = v.x; b0 = tap; }
-        if (first || v.y > best.y) { best.y = v.y; b1 = tap; }
-        if (first || v.z > best.z) { best.z = v.z; b2 = tap; }
-        if (first || v.w > best.w) { best.w = v.w; b3 = tap; }
-        first = false;
+// One block walks whole image ROWS (grid-stride over n * rows): the row decode is scalar and 32-bit, a lane splits only its
+// element index into (column, channel quad).  (r04: the flat 64-bit index per thread cost three emulated 64-bit divisions -
+// backward 697 us for 1.4 GB = 2.0 TB/s at 256 images.)
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, int Ho, int Wo,
+                                                          float* __restrict__ y, int8_t* __restrict__ idx) {
+  const int C4 = C / 4, per_row = Wo * C4;
+  for (int row = blockIdx.x; row < N * Ho; row += gridDim.x) {
+    const int n = row / Ho, ho = row - n * Ho;
+    const float* xn = x + (size_t)n * H * W * C;
+    const size_t obase = (size_t)row * per_row;
+    for (int e = threadIdx.x; e < per_row; e += blockDim.x) {
+      const int wo = e / C4, c = (e - wo * C4) * 4;
+      float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+      bool first = true;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int hi = ho * 2 - 1 + r;
+        if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const int wi = wo * 2 - 1 + s;
+          if ((unsigned)wi >= (unsigned)W) continue;
+          const float4 v = *reinterpret_cast<const float4*>(xn + ((size_t)hi * W + wi) * C + c);
+          const int tap = r * 3 + s;
+          if (first || v.x > best.x) { best.x = v.x; b0 = tap; }
+          if (first || v.y > best.y) { best.y = v.y; b1 = tap; }
+          if (first || v.z > best.z) { best.z = v.z; b2 = tap; }
+          if (first || v.w > best.w) { best.w = v.w; b3 = tap; }
+          first = false;
+        }
       }
+      *reinterpret_cast<float4*>(y + (obase + e) * 4) = best;
+      *reinterpret_cast<char4*>(idx + (obase + e) * 4) = make_char4((char)b0, (char)b1, (char)b2, (char)b3);
     }
-    *reinterpret_cast<float4*>(y + i * 4) = best;
-    *reinterpret_cast<char4*>(idx + i * 4) = make_char4((char)b0, (char)b1, (char)b2, (char)b3);
   }
 }
 
-__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int8_t* __restrict__ idx, int N, int H, int W,
-                                   int C, int Ho, int Wo, float* __restrict__ dx) {
-  const int C4 = C / 4;
-  const long total = (long)N * H * W * C4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    long t = i / C4;
-    const int wi = t % W; t /= W;
-    const int hi = t % H; const int n = t / H;
-    float4 acc = make_float4(0, 0, 0, 0);
-    // output windows ho with ho*2-1 <= hi <= ho*2+1
-    for (int ho = (hi) / 2; ho <= (hi + 1) / 2; ++ho) {
-      if (ho >= Ho) continue;
-      const int r = hi - (ho * 2 - 1);
-      if (r < 0 || r > 2) continue;
-      for (int wo = (wi) / 2; wo <= (wi + 1) / 2; ++wo) {
-        if (wo >= Wo) continue;
-        const int s = wi - (wo * 2 - 1);
-        if (s < 0 || s > 2) continue;
-        const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + c;
-        const char4 k = *reinterpret_cast<const char4*>(idx + o);
-        const float4 g = *reinterpret_cast<const float4*>(dy + o);
-        const int tap = r * 3 + s;
-        if (k.x == tap) acc.x += g.x;
-        if (k.y == tap) acc.y += g.y;
-        if (k.z == tap) acc.z += g.z;
-        if (k.w == tap) acc.w += g.w;
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const int8_t* __restrict__ idx, int N, int H,
+                                                          int W, int C, int Ho, int Wo, float* __restrict__ dx) {
+  const int C4 = C / 4, per_row = W * C4;
+  for (int row = blockIdx.x; row < N * H; row += gridDim.x) {
+    const int n = row / H, hi = row - n * H;
+    const size_t obase = (size_t)row * per_row;
+    for (int e = threadIdx.x; e < per_row; e += blockDim.x) {
+      const int wi = e / C4, c = (e - wi * C4) * 4;
+      float4 acc = make_float4(0, 0, 0, 0);
+      // output windows ho with ho*2-1 <= hi <= ho*2+1
+      for (int ho = hi / 2; ho <= (hi + 1) / 2; ++ho) {
+        if (ho >= Ho) continue;
+        const int r = hi - (ho * 2 - 1);
+        if (r < 0 || r > 2) continue;
+        for (int wo = wi / 2; wo <= (wi + 1) / 2; ++wo) {
+          if (wo >= Wo) continue;
+          const int s = wi - (wo * 2 - 1);
+          if (s < 0 || s > 2) continue;
+          const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + c;
+          const char4 k = *reinterpret_cast<const char4*>(idx + o);
+          const float4 g = *reinterpret_cast<const float4*>(dy + o);
+          const int tap = r * 3 + s;
+          if (k.x == tap) acc.x += g.x;
+          if (k.y == tap) acc.y += g.y;
+          if (k.z == tap) acc.z += g.z;
+          if (k.w == tap) acc.w += g.w;
+        }
       }
+      stream_store(reinterpret_cast<float4*>(dx) + obase + e, acc);
     }
-    *reinterpret_cast<float4*>(dx + i * 4) = acc;
   }
 }
 
@@ -1151,8 +1157,10 @@ extern "C" int xas_abs_max(const float* x, long n, float* amax_out, void* stream
 extern "C" int xas_maxpool3x3s2_fwd(const float* x, int N, int H, int W, int C, float* y, int8_t* idx, void* stream) {
   XAS_REQUIRE(x && y && idx && N > 0 && H > 0 && W > 0 && C % 4 == 0, "maxpool: bad arguments");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const long total = (long)N * Ho * Wo * (C / 4);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), x, N, H, W, C, Ho, Wo, y, idx);
+  XAS_REQUIRE((long)N * H < 0x7fffffffl, "maxpool: too many rows");
+  const long rows = (long)N * Ho;                               // one block per output row (grid-stride beyond 8 192 blocks)
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)(rows < 8192 ? rows : 8192)), dim3(256), 0, as_stream(stream), x, N, H, W, C, Ho,
+                     Wo, y, idx);
   XAS_LAUNCH_CHECK();
   return 0;
 }
@@ -1161,8 +1169,10 @@ extern "C" int xas_maxpool3x3s2_bwd(const float* dy, const int8_t* idx, int N, i
                                     void* stream) {
   XAS_REQUIRE(dy && dx && idx && N > 0 && H > 0 && W > 0 && C % 4 == 0, "maxpool bwd: bad arguments");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const long total = (long)N * H * W * (C / 4);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), dy, idx, N, H, W, C, Ho, Wo, dx);
+  XAS_REQUIRE((long)N * H < 0x7fffffffl, "maxpool bwd: too many rows");
+  const long rows = (long)N * H;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)(rows < 16384 ? rows : 16384)), dim3(256), 0, as_stream(stream), dy, idx, N, H,
+                     W, C, Ho, Wo, dx);
   XAS_LAUNCH_CHECK();
   return 0;
 }
