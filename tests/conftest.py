@@ -17,12 +17,42 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
     config.addinivalue_line('markers', 'multiproc: starts worker processes (collected LAST, so that `-x` reaches them only '
                                        'after every single-process parity test has been recorded)')
+    config.addinivalue_line('markers', 'selfcheck: HIP path against itself (another schedule / switch / a second run), not against '
+                                       'the oracle: collected after every oracle / float64 / golden value check')
     config.addinivalue_line('markers', 'limit(seconds): per-test time limit other than the default %d s' % TEST_LIMIT_S)
 
 
+# Order of the GPU tier: evidence must survive a late failure under `-x`.
+#   tier 0  value checks against the oracle / float64 / reference-generated goldens, cheapest files first - the isolated and
+#           large-problem kernels (what bench.py actually runs) before anything that needs a whole network;
+#   tier 1  HIP-against-HIP equivalence (grouped == separate calls, switches agree, reproducibility) and the full-size
+#           self-consistency steps (marker `selfcheck`, or a name listed below);
+#   tier 2  everything that starts worker processes (marker `multiproc`).
+FILE_ORDER = ['test_gpu_kernels_isolated', 'test_gpu_tap_kernels', 'test_gpu_bench_kernels', 'test_gpu_head', 'test_gpu_nn',
+              'test_gpu_eval', 'test_gpu_input', 'test_gpu_precision', 'test_gpu_parity_r3', 'test_gpu_model']
+SELFCHECK_FILES = ('test_gpu_groups', 'test_gpu_fullsize', 'test_gpu_repro')
+SELFCHECK_NAMES = ('test_full_size_step', 'test_optional_step_switches_agree', 'test_step_switches_are_bit_identical',
+                   'test_dedupe_step_is_bit_identical', 'test_discriminator_groups_equal_separate_calls',
+                   'test_tap_and_wide_tile_kernels_equal_the_implicit_gemm', 'test_batched_weight_preparation_is_bit_identical',
+                   'test_stem_weight_gradient_kernel_equals_the_general_kernel', 'test_free_running_steps')
+
+
+def _tier(item):
+    if item.get_closest_marker('multiproc') is not None:
+        return 2
+    mod = item.module.__name__.rsplit('.', 1)[-1]
+    if item.get_closest_marker('selfcheck') is not None or mod in SELFCHECK_FILES or item.originalname in SELFCHECK_NAMES \
+            or any(item.name.startswith(n) for n in SELFCHECK_NAMES):
+        return 1
+    return 0
+
+
 def pytest_collection_modifyitems(config, items):
-    """Single-process oracle / golden parity tests first, everything that starts processes last (stable within each half)."""
-    items.sort(key=lambda it: 1 if it.get_closest_marker('multiproc') is not None else 0)
+    """Stable sort: tier, then the file order above (files not listed keep their alphabetical place after the listed ones)."""
+    def key(it):
+        mod = it.module.__name__.rsplit('.', 1)[-1]
+        return (_tier(it), FILE_ORDER.index(mod) if mod in FILE_ORDER else len(FILE_ORDER))
+    items.sort(key=key)
 
 
 @pytest.fixture(autouse=True)

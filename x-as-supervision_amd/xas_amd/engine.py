@@ -33,6 +33,7 @@ from .optim import FusedAdam
 _BESIDE_ENV = os.environ.get('XAS_DISC_BESIDE_GEN')
 DISC_BESIDE_GEN = _BESIDE_ENV != '0'          # (kept for tools that read it: the single-process setting)
 _aux = {}
+_DEBUG_SYNC = os.environ.get('XAS_DEBUG_SYNC', '').split(',')      # diagnostic sync points (tools/diag_repro.py)
 
 
 def disc_beside_gen():
@@ -200,6 +201,9 @@ class TrainStep:
             if shared is not None:
                 self.model.pseudo_passes(x, *shared)
                 loss_kp, info = self.model.finish(x, self.disc.smpl_discriminator, *shared)
+            elif aux is not None and os.environ.get('XAS_ADV_AUX', '1') == '0':
+                torch.cuda.current_stream().wait_stream(aux)        # (diagnostic: the adversarial term on the main stream)
+                loss_kp, info = self.model.finish(x, self.disc.smpl_discriminator, *self.model.camera_passes(x, dets=dets))
             elif aux is not None:
                 # the adversarial term (the only user of the UPDATED discriminator) stays on the second stream; it starts as
                 # soon as the world joints exist, beside the physique net
@@ -209,6 +213,10 @@ class TrainStep:
                     if 'smpl_gen_loss' in self.model.loss_config:
                         early['v'] = self.model.adversarial_on(aux, x, self.disc.smpl_discriminator,
                                                                {k: v['world'] for k, v in per_cam.items()})
+                        if 'adv_fwd' in _DEBUG_SYNC:
+                            torch.cuda.synchronize()
+                        if 'adv_wait' in _DEBUG_SYNC:
+                            torch.cuda.current_stream().wait_stream(aux)
                 cams = self.model.camera_passes(x, after_geometry=after_geometry, dets=dets)   # beside the discriminator update
                 loss_kp, info = self.model.finish(x, self.disc.smpl_discriminator, *cams, aux=aux, gen_val_early=early.get('v'))
             elif dets is not None:
@@ -219,6 +227,8 @@ class TrainStep:
             total = sum(v.mean() for v in loss_kp.values())
             if self.red_det:
                 self.red_det.arm()
+            if 'pre_bwd' in _DEBUG_SYNC:
+                torch.cuda.synchronize()
             total.backward()
             ops_nn.join_side_stream(reset_chains=True)
             if self.red_det:

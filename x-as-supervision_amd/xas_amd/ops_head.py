@@ -5,6 +5,7 @@ from . import _lib
 from ._lib import call, ptr, query
 
 HEAD_STATS = 16
+peak_probe = None        # measurement hook (tests): called with the int64 depth-peak indices [B,K,Hy] of every head forward
 GEO_NORM, GEO_MONO, GEO_PATCH = 1, 2, 4
 
 
@@ -35,6 +36,8 @@ class _SoftArgmax(torch.autograd.Function):
         ws = torch.empty(query('xas_head_workspace_floats', B, num_kp, D), device=dev, dtype=torch.float32)
         call('xas_head_softargmax_fwd', ptr(logits), B, num_kp, D, num_hypo, neighbor, ptr(kps), ptr(z_idx),
              ptr(dmap), groups, ptr(stats), ptr(ws))
+        if peak_probe is not None:
+            peak_probe(z_idx.clone())
         s = B - logits_tail.shape[0]                     # images of the no-grad prefix (0 outside a prefix pass)
         kps_prefix = kps[:s] if s else kps[:0]
         kps, z_idx_all = (kps[s:], z_idx) if s else (kps, z_idx)
