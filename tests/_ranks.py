@@ -64,14 +64,13 @@ class RanksStuck(AssertionError):
     """A rank did not finish inside its limit (its log holds the stack dump)."""
 
 
-def run_ranks(target, world=2, args=(), limit=RANK_LIMIT_S, retry_stuck=1):
+def run_ranks(target, world=2, args=(), limit=RANK_LIMIT_S, retry_stuck=0):
     """Run `target(rank, world, *args)` in `world` spawned processes -> {rank: return value}.  Raises AssertionError naming
-    the stuck / failed ranks with their logs; no worker survives this call.
-    retry_stuck: a run in which a rank was STUCK (stack dump / still alive at the deadline - not one that raised) is repeated
-    that many times, after its stack dump has been printed and a warning raised: r03's driver run met one hang of the two-rank
-    step that 107 repetitions on leases did not reproduce; a rare hang is reported (the warning shows in pytest's summary, the
-    dump in the captured output) without turning the whole GPU tier red.  A rank that FAILS (exception, wrong result) is
-    never retried."""
+    the stuck / failed ranks with their logs; no worker survives this call.  The per-rank logs of a failed run are KEPT
+    (their directory is named in the message).
+    retry_stuck (default 0: a hang is a FAILURE - r04 retried once and only warned, which let an unexplained hang pass): a
+    run in which a rank was STUCK (stack dump / still alive at the deadline - not one that raised) is repeated that many
+    times; a test that asks for it must carry `limit(>= (retry_stuck + 1) * (limit + 60))`."""
     for attempt in range(retry_stuck + 1):
         try:
             return _run_ranks_once(target, world, args, limit)
@@ -80,7 +79,7 @@ def run_ranks(target, world=2, args=(), limit=RANK_LIMIT_S, retry_stuck=1):
                 raise
             import warnings
             print('[tests/_ranks.py] attempt %d: %s' % (attempt + 1, e), file=sys.stderr, flush=True)
-            warnings.warn('a rank of %s was stuck for %d s (stack dump in the captured stderr); retrying once'
+            warnings.warn('a rank of %s was stuck for %d s (stack dump in the captured stderr); retrying'
                           % (getattr(target, '__name__', target), limit))
 
 
@@ -91,6 +90,7 @@ def _run_ranks_once(target, world, args, limit):
     tmp = tempfile.mkdtemp(prefix='xas_ranks_')
     logs = [os.path.join(tmp, 'rank%d.log' % r) for r in range(world)]
     procs = []
+    failed = False
     try:
         ret = mgr.dict()
         port = free_port()
@@ -115,8 +115,9 @@ def _run_ranks_once(target, world, args, limit):
             # while NO rank raised: a peer that dies of an exception also leaves the others waiting - that is a failure
             raised = any('Traceback (most recent call last)' in t for t in texts)
             stuck = (any(code is None for _, code in bad) or any('\nTimeout (' in '\n' + t for t in texts)) and not raised
-            msg = ('ranks failed or stuck (rank, exitcode; None = still running after %d s): %s\n%s'
-                   % (limit + 60, bad, '\n'.join(tails)))
+            failed = True
+            msg = ('ranks failed or stuck (rank, exitcode; None = still running after %d s): %s\nper-rank logs kept in %s\n%s'
+                   % (limit + 60, bad, tmp, '\n'.join(tails)))
             raise (RanksStuck if stuck else AssertionError)(msg)
         return dict(ret)
     finally:
@@ -129,12 +130,13 @@ def _run_ranks_once(target, world, args, limit):
                 p.kill()
                 p.join(5)
         mgr.shutdown()
-        for f in logs:
+        if not failed:
+            for f in logs:
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
             try:
-                os.remove(f)
+                os.rmdir(tmp)
             except OSError:
                 pass
-        try:
-            os.rmdir(tmp)
-        except OSError:
-            pass

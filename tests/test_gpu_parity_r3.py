@@ -119,85 +119,71 @@ def test_model_wiring_hm36_four_cameras():
     assert rel(dict(reg.named_parameters())['net.backbone.layer1.0.conv2.weight'].grad[:8], T(g['g_l1c2'])) < 5e-2
 
 
+def _schedule_run(name, batch, batched, mode, monkeypatch):
+    """One step of BASELINE config `name` from the seeded initial state (planted depth peaks, _stepcheck.build_step) in one
+    schedule / precision -> captured result (gradient arenas as Adam consumes them, losses, peak indices, parameters)."""
+    import modules.model as mm
+    import _stepcheck as sc
+    from conftest import precision_mode
+    monkeypatch.setattr(mm, 'CAM_BATCH', batched)
+    monkeypatch.setattr(mm, 'JOIN_PSEUDO', batched)
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    step, x = sc.build_step(name, batch)
+    with precision_mode(mode):
+        r = sc.run_captured(step, x)
+    r['peak_gb'] = torch.cuda.max_memory_allocated() / 2**30
+    r['losses'] = dict(zip(r['loss_names'], (float(v) for v in r['loss'])))
+    assert bool(torch.isfinite(r['loss']).all()) and bool(torch.isfinite(r['det']).all()) and bool(torch.isfinite(r['params']).all())
+    del step, x
+    torch.cuda.empty_cache()
+    return r
+
+
+def _schedules_agree(a, b, tol, grad_bar, what):
+    """Two schedules / arithmetics of the SAME step: every loss term within `tol` relative (the adversarial term, which sees
+    the updated discriminator, 10 x), the int64 depth-peak indices identical, and the
+    detector gradient arena within `grad_bar` in norm.  The bar comes from the measured distance of two exact-fp32 evaluations
+    of this gradient with different summation orders (6.5e-3 .. 9e-3, bench.py variant_check) - NOT a sign-flip count after
+    Adam, which measures how many |g| sit near zero, not how far the gradients are apart."""
+    for k, v in b['losses'].items():
+        t = 10 * tol if k == 'smpl_gen' else tol
+        assert abs(a['losses'][k] - v) <= t * abs(v) + 1e-7, (what, k, a['losses'][k], v)
+    # (both schedules run the reference's detector calls in the reference's order: disc real, gen real, gen pseudo)
+    assert a['peaks'].shape == b['peaks'].shape and a['peaks'].numel() > 0
+    n_diff = int((a['peaks'] != b['peaks']).sum())
+    assert n_diff == 0, '%s: %d of %d depth-peak indices differ' % (what, n_diff, a['peaks'].numel())
+    d = float((a['det'].double() - b['det'].double()).norm() / b['det'].double().norm())
+    flips = float(((a['det'] > 0) != (b['det'] > 0)).float().mean())
+    print('%s: gradient arena rel %.3e, sign differences %.4f, losses %s' % (what, d, flips, {k: '%.6g' % v for k, v in a['losses'].items()}))
+    assert d < grad_bar, (what, d)
+    return d
+
+
 def test_full_size_step_b32_four_cameras(monkeypatch):
     """BASELINE config 2 at full size: HM36_Multi_SurS1, 4 cameras, B = 32, one disc + gen step.  The camera-batched step
-    (G = 4 / G = 8 passes of 128 / 256 images) must give the losses of the step that calls the networks once per camera
-    (<= 1e-5 relative), every loss and every parameter must be finite, and the parameters after the step must agree."""
-    import modules.model as mm
-    from xas_amd import engine
-    from xas_amd.synthetic import model_config, synthetic_batch
-    cfg = model_config('HM36_Multi_SurS1')
-    cams = cfg['model_params']['cam_id_list']
-    assert list(cams) == [0, 1, 2, 3]
-    x = synthetic_batch(32, cams, torch.device('cuda'), seed=100)
-    res = []
-    for batched in (True, False):
-        monkeypatch.setattr(mm, 'CAM_BATCH', batched)
-        monkeypatch.setattr(mm, 'JOIN_PSEUDO', batched)
-        torch.cuda.empty_cache()
-        torch.cuda.reset_peak_memory_stats()
-        torch.manual_seed(1234)
-        model, disc, od, odisc = engine.prepare_model(cfg)
-        model.cuda().train(), disc.cuda().train()
-        disc.smpl_discriminator.header.p = 0.0
-        step = engine.TrainStep(cfg, model, disc, od, odisc)
-        ld, lk, tot, out = step(x)
-        torch.cuda.synchronize()
-        assert bool(torch.isfinite(ld)) and bool(torch.isfinite(tot))
-        assert bool(torch.isfinite(od.param_arena).all()) and bool(torch.isfinite(odisc.param_arena).all())
-        res.append((float(ld), float(tot), {k: float(v.mean()) for k, v in lk.items()}, od.param_arena.clone()))
-        # memory bound of the benchmark configuration (VERDICT r03 weak 11): activations of the joint 12-group pass, both
-        # weight-plane formats, gradient arenas and maxima - measured 67 GB batched (50 GB per camera); the part has 288
-        assert torch.cuda.max_memory_allocated() < (80 if batched else 60) * 2**30, torch.cuda.max_memory_allocated() / 2**30
-        del model, disc, od, odisc, step
-        torch.cuda.empty_cache()
-    a, b = res
-    assert abs(a[0] - b[0]) <= 1e-5 * abs(b[0]) + 1e-7, (a[0], b[0])
-    assert abs(a[1] - b[1]) <= 1e-5 * abs(b[1]) + 1e-7, (a[1], b[1])
-    for k in b[2]:
-        assert abs(a[2][k] - b[2][k]) <= 1e-5 * abs(b[2][k]) + 1e-7, (k, a[2][k], b[2][k])
-    # Adam's first step moves a weight by lr * sign(g): only ~zero gradients may flip
-    assert float(((a[3] - b[3]).abs() > 1e-5).float().mean()) < 0.02
+    (ONE grouped pass of 3 x 4 x 32 = 384 images) against the step that calls the networks once per camera: loss terms
+    <= 1e-5 relative, depth-peak indices identical, gradient arena within 3e-2 in norm (measured 8e-3: the distance of two
+    fp32 evaluations of this gradient), memory bound of the benchmark configuration."""
+    a = _schedule_run('HM36_Multi_SurS1', 32, True, 'f16x3', monkeypatch)
+    b = _schedule_run('HM36_Multi_SurS1', 32, False, 'f16x3', monkeypatch)
+    # memory bound of the benchmark configuration (VERDICT r03 weak 11): activations of the joint 12-group pass, both
+    # weight-plane formats, gradient arenas and maxima - measured 67 GB batched (50 GB per camera); the part has 288
+    assert a['peak_gb'] < 80 and b['peak_gb'] < 60, (a['peak_gb'], b['peak_gb'])
+    _schedules_agree(a, b, 1e-5, 3e-2, 'S1 B=32 camera-batched vs per camera')
 
 
+@pytest.mark.limit(300)
 @pytest.mark.parametrize('name,batch', [('HM36_Multi_SurS2', 32), ('HM36_Multi_SynthS2', 64)])
 def test_full_size_step_other_baseline_configs(name, batch, monkeypatch):
     """BASELINE configs 3 and 5 at the size BASELINE.json names (SurS2 finetune: symmetry + adversarial terms active,
-    B = 32; SynthS2: B = 64 per GPU), one disc + gen step: the camera-batched step must give the loss terms of the step that
-    calls the networks once per camera (<= 1e-5 relative; the adversarial term, which sees the UPDATED discriminator, 1e-4),
-    every loss and parameter finite, parameters after the step in agreement, and the f16x3 default must sit on the
-    exact-fp32 MFMA kernels' losses (<= 2e-5 relative)."""
-    import modules.model as mm
-    from conftest import precision_mode
-    from xas_amd import engine
-    from xas_amd.synthetic import model_config, synthetic_batch
-    cfg = model_config(name)
-    cams = cfg['model_params']['cam_id_list']
-    x = synthetic_batch(batch, cams, torch.device('cuda'), seed=100)
-
-    def one(batched, mode):
-        monkeypatch.setattr(mm, 'CAM_BATCH', batched)
-        monkeypatch.setattr(mm, 'JOIN_PSEUDO', batched)
-        torch.manual_seed(1234)
-        model, disc, od, odisc = engine.prepare_model(cfg)
-        model.cuda().train(), disc.cuda().train()
-        disc.smpl_discriminator.header.p = 0.0
-        step = engine.TrainStep(cfg, model, disc, od, odisc)
-        with precision_mode(mode):
-            ld, lk, tot, out = step(x)
-            torch.cuda.synchronize()
-        assert bool(torch.isfinite(ld)) and bool(torch.isfinite(tot))
-        assert bool(torch.isfinite(od.param_arena).all()) and bool(torch.isfinite(odisc.param_arena).all())
-        r = (float(ld), float(tot), {k: float(v.mean()) for k, v in lk.items()}, od.param_arena.clone())
-        del model, disc, od, odisc, step
-        torch.cuda.empty_cache()
-        return r
-
-    a, b, c = one(True, 'f16x3'), one(False, 'f16x3'), one(True, 'f32')
-    for other, tol in ((b, 1e-5), (c, 2e-5)):
-        assert abs(a[0] - other[0]) <= tol * abs(other[0]) + 1e-7, (a[0], other[0])
-        for k in other[2]:
-            t = 10 * tol if k == 'smpl_gen' else tol
-            assert abs(a[2][k] - other[2][k]) <= t * abs(other[2][k]) + 1e-7, (k, a[2][k], other[2][k])
-    assert any(v != 0.0 for k, v in a[2].items() if k in ('symmetry', 'smpl_gen'))          # the S2 terms are live
-    assert float(((a[3] - b[3]).abs() > 1e-5).float().mean()) < 0.02
+    B = 32; SynthS2: B = 64 per GPU), one disc + gen step from a state with PLANTED depth peaks (the selections of
+    modules/model.py:114,162 and keypoint_detector_integral_multi.py:24-34 are then not near-ties): camera-batched vs one
+    call per camera, and the f16x3 default vs the exact-fp32 MFMA kernels: loss terms <= 1e-5 / 2e-5 relative, peak indices
+    identical, gradient arenas within 3e-2 in norm."""
+    a = _schedule_run(name, batch, True, 'f16x3', monkeypatch)
+    b = _schedule_run(name, batch, False, 'f16x3', monkeypatch)
+    c = _schedule_run(name, batch, True, 'f32', monkeypatch)
+    assert any(v != 0.0 for k, v in a['losses'].items() if k in ('symmetry', 'smpl_gen'))          # the S2 terms are live
+    _schedules_agree(a, b, 1e-5, 3e-2, '%s camera-batched vs per camera' % name)
+    _schedules_agree(a, c, 2e-5, 3e-2, '%s f16x3 vs exact fp32' % name)

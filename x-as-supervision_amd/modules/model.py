@@ -248,11 +248,14 @@ class Counter3DModel(torch.nn.Module):
         with torch.cuda.stream(aux):
             return self.adversarial_term(x, smpl_discriminator, world)
 
-    def finish(self, x, smpl_discriminator, per_cam, out, aux=None, gen_val_early=None):
+    def finish(self, x, smpl_discriminator, per_cam, out, aux=None, gen_val_early=None, wait_for=None):
         """Losses from the per-camera results (model.py:98-190).  aux: a second stream that already holds the updated
         discriminator (engine.TrainStep): the adversarial term - the discriminator on the DETACHED poses (model.py:128), so
         its forward and backward share nothing with the rest of the graph - runs there, beside the other losses and, in
-        the backward pass, beside the physique / detector backward (autograd replays a node on the stream it was recorded on)."""
+        the backward pass, beside the physique / detector backward (autograd replays a node on the stream it was recorded on).
+        r05: NOT the default any more (engine.ADV_ON_AUX): with the term's graph on a second stream one step in ~12 read a few
+        64-byte sectors of a small main-stream tensor stale (DESIGN: the r04 driver failure).  wait_for: the stream that
+        carried the discriminator update when the term runs on the CURRENT stream - waited for right before the term."""
         cams = _cams(x, self.cam_id_list)
         lc = self.loss_config
         losses = {}
@@ -278,6 +281,9 @@ class Counter3DModel(torch.nn.Module):
             losses['symmetry'] = total
 
         if 'smpl_gen_loss' in lc:
+            if gen_val is None and wait_for is not None:
+                # the discriminator update ran on stream `wait_for`: its Adam step precedes the adversarial term (train.py:160-190)
+                torch.cuda.current_stream().wait_stream(wait_for)
             losses['smpl_gen'] = gen_val if gen_val is not None else self.adversarial_term(x, smpl_discriminator, world)
 
         if 'smpl_pseudo_img_loss' in lc:

@@ -7,6 +7,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('XAS_HIP_LIB') or os.path.join(_HERE, 'libxas_hip.so')   # override: ablation / A-B builds (tools/build_abl.py, tools/gpu/ab_lib.sh)
 _lib = None
+ABI_VERSION = 3          # include/xas_hip.h / csrc/abi.hip: xas_abi_version()
 
 _T = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float, 'u': ctypes.c_uint,
       'd': ctypes.c_double, 'z': ctypes.c_size_t}
@@ -119,6 +120,12 @@ def load():
         raise RuntimeError('libxas_hip.so is missing (%s): run `python __graft_entry__.py` to build the HIP '
                            'library; the MI355X path has no CPU fallback' % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
+    lib.xas_abi_version.restype = ctypes.c_int
+    lib.xas_abi_version.argtypes = []
+    if lib.xas_abi_version() != ABI_VERSION:
+        # (layout-breaking changes between versions: xas_conv_shape fields, the 1024-float slots of recorded maxima)
+        raise RuntimeError('%s speaks ABI version %d, this binding expects %d (include/xas_hip.h): rebuild it with '
+                           '`python __graft_entry__.py`' % (LIB_PATH, lib.xas_abi_version(), ABI_VERSION))
     lib.xas_last_error.restype = ctypes.c_char_p
     lib.xas_last_error.argtypes = []
     _lib = lib

@@ -32,6 +32,12 @@ from .optim import FusedAdam
 # either; tests/test_gpu_dp_step.py runs the two-rank gloo step all three ways.
 _BESIDE_ENV = os.environ.get('XAS_DISC_BESIDE_GEN')
 DISC_BESIDE_GEN = _BESIDE_ENV != '0'          # (kept for tools that read it: the single-process setting)
+# The adversarial term of the generator step (forward + backward of the discriminator on the detached poses) on the second
+# stream too: OFF since r05.  With it on, one step in ~12 computed a different result - a main-stream kernel read three or six
+# consecutive 64-byte sectors of a small tensor (joints, world joints) as they had been BEFORE the kernel in front of it on the
+# same stream wrote them (tools/diag_repro.py, profiles/r05_step_reproducibility.md); 0 of 200 steps with the term on the
+# main stream, 0 of 100 with the whole update there.  XAS_ADV_AUX=1 restores the r04 schedule.
+ADV_ON_AUX = os.environ.get('XAS_ADV_AUX', '0') == '1'
 _aux = {}
 _DEBUG_SYNC = os.environ.get('XAS_DEBUG_SYNC', '').split(',')      # diagnostic sync points (tools/diag_repro.py)
 
@@ -45,6 +51,8 @@ def disc_beside_gen():
 
 
 def _aux_stream():
+    if os.environ.get('XAS_AUX_IS_SIDE', '0') == '1':       # (diagnostic: ONE secondary stream for the update and the weight gradients)
+        return ops_nn.side_stream()
     dev = torch.cuda.current_device()
     if dev not in _aux:
         _aux[dev] = torch.cuda.Stream()
@@ -112,6 +120,7 @@ class TrainStep:
         self.grad_probe = None      # measurement hook: called as grad_probe('disc' | 'det', gradient arena) just before the
                                     # optimizer consumes it (bench.py's variant check); None on the training path
         self.red_det = self.red_disc = None
+        self._weights_checked = False
         opt_det.grad_arena                       # materialise the gradient arenas: conv weight gradients are
         if opt_disc is not None:                 # accumulated straight into them on a side stream
             opt_disc.grad_arena
@@ -139,9 +148,22 @@ class TrainStep:
             raise RuntimeError('a convolution weight has left the range of the f16x3 arithmetic (|w| >= 64 or NaN): '
                                'run with XAS_PRECISION=2 (bf16x6)')
 
+    def _check_loaded_weights(self):
+        """Before the FIRST forward: the weights as constructed / loaded from a checkpoint must fit the f16x3 weight format -
+        one scan of the detector's parameter arena (a checkpoint that does not fit must not be trained on, not even one step)."""
+        if ops_nn.query('xas_get_precision') != 3 or not self.opt_det.param_arena.is_cuda:
+            return
+        m = float(self.opt_det.param_arena.abs().max())
+        if not m < 64.0:
+            raise RuntimeError('the largest detector / physique weight is %g: outside the range of the f16x3 arithmetic '
+                               '(|w| < 64): run with XAS_PRECISION=2 (bf16x6)' % m)
+
     def __call__(self, x):
         out = {}
         loss_disc, loss_kp, total = None, {}, None
+        if not self._weights_checked:
+            self._check_loaded_weights()
+            self._weights_checked = True
         ops_nn.reset_grad_amax()                    # (every stream of the previous step has joined this one)
         do_disc = self.opt_disc is not None and self.cur_step % self.disc_every == 0
         do_gen = self.cur_step % self.gen_every == 0
@@ -201,9 +223,12 @@ class TrainStep:
             if shared is not None:
                 self.model.pseudo_passes(x, *shared)
                 loss_kp, info = self.model.finish(x, self.disc.smpl_discriminator, *shared)
-            elif aux is not None and os.environ.get('XAS_ADV_AUX', '1') == '0':
-                torch.cuda.current_stream().wait_stream(aux)        # (diagnostic: the adversarial term on the main stream)
-                loss_kp, info = self.model.finish(x, self.disc.smpl_discriminator, *self.model.camera_passes(x, dets=dets))
+            elif aux is not None and not ADV_ON_AUX:
+                # the update itself stays on the second stream (beside the geometry / renderer / physique net of this pass); the
+                # adversarial term - the only user of the UPDATED discriminator - runs on the main stream, after a wait placed
+                # right in front of it
+                loss_kp, info = self.model.finish(x, self.disc.smpl_discriminator, *self.model.camera_passes(x, dets=dets),
+                                                  wait_for=aux)
             elif aux is not None:
                 # the adversarial term (the only user of the UPDATED discriminator) stays on the second stream; it starts as
                 # soon as the world joints exist, beside the physique net
@@ -233,8 +258,6 @@ class TrainStep:
             ops_nn.join_side_stream(reset_chains=True)
             if self.red_det:
                 self.red_det.finish()
-            if self.cur_step == 0:
-                self._check_weight_range()           # BEFORE the first update: weights as loaded (a checkpoint) must fit
             if self.grad_probe is not None:
                 self.grad_probe('det', self.opt_det.grad_arena)
             self.opt_det.step()
