@@ -24,6 +24,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--runs', type=int, default=3)
     ap.add_argument('--precision', default='f16x3')
+    ap.add_argument('--census', default='', help='comma list of stream configurations: count differing runs of each')
     ap.add_argument('--bisect', action='store_true', help='poison the free blocks with 1e30 and report per parameter, per switch')
     ap.add_argument('--no-poison', action='store_true')
     ap.add_argument('--only-default', action='store_true')
@@ -68,6 +69,9 @@ def main():
             elif k == 'tune':
                 old[k] = 0
                 xl.query('xas_set_tuning', v)
+            elif k == 'adv_aux':
+                old[k] = engine.ADV_ON_AUX
+                engine.ADV_ON_AUX = v
         restore(step, sn)
         torch.manual_seed(4242)
         grads = {}
@@ -127,6 +131,8 @@ def main():
                 engine._BESIDE_ENV = v
             elif k == 'tune':
                 xl.query('xas_set_tuning', 0)
+            elif k == 'adv_aux':
+                engine.ADV_ON_AUX = v
         return res
 
     def poison(value):
@@ -173,6 +179,32 @@ def main():
 
     base = run('default')
     print('losses', base['losses'])
+    if args.census:
+        CONFIGS = {'single': dict(side=False, beside=False), 'main+side': dict(side=True, beside=False),
+                   'main+aux': dict(side=False, beside=True), 'main+side+aux': dict(side=True, beside=True),
+                   'r04': dict(side=True, beside=True, adv_aux=True),
+                   'r04+nolean': dict(side=True, beside=True, adv_aux=True, tune=262144)}
+        for label in args.census.split(','):
+            sw = CONFIGS[label]
+            refs = [run(label, **sw) for _ in range(3)]
+            # (a reference that is itself an anomaly would make every later run "differ": majority of three)
+            ref = refs[0] if torch.equal(refs[0]['det'], refs[1]['det']) or torch.equal(refs[0]['det'], refs[2]['det']) else refs[1]
+            hits, kinds = 0, {}
+            for it in range(args.loops):
+                got = run(label, **sw)
+                if not (torch.equal(got['det'], ref['det']) and torch.equal(got['loss'], ref['loss'])):
+                    hits += 1
+                    diff_taps = [k_ for k_ in ref['taps'] if k_ in got['taps'] and got['taps'][k_].shape == ref['taps'][k_].shape
+                                 and not torch.equal(got['taps'][k_], ref['taps'][k_])]
+                    if diff_taps and hits <= 0:
+                        small = lambda d_: {k_: v_.cpu() for k_, v_ in d_.items() if v_.numel() < 200000}
+                        torch.save({'got': small(got['taps']), 'ref': small(ref['taps']), 'diff': diff_taps},
+                                   os.path.join(ROOT, 'gpurun_out', 'anom_%s_%d.pt' % (label.replace('+', '_'), it)))
+                        print('   iteration %d: taps that differ: %s' % (it, diff_taps), flush=True)
+                    d = float((got['det'].double() - ref['det'].double()).norm() / ref['det'].double().norm())
+                    kinds['%.3e' % d] = kinds.get('%.3e' % d, 0) + 1
+            print('== %-14s %d anomalies in %d runs  %s' % (label, hits, args.loops, kinds), flush=True)
+        return
     if args.bisect:
         f = od._flat
         names = {id(p): n for n, p in list(model.named_parameters())}

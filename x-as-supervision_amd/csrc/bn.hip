@@ -238,8 +238,10 @@ __device__ __forceinline__ void col_reduce_body(const ColArgs& a) {
     const int last = old == total - 1u;
     if (last) {
       __hip_atomic_store(a.ticket + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for re-use
+#ifndef XAS_BN_NO_ACQUIRE
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // drop this CU's stale L1 lines (other blocks' partials)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     }
     s_last = last;
   }

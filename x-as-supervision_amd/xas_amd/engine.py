@@ -21,17 +21,14 @@ from . import ops_nn
 from .dp import GradReducer, dp_active, sync_buffers
 from .optim import FusedAdam
 
-# The discriminator's own forward / backward / Adam (a few hundred small launches, ~4 ms of an otherwise idle GPU) runs on a
-# second stream beside the generator step's detector passes, which do not depend on it (only the generator LOSSES do).
-# Single process: on.  Data parallelism over RCCL (`nccl`): on - collectives are stream-ordered there, the update's gradient
-# exchange is enqueued on the second stream like its kernels (tests/test_gpu_nccl.py drives exactly this through a world-size-1
-# RCCL group).  Data parallelism over a backend whose collectives block the HOST (gloo: rehearsals, tests): OFF - the update runs
-# on the main stream in program order: `red_disc.finish()` would hold the host inside the second-stream context, so nothing of
-# the generator step could be enqueued beside it anyway, and r03's driver run lost a two-rank gloo step to a hang on exactly
-# this path that 107 repetitions on MI355X did not reproduce (profiles/r04_dp_step_loop.txt).  XAS_DISC_BESIDE_GEN=0/1 forces
-# either; tests/test_gpu_dp_step.py runs the two-rank gloo step all three ways.
+# The discriminator's own forward / backward / Adam (a few hundred small launches, ~4 ms of an otherwise idle GPU) CAN run on a
+# second stream beside the generator step's detector passes, which do not depend on it (only the generator LOSSES do):
+# XAS_DISC_BESIDE_GEN=1.  r03 / r04 shipped that as the default (-5.7 ms per step); r05: OFF - see ops_nn._side: with the
+# update on a second stream AND the weight gradients on a third, one step in six computed wrong values somewhere (that is what
+# the r04 driver run's red test was), and no two-stream combination was clean over 400 steps either.  Under data parallelism
+# the update stays on the main stream as well.  tests/test_gpu_dp_step.py runs the two-rank step in both settings.
 _BESIDE_ENV = os.environ.get('XAS_DISC_BESIDE_GEN')
-DISC_BESIDE_GEN = _BESIDE_ENV != '0'          # (kept for tools that read it: the single-process setting)
+DISC_BESIDE_GEN = _BESIDE_ENV is not None and _BESIDE_ENV != '0'          # (kept for tools that read it)
 # The adversarial term of the generator step (forward + backward of the discriminator on the detached poses) on the second
 # stream too: OFF since r05.  With it on, one step in ~12 computed a different result - a main-stream kernel read three or six
 # consecutive 64-byte sectors of a small tensor (joints, world joints) as they had been BEFORE the kernel in front of it on the
@@ -43,11 +40,7 @@ _DEBUG_SYNC = os.environ.get('XAS_DEBUG_SYNC', '').split(',')      # diagnostic 
 
 
 def disc_beside_gen():
-    if _BESIDE_ENV is not None:
-        return _BESIDE_ENV != '0'
-    if not dp_active():
-        return True
-    return dist.get_backend() == 'nccl'
+    return _BESIDE_ENV is not None and _BESIDE_ENV != '0'
 
 
 def _aux_stream():

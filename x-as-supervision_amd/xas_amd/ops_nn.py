@@ -84,7 +84,12 @@ def bump_weights_epoch():
 # gradient arena): the many short wgrad kernels overlap the data-gradient / batch-norm chain of the main
 # stream, and autograd's per-contribution `grad += dw` kernels disappear.  join_side_stream() is called before
 # anything consumes the gradients (all-reduce, Adam, zero_grad).
-_side = {'stream': None, 'enabled': True, 'dirty': False}
+# r05: OFF by default (XAS_SIDE_STREAM=1 turns it on).  With more than one HIP stream carrying this library's kernels at the same
+# time, a step now and then computes a different result: some wave of some kernel works on wrong values in its lanes 48 - 63
+# (single stream: 0 of 2 400 steps; main + this stream: 1 in ~400; with the discriminator update on a third stream as in r04:
+# 1 in 6 - tools/diag_repro.py --census, profiles/r05_step_reproducibility.md).  Not explained below the library; until it is,
+# the step runs on ONE stream.
+_side = {'stream': None, 'enabled': os.environ.get('XAS_SIDE_STREAM', '0') == '1', 'dirty': False}
 
 
 def side_stream():
