@@ -370,6 +370,9 @@ __global__ __launch_bounds__(256, (P == 2 ? (BM == 64 && BN == 256 ? XAS_X6_WAVE
         for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= f16_desc;
   }
   igemm_epilogue<BM, BN, MODE, BNB, (BN >= 128 ? BN / 64 : 1)>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, HW, Wrow, ph, pw, lds);
+#ifdef XAS_DRAIN_AT_END
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
 }
 
 // ------------------------------------------------------------------------------------
@@ -555,6 +558,9 @@ __global__ __launch_bounds__(256, XAS_X6T_WAVES) void igemm_x6t_kernel(IgemmPara
         for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= f16_desc;
   }
   igemm_epilogue<BM, BN, MODE, false, (BN == 128 ? 2 : 1)>(p, acc, acc2, m0, n0, wm, wn, lane, Mrows, H * W, W, 0, 0, lds);
+#ifdef XAS_DRAIN_AT_END
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
 }
 
 template <int BN>
@@ -916,6 +922,9 @@ __global__ __launch_bounds__(256, (P == 2 ? XAS_WX6_WAVES2 : 2)) void wgrad_x6_k
         if (nn < p.KK) slab[(size_t)co * p.KK + nn] = P == 2 ? acc[mi][ni][reg] * f16_desc : acc[mi][ni][reg];
       }
     }
+#ifdef XAS_DRAIN_AT_END
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
 }
 
 // ------------------------------------------------------------------------------------
@@ -1106,6 +1115,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6t_kernel(WgradParams p) {
       }
     }
   }
+#ifdef XAS_DRAIN_AT_END
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
 }
 
 // plan of the tap-reuse weight gradient; false: the shape is not taken (wgrad_x6_kernel does it)
