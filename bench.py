@@ -43,9 +43,21 @@ def host_threads():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(workload, threads):
-    """Oracle (CPU restatement of the reference step, stock PyTorch fp32) on a bounded sample: full disc+gen steps at B=8
-    on the host cores, 1 warm-up + 3 timed steps, median (BASELINE.md section 3 protocol, bounded to ~60 s)."""
+def cpu_model_name():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(workload, threads, B=2, warm=3, timed=5):
+    """Oracle (CPU restatement of the reference step, stock PyTorch fp32) on a bounded sample: full disc+gen steps on the host
+    cores.  BASELINE.md section 3 protocol: B = 2 (config 1's batch), 3 warm-up + 5 timed steps, median samples/s (reported as
+    images/s like the headline); bench.py also times B = 8 (1 + 3) as `cpu_baseline_b8`, the r01-r04 figure."""
     from oracle import step as ostep
     from oracle.nets import GCNDecouple, PhysiqueNet
     from xas_amd.synthetic import model_config, synthetic_batch
@@ -59,20 +71,19 @@ def cpu_baseline(workload, threads):
     disc.parent_ids, disc.child_ids = skeleton_links(cfg['parent_ids'], cfg['line_select_ids'], False, False)
     o_det = torch.optim.Adam(list(reg.parameters()) + list(phys.parameters()), lr=2e-4, betas=(0.5, 0.999))
     o_disc = torch.optim.Adam(disc.parameters(), lr=2e-4, betas=(0.5, 0.999))
-    B = 8                      # ~12 s of host work per step on a 16-core share; the GPU leg runs B = 32
     x = synthetic_batch(B, cfg['cam_id_list'], torch.device('cpu'), seed=1)
     times = []
-    for i in range(4):
+    for i in range(warm + timed):
         t0 = time.perf_counter()
         ostep.train_step(cfg, reg, phys, disc, o_det, o_disc, x)
         times.append(time.perf_counter() - t0)
-    timed = sorted(times[1:])
-    dt = timed[len(timed) // 2]
+    ts = sorted(times[warm:])
+    dt = ts[len(ts) // 2]
     per_sample = IMAGES_PER_SAMPLE['MPI' if workload.startswith('MPI') else 'HM36']
-    return {'value': B * per_sample / dt, 'unit': 'images/s', 'cores': threads, 'kind': 'port',
-            'protocol': '1 warm-up + 3 timed steps, median',
-            'sample': 'full disc+gen steps incl. Adam, %s, B=%d, fp32, oracle on torch CPU (warm-up %.1f s, timed %s s)'
-                      % (workload, B, times[0], ' '.join('%.1f' % t for t in times[1:]))}
+    return {'value': B * per_sample / dt, 'unit': 'images/s', 'samples_per_s': B / dt, 'cores': threads, 'cpu': cpu_model_name(),
+            'kind': 'port', 'protocol': '%d warm-up + %d timed steps, median (BASELINE.md section 3)' % (warm, timed),
+            'sample': 'full disc+gen steps incl. Adam, %s, B=%d, fp32, oracle on torch CPU (warm-up %s s, timed %s s)'
+                      % (workload, B, ' '.join('%.1f' % t for t in times[:warm]), ' '.join('%.1f' % t for t in times[warm:]))}
 
 
 def train_step_variant_check(step, x, model, disc, opt_det, opt_disc, xl, precision, base_tune=0):
@@ -192,6 +203,8 @@ def main():
     ap.add_argument('--dedupe', action='store_true',
                     help='NOT the headline: share the real-image detector forward between the discriminator and the '
                          'generator update (engine.TrainStep(dedupe=True)); the JSON line is marked config.dedupe')
+    ap.add_argument('--ref-n1', type=float, default=None,
+                    help='samples/s of the SAME build at N = 1 (a previous run of this script): adds comm.per_rank_over_n1 to the line')
     ap.add_argument('--shape-report', default=None, help='write a per-conv-shape timing table to this file')
     args = ap.parse_args()
 
@@ -273,6 +286,32 @@ def main():
     log('timed %d steps: %.1f ms/step' % (args.steps, dt / args.steps * 1e3))
     log('memory: peak allocated %.1f GB, reserved %.1f GB' % (torch.cuda.max_memory_allocated() / 2**30, torch.cuda.memory_reserved() / 2**30))
 
+    # N > 1: one extra, UNTIMED step with the data-parallel exchanges instrumented (xas_amd/dp.py comm_stats): what the step waits
+    # for - the exposed part of the gradient buckets, the host-visible time of the SyncBatchNorm exchanges - and what it sends
+    comm = None
+    if world > 1:
+        from xas_amd import dp as _dp
+        _dp.comm_begin()
+        tc0 = time.perf_counter()
+        step(x)
+        torch.cuda.synchronize()
+        comm_ms = (time.perf_counter() - tc0) * 1e3
+        st = _dp.comm_end()
+        if rank == 0:
+            nb = st['buckets']
+            comm = {'what': 'ONE extra untimed step with the exchanges instrumented, rank 0',
+                    'step_ms': comm_ms,
+                    'gradient_buckets': [{'reducer': n_, 'MB': b_ / 1e6, 'launched_during_backward': e_} for n_, b_, e_ in nb],
+                    'gradient_MB_per_step': sum(b_ for _, b_, _ in nb) / 1e6,
+                    'gradient_wait_compute_stream_ms': st['grad_wait_stream_ms'],
+                    'gradient_wait_host_ms': st['grad_wait_host_ms'],
+                    'syncbn_exchanges_per_step': st['syncbn_calls'], 'syncbn_KB_per_exchange': (st['syncbn_bytes'] / max(1, st['syncbn_calls'])) / 1e3,
+                    'syncbn_host_ms': st['syncbn_host_ms'],
+                    'backend': args.backend,
+                    'note': 'gradient_wait_* = the EXPOSED part of the bucket all-reduces (the rest ran beside backward on the '
+                            'communication stream); syncbn_host_ms = host-visible time of the per-layer statistic exchanges (gloo '
+                            'blocks the host; RCCL only enqueues, the stream-side cost is inside step_ms)'}
+    sync()
     # one extra, UNTIMED step with the side stream disabled: the same kernels measured without concurrent
     # neighbours (kernel quality), beside the overlapped figures of the timed region (step throughput)
     from xas_amd import ops_nn as _ops
@@ -421,6 +460,11 @@ def main():
                                           'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 else 0.0}
                                       for k, v in summ.items()}},
         }
+        if comm is not None:
+            if args.ref_n1:
+                comm['per_rank_over_n1'] = (samples / dt / world) / args.ref_n1
+                comm['ref_n1_samples_per_s'] = args.ref_n1
+            line['comm'] = comm
         if f32_ms is not None:
             line['exact_fp32_mfma'] = {'ms_per_step': f32_ms, 'images_per_s': world * args.batch * per_sample / (f32_ms * 1e-3),
                                        'steps': args.f32_steps, 'peak_TFLOPs': PEAK_FP32_MFMA_TFLOPS,
@@ -465,8 +509,9 @@ def main():
                     f.write('%-16s %-36s %5d %9.3f %7.2f\n' % (name, sig, n, ms_, tf))
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only (the other ranks would sit in a barrier)
             threads = host_threads()
-            log('timing the CPU oracle (B=8, 1 warm-up + 3 timed steps) on %d host threads' % threads)
-            line['cpu_baseline'] = cpu_baseline(args.workload, threads)
+            log('timing the CPU oracle (B=2: 3 warm-up + 5 timed steps; B=8: 1 + 3) on %d host threads' % threads)
+            line['cpu_baseline'] = cpu_baseline(args.workload, threads, B=2, warm=3, timed=5)
+            line['cpu_baseline_b8'] = cpu_baseline(args.workload, threads, B=8, warm=1, timed=3)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

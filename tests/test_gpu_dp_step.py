@@ -91,10 +91,21 @@ def test_bench_two_rank_rehearsal():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     env.pop('XAS_DISC_BESIDE_GEN', None)
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--batch', '4', '--steps', '2',
-                        '--warmup', '1', '--f32-steps', '0', '--no-cpu-baseline'], capture_output=True, text=True, timeout=200, env=env, cwd=root)
+                        '--warmup', '1', '--f32-steps', '0', '--no-cpu-baseline', '--ref-n1', '100.0'], capture_output=True, text=True,
+                       timeout=200, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['config']['ranks'] == 2 and line['config']['parallelism'] == 'dp2'
     assert line['scaling'] == 'weak' and line['steps'] == 2 and line['warmup'] == 1
     assert abs(line['value'] - 2 * 4 * 8 * 2 / (line['ms_per_step'] * 2e-3)) < 1e-6 * line['value']      # whole-job images / time
     assert line['config']['replicas_identical'] is True, line['config']['param_checksum_per_rank']
+    # the self-explaining multi-GPU line: what the step sends and what it waits for
+    c = line['comm']
+    for k in ('gradient_buckets', 'gradient_MB_per_step', 'gradient_wait_compute_stream_ms', 'gradient_wait_host_ms',
+              'syncbn_exchanges_per_step', 'syncbn_KB_per_exchange', 'syncbn_host_ms', 'per_rank_over_n1', 'step_ms'):
+        assert k in c, k
+    names = [b['reducer'] for b in c['gradient_buckets']]
+    assert names.count('detector') == 4 and names.count('discriminator') == 1, names          # 4 + 1 buckets (train.py:87-88: two DDP wrappers)
+    assert 130 < c['gradient_MB_per_step'] < 160                                             # 138.8 MB + 10.8 MB of gradients
+    assert c['syncbn_exchanges_per_step'] > 0 and c['syncbn_KB_per_exchange'] > 0
+    assert abs(c['per_rank_over_n1'] - line['config']['samples_per_s_per_rank'] / 100.0) < 1e-9

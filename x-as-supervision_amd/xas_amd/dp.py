@@ -35,6 +35,51 @@ import torch
 import torch.distributed as dist
 
 
+# ---- measurement: what the data-parallel exchanges cost a step (bench.py N > 1 line: `comm`) -------------------------------
+# None: off (the training path).  bench.py sets a dict; the reducers and the SyncBatchNorm exchanges add to it:
+#   syncbn_calls / syncbn_bytes / syncbn_host_ms : per-layer statistic exchanges (one all-gather forward, one all-reduce backward),
+#                                                  bytes sent per rank, host-visible time of the calls (gloo blocks the host;
+#                                                  on RCCL the call only enqueues - the stream-side cost is in the step time)
+#   buckets                                      : [(reducer, bytes, launched_early)] of every gradient bucket of the step
+#   grad_wait_host_ms / grad_wait_stream_ms      : time finish() held the host / the compute stream waiting for the buckets
+#                                                  (the EXPOSED part of the gradient exchange: everything else ran beside backward)
+comm_stats = None
+
+
+def comm_begin():
+    """Start collecting (resets the counters); -> the dict that fills."""
+    global comm_stats
+    comm_stats = {'syncbn_calls': 0, 'syncbn_bytes': 0, 'syncbn_host_ms': 0.0, 'buckets': [], 'grad_wait_host_ms': 0.0,
+                  'grad_wait_stream_ms': 0.0, '_events': []}
+    return comm_stats
+
+
+def comm_end():
+    """Stop collecting; resolves the event pairs (one device synchronisation).  -> the dict."""
+    global comm_stats
+    st, comm_stats = comm_stats, None
+    if st is None:
+        return None
+    if st['_events']:
+        torch.cuda.synchronize()
+        st['grad_wait_stream_ms'] = sum(a.elapsed_time(b) for a, b in st['_events'])
+    del st['_events']
+    return st
+
+
+def timed_collective(fn, nbytes):
+    """Run a SyncBatchNorm exchange, adding it to comm_stats when collecting."""
+    if comm_stats is None:
+        return fn()
+    import time
+    t0 = time.perf_counter()
+    r = fn()
+    comm_stats['syncbn_calls'] += 1
+    comm_stats['syncbn_bytes'] += int(nbytes)
+    comm_stats['syncbn_host_ms'] += (time.perf_counter() - t0) * 1e3
+    return r
+
+
 def dp_active(group=None):
     """True when the data-parallel exchange code should run: a process group with more than one rank, or
     XAS_FORCE_DP=1 with an initialised group of ANY size (a single-GPU box can then drive every RCCL call of the
@@ -45,8 +90,9 @@ def dp_active(group=None):
 
 
 class GradReducer:
-    def __init__(self, arena, params, offsets, num_buckets=4, group=None, use_side_stream=True, own_group=True):
+    def __init__(self, arena, params, offsets, num_buckets=4, group=None, use_side_stream=True, own_group=True, name='grad'):
         self.arena = arena
+        self.name = name
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.enabled = dp_active(group)
         # The gradient buckets travel on their OWN communicator: on RCCL a communicator's collectives run in issue order on
@@ -136,6 +182,8 @@ class GradReducer:
         else:
             work = dist.all_reduce(view, group=self.group, async_op=True)
         b['launched'] = True
+        if comm_stats is not None:
+            comm_stats['buckets'].append((self.name, int(view.numel()) * 4, bool(self._armed)))
         self.pending.append(work)
 
     def arm(self):
@@ -164,11 +212,23 @@ class GradReducer:
         for b in self.buckets:
             if not b.get('launched'):
                 self._launch(b)
+        collecting = comm_stats is not None
+        if collecting:
+            import time
+            t0 = time.perf_counter()
+            if self.arena.is_cuda:
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record()
         for w in self.pending:
             w.wait()
         self.pending = []
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
+        if collecting:
+            comm_stats['grad_wait_host_ms'] += (time.perf_counter() - t0) * 1e3
+            if self.arena.is_cuda:
+                eb.record()
+                comm_stats['_events'].append((ea, eb))
         self.arena.mul_(1.0 / self.world)
 
 

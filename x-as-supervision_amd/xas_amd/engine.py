@@ -120,11 +120,11 @@ class TrainStep:
         if dp_active():
             f = opt_det
             f.grad_arena
-            self.red_det = GradReducer(f._flat['g'], f._flat['params'], f._flat['offs'], num_buckets)
+            self.red_det = GradReducer(f._flat['g'], f._flat['params'], f._flat['offs'], num_buckets, name='detector')
             if opt_disc is not None:
                 opt_disc.grad_arena
                 g = opt_disc
-                self.red_disc = GradReducer(g._flat['g'], g._flat['params'], g._flat['offs'], 1)
+                self.red_disc = GradReducer(g._flat['g'], g._flat['params'], g._flat['offs'], 1, name='discriminator')
             sync_buffers(self.model)
             dist.broadcast(opt_det.param_arena, src=0)
             if opt_disc is not None:

@@ -1005,7 +1005,8 @@ def _bn_forward(x, gamma, beta, running_mean, running_var, residual, training, m
             msg = torch.empty(G, stride, device=dev, dtype=torch.float32)
             stats_fn(ptr(msg), ptr(msg[:, c:]), stride, ptr(msg[:, 2 * c:]), None, None, momentum)
             gathered = torch.empty(world * G * stride, device=dev, dtype=torch.float32)     # [world][G][stride]
-            dist.all_gather_into_tensor(gathered, msg.view(-1), group=group)
+            from . import dp as _dp
+            _dp.timed_collective(lambda: dist.all_gather_into_tensor(gathered, msg.view(-1), group=group), msg.numel() * 4)
             mean = torch.empty(G, c, device=dev, dtype=torch.float32)
             var = torch.empty(G, c, device=dev, dtype=torch.float32)
             count = float(Mg) * world                          # equal per-rank batches (train.py:274)
@@ -1104,7 +1105,8 @@ def _bn_backward(saved, cfg, gamma, beta, dy, want_param_grads, want_dres=True):
     else:
         dgamma, dbeta = sums[:, 1].sum(0), sums[:, 0].sum(0)              # local sums (before the exchange)
     if group is not None:
-        dist.all_reduce(sums, group=group)                # one coalesced message per layer (all groups)
+        from . import dp as _dp
+        _dp.timed_collective(lambda: dist.all_reduce(sums, group=group), sums.numel() * 4)     # one coalesced message per layer (all groups)
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if (has_res and (want_dres or not masked)) else None
     slot = grad_amax_slot(dev)
