@@ -195,10 +195,17 @@ def forget_uses(keys):
 
 
 def _wgrad_into_grad(x, dy, shp, weight):
-    """Accumulate the OIHW weight gradient into weight.grad on the side stream; False if not applicable."""
+    """Accumulate the OIHW weight gradient straight into weight.grad (a view of the optimizer's gradient arena): on the side
+    stream when that is on, else on the current stream - either way without a gradient tensor of its own and without autograd's
+    `grad += dw` kernel (one per parameter and step otherwise: 160 launches).  False if not applicable."""
     g = weight.grad
-    if not _side['enabled'] or g is None or not g.is_contiguous() or g.dtype != torch.float32:
+    if g is None or not g.is_contiguous() or g.dtype != torch.float32 or not g.is_cuda:
         return False
+    if not _side['enabled']:
+        ws = torch.empty(max(1, query('xas_conv_wgrad_workspace_floats', shp)), device=x.device, dtype=torch.float32)
+        call('xas_conv_wgrad_acc', ptr(x), ptr(dy), ptr(g), ptr(ws), shp)
+        grad_ready(weight)
+        return True
     main, side = torch.cuda.current_stream(), side_stream()
     side.wait_stream(main)
     with torch.cuda.stream(side):
@@ -218,9 +225,14 @@ BIAS_ON_SIDE = os.environ.get('XAS_BIAS_SIDE', '0') == '1'
 def _bias_into_grad(dy, M, C, bias, force=False):
     """bias.grad += column sums of dy [M, C] on the side stream (off the critical stream); False if not applicable."""
     g = bias.grad
-    if (not (BIAS_ON_SIDE or force) or not _side['enabled'] or g is None or not g.is_contiguous() or g.dtype != torch.float32 or C % 4
-            or g.data_ptr() % 16):
+    if (not (BIAS_ON_SIDE or force or not _side['enabled']) or g is None or not g.is_contiguous() or g.dtype != torch.float32 or C % 4
+            or g.data_ptr() % 16 or not g.is_cuda):
         return False
+    if not _side['enabled']:
+        ws = torch.empty(query('xas_bn_workspace_floats', M, C, 1), device=dy.device, dtype=torch.float32)
+        call('xas_col_sum_acc', ptr(dy), M, C, ptr(g), ptr(ws))
+        grad_ready(bias)
+        return True
     main, side = torch.cuda.current_stream(), side_stream()
     side.wait_stream(main)
     with torch.cuda.stream(side):
