@@ -98,6 +98,11 @@ int xas_head_softargmax_fwd(const float* logits, int B, int K, int D, int num_hy
                             float* partial, void* stream);
 /* grad_logits [B][H][W][K*D] = d loss / d logits given grad_kps [B][num_hypo][K][3].
  * coef: workspace of B*K*(4+D) floats. */
+/* Second pass of xas_head_softargmax_fwd over partial records produced elsewhere (xas_conv_fwd_head): same outputs. */
+int xas_head_softargmax_from_partials(const float* partial, int B, int K, int D, int nchunk, int num_hypo, int neighbor,
+                                      float* kps, int64_t* z_idx, float* depth_prob_map, int groups, float* stats,
+                                      void* stream);
+
 int xas_head_softargmax_bwd(const float* logits, const float* stats, const int64_t* z_idx,
                             const float* grad_kps, int B, int K, int D, int num_hypo, int neighbor,
                             float* grad_logits, float* coef, void* stream);
@@ -206,6 +211,15 @@ int xas_prepare_weights(const void* descs, int n, long blocks, void* stream);
 
 int xas_conv_fwd(const float* x, const float* w_packed, const float* bias, float* y,
                  const xas_conv_shape* s, void* stream);
+
+/* Final 1x1 convolution of the detector with the soft-argmax head's first pass in its epilogue (forward half):
+ * replaces modules/integral_base_modules/deconv_head.py:34-35 followed by the softmax / marginal reductions of
+ * modules/keypoint_detector_integral_multi.py:36-62,70-74.  y (the logits, kept for the backward) is written as by xas_conv_fwd;
+ * head_partial receives [N][chunks][K][3 + D] floats, chunks = xas_conv_fwd_head_chunks(s, K, D) records of 64 pixels per image
+ * (0: the shape is not taken - call xas_conv_fwd and xas_head_softargmax_fwd).  Finish with xas_head_softargmax_from_partials. */
+int xas_conv_fwd_head_chunks(const xas_conv_shape* s, int K, int D);
+int xas_conv_fwd_head(const float* x, const float* w_packed, const float* bias, float* y, const xas_conv_shape* s,
+                      int K, int D, float* head_partial, void* stream);
 /* Bias-free convolution followed by training-mode batch norm (resnet.py:17-18 conv1/bn1 and every torchvision Bottleneck
  * conv/bn pair, resnet.py:2): y = conv(x, w) AND the per-group batch statistics of y in one call - the conv epilogue
  * emits per-tile column sums, so y is not read again for its statistics (falls back to xas_conv_fwd + xas_bn_stats when

@@ -138,3 +138,86 @@ def test_draw_lines_17_and_full_batch():
     mz = ops_head.draw_lines_max(z, 64, p, c, 3.0e-3)
     mz.sum().backward()
     assert torch.isfinite(mz).all() and torch.isfinite(z.grad).all()
+
+
+# ---- the head's first pass in the final convolution's epilogue (forward half; xas_conv_fwd_head) ------------------
+def _final_conv(cin, seed, identity=False):
+    """layers.Conv2d(cin -> 18 * 64, 1x1, bias) marked as the producer of the head's logits (what KPDetector3DMulti does)."""
+    from xas_amd import layers as L
+    m = L.Conv2d(cin, 18 * 64, 1, bias=True).cuda()
+    m.head_kd = (18, 64)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        if identity:
+            m.weight.copy_(torch.eye(18 * 64).view(18 * 64, 18 * 64, 1, 1))
+            m.bias.zero_()
+        else:
+            m.weight.copy_(torch.randn(18 * 64, cin, 1, 1, generator=g) * 0.3)
+            m.bias.copy_(torch.randn(18 * 64, generator=g))
+    return m
+
+
+def test_head_in_conv_epilogue_vs_reference_golden():
+    """The planted-peak logits of golden `head_full` (written by the reference's KPDetector3DMulti head) pushed through an
+    IDENTITY 1x1 convolution whose epilogue emits the head's first-pass records: joints against the reference's (bar 1e-4),
+    int64 peak indices bit-exact, depth maps, and the convolution's own output equal to its input to split-arithmetic accuracy."""
+    from xas_amd import ops_head, ops_nn
+    g = golden('head_full')
+    lg, _ = gi.planted_logits(1, 18, 64, seed=12)
+    x = dev(lg).contiguous(memory_format=torch.channels_last)
+    before = dict(ops_nn.head_stats)
+    y = _final_conv(18 * 64, 0, identity=True)(x)
+    assert getattr(y, '_xas_head', None) is not None
+    kps, dmap, idx = ops_head.softargmax_multi(y, 18, 3, 15)
+    assert ops_nn.head_stats['fused'] == before['fused'] + 1 and ops_nn.head_stats['separate'] == before['separate']
+    assert float((y - x).abs().max()) < 2e-5 * float(x.abs().max())
+    assert np.array_equal(idx.cpu().numpy(), g['z_idx'])
+    close(kps, g['kps'], 2e-5)
+    close(dmap, g['depth_prob_map'], 1e-6)
+
+
+@pytest.mark.parametrize('n,cin', [(3, 256), (2, 64), (130, 32)])
+def test_head_in_conv_epilogue_equals_the_two_pass_head(n, cin, monkeypatch):
+    """Same convolution, same input: records from the epilogue + xas_head_softargmax_from_partials against xas_conv_fwd followed
+    by the head's own two passes (XAS_HEAD_IN_EPILOGUE off): logits bit-identical (one kernel, one tile shape), joints to 2e-6
+    (64- instead of 128-pixel records: another summation order), peak indices identical, gradients of both forms equal.
+    n = 130: more than the 2 GiB / 18.9 MB = 113 images of one launch - the records of the second image range land behind
+    the first's."""
+    from xas_amd import ops_head, ops_nn
+    gen = torch.Generator().manual_seed(n + cin)
+    x = (torch.randn(n, cin, 64, 64, generator=gen).cuda() * 0.7).contiguous(memory_format=torch.channels_last)
+    conv = _final_conv(cin, 5)
+    gw = torch.randn(n, 3, 18, 3, generator=gen).cuda()
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops_nn, 'HEAD_IN_EPILOGUE', fused)
+        before = dict(ops_nn.head_stats)
+        xi = x.clone().requires_grad_(True)
+        conv.zero_grad()
+        y = conv(xi)
+        kps, dmap, idx = ops_head.softargmax_multi(y, 18, 3, 15)
+        assert ops_nn.head_stats['fused' if fused else 'separate'] == before['fused' if fused else 'separate'] + 1
+        (kps * gw).sum().backward()
+        torch.cuda.synchronize()
+        res.append((y.detach().clone(), kps.detach().clone(), idx.clone(), dmap.clone(), xi.grad.clone(), conv.weight.grad.clone()))
+    a, b = res
+    assert torch.equal(a[2], b[2])
+    assert float((a[1] - b[1]).abs().max()) < 2e-6
+    assert float((a[3] - b[3]).abs().max()) < 1e-6
+    rel = lambda u, v: float((u.double() - v.double()).norm() / v.double().norm().clamp_min(1e-300))
+    assert rel(a[4], b[4]) < 1e-4 and rel(a[5], b[5]) < 1e-4          # (the backward sees kps / statistics that differ by 1e-7)
+    if n <= 113:
+        assert torch.equal(a[0], b[0])
+
+
+def test_detector_runs_the_head_from_the_conv_epilogue():
+    """KPDetector3DMulti marks its final convolution: one detector forward = one fused launch, no separate first pass."""
+    from modules.keypoint_detector_integral_multi import KPDetector3DMulti
+    from xas_amd import ops_nn
+    det = KPDetector3DMulti('resnet_multi', 18, 64, 3, 15).cuda().train()
+    assert det.net.head.features[-1].head_kd == (18, 64)
+    before = dict(ops_nn.head_stats)
+    kps, _ = det(torch.rand(2, 3, 256, 256).cuda())
+    torch.cuda.synchronize()
+    assert ops_nn.head_stats['fused'] == before['fused'] + 1 and ops_nn.head_stats['separate'] == before['separate']
+    assert kps.shape == (2, 3, 18, 3) and bool(torch.isfinite(kps).all())

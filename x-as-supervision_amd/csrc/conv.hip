@@ -1643,7 +1643,7 @@ extern "C" int xas_set_precision(int mode) {
 extern "C" int xas_get_precision(void) { return g_precision; }
 
 static int conv_fwd_impl(const float* x, const float* w_packed, const float* bias, float* y, const xas_conv_shape* s,
-                         void* stream, float* stat_partial, const float* stat_pivot);
+                         void* stream, float* stat_partial, const float* stat_pivot, float* head_partial = nullptr);
 
 namespace xas {
 int stem_weight_overflow(int reset) {
@@ -1683,7 +1683,7 @@ static int fwd_stats_tile_rows(const xas_conv_shape* s, int groups) {
 }
 
 static int conv_fwd_impl(const float* x, const float* w_packed, const float* bias, float* y, const xas_conv_shape* s,
-                         void* stream, float* stat_partial, const float* stat_pivot) {
+                         void* stream, float* stat_partial, const float* stat_pivot, float* head_partial) {
   if (check_shape(s, "conv_fwd") || check_fwd_dims(s, "conv_fwd")) return 1;
   XAS_REQUIRE(x && w_packed && y, "conv_fwd: null buffer");
   {
@@ -1694,7 +1694,9 @@ static int conv_fwd_impl(const float* x, const float* w_packed, const float* bia
       for (int n0 = 0; n0 < s->N; n0 += per) {
         xas_conv_shape part = *s;
         part.N = s->N - n0 < per ? s->N - n0 : per;
-        const int rc = xas_conv_fwd(x + (size_t)n0 * xi, w_packed, bias, y + (size_t)n0 * yi, &part, stream);
+        // (head partial records: [image][Ho * Wo / 64][Cout / 64][67] - the image range of this launch)
+        float* hp = head_partial ? head_partial + (size_t)n0 * (s->Ho * s->Wo / 64) * (s->Cout / 64) * 67 : nullptr;
+        const int rc = conv_fwd_impl(x + (size_t)n0 * xi, w_packed, bias, y + (size_t)n0 * yi, &part, stream, nullptr, nullptr, hp);
         if (rc) return rc;
       }
       return 0;
@@ -1743,7 +1745,26 @@ static int conv_fwd_impl(const float* x, const float* w_packed, const float* bia
   p.div_hw.init((unsigned)(s->Ho * s->Wo)); p.div_w.init((unsigned)s->Wo);
   p.src_elems = (long)p.N * p.Hs * p.Ws * p.Cs; p.wgt_elems = (long)p.Cd * p.R * p.S * p.Cs;
   p.stat_partial = stat_partial; p.stat_pivot = stat_pivot;
+  p.head_partial = head_partial;
   return dispatch_igemm<0>(p, precision_of(s), s->N * s->Ho * s->Wo, 1, st);
+}
+
+// Final 1x1 convolution of the detector + the soft-argmax head's pass over its result (forward
+// half): deconv_head.py:34-35 -> keypoint_detector_integral_multi.py:36-62,70-74.  The logits are still written (the backward
+// needs them); what disappears is head_partial_kernel's read of them (18.9 MB per image).
+// -> xas_conv_fwd_head_chunks: records per image (Ho * Wo / 64) when the fused path takes this shape, else 0: a 1x1 stride-1
+//    convolution on the split-arithmetic MFMA kernels whose output is [N][64 x 64][K * 64] (depth_dim = 64, 64 x 64 heat maps).
+extern "C" int xas_conv_fwd_head_chunks(const xas_conv_shape* s, int K, int D) {
+  if (!s || K < 1 || D != 64) return 0;
+  if (s->R != 1 || s->S != 1 || s->stride != 1 || s->pad != 0 || s->Wo != 64 || (s->Ho * s->Wo) % 64 != 0) return 0;
+  if (s->Cout != K * D || s->Cin % BK != 0 || precision_of(s) == XAS_PREC_F32) return 0;
+  return s->Ho * s->Wo / 64;
+}
+
+extern "C" int xas_conv_fwd_head(const float* x, const float* w_packed, const float* bias, float* y, const xas_conv_shape* s,
+                                 int K, int D, float* head_partial, void* stream) {
+  XAS_REQUIRE(head_partial && xas_conv_fwd_head_chunks(s, K, D) > 0, "conv_fwd_head: shape not taken (xas_conv_fwd_head_chunks) or null buffer");
+  return conv_fwd_impl(x, w_packed, bias, y, s, stream, nullptr, nullptr, head_partial);
 }
 
 // Which weight buffer the forward (pass 0: xas_conv_fwd*, ConvTranspose backward) or data-gradient (pass 1: xas_conv_dgrad*,

@@ -64,6 +64,12 @@ struct IgemmParams {
   // f16x3 launches: device pointer to max |v| over the gathered tensor (activation or gradient): scale = the power of two
   // that puts the maximum just below 2^15 (required: a launch without it runs as bf16x6)
   const float* a_amax;
+  // fwd only, 64 x 256 tiles (xas_conv_fwd_head): the result is the logit tensor of the soft-argmax head
+  // (keypoint_detector_integral_multi.py:70-74: channel = joint * 64 + depth bin, 64 x 64 maps): every 64-pixel x 64-channel
+  // staging pass of the epilogue - ONE image row of ONE joint - also emits that joint's online-softmax partial record
+  // {max, sum e * w, sum e * h, sum_pixels e per depth bin} while the logits are still on chip: head_partial[image][HW / 64]
+  // [joint][3 + 64], the layout head_finalize_kernel merges (head.hip).  The head's own pass over the logits disappears.
+  float* head_partial;
 };
 
 constexpr int kMaxDevices = 16;
@@ -373,7 +379,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
       }
     }
   }
-  if (!(want_stats || rows_from_lds)) return;
+  const bool want_head = MODE == 0 && BM == 64 && BN / HALVES == 64 && p.head_partial != nullptr;
+  if (!(want_stats || rows_from_lds || want_head)) return;
   // ---- staged passes: T[pixel][channel of this half] -> whole rows to memory and / or per-channel sums
   constexpr int C4 = BNH / 4, RPP = 256 / C4, NR = BM / RPP;   // float4 per row, rows per pass of the block, rows per thread
   static_assert(BM % RPP == 0, "row pass does not tile the block rows");
@@ -436,6 +443,46 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
           v.z += (mb & 4u) ? o.z : 0.f; v.w += (mb & 8u) ? o.w : 0.f;
         }
         stream_store(reinterpret_cast<float4*>(p.out + orow * p.Cd + nn), v);
+      }
+    }
+    if constexpr (MODE == 0 && BM == 64 && BNH == 64) {
+      if (p.head_partial != nullptr && nh0 < p.Cd) {
+        // one joint (64 depth bins = the 64 channels of this half) over the 64 pixels of one image row: T[pixel][bin] + bias
+        const int tid = threadIdx.x;
+        const int c = tid & 63, part = tid >> 6;           // thread: depth bin c, pixels part, part + 4, ...
+        const float bc = p.bias ? p.bias[nh0 + c] : 0.f;
+        float v[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { v[j] = lds[(part + 4 * j) * LDT + c] + bc; mx = fmaxf(mx, v[j]); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float* red = lds + BM * LDT;                       // 512 floats behind the tile
+        if (c == 0) red[part] = mx;
+        __syncthreads();
+        const float Mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float z = 0.f, sx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float e = __expf(v[j] - Mx);
+          z += e;
+          sx = fmaf(e, (float)(part + 4 * j), sx);         // pixel r of the tile row = image column w (m0 % 64 == 0)
+        }
+        red[8 + part * 64 + c] = z;                        // per (pixel part, bin)
+        float zs = z;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { zs += __shfl_xor(zs, o, 64); sx += __shfl_xor(sx, o, 64); }
+        if (c == 0) { red[264 + part] = zs; red[268 + part] = sx; }
+        __syncthreads();
+        const int img = m0 / HW, pix0 = m0 - img * HW;     // (forward: HW = Ho * Wo = 4096; the tile is one image row)
+        float* rec = p.head_partial + (((size_t)img * (HW >> 6) + (pix0 >> 6)) * (p.Cd >> 6) + (nh0 >> 6)) * 67;
+        if (part == 0) rec[3 + c] = (red[8 + c] + red[8 + 64 + c]) + (red[8 + 128 + c] + red[8 + 192 + c]);
+        if (tid == 64) {
+          const float tot = (red[264] + red[265]) + (red[266] + red[267]);
+          rec[0] = Mx;
+          rec[1] = (red[268] + red[269]) + (red[270] + red[271]);
+          rec[2] = tot * (float)(pix0 >> 6);               // every pixel of the tile has the same h
+        }
       }
     }
     if (MODE == 0 && want_stats) {

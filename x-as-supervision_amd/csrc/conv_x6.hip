@@ -663,6 +663,9 @@ static int launch_igemm_x6t(const IgemmParams& p, int Mrows_max, hipStream_t st)
 template <int MODE, int P>
 static int launch_igemm_x6_p(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
   int bm, bn;
+  if constexpr (MODE == 0) {                           // the head epilogue lives in the 64 x 256 tile (one image row x four joints)
+    if (p.head_partial) return launch_igemm_x6_t<64, 256, 0, P, false>(p, Mrows_max, phases, st);
+  }
   pick_tile(p.Cd, Mrows_max, phases, &bm, &bn);
   if (x6t_takes(p, bm, phases)) {
     if (bn == 128) return launch_igemm_x6t<128, MODE, P>(p, Mrows_max, st);

@@ -279,6 +279,27 @@ extern "C" int xas_head_softargmax_fwd(const float* logits, int B, int K, int D,
   return 0;
 }
 
+// The second pass alone, over partial records that something else produced: xas_conv_fwd_head (conv.hip) emits them from the
+// final convolution's epilogue, `nchunk` records of 64 pixels per image in the layout of head_partial_kernel
+// ([image][chunk][joint][3 + D]).  Everything downstream (kps, int64 peak indices, depth maps, statistics for the backward)
+// is what xas_head_softargmax_fwd writes.
+extern "C" int xas_head_softargmax_from_partials(const float* partial, int B, int K, int D, int nchunk, int num_hypo, int neighbor,
+                                                 float* kps, int64_t* z_idx, float* depth_prob_map, int groups, float* stats,
+                                                 void* stream) {
+  HeadGeom g;
+  if (make_geom(B, K, D, &g)) return 1;
+  XAS_REQUIRE(partial && kps && depth_prob_map && stats && nchunk >= 1, "head from partials: null buffer");
+  XAS_REQUIRE(num_hypo >= 1 && num_hypo <= 6, "head from partials: num_hypo %d not in [1,6]", num_hypo);
+  XAS_REQUIRE(neighbor >= 0 && (neighbor > 0 || num_hypo == 1), "head from partials: single-hypothesis mode needs num_hypo == 1");
+  XAS_REQUIRE(neighbor == 0 || (z_idx != nullptr && num_hypo <= D - 2), "head from partials: z_idx required / too many hypotheses");
+  XAS_REQUIRE(groups >= 1 && B % groups == 0, "head from partials: B=%d does not split into %d groups", B, groups);
+  g.nchunk = nchunk;
+  hipLaunchKernelGGL(head_finalize_kernel, dim3(B * K), dim3(64), 0, as_stream(stream), partial, g, num_hypo,
+                     neighbor, kps, z_idx, depth_prob_map, B / groups, stats);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int xas_head_softargmax_bwd(const float* logits, const float* stats, const int64_t* z_idx,
                                        const float* grad_kps, int B, int K, int D, int num_hypo, int neighbor,
                                        float* grad_logits, float* coef, void* stream) {

@@ -22,6 +22,10 @@ class KPDetector3DMulti(nn.Module):
         self.num_kp = num_kp
         self.net = get_pose_net(cfg, num_joints=num_kp)
         self.name = name
+        # the final 1x1 convolution writes the head's first-pass records from its epilogue (forward half)
+        last = self.net.head.features[-1]
+        if hasattr(last, 'head_kd') and depth_dim == 64:
+            last.head_kd = (num_kp, depth_dim)
         self.last_peak_indices = None      # int64 [B, K, num_hypo] of the latest forward (diagnostics / tests)
 
     def forward(self, x):

@@ -49,6 +49,9 @@ SIGNATURES = {
     'xas_draw_lines_max_fwd': ('plliippiufipp', 'i'),
     'xas_draw_lines_max_bwd': ('plliippiufipppp', 'i'),
     'xas_conv_fwd': ('ppppsp', 'i'),
+    'xas_conv_fwd_head_chunks': ('sii', 'i'),
+    'xas_conv_fwd_head': ('ppppsiipp', 'i'),
+    'xas_head_softargmax_from_partials': ('piiiiiipppipp', 'i'),
     'xas_conv_fwd_bnstats_workspace_floats': ('si', 'z'),
     'xas_conv_fwd_bnstats': ('pppsippplppppfp', 'i'),
     'xas_conv_dgrad_bn_bwd_workspace_floats': ('si', 'z'),

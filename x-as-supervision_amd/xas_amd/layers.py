@@ -30,9 +30,11 @@ class Conv2d(nn.Module):
                 bound = 1 / math.sqrt(cin * k * k)
                 nn.init.uniform_(self.bias, -bound, bound)
         self._cache = F._PackCache()
+        self.head_kd = None            # (joints, depth bins): this conv produces the logits of the soft-argmax head - its epilogue
+                                       # then also emits the head's first-pass records (ops_nn.conv2d, xas_conv_fwd_head)
 
     def forward(self, x):
-        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self._cache)
+        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self._cache, self.head_kd)
 
 
 class ConvTranspose2d(nn.Module):

@@ -22,6 +22,7 @@ class _SoftArgmax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, num_kp, num_hypo, neighbor, groups):
         from . import ops_nn
+        logits_in = logits
         logits_tail = _nhwc_storage(logits)
         logits = ops_nn._full(logits_tail)               # prefix pass (ops_nn): prefix + graph images in one launch
         B, C, H, W = logits.shape
@@ -33,9 +34,16 @@ class _SoftArgmax(torch.autograd.Function):
         z_idx = torch.empty(B, num_kp, num_hypo, device=dev, dtype=torch.int64)
         dmap = torch.empty(groups, num_kp, D, device=dev, dtype=torch.float32)
         stats = torch.empty(B, num_kp, HEAD_STATS, device=dev, dtype=torch.float32)
-        ws = torch.empty(query('xas_head_workspace_floats', B, num_kp, D), device=dev, dtype=torch.float32)
-        call('xas_head_softargmax_fwd', ptr(logits), B, num_kp, D, num_hypo, neighbor, ptr(kps), ptr(z_idx),
-             ptr(dmap), groups, ptr(stats), ptr(ws))
+        pre = getattr(logits_in, '_xas_head', None)      # first-pass records from the final convolution's epilogue (ops_nn._Conv2d)
+        if pre is not None and pre[2] == logits_in._version and pre[0].shape[0] == B and pre[0].shape[2] == num_kp:
+            ops_nn.head_stats['fused'] += 1
+            call('xas_head_softargmax_from_partials', ptr(pre[0]), B, num_kp, D, pre[1], num_hypo, neighbor, ptr(kps), ptr(z_idx),
+                 ptr(dmap), groups, ptr(stats))
+        else:
+            ops_nn.head_stats['separate'] += 1
+            ws = torch.empty(query('xas_head_workspace_floats', B, num_kp, D), device=dev, dtype=torch.float32)
+            call('xas_head_softargmax_fwd', ptr(logits), B, num_kp, D, num_hypo, neighbor, ptr(kps), ptr(z_idx),
+                 ptr(dmap), groups, ptr(stats), ptr(ws))
         if peak_probe is not None:
             peak_probe(z_idx.clone())
         s = B - logits_tail.shape[0]                     # images of the no-grad prefix (0 outside a prefix pass)

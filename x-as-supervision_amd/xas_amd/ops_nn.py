@@ -518,9 +518,16 @@ def _wgrad(x, dy, shp, w_shape, transposed=False):
     return dw
 
 
+# The final 1x1 convolution of the detector hands the soft-argmax head its first-pass records (xas_conv_fwd_head): the logits
+# tensor carries them to ops_head._SoftArgmax as `_xas_head` = (records, chunks per image, version of the logits).
+# XAS_HEAD_IN_EPILOGUE=0: the head reads the logits itself (head_partial_kernel), as before r05.
+HEAD_IN_EPILOGUE = os.environ.get('XAS_HEAD_IN_EPILOGUE', '1') == '1'
+head_stats = {'fused': 0, 'separate': 0}      # launches of either form (tests)
+
+
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, cache):
+    def forward(ctx, x, weight, bias, stride, pad, cache, head_kd=None):
         x = to_cl(x)
         n, ci, hi, wi = x.shape
         co, ci2, r, s = weight.shape
@@ -531,8 +538,15 @@ class _Conv2d(torch.autograd.Function):
         xf = _full(x)                                     # (prefix pass: the kernel runs over prefix + graph images)
         yf = empty_cl(xf.shape[0], co, ho, wo, x)
         shp_f = _with_n(shp, xf.shape[0])
-        call('xas_conv_fwd', ptr(xf), ptr(cache.get(weight, 0, shp_f)), ptr(bias), ptr(yf), shp_f)
+        chunks = query('xas_conv_fwd_head_chunks', shp_f, head_kd[0], head_kd[1]) if (head_kd and HEAD_IN_EPILOGUE and x.is_cuda) else 0
+        if chunks:
+            rec = torch.empty(xf.shape[0], chunks, head_kd[0], 3 + head_kd[1], device=x.device, dtype=torch.float32)
+            call('xas_conv_fwd_head', ptr(xf), ptr(cache.get(weight, 0, shp_f)), ptr(bias), ptr(yf), shp_f, head_kd[0], head_kd[1], ptr(rec))
+        else:
+            call('xas_conv_fwd', ptr(xf), ptr(cache.get(weight, 0, shp_f)), ptr(bias), ptr(yf), shp_f)
         y = _tail(yf)
+        if chunks:
+            y._xas_head = (rec, chunks, y._version)
         ctx.save_for_backward(x, weight, *([bias] if bias is not None else []))
         ctx.shp, ctx.cache, ctx.has_bias, ctx.x_slot = shp, cache, bias is not None, x_slot
         if ctx.needs_input_grad[1]:
@@ -556,11 +570,11 @@ class _Conv2d(torch.autograd.Function):
             M = shp.N * shp.Ho * shp.Wo
             if not _bias_into_grad(dy, M, shp.Cout, rest[0]):
                 db = _bias_grad(dy, M, shp.Cout)          # (autograd accumulates it and its hook reports readiness)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv2d(x, weight, bias, stride, pad, cache):
-    return _Conv2d.apply(x, weight, bias, stride, pad, cache)
+def conv2d(x, weight, bias, stride, pad, cache, head_kd=None):
+    return _Conv2d.apply(x, weight, bias, stride, pad, cache, head_kd)
 
 
 def _conv_forward(x, weight, stride, pad, cache):
