@@ -446,7 +446,7 @@ def test_detector_bf16_close_to_fp32():
 def test_free_running_steps_split_modes_vs_exact_fp32():
     """Three consecutive optimisation steps (disc + gen, Adam, no re-synchronisation) in the default mode and in bf16x6
     against the exact-fp32 kernels from the same initial state and batch.  Step 1 (identical state): every loss term within
-    5e-6 relative.  Step 2 (after one Adam update, which maps ANY non-zero gradient to a step of +-lr: rounding-level
+    1e-5 relative.  Step 2 (after one Adam update, which maps ANY non-zero gradient to a step of +-lr: rounding-level
     differences of near-zero gradients become 2 lr differences of single weights): the default mode within max(1.2e-2, three
     times the drift of bf16x6 in the same run).  Step 3 is printed, not
     asserted - the trajectories separate at the same rate in both split modes (measured: f16x3 5e-2, bf16x6 4e-1 on the
@@ -485,7 +485,9 @@ def test_free_running_steps_split_modes_vs_exact_fp32():
         # into 2 lr steps of single weights; measured 2e-4 .. 6e-3 depending only on which launches share a pass - r04's joint
         # prefix pass moved it from 3e-3 to 5.8e-3 with the arithmetic of every product unchanged - hence a bar of 3e-2)
         errs[mode + '_steps'] = rel_e
-        assert float(rel_e[0].max()) < 5e-6, (mode, rel_e)
+        # (r05: the split modes take the head's first pass from the final convolution's epilogue, the exact-fp32 kernels run the
+        # head's own two passes - another summation order of the soft-argmax sums: 4.6e-6 / 5.3e-6 measured, was 3e-6)
+        assert float(rel_e[0].max()) < 1e-5, (mode, rel_e)
     # step 2 against a YARDSTICK from the same state instead of a loose constant: the default mode may not drift
     # further from exact fp32 than 1.2e-2 (twice the largest value measured for it, 5.8e-3) or three times what the range-free
     # six-product mode drifts in the same run, whichever is larger
