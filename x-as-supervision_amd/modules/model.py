@@ -167,10 +167,10 @@ class Counter3DModel(torch.nn.Module):
                     assert kps.dim() == 4, "use aligned multi-hypothesis settings"
                     # (slices, not the reference's `[[0]]` lists: a list index is an index TENSOR that torch uploads with a
                     # blocking copy - 46 pipeline drains per step; the values are the same)
-                    out['pose_2d_pred_{}_ori'.format(key)] = kps[0:1, 0].detach().clone()
+                    out['pose_2d_pred_{}_ori'.format(key)] = kps[0:1, 0].detach()        # (a view: nothing writes kps in place)
                     out['depth_map_{}'.format(key)] = depth_map
                     world = _to_world(kps, x, key, cam == 'mono')                  # [B, Hy, K, 3], one launch
-                    out['pose_3d_depth_{}'.format(key)] = world[:, 0].detach().clone()
+                    out['pose_3d_depth_{}'.format(key)] = world[:, 0].detach()
                     # multi-hypothesis only changes z, so one mask per camera (hypothesis 0's x, y)
                     recon = draw_lines_max(kps[:, 0, :, :2], x[key + '_img'].shape[-1], self.parent_ids, self.child_ids,
                                            self.body_width)
@@ -211,7 +211,7 @@ class Counter3DModel(torch.nn.Module):
             dets = _grouped(self.regressor, [x[k + '_pseudo_img'] for k in keys])
         for key, (pred, _) in zip(keys, dets):
             gt = x[key + '_pseudo_joints']
-            out['pose_2d_pred_{}_pseudo'.format(key)] = pred[0:1, 0].detach().clone()
+            out['pose_2d_pred_{}_pseudo'.format(key)] = pred[0:1, 0].detach()
             out['pose_3d_pred_{}_pseudo'.format(key)] = _to_world(pred[:, 0].detach(), x, key, True)[0:1]
             out['pose_3d_gt_{}_pseudo'.format(key)] = _to_world(gt, x, key, True)[0:1]
             per_cam[key]['pseudo'] = compute_supervision_min(pred, gt)
@@ -349,7 +349,7 @@ class Counter3DDisc(torch.nn.Module):
             real = reals[key]
             real_world = _to_world(real, x, key, True)
             out['pose_smpl_2d_{}'.format(key)] = real[0:1]
-            out['pose_smpl_3d_{}'.format(key)] = real_world[0:1].clone()
+            out['pose_smpl_3d_{}'.format(key)] = real_world[0:1].detach()
             mine = logits[ci * per_cam:(ci + 1) * per_cam]
             fake_logits, real_logits = torch.stack(mine[:-1], dim=1), mine[-1]
             out['smpl_logits_{}'.format(key)] = real_logits[0:1]
