@@ -378,7 +378,7 @@ def main():
         scl = classes(serial.summary())
         traffic = None
         tsrc = None
-        for tname in ('r04_conv_traffic.json', 'r03_conv_traffic.json', 'r02_conv_traffic.json'):
+        for tname in ('r05_conv_traffic.json', 'r04_conv_traffic.json', 'r03_conv_traffic.json', 'r02_conv_traffic.json'):
             tpath = os.path.join(ROOT, 'profiles', tname)
             if os.path.exists(tpath) and args.workload == 'HM36_Multi_SurS1' and args.batch == 32:
                 with open(tpath) as tf:
