@@ -266,7 +266,7 @@ def main():
     # HIP events bracket every conv-family launch of the LAST timed step (1 818 launches): bracketing all K steps cost
     # ~4 % of the headline (two event packets per launch on the queue), one step costs < 1 %.
     from xas_amd.prof import CONV_ENTRIES
-    HEAD = ('xas_head_softargmax_fwd', 'xas_head_softargmax_bwd', 'xas_head_softargmax_bwd_amax')
+    HEAD = ('xas_head_softargmax_fwd', 'xas_head_softargmax_from_partials', 'xas_head_softargmax_bwd', 'xas_head_softargmax_bwd_amax')
     from xas_amd.prof import BN_ENTRIES
     timer = KernelTimer(CONV_ENTRIES + HEAD + BN_ENTRIES)
     t0 = time.perf_counter()
@@ -475,11 +475,13 @@ def main():
         for k, v in head.items():
             if v['ms'] > 0:
                 tbs = v['flops'] / (v['ms'] * 1e-3) / 1e12
-                hd[k.replace('xas_head_softargmax_', '').replace(':direct', '').replace('_amax', '')] = {
+                hd[k.replace('xas_head_softargmax_', '').replace(':direct', '').replace('_amax', '').replace('from_partials', 'fwd_second_pass')] = {
                     'launches': v['launches'], 'us_per_launch': v['ms'] * 1e3 / v['launches'],
                     'algorithmic_MB_per_launch': v['flops'] / v['launches'] / 1e6, 'achieved_TBps': tbs, 'frac_of_8TBps': tbs / 8.0}
-        line['roofline']['head'] = dict(hd, kernel='head_partial_kernel + head_finalize_kernel (fwd), head_bwd_coef_kernel + '
-                                        'head_bwd_kernel (bwd)', bound='hbm', peak_TBps=8.0,
+        line['roofline']['head'] = dict(hd, kernel='fwd: first pass (online softmax, marginals) in the epilogue of the final 1x1 convolution '
+                                        '(igemm_x6_kernel<64,256,0,.>, xas_conv_fwd_head: the logits are NOT read again) + head_finalize_kernel '
+                                        'over its records (fwd_second_pass; head_partial_kernel + head_finalize_kernel = `fwd` when the '
+                                        'fused form is off or not taken); bwd: head_bwd_coef_kernel + head_bwd_kernel', bound='hbm', peak_TBps=8.0,
                                         note='logits of one grouped detector pass (18.87 MB per image; forward: every image of the pass - with the '
                                              'joint prefix pass 3 x cameras x B = %d, else 2 x cameras x B -, read once; backward: the 2 x cameras x B = %d '
                                              'graph images, read + written)' % (3 * args.batch * len(cams), 2 * args.batch * len(cams)))

@@ -6,7 +6,7 @@ import torch
 from . import _lib
 
 # (xas_conv_fwd_bnstats: the bracket also holds the ~10 us reduction of the per-tile partial sums that follows the convolution)
-CONV_ENTRIES = ('xas_conv_fwd', 'xas_conv_fwd_bnstats', 'xas_conv_dgrad', 'xas_conv_dgrad_acc', 'xas_conv_dgrad_acc_masked', 'xas_conv_wgrad',
+CONV_ENTRIES = ('xas_conv_fwd', 'xas_conv_fwd_head', 'xas_conv_fwd_bnstats', 'xas_conv_dgrad', 'xas_conv_dgrad_acc', 'xas_conv_dgrad_acc_masked', 'xas_conv_wgrad',
                 'xas_conv_wgrad_oihw', 'xas_conv_wgrad_acc')
 
 
@@ -64,7 +64,7 @@ class KernelTimer:
             raise RuntimeError('%s failed (%d): %s' % (name, rc, _lib.load().xas_last_error().decode()))
         mfma = 0                   # kernel class of the launch: 0 no MFMA, 1 exact-fp32 MFMA, 2 bf16 MFMA, 3 bf16x6 MFMA, 4 f16x3 MFMA
         if shape is not None:
-            kind = 0 if name in ('xas_conv_fwd', 'xas_conv_fwd_bnstats') else (
+            kind = 0 if name in ('xas_conv_fwd', 'xas_conv_fwd_head', 'xas_conv_fwd_bnstats') else (
                 1 if name in ('xas_conv_dgrad', 'xas_conv_dgrad_acc', 'xas_conv_dgrad_acc_masked', 'xas_conv_dgrad_bn_bwd') else 2)
             mfma = _lib.query('xas_conv_kernel_class', shape, kind)
         sig = None
@@ -74,6 +74,9 @@ class KernelTimer:
         if name == 'xas_head_softargmax_fwd':          # (logits, B, K, D, ...): the logits are read once
             B, K, D = args[1], args[2], args[3]
             work, sig = 4.0 * B * K * D * D * D, (B, K, D)
+        elif name == 'xas_head_softargmax_from_partials':   # (records, B, K, D, nchunk, ...): the first-pass records are read once
+            B, K, D, nch = args[1], args[2], args[3], args[4]
+            work, sig = 4.0 * B * nch * K * (3 + D), (B, K, D)
         elif name in BN_ENTRIES:
             work, sig = bn_bytes(name, args), None
         elif name in ('xas_head_softargmax_bwd', 'xas_head_softargmax_bwd_amax'):        # (logits, stats, z_idx, grad_kps, B, K, D, ...): read + write
