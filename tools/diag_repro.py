@@ -54,6 +54,8 @@ def main():
     def run(label, **sw):
         old = {}
         for k, v in sw.items():
+            if k == 'foreign':
+                continue
             if k == 'side':
                 old[k] = ops_nn._side['enabled']
                 ops_nn._side['enabled'] = v
@@ -73,6 +75,24 @@ def main():
                 old[k] = engine.ADV_ON_AUX
                 engine.ADV_ON_AUX = v
         restore(step, sn)
+        if sw.get('foreign'):
+            # stock PyTorch kernels (elementwise over 268 MB, 4096^3 matmuls) queued on ANOTHER stream for the whole length of the
+            # step: what a communication stream's kernels would be to the step - foreign work beside the library's kernels
+            fs = _foreign.setdefault('stream', torch.cuda.Stream())
+            if 'a' not in _foreign:
+                g_ = torch.Generator(device=dev).manual_seed(3)
+                _foreign['a'] = torch.randn(64, 256, 64, 64, device=dev, generator=g_)
+                _foreign['m'] = torch.randn(4096, 4096, device=dev, generator=g_)
+            fs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(fs):
+                acc_ = torch.zeros(2, device=dev, dtype=torch.float64)
+                for _ in range(int(sw['foreign'])):
+                    t_ = torch.relu(_foreign['a'] * 1.0001 + 0.5)
+                    u_ = _foreign['m'] @ _foreign['m']
+                    acc_[0] += t_.double().sum()                 # (the foreign kernels are victims too: their results must repeat)
+                    acc_[1] += u_.double().sum()
+                    del t_, u_
+                _foreign['acc'] = acc_
         torch.manual_seed(4242)
         grads = {}
         step.grad_probe = lambda which, arena: grads.__setitem__(which, arena.clone())
@@ -113,6 +133,8 @@ def main():
         step.grad_probe = None
         torch.cuda.synchronize()
         res = dict(grads)
+        if sw.get('foreign'):
+            res['foreign'] = _foreign['acc'].clone()
         for k_ in [k_ for k_ in taps if k_.startswith('_saved_')]:
             taps['saved_kps_after_step' + k_[6:]] = taps.pop(k_).clone()
         res['taps'] = taps
@@ -134,6 +156,8 @@ def main():
             elif k == 'adv_aux':
                 engine.ADV_ON_AUX = v
         return res
+
+    _foreign = {}
 
     def poison(value):
         """Fill every FREE block of the caching allocator with `value` (bit pattern of a float32): take blocks of falling
@@ -183,15 +207,18 @@ def main():
         CONFIGS = {'single': dict(side=False, beside=False), 'main+side': dict(side=True, beside=False),
                    'main+aux': dict(side=False, beside=True), 'main+side+aux': dict(side=True, beside=True),
                    'r04': dict(side=True, beside=True, adv_aux=True),
+                   'single+foreign': dict(side=False, beside=False, foreign=60),
                    'r04+nolean': dict(side=True, beside=True, adv_aux=True, tune=262144)}
         for label in args.census.split(','):
             sw = CONFIGS[label]
             refs = [run(label, **sw) for _ in range(3)]
             # (a reference that is itself an anomaly would make every later run "differ": majority of three)
             ref = refs[0] if torch.equal(refs[0]['det'], refs[1]['det']) or torch.equal(refs[0]['det'], refs[2]['det']) else refs[1]
-            hits, kinds = 0, {}
+            hits, kinds, fbad = 0, {}, 0
             for it in range(args.loops):
                 got = run(label, **sw)
+                if 'foreign' in got and not torch.equal(got['foreign'], ref['foreign']):
+                    fbad += 1
                 if not (torch.equal(got['det'], ref['det']) and torch.equal(got['loss'], ref['loss'])):
                     hits += 1
                     diff_taps = [k_ for k_ in ref['taps'] if k_ in got['taps'] and got['taps'][k_].shape == ref['taps'][k_].shape
@@ -203,7 +230,8 @@ def main():
                         print('   iteration %d: taps that differ: %s' % (it, diff_taps), flush=True)
                     d = float((got['det'].double() - ref['det'].double()).norm() / ref['det'].double().norm())
                     kinds['%.3e' % d] = kinds.get('%.3e' % d, 0) + 1
-            print('== %-14s %d anomalies in %d runs  %s' % (label, hits, args.loops, kinds), flush=True)
+            print('== %-14s %d anomalies in %d runs  %s%s' % (label, hits, args.loops, kinds,
+                                                               ('  foreign-stream checksums differing: %d' % fbad) if 'foreign' in ref else ''), flush=True)
         return
     if args.bisect:
         f = od._flat

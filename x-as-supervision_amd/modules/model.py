@@ -226,6 +226,7 @@ class Counter3DModel(torch.nn.Module):
             key = 'cam_{}'.format(cam)
             rels[key] = ((world[key] - world[key][:, 0:1]) / 1000)[..., :self.DISC_SUP_DIMENSION].detach()
         hy = world['cam_{}'.format(cams[0])].shape[1]
+        ops_nn.prepack(smpl_discriminator)               # (the update has just rewritten its weights: ONE launch re-splits all of them)
         flat = _disc_many(smpl_discriminator, [rels['cam_{}'.format(c)][:, h] for c in cams for h in range(hy)])
         for ci, cam in enumerate(cams):
             key = 'cam_{}'.format(cam)
@@ -339,6 +340,7 @@ class Counter3DDisc(torch.nn.Module):
             preds = {k: v.detach() for k, v in preds.items()}
         else:
             preds = self.detector_pass(x, regressor)
+        ops_nn.prepack(self.smpl_discriminator)
         for cam in cams:
             key = 'cam_{}'.format(cam)
             inputs += [preds[key][:, h, :, :d] for h in range(preds[key].shape[1])] + [reals[key][..., :d]]

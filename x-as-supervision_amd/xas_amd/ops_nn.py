@@ -1267,6 +1267,16 @@ def _conv_entries(module):
                 ho = (hi + 2 * pad - r) // stride + 1
                 shp = _shape(1, hi, hi, b, a, r, s, stride, pad, ho, ho)
             out.append((m, cache, w, shp))
+        elif isinstance(cache, _PackCache) and w is not None and w.dim() == 2 and w.is_cuda and LINEAR_MFMA and w.is_contiguous() \
+                and w.shape[1] % 32 == 0 and w.shape[0] >= 16 and w.shape[0] % 4 == 0:
+            # a linear layer wide enough for the MFMA tiles (ops_nn.linear): its weight as a 1x1 filter; its launches never come
+            # with operand maxima, so both passes take the format of the shape WITHOUT maxima (f16x3 mode: three bf16 planes)
+            co, ci = w.shape
+            w4 = w.detach().view(co, ci, 1, 1)
+            w4._xas_epoch = getattr(w, '_xas_epoch', _weights_epoch)
+            shp = _shape(1, 8, 32, ci, co, 1, 1, 1, 0, 8, 32)
+            shp._linear = True
+            out.append((m, cache, w4, shp))
     return out
 
 
@@ -1282,6 +1292,10 @@ def prepack(module):
     prec = query('xas_get_precision')
     if not BATCH_PREP:
         for _, cache, w, shp in entries:
+            if getattr(shp, '_linear', False):
+                cache.get(w, 0, shp)
+                cache.get(w, 1, shp)
+                continue
             f16 = (prec == _lib.PREC_F16X3 and GRAD_F16 and shp.mode == 0 and query('xas_conv_weight_planes', shp, 1) == 3)
             if not (f16 and query('xas_conv_weight_planes', shp, 0) == 3):
                 cache.get(w, 0, shp)                   # (f16x3: the three-plane forward format is built on demand only)
@@ -1296,15 +1310,19 @@ def prepack(module):
         rows_of, views, desc, blk, off = [], [], [], 0, 0
         sizes = []
         for idx, (_, cache, w, shp) in enumerate(entries):
-            f16 = prec == _lib.PREC_F16X3 and GRAD_F16 and shp.mode == 0
+            lin = getattr(shp, '_linear', False)
+            f16 = prec == _lib.PREC_F16X3 and GRAD_F16 and shp.mode == 0 and not lin
             for t, extra in ((0, False), (1, False), (0, True), (1, True)):
                 planes = query('xas_conv_weight_planes', shp, t)      # (dummy shape without operand maxima)
+                if lin and extra:
+                    continue
                 if extra:                      # f16x3: launches that come with the maxima of their operands run on two fp16
                     if not (planes == 3 and f16):                      # planes - every forward, every data gradient whose
                         continue                                       # dy was tagged
                     planes = 2
                 elif t == 0 and planes == 3 and f16:
                     continue                   # forward launches always come with max |x| (act_amax): three planes only on demand
+                                               # (linear layers: never - their three-plane forward format is in the table)
                 if not planes or not w.is_contiguous():
                     continue
                 co, ci, r, s = w.shape
