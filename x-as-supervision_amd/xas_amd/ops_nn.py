@@ -106,7 +106,7 @@ def side_stream():
 # timed steps (seconds when the memory had just been released by another process).  Instead the tensors are kept alive in a
 # short FIFO; when an entry leaves it the MAIN stream is made to wait for that entry's side-stream event (long past on the
 # GPU by then), so whatever re-uses the memory is ordered after its last reader on the device, and nothing is deferred.
-_KEEP_DEPTH = 8
+_KEEP_DEPTH = int(os.environ.get('XAS_KEEP_DEPTH', '8'))
 
 
 def _keep_for_side(*tensors):
