@@ -20,7 +20,30 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-RESNET_DEPTHS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+RESNET_DEPTHS = {18: (2, 2, 2, 2), 34: (3, 4, 6, 3), 50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+BASIC_DEPTHS = (18, 34)          # resnet.py:5-6: torchvision BasicBlock (expansion 1), the others Bottleneck (expansion 4)
+
+
+class _BasicBlock(nn.Module):
+    """torchvision BasicBlock restated (absent third-party code, like _Bottleneck below): conv3x3(stride)-BN-ReLU-conv3x3-BN,
+    + identity / (conv1x1(stride)-BN), ReLU."""
+
+    def __init__(self, cin, planes, stride, project):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        if project:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+        else:
+            self.downsample = None
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        skip = x if self.downsample is None else self.downsample(x)
+        return F.relu(y + skip)
 
 
 class _Bottleneck(nn.Module):
@@ -52,13 +75,19 @@ class _Backbone(nn.Module):
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         cin = 64
+        basic = depth in BASIC_DEPTHS
+        self.out_channels = 512 if basic else 2048
         for li, nblk in enumerate(RESNET_DEPTHS[depth]):
             planes = 64 << li
             blocks = []
             for bi in range(nblk):
                 stride = 2 if (bi == 0 and li > 0) else 1
-                blocks.append(_Bottleneck(cin, planes, stride, project=(bi == 0)))
-                cin = planes * 4
+                if basic:               # resnet.py:35-36: a projection only where the stride or the width changes
+                    blocks.append(_BasicBlock(cin, planes, stride, project=(stride != 1 or cin != planes)))
+                    cin = planes
+                else:
+                    blocks.append(_Bottleneck(cin, planes, stride, project=(bi == 0)))
+                    cin = planes * 4
             setattr(self, 'layer%d' % (li + 1), nn.Sequential(*blocks))
 
     def forward(self, x):
@@ -86,7 +115,7 @@ class _PoseNet(nn.Module):
     def __init__(self, depth, cout):
         super().__init__()
         self.backbone = _Backbone(depth)
-        self.head = _DeconvHead(2048, cout)
+        self.head = _DeconvHead(self.backbone.out_channels, cout)
 
     def forward(self, x):
         return self.head(self.backbone(x))

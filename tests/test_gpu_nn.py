@@ -318,3 +318,29 @@ def test_upsample2x_shapes(n, c, h, w):
     (yg * gy.cuda()).sum().backward()
     assert yg.shape == yc.shape
     assert maxabs(yg, yc) < 1e-6 and maxabs(xg.grad, xc.grad) < 2e-6
+
+
+@pytest.mark.parametrize('depth', [18, 34])
+def test_basic_block_detectors_vs_oracle(depth):
+    """ResNet-18 / 34 detectors (`num_layers` of both detector classes, resnet.py:5-6: torchvision BasicBlock): same state-dict
+    keys as the oracle's restatement, joints within 1e-4, parameter gradients of the first and last block within 2e-3."""
+    from modules.keypoint_detector_integral_multi import KPDetector3DMulti
+    from oracle import step as ostep
+    import inputs as gi
+    ora = gi.seeded_fill_(ostep.Regressor('resnet_multi', 18, 64, 3, 15, num_layers=depth), seed=40 + depth)
+    hip = KPDetector3DMulti('resnet_multi', 18, 64, 3, 15, num_layers=depth)
+    assert list(hip.state_dict().keys()) == list(ora.state_dict().keys())
+    hip.load_state_dict(ora.state_dict(), strict=True)
+    hip.cuda().train(); ora.train()
+    x = torch.from_numpy(gi.synthetic_batch(2, [0], seed=7)['cam_0_img'])
+    kc, _ = ora(x)
+    kg, _ = hip(x.cuda())
+    assert float((kg.cpu() - kc).abs().max()) < 1e-4
+    gw = torch.randn(kc.shape, generator=torch.Generator().manual_seed(3))
+    (kc * gw).sum().backward()
+    (kg * gw.cuda()).sum().backward()
+    pc, pg = dict(ora.named_parameters()), dict(hip.named_parameters())
+    rel = lambda a, b: float((a.detach().cpu().double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    for n in ('net.backbone.layer1.0.conv1.weight', 'net.backbone.layer2.0.downsample.0.weight', 'net.backbone.layer4.1.conv2.weight',
+              'net.head.features.0.weight'):
+        assert rel(pg[n].grad, pc[n].grad) < 5e-3, (n, rel(pg[n].grad, pc[n].grad))

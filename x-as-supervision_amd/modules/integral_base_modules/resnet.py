@@ -45,9 +45,31 @@ class Bottleneck(nn.Module):
         return self.bn3(self.conv3(y), residual=skip)
 
 
-# depth -> (block, blocks per stage, stage widths, torchvision name); 18/34 need BasicBlock,
-# which no shipped config uses (config/*.yaml: num_layers defaults to 50).
-resnet_spec = {50: (Bottleneck, [3, 4, 6, 3], [64, 256, 512, 1024, 2048], 'resnet50'),
+class BasicBlock(nn.Module):
+    """torchvision 0.17.2 BasicBlock (the reference imports it at resnet.py:2 for num_layers 18 / 34, resnet.py:5-6):
+    conv3x3(stride) - BN - ReLU - conv3x3 - BN, + identity / downsample, ReLU.  Layer-by-layer on the same kernels as the
+    bottleneck (the residual add and the final ReLU folded into bn2's apply kernel); no shipped YAML selects it."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        k = 'kaiming_fan_out'
+        self.conv1 = L.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=False, init=k)
+        self.bn1 = L.BatchNorm2d(planes, act=ACT_RELU)
+        self.conv2 = L.Conv2d(planes, planes, 3, padding=1, bias=False, init=k)
+        self.bn2 = L.BatchNorm2d(planes, act=ACT_RELU)          # applied after the residual add
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        skip = x if self.downsample is None else self.downsample(x)
+        return self.bn2(self.conv2(self.bn1(self.conv1(x))), residual=skip)
+
+
+# depth -> (block, blocks per stage, stage widths, torchvision name)  (resnet.py:5-9)
+resnet_spec = {18: (BasicBlock, [2, 2, 2, 2], [64, 64, 128, 256, 512], 'resnet18'),
+               34: (BasicBlock, [3, 4, 6, 3], [64, 64, 128, 256, 512], 'resnet34'),
+               50: (Bottleneck, [3, 4, 6, 3], [64, 256, 512, 1024, 2048], 'resnet50'),
                101: (Bottleneck, [3, 4, 23, 3], [64, 256, 512, 1024, 2048], 'resnet101'),
                152: (Bottleneck, [3, 8, 36, 3], [64, 256, 512, 1024, 2048], 'resnet152')}
 
