@@ -128,6 +128,7 @@ class Counter3DModel(torch.nn.Module):
         buf = ops_nn.stack_nchw(imgs)
         if not buf.is_contiguous(memory_format=torch.channels_last):
             buf = ops_nn.from_nchw(buf)
+        ops_nn.mark_prefix_buffer(buf)
         kps, dmap, kps_prefix = self.regressor.forward_groups(buf[P * B:], G, prefix_groups=P)
         dmap = dmap.reshape(G, *dmap.shape[-2:])
         preds = {k: kps_prefix[g * B:(g + 1) * B] for g, k in enumerate(keys)}

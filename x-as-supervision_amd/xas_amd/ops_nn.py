@@ -46,17 +46,30 @@ class bn_groups:
     def __exit__(self, *exc):
         _groups[0] = self.prev
         _prefix[0], _prefix[1] = self.prev_prefix
+        if not _prefix[0]:
+            _prefix_storages.clear()
+
+
+_prefix_storages = set()      # storages of the buffers of the current prefix pass (mark_prefix_buffer / _tail register them)
+
+
+def mark_prefix_buffer(buf):
+    """Declare `buf` [prefix images + graph images, ...] a buffer of the current prefix pass: only tail views of declared
+    buffers are extended backwards by _full (offset arithmetic alone would accept a slice of any user buffer)."""
+    _prefix_storages.add(buf.untyped_storage().data_ptr())
 
 
 def _full(x):
-    """The whole buffer of a prefix pass (prefix images + x) from its tail view x; x itself outside a prefix pass."""
+    """The whole buffer of a prefix pass (prefix images + x) from its tail view x; x itself outside a prefix pass.  Outputs of
+    a prefix pass are views of such buffers: they must not be modified in place."""
     s = _prefix[0]
     if not s or x is None:
         return x
     per = x.stride(0)
     off = x.storage_offset() - s * per
     if (x.dim() != 4 or not x.is_contiguous(memory_format=CL) or off < 0
-            or (x.storage_offset() + x.numel()) * 4 > x.untyped_storage().nbytes()):
+            or (x.storage_offset() + x.numel()) * 4 > x.untyped_storage().nbytes()
+            or x.untyped_storage().data_ptr() not in _prefix_storages):
         raise RuntimeError('prefix pass: an activation arrived without its %d prefix images in front of it' % s)
     return torch.as_strided(x, (x.shape[0] + s,) + tuple(x.shape[1:]), x.stride(), off)
 
@@ -67,6 +80,7 @@ def _tail(tf, per_image=None):
     s = _prefix[0]
     if not s:
         return tf
+    _prefix_storages.add(tf.untyped_storage().data_ptr())        # (a buffer this pass produced)
     return tf[s * per_image:] if per_image is not None else tf[s:]
 
 
