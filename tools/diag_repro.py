@@ -24,6 +24,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--runs', type=int, default=3)
     ap.add_argument('--precision', default='f16x3')
+    ap.add_argument('--p2w', action='store_true', help='diagnosis build of the library (-DXAS_P2W_DEBUG): per-lane record of patch_to_world')
     ap.add_argument('--census', default='', help='comma list of stream configurations: count differing runs of each')
     ap.add_argument('--bisect', action='store_true', help='poison the free blocks with 1e30 and report per parameter, per switch')
     ap.add_argument('--no-poison', action='store_true')
@@ -75,6 +76,14 @@ def main():
                 old[k] = engine.ADV_ON_AUX
                 engine.ADV_ON_AUX = v
         restore(step, sn)
+        if args.p2w:
+            import ctypes
+            lib_ = xl.load()
+            lib_.xas_debug_p2w.argtypes = [ctypes.c_void_p]
+            lib_.xas_debug_p2w.restype = ctypes.c_int
+            _foreign['p2w'] = torch.zeros(32 * 4096 * 32, device=dev)
+            torch.cuda.synchronize()
+            assert lib_.xas_debug_p2w(_foreign['p2w'].data_ptr()) == 0
         if sw.get('foreign'):
             # stock PyTorch kernels (elementwise over 268 MB, 4096^3 matmuls) queued on ANOTHER stream for the whole length of the
             # step: what a communication stream's kernels would be to the step - foreign work beside the library's kernels
@@ -133,6 +142,8 @@ def main():
         step.grad_probe = None
         torch.cuda.synchronize()
         res = dict(grads)
+        if args.p2w:
+            res['p2w'] = _foreign['p2w'].view(32, 4096, 32).clone()
         if sw.get('foreign'):
             res['foreign'] = _foreign['acc'].clone()
         for k_ in [k_ for k_ in taps if k_.startswith('_saved_')]:
@@ -221,6 +232,38 @@ def main():
                     fbad += 1
                 if not (torch.equal(got['det'], ref['det']) and torch.equal(got['loss'], ref['loss'])):
                     hits += 1
+                    if args.p2w:
+                        for ck in ('cam_0', 'cam_1', 'cam_2', 'cam_3'):
+                            ta, tb = got['taps'].get('world_out_' + ck), ref['taps'].get('world_out_' + ck)
+                            if ta is None or torch.equal(ta, tb):
+                                continue
+                            slot = 4 + int(ck[-1])
+                            wrong = (ta != tb).any(-1).reshape(-1).nonzero().flatten()
+                            rec, recr = got['p2w'][slot], ref['p2w'][slot]
+                            kin = ref['taps']['world_in_' + ck].reshape(-1, 3)
+                            n_pts = kin.shape[0]
+                            in_ok = (rec[:n_pts, 0:3] == kin).all(-1)
+                            out_is_got = (rec[:n_pts, 3:6] == ta.reshape(-1, 3)).all(-1)
+                            out_is_ref = (rec[:n_pts, 3:6] == tb.reshape(-1, 3)).all(-1)
+                            print('   iteration %d %s (launch slot %d): %d wrong points %d..%d' % (it, ck, slot, wrong.numel(), int(wrong.min()), int(wrong.max())))
+                            print('      at the wrong points: loaded inputs equal the true joints: %d of %d; recorded outputs equal the (wrong) memory: %d, equal the reference: %d'
+                                  % (int(in_ok[wrong].sum()), wrong.numel(), int(out_is_got[wrong].sum()), int(out_is_ref[wrong].sum())))
+                            print('      elsewhere: inputs true %d of %d, outputs = memory %d' % (int(in_ok.sum()) - int(in_ok[wrong].sum()), n_pts - wrong.numel(),
+                                                                                                  int(out_is_got.sum()) - int(out_is_got[wrong].sum())))
+                            print('      XCD of the wrong points %s; XCDs of the launch %s; pz recorded vs reference run at wrong points equal: %s' % (
+                                sorted(set(rec[wrong, 6].int().tolist())), sorted(set(rec[:n_pts, 6].int().tolist())),
+                                bool((rec[wrong, 7] == recr[wrong, 7]).all())))
+                            names_ = ['P0', 'P1', 'P2', 'Q0', 'Q1', 'Q2', 'fx', 'fy', 'cx', 'cy'] + ['r%d' % e for e in range(9)] + ['tw0', 'tw1', 'tw2']
+                            bad_fields = [names_[f] for f in range(22) if not torch.equal(rec[wrong, 8 + f], recr[wrong, 8 + f])]
+                            print('      camera fields that differ from the reference run at the wrong points: %s; sample index equal: %s; HW_ID of the wrong points %s'
+                                  % (bad_fields, bool(torch.equal(rec[wrong, 31], recr[wrong, 31])),
+                                     sorted(set(hex(v) for v in rec[wrong, 30].view(torch.int32).tolist()))))
+                            for f in bad_fields[:6]:
+                                fi = 8 + names_.index(f)
+                                print('         %s: got %s reference %s' % (f, rec[wrong[:4], fi].tolist(), recr[wrong[:4], fi].tolist()))
+                            w0 = int(wrong[0])
+                            print('      first wrong point %d: loaded %s true %s | computed %s memory %s reference %s' % (
+                                w0, rec[w0, 0:3].tolist(), kin[w0].tolist(), rec[w0, 3:6].tolist(), ta.reshape(-1, 3)[w0].tolist(), tb.reshape(-1, 3)[w0].tolist()))
                     diff_taps = [k_ for k_ in ref['taps'] if k_ in got['taps'] and got['taps'][k_].shape == ref['taps'][k_].shape
                                  and not torch.equal(got['taps'][k_], ref['taps'][k_])]
                     if diff_taps and hits <= 0:

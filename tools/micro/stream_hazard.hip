@@ -79,16 +79,20 @@ int main(int argc, char** argv) {
     victim<<<(n + 127) / 128, 128, 0, M>>>(src[k], cam, n, PER, refs[k]);
   }
   CK(hipDeviceSynchronize());
-  // stream B: linear 128 -> 128 over 6912 rows as one 72 x 96 image
-  xas_conv_shape sb = {1, 72, 96, 128, 128, 1, 1, 1, 0, 72, 96, (mask & 4) ? 1 + XAS_PREC_F32 : 0, nullptr, nullptr};
-  float* xb = dev_rand((size_t)72 * 96 * 128, 1.f, 3); float* wb = dev_rand(128 * 128, 0.1f, 4); float* bb = dev_rand(128, 0.1f, 5);
-  float* yb; CK(hipMalloc(&yb, (size_t)72 * 96 * 128 * 4));
+  // stream B: linear 128 -> 128 over 6912 rows as one 72 x 96 image; bit7: a chip-filling forward conv instead (256 images of
+  // 64 x 64, 64 -> 256: every SIMD hosts its waves, so the victim's waves must share SIMDs with them)
+  const bool bigb = (mask & 128) != 0;
+  const int bn_ = bigb ? 256 : 1, bh = bigb ? 64 : 72, bw = bigb ? 64 : 96, bci = bigb ? 64 : 128, bco = bigb ? 256 : 128;
+  xas_conv_shape sb = {bn_, bh, bw, bci, bco, 1, 1, 1, 0, bh, bw, (mask & 4) ? 1 + XAS_PREC_F32 : 0, nullptr, nullptr};
+  float* xb = dev_rand((size_t)bn_ * bh * bw * bci, 1.f, 3); float* wb = dev_rand((size_t)bco * bci, 0.1f, 4); float* bb = dev_rand(bco, 0.1f, 5);
+  float* yb; CK(hipMalloc(&yb, (size_t)bn_ * bh * bw * bco * 4));
   const int planes_b = xas_conv_weight_planes(&sb, 0);
   void* wpb = wb;
-  if (planes_b) { CK(hipMalloc(&wpb, xas_split_weight_bytes(128, 128, planes_b))); XK(xas_split_weight(wb, wpb, 128, 128, planes_b, B)); }
+  if (planes_b) { CK(hipMalloc(&wpb, xas_split_weight_bytes(bco, bci, planes_b))); XK(xas_split_weight(wb, wpb, bco, bci, planes_b, B)); }
   // stream C: weight gradient of a bottleneck 1x1 (64 -> 256 on 64 x 64 maps, 16 images)
-  xas_conv_shape sc = {16, 64, 64, 64, 256, 1, 1, 1, 0, 64, 64, (mask & 8) ? 1 + XAS_PREC_F32 : 0, nullptr, nullptr};
-  float* xc = dev_rand((size_t)16 * 4096 * 64, 1.f, 6); float* dyc = dev_rand((size_t)16 * 4096 * 256, 1e-3f, 7);
+  const int cn = bigb ? 256 : 16;
+  xas_conv_shape sc = {cn, 64, 64, 64, 256, 1, 1, 1, 0, 64, 64, (mask & 8) ? 1 + XAS_PREC_F32 : 0, nullptr, nullptr};
+  float* xc = dev_rand((size_t)cn * 4096 * 64, 1.f, 6); float* dyc = dev_rand((size_t)cn * 4096 * 256, 1e-3f, 7);
   float* gc; CK(hipMalloc(&gc, 256 * 64 * 4)); CK(hipMemset(gc, 0, 256 * 64 * 4));
   float* wsc; CK(hipMalloc(&wsc, (xas_conv_wgrad_workspace_floats(&sc) + 1) * 4));
   printf("B: kernel class %d (planes %d), C: kernel class %d; iterations %d, mask %d\n", xas_conv_kernel_class(&sb, 0), planes_b,
@@ -104,8 +108,8 @@ int main(int argc, char** argv) {
       victim<<<(n + 127) / 128, 128, 0, M>>>(in, cam, n, PER, out);
       check<<<(n + 127) / 128, 128, 0, M>>>(out, ref, n, bad);
     }
-    if (mask & 1) { XK(xas_conv_fwd(xb, (const float*)wpb, bb, yb, &sb, B)); XK(xas_conv_fwd(xb, (const float*)wpb, bb, yb, &sb, B)); }
-    if (mask & 2) XK(xas_conv_wgrad_acc(xc, dyc, gc, wsc, &sc, C));
+    if ((mask & 1) && (!bigb || (it & 31) == 0)) { XK(xas_conv_fwd(xb, (const float*)wpb, bb, yb, &sb, B)); if (!bigb) XK(xas_conv_fwd(xb, (const float*)wpb, bb, yb, &sb, B)); }
+    if ((mask & 2) && (!bigb || (it & 31) == 16)) XK(xas_conv_wgrad_acc(xc, dyc, gc, wsc, &sc, C));
     if (mask & 32) {                                   // bit5: cross-stream waits as torch's wait_stream issues them (fresh event each)
       hipEvent_t e1, e2;
       CK(hipEventCreateWithFlags(&e1, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));

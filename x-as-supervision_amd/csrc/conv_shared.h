@@ -201,6 +201,30 @@ template <> struct Products<2> { static constexpr int N = 3; static constexpr in
 template <> struct Products<1> { static constexpr int N = 1; static constexpr int A[1] = {0}; static constexpr int B[1] = {0}; };
 template <int P>
 __device__ __forceinline__ f32x16 mfma_piece(uint4 a, uint4 b, f32x16 c) {
+#ifdef XAS_MFMA_X8
+  // diagnosis build: the K = 16 matrix instructions of gfx950 replaced by two K = 8 ones of the previous generation (the low /
+  // high 64 bits of each lane's operand pair up the same k indices on both sides, so every dot product has the same terms)
+  typedef short s16x4v __attribute__((ext_vector_type(4)));
+  typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+  const uint2 alo = make_uint2(a.x, a.y), ahi = make_uint2(a.z, a.w), blo = make_uint2(b.x, b.y), bhi = make_uint2(b.z, b.w);
+  if constexpr (P == 2) {
+    c = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_bit_cast(f16x4v, alo), __builtin_bit_cast(f16x4v, blo), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_bit_cast(f16x4v, ahi), __builtin_bit_cast(f16x4v, bhi), c, 0, 0, 0);
+  } else {
+    c = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4v, alo), __builtin_bit_cast(s16x4v, blo), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4v, ahi), __builtin_bit_cast(s16x4v, bhi), c, 0, 0, 0);
+  }
+#endif
+#ifdef XAS_MFMA_X16_TWICE
+  // diagnosis control for XAS_MFMA_X8: the K = 16 instruction issued TWICE (second result thrown away): the timing of the K = 8
+  // build with the instruction of the shipped one
+  {
+    f32x16 waste = c;
+    if constexpr (P == 2) waste = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), waste, 0, 0, 0);
+    else waste = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), waste, 0, 0, 0);
+    asm volatile("" :: "v"(waste));
+  }
+#endif
   if constexpr (P == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }

@@ -41,14 +41,27 @@ __device__ __forceinline__ CamParams load_cam(const float* ti, const float* km, 
   return c;
 }
 
+#ifdef XAS_P2W_DEBUG
+// diagnosis build (tools/diag_repro.py --bisect, profiles/r05_step_reproducibility.md): every launch records, per point, what the
+// lane LOADED and what it COMPUTED, with the XCD it ran on: [32 launch slots][4096 points][32 floats]
+__device__ float* g_p2w_dbg = nullptr;
+static int g_p2w_launch = 0;
+#define P2W_DBG_ARG , int dbg_slot
+#else
+#define P2W_DBG_ARG
+#endif
+
 __global__ void patch_to_world_fwd_kernel(const float* __restrict__ kps, const float* ti, const float* km,
                                           const float* pv, const float* rw, const float* tw, int B, int HK,
-                                          float S, float rect, int flags, float* __restrict__ world) {
+                                          float S, float rect, int flags, float* __restrict__ world P2W_DBG_ARG) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * HK) return;
   const int b = i / HK;
   const CamParams c = load_cam(ti, km, pv, rw, tw, b, !(flags & XAS_GEO_IMAGE));
   float p0 = kps[i * 3], p1 = kps[i * 3 + 1], p2 = kps[i * 3 + 2];
+#ifdef XAS_P2W_DEBUG
+  const float in0 = p0, in1 = p1, in2 = p2;
+#endif
   if (flags & XAS_GEO_PATCH) {
     if (flags & XAS_GEO_NORM) {
       p0 = (p0 + 1.f) / 2.f * (S - 1.f);
@@ -65,17 +78,37 @@ __global__ void patch_to_world_fwd_kernel(const float* __restrict__ kps, const f
     return;
   }
   float o0, o1, o2;
+#ifdef XAS_P2W_DEBUG
+  float dq0 = 0.f, dq1 = 0.f, dq2 = 0.f;
+#endif
   if (flags & XAS_GEO_MONO) {
     o0 = -p0; o1 = -(p2 + 128.f); o2 = -p1;
   } else {
     const float q0 = (p0 - c.cx) / c.fx * p2 - c.tw[0];
     const float q1 = (p1 - c.cy) / c.fy * p2 - c.tw[1];
     const float q2 = p2 - c.tw[2];
+#ifdef XAS_P2W_DEBUG
+    dq0 = q0; dq1 = q1; dq2 = q2;
+#endif
     o0 = c.r[0] * q0 + c.r[1] * q1 + c.r[2] * q2;
     o1 = c.r[3] * q0 + c.r[4] * q1 + c.r[5] * q2;
     o2 = c.r[6] * q0 + c.r[7] * q1 + c.r[8] * q2;
   }
   world[i * 3] = o0; world[i * 3 + 1] = o1; world[i * 3 + 2] = o2;
+#ifdef XAS_P2W_DEBUG
+  if (g_p2w_dbg && i < 4096) {
+    float* d = g_p2w_dbg + ((size_t)(dbg_slot & 31) * 4096 + i) * 32;
+    unsigned xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    d[0] = in0; d[1] = in1; d[2] = in2; d[3] = o0; d[4] = o1; d[5] = o2; d[6] = (float)(xcc & 15); d[7] = c.pz;
+    d[8] = p0; d[9] = p1; d[10] = p2; d[11] = dq0; d[12] = dq1; d[13] = dq2;      // after the patch stage; after the back projection
+    d[14] = c.fx; d[15] = c.fy; d[16] = c.cx; d[17] = c.cy;
+    for (int e = 0; e < 9; ++e) d[18 + e] = c.r[e];
+    d[27] = c.tw[0]; d[28] = c.tw[1]; d[29] = c.tw[2];
+    d[30] = __uint_as_float(hwid); d[31] = (float)b;
+  }
+#endif
 }
 
 __global__ void patch_to_world_bwd_kernel(const float* __restrict__ kps, const float* __restrict__ gw, const float* ti,
@@ -287,11 +320,24 @@ extern "C" int xas_patch_to_world_fwd(const float* kps, const float* trans_image
   XAS_REQUIRE((flags & XAS_GEO_IMAGE) || (k_mat && rot_world && trans_world), "patch_to_world: null camera buffer");
   XAS_REQUIRE(B > 0 && Hy > 0 && K > 0, "patch_to_world: bad shape B=%d Hy=%d K=%d", B, Hy, K);
   const int n = B * Hy * K;
+#ifdef XAS_P2W_DEBUG
+  hipLaunchKernelGGL(patch_to_world_fwd_kernel, dim3(cdiv(n, 128)), dim3(128), 0, as_stream(stream), kps, trans_image,
+                     k_mat, pelvis, rot_world, trans_world, B, Hy * K, image_size, rect_width, flags, world, g_p2w_launch++);
+#else
   hipLaunchKernelGGL(patch_to_world_fwd_kernel, dim3(cdiv(n, 128)), dim3(128), 0, as_stream(stream), kps, trans_image,
                      k_mat, pelvis, rot_world, trans_world, B, Hy * K, image_size, rect_width, flags, world);
+#endif
   XAS_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef XAS_P2W_DEBUG
+// (diagnosis build only) buf: 32 * 4096 * 32 device floats, or NULL to stop recording; resets the launch counter
+extern "C" int xas_debug_p2w(float* buf) {
+  g_p2w_launch = 0;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_p2w_dbg), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int xas_patch_to_world_bwd(const float* kps, const float* grad_world, const float* trans_image,
                                       const float* k_mat, const float* pelvis, const float* rot_world,
