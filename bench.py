@@ -307,9 +307,11 @@ def main():
                     'gradient_wait_host_ms': st['grad_wait_host_ms'],
                     'syncbn_exchanges_per_step': st['syncbn_calls'], 'syncbn_KB_per_exchange': (st['syncbn_bytes'] / max(1, st['syncbn_calls'])) / 1e3,
                     'syncbn_host_ms': st['syncbn_host_ms'],
-                    'backend': args.backend,
-                    'note': 'gradient_wait_* = the EXPOSED part of the bucket all-reduces (the rest ran beside backward on the '
-                            'communication stream); syncbn_host_ms = host-visible time of the per-layer statistic exchanges (gloo '
+                    'backend': args.backend, 'overlap_with_backward': _dp.overlap_enabled(),
+                    'note': 'gradient_wait_* = the EXPOSED part of the bucket all-reduces: by default (XAS_DP_OVERLAP=0) the buckets '
+                            'leave after backward with the compute stream waiting, so it is the whole exchange (DESIGN section 5: no '
+                            'kernel runs beside this library\'s MFMA kernels); with XAS_DP_OVERLAP=1 the rest runs beside backward on '
+                            'the communication stream; syncbn_host_ms = host-visible time of the per-layer statistic exchanges (gloo '
                             'blocks the host; RCCL only enqueues, the stream-side cost is inside step_ms)'}
     sync()
     # one extra, UNTIMED step with the side stream disabled: the same kernels measured without concurrent

@@ -64,8 +64,15 @@ def _reducer_case(rank, world):
     return [float((o - ref).abs().max()) for o in out]
 
 
-def test_bucketed_reducer_world2():
-    res = _run(_reducer_case)
+def _reducer_case_overlap(rank, world):
+    import os
+    os.environ['XAS_DP_OVERLAP'] = '1'              # buckets leave from the hooks, during backward (the r02-r04 schedule)
+    return _reducer_case(rank, world)
+
+
+@pytest.mark.parametrize('case', [_reducer_case, _reducer_case_overlap], ids=['at_finish', 'overlap'])
+def test_bucketed_reducer_world2(case):
+    res = _run(case)
     for r in (0, 1):
         assert max(res[r]) < 1e-6
 

@@ -14,7 +14,8 @@ pytestmark = [pytest.mark.gpu, pytest.mark.multiproc]
 
 def _worker(rank, world, opts=None):
     opts = opts or {}
-    os.environ.update(XAS_DP_NOTIFY=str(opts.get('notify', 1)), XAS_CAM_BATCH=str(opts.get('cam_batch', 1)))
+    os.environ.update(XAS_DP_NOTIFY=str(opts.get('notify', 1)), XAS_CAM_BATCH=str(opts.get('cam_batch', 1)),
+                      XAS_DP_OVERLAP=str(opts.get('overlap', 0)))
     os.environ.pop('XAS_DISC_BESIDE_GEN', None)               # unset = the data-parallel default (main stream, engine.py)
     if opts.get('beside') is not None:
         os.environ['XAS_DISC_BESIDE_GEN'] = str(opts['beside'])
@@ -66,12 +67,13 @@ def test_two_rank_step_keeps_replicas_identical(beside):
 
 @pytest.mark.parametrize('dedupe,cam_batch', [(False, 1), (True, 1), (True, 0)])
 def test_early_bucket_launch_equals_launch_at_finish(dedupe, cam_batch):
-    """Buckets launched from the readiness reports during backward (XAS_DP_NOTIFY=1) must carry COMPLETE gradients: the
+    """(XAS_DP_OVERLAP=1, the r02-r04 schedule - off by default since r05.)
+    Buckets launched from the readiness reports during backward (XAS_DP_NOTIFY=1) must carry COMPLETE gradients: the
     step must be bit-identical to the one whose buckets are all launched by finish() (XAS_DP_NOTIFY=0), with two ranks
     (the all-reduce is not the identity), with and without TrainStep(dedupe=True) - whose real-image detector forward is
     counted before the discriminator step (r02 ADVICE: those counts were wiped and buckets left early, incomplete) - and
     with one detector call per camera (XAS_CAM_BATCH=0: several uses per parameter and pass)."""
-    opts = dict(dedupe=dedupe, cam_batch=cam_batch, cams=[0, 1])
+    opts = dict(dedupe=dedupe, cam_batch=cam_batch, cams=[0, 1], overlap=1)
     a1, b1 = _run2(dict(opts, notify=1))
     a0, b0 = _run2(dict(opts, notify=0))
     assert a1[5] and a0[5]

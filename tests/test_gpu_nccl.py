@@ -1,8 +1,8 @@
 """The RCCL (`nccl` backend) code path of the data-parallel step on ONE GPU: a world-size-1 nccl process group with
 XAS_FORCE_DP=1 drives every collective call of the path through RCCL - parameter broadcast, packed SyncBatchNorm
-all-gather + merge kernel, backward all-reduce, bucketed gradient all-reduce on the communication stream (own
-communicator, launched from the readiness hooks during backward).  With one rank the exchange must be the identity:
-the step must equal the step without a process group."""
+all-gather + merge kernel, backward all-reduce, bucketed gradient all-reduce (own communicator; by default launched by
+finish() after backward, with XAS_DP_OVERLAP=1 from the readiness hooks during backward on the communication stream).  With
+one rank the exchange must be the identity: the step must equal the step without a process group."""
 import os
 
 import pytest
@@ -16,8 +16,10 @@ pytestmark = [pytest.mark.gpu, pytest.mark.multiproc]
 def _worker(rank, world, mode):
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    if mode == 'nccl':
+    if mode.startswith('nccl'):
         os.environ['XAS_FORCE_DP'] = '1'
+        os.environ['XAS_DP_OVERLAP'] = '1' if mode == 'nccl_overlap' else '0'
+        mode = 'nccl'
         init_group('nccl', 0, 1, device_id=torch.device('cuda', 0))
     from xas_amd import engine
     from xas_amd.synthetic import model_config, synthetic_batch
@@ -50,11 +52,16 @@ def _worker(rank, world, mode):
     return res
 
 
-def test_nccl_world1_step_equals_plain_step():
+@pytest.mark.parametrize('mode', ['nccl', 'nccl_overlap'])
+def test_nccl_world1_step_equals_plain_step(mode):
     a = run_ranks(_worker, 1, ('plain',))[0]
-    b = run_ranks(_worker, 1, ('nccl',))[0]
+    b = run_ranks(_worker, 1, (mode,))[0]
     early, total = b[6]
-    assert total == 2 * 3 and early >= 1                     # 3 buckets per generator step; some launched from the hooks
+    assert total == 2 * 3                                    # 3 buckets per generator step
+    if mode == 'nccl_overlap':
+        assert early >= 1                                    # some launched from the hooks, during backward
+    else:
+        assert early == 0                                    # default: nothing travels beside backward
     for (la, ta), (lb, tb) in zip(a[0], b[0]):
         assert abs(la - lb) <= 1e-6 * max(1.0, abs(la)) and abs(ta - tb) <= 1e-5 * max(1.0, abs(ta))
     # identity exchange: parameters and synchronised running statistics agree with the plain step (the merge kernel

@@ -212,6 +212,9 @@ def main():
             line.append('%s: %d differ, rel %.3e%s' % (k, ne, reln, extra))
         print('%-44s %s' % (what, ' | '.join(line)), flush=True)
 
+    def beq(a_, b_):          # bit patterns (a diagnosis build that computes NaNs must still compare equal to itself)
+        return torch.equal(a_.contiguous().view(torch.int32), b_.contiguous().view(torch.int32))
+
     base = run('default')
     print('losses', base['losses'])
     if args.census:
@@ -224,13 +227,13 @@ def main():
             sw = CONFIGS[label]
             refs = [run(label, **sw) for _ in range(3)]
             # (a reference that is itself an anomaly would make every later run "differ": majority of three)
-            ref = refs[0] if torch.equal(refs[0]['det'], refs[1]['det']) or torch.equal(refs[0]['det'], refs[2]['det']) else refs[1]
+            ref = refs[0] if beq(refs[0]['det'], refs[1]['det']) or beq(refs[0]['det'], refs[2]['det']) else refs[1]
             hits, kinds, fbad = 0, {}, 0
             for it in range(args.loops):
                 got = run(label, **sw)
                 if 'foreign' in got and not torch.equal(got['foreign'], ref['foreign']):
                     fbad += 1
-                if not (torch.equal(got['det'], ref['det']) and torch.equal(got['loss'], ref['loss'])):
+                if not (beq(got['det'], ref['det']) and beq(got['loss'], ref['loss'])):
                     hits += 1
                     if args.p2w:
                         for ck in ('cam_0', 'cam_1', 'cam_2', 'cam_3'):
@@ -317,7 +320,7 @@ def main():
                 for tune in (0, 65536):
                     got = run(label, tune=tune, **sw)
                     ref = refs[tune]
-                    if not (torch.equal(got['det'], ref['det']) and torch.equal(got['loss'], ref['loss'])):
+                    if not (beq(got['det'], ref['det']) and beq(got['loss'], ref['loss'])):
                         hits += 1
                         cmp(got, ref, '%s tune %d iteration %d: DIFFERS' % (label, tune, it))
                         print('      losses', ['%.6g' % float(v) for v in got['loss']], ['%.6g' % float(v) for v in ref['loss']])

@@ -215,6 +215,22 @@ __device__ __forceinline__ f32x16 mfma_piece(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4v, ahi), __builtin_bit_cast(s16x4v, bhi), c, 0, 0, 0);
   }
 #endif
+#ifdef XAS_MFMA_16X16
+  // diagnosis build (WRONG RESULTS ON PURPOSE - only run-to-run reproducibility is looked at): gfx950's other new shape,
+  // 16x16x32, in place of 32x32x16 - four of them, one per quarter of the accumulator, on the same operand registers.  Every
+  // accumulator element still receives a 32-term dot product of operand values of the right scale, so the step stays finite.
+  {
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4v t = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+      if constexpr (P == 2) t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), t, 0, 0, 0);
+      else t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), t, 0, 0, 0);
+      c[4 * q] = t[0]; c[4 * q + 1] = t[1]; c[4 * q + 2] = t[2]; c[4 * q + 3] = t[3];
+    }
+    return c;
+  }
+#endif
 #ifdef XAS_MFMA_X16_TWICE
   // diagnosis control for XAS_MFMA_X8: the K = 16 instruction issued TWICE (second result thrown away): the timing of the K = 8
   // build with the instruction of the shipped one
