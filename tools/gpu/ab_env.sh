@@ -7,7 +7,7 @@ mkdir -p $OUT
 for i in $(seq 1 $R); do
   for which in base other; do
     if [ $which = base ]; then E=""; else E="$SET"; fi
-    env $E timeout -k 10 300 python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --f32-steps 0 > $OUT/b.json 2> $OUT/b.err || exit 1
+    env $E timeout -k 10 300 python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --f32-steps 0 --cse-steps 0 > $OUT/b.json 2> $OUT/b.err || exit 1
     python3 -c "
 import json; d=json.load(open('$OUT/b.json')); print('$which [$E]', round(d['ms_per_step'],2))" >> $OUT/ab.txt
   done

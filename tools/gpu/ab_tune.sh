@@ -5,7 +5,7 @@ mkdir -p $OUT
 : > $OUT/ab.txt
 for i in $(seq 1 $R); do
   for t in $1; do
-    timeout -k 10 300 python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --f32-steps 0 --tune $t > $OUT/b.json 2> $OUT/b.err || exit 1
+    timeout -k 10 300 python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --f32-steps 0 --cse-steps 0 --tune $t > $OUT/b.json 2> $OUT/b.err || exit 1
     python3 -c "
 import json; d=json.load(open('$OUT/b.json')); print('tune $t', round(d['ms_per_step'],2), 'serial conv', round(d['roofline']['serial']['by_kernel_class'].get('f16x3', d['roofline']['serial']['by_kernel_class'].get('bf16x6'))['ms'],2))" >> $OUT/ab.txt
   done
