@@ -28,7 +28,7 @@ def pytest_configure(config):
 #   tier 1  HIP-against-HIP equivalence (grouped == separate calls, switches agree, reproducibility) and the full-size
 #           self-consistency steps (marker `selfcheck`, or a name listed below);
 #   tier 2  everything that starts worker processes (marker `multiproc`).
-FILE_ORDER = ['test_gpu_kernels_isolated', 'test_gpu_tap_kernels', 'test_gpu_bench_kernels', 'test_gpu_head', 'test_gpu_nn',
+FILE_ORDER = ['test_gpu_kernels_isolated', 'test_gpu_tap_kernels', 'test_gpu_bench_kernels', 'test_gpu_persistent_gemm', 'test_gpu_head', 'test_gpu_nn',
               'test_gpu_eval', 'test_gpu_input', 'test_gpu_precision', 'test_gpu_parity_r3', 'test_gpu_model']
 SELFCHECK_FILES = ('test_gpu_groups', 'test_gpu_fullsize', 'test_gpu_repro')
 SELFCHECK_NAMES = ('test_full_size_step', 'test_optional_step_switches_agree', 'test_step_switches_are_bit_identical',

@@ -41,6 +41,7 @@ struct IgemmParams {
   int nMt, nNt, mt_per_xcd;   // tile counts and M-tiles per XCD for the XCD-aware block order
   int t2d_tw;                 // != 0: the rows of a 128-row tile are an 8 x t2d_tw pixel patch of one image (t2d_tw = 16) or of two
                               // images (t2d_tw = 8) instead of 128 consecutive pixels (igemm_x6t_kernel); the epilogue maps rows with tile_row()
+  int tpb;                    // igemm_x6p_kernel: consecutive M-tiles per block (mt_per_xcd then counts groups of tpb tiles)
   int xn, nt_per_x;           // bf16-split kernels: the 8 XCDs form an (8 / xn) x xn grid over (M-tiles, N-tiles); xn = 1: every XCD owns all N-tiles of its M-tiles
   long src_elems, wgt_elems;  // sizes of src / wgt (buffer-load kernel: range of the buffer descriptors)
   int accumulate;             // epilogue: 1: out += result (residual gradient already in the buffer);
@@ -330,7 +331,7 @@ __device__ __forceinline__ size_t tile_row(const IgemmParams& p, int m0, int ml)
 // HALVES = 2: the LDS staging of the row / statistics epilogue is done in two passes over BN / 2 columns each, so that the
 // staging area is half as large (the bf16-split kernels need 36.9 KB of LDS for their operands; a full 128 x 128 staging
 // tile would double their footprint and halve their residency).
-template <int BM, int BN, int MODE, bool BNB = false, int HALVES = 1>
+template <int BM, int BN, int MODE, bool BNB = false, int HALVES = 1, bool HEAD = true>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&acc)[TileCfg<BM, BN>::MI][TileCfg<BM, BN>::NI],
                                                f32x16& acc2, int m0, int n0, int wm, int wn, int lane, int Mrows, int HW,
                                                int Wrow, int ph, int pw, float* lds = nullptr) {
@@ -419,7 +420,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
       }
     }
   }
-  const bool want_head = MODE == 0 && BM == 64 && BN / HALVES == 64 && p.head_partial != nullptr;
+  const bool want_head = HEAD && MODE == 0 && BM == 64 && BN / HALVES == 64 && p.head_partial != nullptr;
   if (!(want_stats || rows_from_lds || want_head)) return;
   // ---- staged passes: T[pixel][channel of this half] -> whole rows to memory and / or per-channel sums
   constexpr int C4 = BNH / 4, RPP = 256 / C4, NR = BM / RPP;   // float4 per row, rows per pass of the block, rows per thread
@@ -485,7 +486,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
         stream_store(reinterpret_cast<float4*>(p.out + orow * p.Cd + nn), v);
       }
     }
-    if constexpr (MODE == 0 && BM == 64 && BNH == 64) {
+    if constexpr (HEAD && MODE == 0 && BM == 64 && BNH == 64) {
       if (p.head_partial != nullptr && nh0 < p.Cd) {
         // one joint (64 depth bins = the 64 channels of this half) over the 64 pixels of one image row: T[pixel][bin] + bias
         const int tid = threadIdx.x;

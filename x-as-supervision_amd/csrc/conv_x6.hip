@@ -376,6 +376,153 @@ __global__ __launch_bounds__(256, (P == 2 ? (BM == 64 && BN == 256 ? XAS_X6_WAVE
 }
 
 // ------------------------------------------------------------------------------------
+// Persistent variant of the 64 x 256 tile for PURE GEMMs (1x1, stride 1, no padding; f16x3): igemm_x6p_kernel.
+//
+// The expanding 1x1 layers of the bottlenecks (P -> 4P forward, and the accumulate-and-mask data gradient of the contracting
+// ones) have K = 64 ... 512: a 64 x 256 tile is two to sixteen K-steps and a 64 KB epilogue.  With one tile per block the
+// activation loads of a tile are only in flight during its short K loop - 3 blocks x 16 KB per CU at best, far from the
+// ~40 KB per CU that 5 TB/s at 2 us of latency needs - and these launches ran at 3.0-3.7 TB/s.  Here a block walks over
+// `tpb` consecutive M-tiles of one N-tile and its load streams simply continue into the next tile: the last two K-steps of
+// tile t request the ACTIVATIONS of the first two K-steps of tile t + 1 (all of it for K = 64), which then fly during the
+// epilogue of t.
+// Same LDS layout, fragment reads, MFMA order and epilogue (igemm_epilogue) as igemm_x6_kernel<64, 256, MODE, 2>: results
+// are bit-identical to that kernel's.
+// ------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void igemm_x6p_kernel(IgemmParams p) {
+  constexpr int BM = 64, BN = 256, P = 2;
+  using C = TileCfg<BM, BN>;
+  static_assert(C::WAVES_M == 1 && C::MI == 2 && C::NI == 2, "written for four waves side by side");
+  constexpr int PLANE = BM * XLDH, HBUF = P * PLANE, NT = Products<P>::N;
+  extern __shared__ __align__(16) float lds[];
+  unsigned short* S = reinterpret_cast<unsigned short*>(lds);     // [2][P][BM][XLDH]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq4 = tid & 3, arow = tid >> 2;
+  const int Hrow = MODE == 0 ? p.Hrow : p.Hd, Wrow = MODE == 0 ? p.Wrow : p.Wd;
+  const int HW = Hrow * Wrow, Mrows = p.N * HW;
+  // block -> (group of tpb M-tiles, N-tile): the XCD-aware order of igemm_x6_kernel with the group as the unit
+  const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+  const int xi = xcd / p.xn, xj = xcd - xi * p.xn;
+  const int ml = qb / p.nt_per_x;
+  const int mt0 = (xi * p.mt_per_xcd + ml) * p.tpb;
+  const int nt = xj * p.nt_per_x + (qb - ml * p.nt_per_x);
+  if (mt0 >= p.nMt || nt >= p.nNt) return;
+  const int ntl = min(p.tpb, p.nMt - mt0);
+  const int n0 = nt * BN;
+  const int nk = p.Cs / BK;                              // even (launcher)
+  float f16_sa = kF16AScale, f16_desc = kF16Descale;
+  if (p.a_amax) { float inv; f16_sa = f16_grad_scale(p.a_amax, &inv); f16_desc = inv * (1.f / kF16WScale); }
+
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, (int)(p.src_elems * 4), 0x00020000);
+  auto voff_of = [&](int t) -> unsigned {
+    const int m = (mt0 + t) * BM + arow;
+    return (t < ntl && m < Mrows) ? (unsigned)(((long)m * p.Cs + kq4 * 4) * 4) : kOOB;
+  };
+  const unsigned blk_bytes = (unsigned)(p.Cs / 16) * P * 1024u;           // one 32-row block of the weights over the whole K
+  const long wbytes = (long)((p.Cd + 31) / 32) * blk_bytes;
+  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, (int)wbytes, 0x00020000);
+  const unsigned voffB = (unsigned)lane * 16u;
+  const unsigned nblk0 = (unsigned)(n0 / 32 + wn * (C::WN / 32));
+
+  // the two load streams: they run THROUGH the tiles of the block (activations: tile after tile; weights: the same N-tile again)
+  int a_t = 0, a_c = 0, b_c = 0;
+  unsigned voffA = voff_of(0);
+  float4 ra_0[2], ra_1[2];
+  auto load_a = [&](float4 (&ra)[2]) {
+    const unsigned soff = (unsigned)(a_c * BK) * 4u;
+    ra[0] = buf_load16(rsrcA, voffA, soff);
+    ra[1] = buf_load16(rsrcA, voffA, soff + XH * 4u);
+    if (++a_c == nk) { a_c = 0; ++a_t; voffA = voff_of(a_t); }
+  };
+  auto load_b = [&](uint4 (&gb)[P][C::NI], int h) {
+    const unsigned hc = (unsigned)(b_c * (BK / 16) + h);
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+      for (int pc = 0; pc < P; ++pc)
+        gb[pc][ni] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+            rsrcB, (int)voffB, (int)((nblk0 + ni) * blk_bytes + (hc * P + pc) * 1024u), 0));
+    if (h) { if (++b_c == nk) b_c = 0; }
+  };
+  auto split_store = [&](int buf, int h, const float4 (&ra)[2]) {
+    const Pieces<P> pcs = split_pieces<P>(ra[h], f16_sa);
+#pragma unroll
+    for (int pc = 0; pc < P; ++pc)
+      *reinterpret_cast<uint2*>(S + buf * HBUF + pc * PLANE + arow * XLDH + xswz(arow, kq4 >> 1) + (kq4 & 1) * 4) = pcs.q[pc];
+  };
+  const int i = lane & 31, hh = lane >> 5;
+  f32x16 acc[C::MI][C::NI];
+  auto compute = [&](int buf, const uint4 (&gb)[P][C::NI]) {
+    const unsigned short* sb = S + buf * HBUF;
+    uint4 fa[P][C::MI];
+#pragma unroll
+    for (int pc = P - 1; pc >= 0; --pc)
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi)
+        fa[pc][mi] = *reinterpret_cast<const uint4*>(sb + pc * PLANE + (mi * 32 + i) * XLDH + xswz(i, hh));
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni)
+          acc[mi][ni] = mfma_piece<P>(gb[Products<P>::B[t]][ni], fa[Products<P>::A[t]][mi], acc[mi][ni]);
+  };
+  uint4 gb_0[P][C::NI], gb_1[P][C::NI];
+  load_a(ra_0);                                          // tile 0: K-steps 0 and 1
+  load_a(ra_1);
+  for (int t = 0; t < ntl; ++t) {
+    // the weight fragments are NOT carried across the epilogue (32 registers: the third block per CU is worth more than the
+    // ~0.5 us of L2 latency this exposes at the head of a tile, which the other blocks on the CU cover)
+    b_c = 0;
+    load_b(gb_0, 0);
+    load_b(gb_1, 1);
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+    split_store(0, 0, ra_0);                             // (the staging of the previous epilogue is done: barrier below)
+    for (int ks = 0; ks < nk; ks += 2) {
+      __syncthreads();
+      compute(0, gb_0);                                  // half-step 2 ks
+      load_b(gb_0, 0);
+      split_store(1, 1, ra_0);
+      __syncthreads();
+      load_a(ra_0);                                      // K-step ks + 2 - of the NEXT tile when this one has none left
+      compute(1, gb_1);
+      load_b(gb_1, 1);
+      split_store(0, 0, ra_1);
+      __syncthreads();
+      compute(0, gb_0);
+      if (ks + 2 < nk) load_b(gb_0, 0);
+      split_store(1, 1, ra_1);
+      __syncthreads();
+      load_a(ra_1);                                      // K-step ks + 3
+      compute(1, gb_1);
+      if (ks + 2 < nk) { load_b(gb_1, 1); split_store(0, 0, ra_0); }   // else ra_0 is the next tile's first K-step: stored after the epilogue
+    }
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= f16_desc;
+    f32x16 unused;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) unused[e] = 0.f;
+    // (opaque copies: everything the epilogue derives from them would otherwise be hoisted out of the tile loop and stay in
+    //  registers through the K loop - 256 registers and spills instead of ~200)
+    int n0v = n0, lanev = lane, wnv = wn;
+    asm volatile("" : "+s"(n0v), "+v"(lanev), "+s"(wnv));
+    igemm_epilogue<BM, BN, MODE, false, BN / 64, false>(p, acc, unused, (mt0 + t) * BM, n0v, 0, wnv, lanev, Mrows, HW, Wrow, 0, 0, lds);
+    __syncthreads();                                     // the staging area is the operand area again
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // forward / data gradient of STRIDE-1 3x3 convolutions with tap re-use ("igemm_x6t").  In the implicit GEMM above every
 // activation element is loaded, split and stored once PER TAP - nine times for a 3x3 filter - and that conversion work,
 // not the matrix pipe, bounds the kernel (and utterly so for the 32-channel layers of the physique net, whose 32-column
@@ -660,6 +807,50 @@ static int launch_igemm_x6t(const IgemmParams& p, int Mrows_max, hipStream_t st)
   return 0;
 }
 
+// pure GEMM with an even number of K-steps: what igemm_x6p_kernel is written for (tune bit 26: never; bit 27: any K).
+// Measured alone at 384 / 256 images (r05): K = 64: 505 -> 437 us forward (4.6 TB/s), 427 -> 362 us data gradient; K = 128:
+// -5 % / -9 %; K >= 256: +-2 % either way - the K loop is long enough to cover its own loads, so those keep the one-tile kernel.
+static bool x6p_takes(const IgemmParams& p, int mode, int phases) {
+  if (p.tune & (1 << 26)) return false;
+  if (p.Cs > 128 && !(p.tune & (1 << 27))) return false;
+  const int hr = mode == 0 ? p.Hrow : p.Hd, wr = mode == 0 ? p.Wrow : p.Wd;
+  return p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && phases == 1 && p.Cs % (2 * BK) == 0 && p.Hs == hr && p.Ws == wr &&
+         !p.t2d_tw && !p.bnb_x && p.a_amax != nullptr && (p.Cd & 3) == 0;
+}
+
+template <int MODE>
+static int launch_igemm_x6p(const IgemmParams& p, int Mrows_max, hipStream_t st) {
+  constexpr size_t lds = igemm_x6_lds<64, 256>(2, false);
+  IgemmParams q = p;
+  q.nMt = (int)cdiv(Mrows_max, 64); q.nNt = (int)cdiv(p.Cd, 256);
+  // tiles per block: long enough for the stream to matter, short enough for >= 4 rounds of the ~768 resident blocks
+  const long tiles = (long)q.nMt * q.nNt;
+  int tpb = (int)(tiles / (768 * 4));
+  tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
+  q.tpb = tpb;
+  const int nMg = (int)cdiv(q.nMt, tpb);
+  {                                                    // XCD grid: the model of launch_igemm_x6_t, M-groups as the unit
+    const double a_bytes = (double)Mrows_max * p.Cs * 4.0;
+    const double b_bytes = (double)p.Cd * p.Cs * 2.0 * 2;
+    double best = 0;
+    q.xn = 1;
+    for (int xn = 1; xn <= 8; xn *= 2) {
+      if (q.nNt % xn != 0 || nMg < 8 / xn) continue;
+      const int xm = 8 / xn, ntx = q.nNt / xn, mtx = (int)cdiv(q.nMt, xm);
+      const double slice = b_bytes / xn;
+      const double rounds = slice <= 2.5e6 ? 1.0 : (double)cdiv(mtx, 64 / ntx > 0 ? 64 / ntx : 1);
+      const double cost = a_bytes * xn + slice * 8 * rounds;
+      if (xn == 1 || cost < best * 0.9) { best = cost; q.xn = xn; }
+    }
+  }
+  q.nt_per_x = q.nNt / q.xn;
+  q.mt_per_xcd = (int)cdiv(nMg, 8 / q.xn);            // in groups
+  dim3 grid((unsigned)(8 * q.mt_per_xcd * q.nt_per_x), 1, 1);
+  hipLaunchKernelGGL((igemm_x6p_kernel<MODE>), grid, dim3(256), lds, st, q);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int MODE, int P>
 static int launch_igemm_x6_p(const IgemmParams& p, int Mrows_max, int phases, hipStream_t st) {
   int bm, bn;
@@ -682,6 +873,9 @@ static int launch_igemm_x6_p(const IgemmParams& p, int Mrows_max, int phases, hi
   }
   if (!(p.tune & (1 << 23))) {                         // tune bit 23: no 64 x 256 tiles
     pick_tile(p.Cd, Mrows_max, phases, &bm, &bn, true);
+    if constexpr (P == 2) {
+      if (bn == 256 && x6p_takes(p, MODE, phases)) return launch_igemm_x6p<MODE>(p, Mrows_max, st);
+    }
     if (bn == 256) return launch_igemm_x6_t<64, 256, MODE, P, false>(p, Mrows_max, phases, st);
   }
   if (bn == 128) return launch_igemm_x6_t<128, 128, MODE, P, false>(p, Mrows_max, phases, st);
