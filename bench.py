@@ -527,7 +527,8 @@ def main():
                 'by_entry': {k: {'launches': v['launches'], 'ms': v['ms'], 'TBps': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 else 0.0}
                              for k, v in bnfam.items()},
                 'kernel': 'col_reduce(_lean)_kernel, bn_apply_stream_kernel, bn_bwd_apply_stream_kernel (bn.hip)',
-                'note': 'per-call times include sharing the chip with the weight-gradient stream'}
+                'note': ('per-call times include sharing the chip with the weight-gradient stream' if _ops._side['enabled'] else
+                         'one stream: the calls run alone on the chip')}
         if traffic is not None:
             line['roofline']['mfma_busy_pct_pmc'] = pmc.get('mfma_busy_pct')      # same static source as `traffic`
         if args.shape_report:
