@@ -197,6 +197,11 @@ int xas_conv_kernel_class(const xas_conv_shape* s, int pass);
  * inf / NaN; 0 otherwise; -1 on a HIP error.  SYNCHRONISES the device (call it rarely: engine.TrainStep every 64 steps).
  * reset != 0 clears the flag.  Remedy: XAS_PREC_BF16X6. */
 int xas_f16_weight_overflow(int reset);
+/* The same flag WITHOUT a synchronisation: writes it (0 / 1) to the device word *device_out on `stream`; the flag is not
+ * cleared.  The caller copies the word to pinned host memory asynchronously and reads it once that copy has completed:
+ * engine.TrainStep looks at it one step late, every step, so that a weight leaving the range is reported within a step or two
+ * instead of at the next 64-step poll. */
+int xas_f16_weight_overflow_peek(unsigned* device_out, void* stream);
 size_t xas_split_weight_bytes(long rows, long K, int pieces);
 int xas_split_weight(const float* w_packed, void* w_split, long rows, long K, int pieces, void* stream);
 

@@ -60,6 +60,19 @@ def _entry(target, rank, world, port, ret, args, log_path, limit):
     log.flush()
 
 
+def release_gpu_memory():
+    """Give the memory this process only CACHES back to the driver before another process is started on the same card.  After
+    the full-size tests the caching allocator of the pytest process holds most of the 288 GB (r05: 287.9 GB reserved when the
+    first two-rank test started, whose ranks then died of `HIP out of memory` with 0.6 GB of their own) - a child process
+    cannot use what the parent merely keeps for re-use."""
+    import gc
+    import torch
+    gc.collect()
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+
 class RanksStuck(AssertionError):
     """A rank did not finish inside its limit (its log holds the stack dump)."""
 
@@ -71,6 +84,7 @@ def run_ranks(target, world=2, args=(), limit=RANK_LIMIT_S, retry_stuck=0):
     retry_stuck (default 0: a hang is a FAILURE - r04 retried once and only warned, which let an unexplained hang pass): a
     run in which a rank was STUCK (stack dump / still alive at the deadline - not one that raised) is repeated that many
     times; a test that asks for it must carry `limit(>= (retry_stuck + 1) * (limit + 60))`."""
+    release_gpu_memory()
     for attempt in range(retry_stuck + 1):
         try:
             return _run_ranks_once(target, world, args, limit)

@@ -85,25 +85,27 @@ def digest(res):
 
 
 def poison_free_memory(value, device='cuda'):
-    """Fill every FREE block of the caching allocator with `value`: take blocks of falling size for as long as the allocator
-    serves them from its cache, write, release.  A kernel that reads memory nobody wrote then reads `value`.  -> bytes."""
+    """Fill every FREE block of the caching allocator with `value`: the allocator's own snapshot names its inactive blocks; take
+    them back largest first (each request is served from the cache - nothing new is asked of the driver, so repeated calls do
+    not grow the process's reservation), write, release.  A kernel that reads memory nobody wrote then reads `value`.  -> bytes."""
     import torch
     torch.cuda.synchronize()
-    held, size = [], 1 << 33
-    while size >= 512:
-        while len(held) < 100000:
-            before = torch.cuda.memory_reserved()
-            try:
-                t = torch.empty(size // 4, device=device, dtype=torch.float32)
-            except torch.OutOfMemoryError:
-                break
-            if torch.cuda.memory_reserved() > before:      # came from the driver, not from the cache: this size class is used up
-                del t
-                break
-            t.fill_(value)
-            held.append(t)
-        size >>= 1
-    n = sum(t.numel() for t in held) * 4
+    sizes = sorted((b['size'] for seg in torch.cuda.memory_snapshot() for b in seg['blocks'] if b['state'] == 'inactive'), reverse=True)
+    held, n = [], 0
+    for size in sizes:
+        if size < 512:
+            continue
+        before = torch.cuda.memory_reserved()
+        try:
+            t = torch.empty(size // 4, device=device, dtype=torch.float32)
+        except torch.OutOfMemoryError:
+            continue
+        if torch.cuda.memory_reserved() > before:          # (did not fit a cached block after all: give it straight back)
+            del t
+            continue
+        t.fill_(value)
+        held.append(t)
+        n += t.numel() * 4
     del held
     torch.cuda.synchronize()
     return n

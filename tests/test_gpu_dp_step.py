@@ -92,6 +92,8 @@ def test_bench_two_rank_rehearsal():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     env.pop('XAS_DISC_BESIDE_GEN', None)
+    from _ranks import release_gpu_memory
+    release_gpu_memory()                     # the child needs the card's memory, not this process's cache
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--batch', '4', '--steps', '2',
                         '--warmup', '1', '--f32-steps', '0', '--no-cpu-baseline', '--ref-n1', '100.0'], capture_output=True, text=True,
                        timeout=200, env=env, cwd=root)

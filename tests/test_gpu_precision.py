@@ -516,3 +516,32 @@ def test_f16x3_weight_range_is_checked():
         torch.cuda.synchronize()
         assert query('xas_f16_weight_overflow', 1) == 1
         assert query('xas_f16_weight_overflow', 0) == 0          # cleared by the previous call
+
+
+def test_train_step_reports_a_weight_leaving_the_range_within_a_few_steps():
+    """engine.TrainStep reads the flag WITHOUT a synchronisation, one step late (xas_f16_weight_overflow_peek + an asynchronous
+    copy to pinned memory): a weight that an update pushes beyond |w| < 64 stops the training a step or two later, not at the
+    next 64-step poll."""
+    from xas_amd import engine
+    from xas_amd._lib import query
+    from xas_amd.synthetic import model_config, synthetic_batch
+    query('xas_f16_weight_overflow', 1)
+    cfg = model_config('HM36_Multi_SurS2')
+    cfg['model_params']['cam_id_list'] = [0]
+    torch.manual_seed(3)
+    model, disc, od, odisc = engine.prepare_model(cfg)
+    model.cuda().train(), disc.cuda().train()
+    step = engine.TrainStep(cfg, model, disc, od, odisc)
+    x = synthetic_batch(2, [0], torch.device('cuda'), seed=4)
+    with precision_mode('f16x3'):
+        for _ in range(3):
+            step(x)                                                   # in range: nothing is raised
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            model.regressor.net.backbone.layer2[1].conv2.weight[7, 9, 1, 1] = 300.0      # "an update" that leaves the range
+        od._epoch[0] += 1
+        with pytest.raises(RuntimeError, match='left the range'):
+            for _ in range(6):                                        # far fewer than the 64 steps of the synchronising poll
+                step(x)
+                torch.cuda.synchronize()
+        assert query('xas_f16_weight_overflow', 1) == 1               # (the peek does not clear the flag)

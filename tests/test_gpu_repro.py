@@ -39,6 +39,8 @@ def test_step_is_bitwise_reproducible(name):
     assert bool(torch.isfinite(first['det']).all()) and bool(torch.isfinite(first['loss']).all())
     assert first['peaks'].numel() == 3 * 4 * 32 * 18 * 3          # every detector call of the step reported its indices
     # second process, same construction: digests of the same quantities
+    from _ranks import release_gpu_memory
+    release_gpu_memory()                     # the child needs the card's memory, not this process's cache
     p = subprocess.run([sys.executable, os.path.join(HERE, '_stepcheck.py'), name, '32'], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith('STEPCHECK ')][-1]

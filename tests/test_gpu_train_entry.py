@@ -24,6 +24,8 @@ def test_train_entry_synthetic(tmp_path):
     base = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
             '--master-port', '29541', os.path.join(PKG, 'train.py'), '--config', str(cfg_path), '--synthetic', '2',
             '--log_dir', str(tmp_path / 'log'), '--seed', '3']
+    from _ranks import release_gpu_memory
+    release_gpu_memory()                     # the child needs the card's memory, not this process's cache
     r = subprocess.run(base, env=env, capture_output=True, text=True, timeout=150)
     assert r.returncode == 0, r.stderr[-3000:]
     runs = os.listdir(tmp_path / 'log')

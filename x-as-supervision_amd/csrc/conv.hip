@@ -1646,6 +1646,12 @@ static int conv_fwd_impl(const float* x, const float* w_packed, const float* bia
                          void* stream, float* stat_partial, const float* stat_pivot, float* head_partial = nullptr);
 
 namespace xas {
+__global__ void stem_overflow_peek_kernel(unsigned* out) { if (g_f16_weight_overflow_stem) atomicOr(out, 1u); }
+int stem_weight_overflow_peek(unsigned* device_out, void* stream) {
+  hipLaunchKernelGGL(stem_overflow_peek_kernel, dim3(1), dim3(1), 0, as_stream(stream), device_out);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
 int stem_weight_overflow(int reset) {
   unsigned v = 0u;
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_f16_weight_overflow_stem), sizeof(v)) != hipSuccess) return -1;

@@ -127,6 +127,7 @@ constexpr float kF16WScale = 1024.f;           // weights are split as 2^10 w: t
 constexpr float kF16AScale = 16.f;             // (initial value of the per-launch tensor scale only: every f16x3 launch derives
                                                // its scales from the recorded maxima of its operands, f16_grad_scale below)
 int stem_weight_overflow(int reset);           // conv.hip: flag of the stem kernel's in-kernel weight split (-1: read failed)
+int stem_weight_overflow_peek(unsigned* device_out, void* stream);   // conv.hip: ORs that flag into *device_out on `stream`
 constexpr float kF16Descale = 1.f / (kF16WScale * kF16AScale);
 // scale of a gradient operand from its maximum magnitude (wave-uniform): amax in [2^(e-127), 2^(e-126)) -> 2^(141 - e), i.e.
 // amax * scale in [2^14, 2^15).  Zero / denormal-range maxima: 1 (nothing to resolve).  *inv = 1 / scale (exact).

@@ -1482,6 +1482,17 @@ extern "C" int xas_prepare_weights(const void* descs, int n, long blocks, void* 
   return 0;
 }
 
+__global__ void weight_overflow_peek_kernel(unsigned* out) { *out = g_f16_weight_overflow ? 1u : 0u; }
+
+// The flag without a device synchronisation: written (0 / 1) to a device word on `stream` (the caller copies that word to pinned host
+// memory asynchronously and looks at it a step later - engine.TrainStep).  Does not clear the flag.
+extern "C" int xas_f16_weight_overflow_peek(unsigned* device_out, void* stream) {
+  XAS_REQUIRE(device_out, "f16_weight_overflow_peek: null output");
+  hipLaunchKernelGGL(weight_overflow_peek_kernel, dim3(1), dim3(1), 0, as_stream(stream), device_out);
+  XAS_LAUNCH_CHECK();
+  return stem_weight_overflow_peek(device_out, stream);
+}
+
 extern "C" int xas_f16_weight_overflow(int reset) {
   unsigned v = 0u;
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_f16_weight_overflow), sizeof(v)) != hipSuccess) return -1;     // (synchronises)

@@ -36,6 +36,7 @@ SIGNATURES = {
     'xas_conv_weight_planes': ('si', 'i'),
     'xas_conv_kernel_class': ('si', 'i'),
     'xas_f16_weight_overflow': ('i', 'i'),
+    'xas_f16_weight_overflow_peek': ('pp', 'i'),
     'xas_split_weight_bytes': ('lli', 'z'),
     'xas_split_weight': ('ppllip', 'i'),
     'xas_prepare_weights': ('pilp', 'i'),

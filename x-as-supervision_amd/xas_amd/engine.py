@@ -18,6 +18,7 @@ from modules.model import Counter3DDisc, Counter3DModel
 from modules.physique_network import PhysiqueMaskGenerator
 
 from . import ops_nn
+from ._lib import call, ptr
 from .dp import GradReducer, dp_active, sync_buffers
 from .optim import FusedAdam
 
@@ -114,6 +115,7 @@ class TrainStep:
                                     # optimizer consumes it (bench.py's variant check); None on the training path
         self.red_det = self.red_disc = None
         self._weights_checked = False
+        self._range_polls = []      # [(event, pinned int32)]: xas_f16_weight_overflow_peek results in flight (read one step late)
         opt_det.grad_arena                       # materialise the gradient arenas: conv weight gradients are
         if opt_disc is not None:                 # accumulated straight into them on a side stream
             opt_disc.grad_arena
@@ -140,6 +142,30 @@ class TrainStep:
         if ops_nn.query('xas_get_precision') == 3 and ops_nn.query('xas_f16_weight_overflow', 1) == 1:
             raise RuntimeError('a convolution weight has left the range of the f16x3 arithmetic (|w| >= 64 or NaN): '
                                'run with XAS_PRECISION=2 (bf16x6)')
+
+    def _poll_weight_range(self):
+        """Every step, without a synchronisation: the weight-preparation kernels of THIS step have raised the device flag if a
+        weight left the f16x3 range; its value travels to pinned host memory behind the step's work and is read when that copy
+        has completed - normally at the next call.  A weight that leaves the range is reported one or two steps after the
+        update that produced it (the 64-step synchronising poll stays as the backstop)."""
+        if ops_nn.query('xas_get_precision') != 3 or not self.opt_det.param_arena.is_cuda:
+            return
+        while self._range_polls and self._range_polls[0][0].query():
+            _, host = self._range_polls.pop(0)
+            if int(host[0]) != 0:
+                self._range_polls.clear()
+                raise RuntimeError('a convolution weight has left the range of the f16x3 arithmetic (|w| >= 64 or NaN) during '
+                                   'the last steps: run with XAS_PRECISION=2 (bf16x6)')
+        if len(self._range_polls) >= 8:               # (the host runs many steps ahead: do not pile up events)
+            return
+        dev = self.opt_det.param_arena.device
+        word = torch.empty(1, device=dev, dtype=torch.int32)
+        call('xas_f16_weight_overflow_peek', ptr(word))
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(word, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._range_polls.append((ev, host))
 
     def _check_loaded_weights(self):
         """Before the FIRST forward: the weights as constructed / loaded from a checkpoint must fit the f16x3 weight format -
@@ -258,6 +284,7 @@ class TrainStep:
         if aux is not None:
             torch.cuda.current_stream().wait_stream(aux)     # (already joined when the adversarial term is part of the losses)
         self.cur_step += 1
+        self._poll_weight_range()
         if self.cur_step % 64 == 0:
             self._check_weight_range()               # then every 64 steps (weights drift slowly; one device synchronisation)
         return loss_disc, loss_kp, total, out

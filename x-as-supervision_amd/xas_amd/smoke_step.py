@@ -32,4 +32,4 @@ def run():
     ld, lk, tot, _ = step(synthetic_batch(2, [0], torch.device('cuda'), seed=3))
     torch.cuda.synchronize()
     assert torch.isfinite(tot) and torch.isfinite(ld)
-    print('[smoke] full step ok: loss_disc=%.4f total=%.4f' % (float(ld), float(tot)))
+    print('[smoke] full step ok: loss_disc=%.4f total=%.4f' % (float(ld.detach()), float(tot.detach())))
