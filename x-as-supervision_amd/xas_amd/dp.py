@@ -101,13 +101,14 @@ class GradReducer:
         self.name = name
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.enabled = dp_active(group)
-        # The gradient buckets travel on their OWN communicator: on RCCL a communicator's collectives run in issue order on
-        # one internal stream, and a 35 MB bucket all-reduce launched early must not sit in front of the latency-bound
-        # SyncBatchNorm exchanges that the rest of backward is waiting for (default group).
-        self.group = dist.new_group() if (self.enabled and group is None and own_group) else group
+        self.overlap = overlap_enabled()
+        # With XAS_DP_OVERLAP=1 the gradient buckets travel on their OWN communicator: on RCCL a communicator's collectives run
+        # in issue order on one internal stream, and a 35 MB bucket all-reduce launched early must not sit in front of the
+        # latency-bound SyncBatchNorm exchanges that the rest of backward is waiting for (default group).  Without the overlap
+        # (the default) nothing is in flight when the buckets leave: the default group serves, no extra communicator is built.
+        self.group = dist.new_group() if (self.enabled and group is None and own_group and self.overlap) else group
         self.pending = []
         self.stream = None
-        self.overlap = overlap_enabled()
         if not self.enabled:
             return
         n = arena.numel()
