@@ -34,6 +34,8 @@ FWD = [(384, 64, 64, 64, 256),        # layer1 conv3 at the bench's size: 24 576
        (101, 64, 64, 64, 256),        # 6 464 tiles -> 2 per block, an even count
        (203, 40, 40, 64, 256),        # 5 075 tiles -> 1 per block... and
        (317, 40, 40, 128, 256),       # 7 925 tiles -> 2 per block, ODD count: the last block has one tile
+       (45, 36, 36, 64, 256),         # 58 320 rows = 911.25 tiles: a ragged last tile (register epilogue, out-of-range rows not loaded)
+       (333, 36, 36, 128, 256),       # 431 568 rows = 6 743.25 tiles -> 2 per block, ragged
        (64, 64, 64, 256, 1024)]       # four N-tiles, 4 096 x 4 tiles -> 5 per block: the last group of an N-tile has one tile
 
 
