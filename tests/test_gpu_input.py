@@ -102,6 +102,37 @@ def test_geodesic_weight_vs_fast_marching_oracle():
     assert out[0].min() >= 21.9 and out[0].max() <= np.exp(2.0) + 1 + 3 + 20 + 1e-3
 
 
+def test_geodesic_weight_several_sources_vs_fast_marching_oracle():
+    """geodesic_pt_list (dataloader.py:189-191): several source joints per image - every source is a zero of the inside solve;
+    one source on the background turns the whole map into ones (geodesic.py:22-27)."""
+    from oracle import input_pipeline as O
+    from human_utils.common.utility.geodesic import compute_geodesic_dis, compute_geodesic_dis_batch
+    P = 96
+    m = gi.blob_mask(4, P, seed=11).astype(np.float32)
+    rng = np.random.default_rng(5)
+    cen = np.zeros((4, 3, 2), np.int32)
+    for i in range(4):
+        ys, xs = np.nonzero(m[i, 0])
+        pick = rng.choice(len(ys), 3, replace=False)
+        cen[i, :, 0], cen[i, :, 1] = xs[pick], ys[pick]
+    ys, xs = np.nonzero(m[2, 0] == 0)
+    cen[2, 1] = (xs[0], ys[0])                                           # image 2: its second source lies on the background
+    params = [2, 1, 3, 20, 0.0]
+    out, c = compute_geodesic_dis_batch(torch.from_numpy(m).cuda(), params, torch.from_numpy(cen))
+    out = out.cpu().numpy()
+    assert c.cpu().numpy().tolist() == cen.tolist()
+    for i in range(4):
+        ref, _ = O.compute_geodesic_dis(m[i], params, centers=cen[i])
+        assert np.abs(out[i] - ref.astype(np.float64)).max() < 2e-4 * np.abs(ref).max(), (i, np.abs(out[i] - ref).max())
+    assert (out[2] == 1.0).all()
+    # differs from the single-source map (the sources are really used)
+    one, _ = compute_geodesic_dis_batch(torch.from_numpy(m).cuda(), params, torch.from_numpy(np.ascontiguousarray(cen[:, 0])))
+    assert np.abs(one.cpu().numpy()[0] - out[0]).max() > 1e-2
+    # the reference signature with several centres (numpy in, numpy out)
+    o2, c2 = compute_geodesic_dis(m[0], 'img', params, centers=cen[0])
+    assert np.abs(o2 - out[0]).max() < 1e-5 and c2.tolist() == cen[0].tolist()   # (the in-place sweeps are order-dependent in the last ulp)
+
+
 def test_geodesic_full_size_properties():
     """256 x 256, B = 32 (one camera of the benchmark batch): finite, bounded, centre value, monotone away from the mask."""
     from human_utils.common.utility.geodesic import compute_geodesic_dis_batch as compute_geodesic_dis

@@ -154,14 +154,14 @@ __device__ float block_max(float v, float* red) {      // red: >= 33 floats; res
   return red[32];
 }
 
-__global__ __launch_bounds__(kGeoThreads) void geodesic_weight_kernel(const float* __restrict__ mask, const int* __restrict__ centers,
+__global__ __launch_bounds__(kGeoThreads) void geodesic_weight_kernel(const float* __restrict__ mask, const int* __restrict__ centers, int nc,
                                                                       float p0, float p1, float p2, float p3, int P,
                                                                       float* __restrict__ work /*[B][2][P*P]*/,
                                                                       uint8_t* __restrict__ dom /*[B][P*P]*/,
                                                                       float* __restrict__ out, int* __restrict__ center_out) {
   __shared__ float red[33];
   __shared__ double sred[3][16];
-  __shared__ int s_c[2];
+  __shared__ int s_c[3];
   const int b = blockIdx.x, n = P * P;
   const float* m = mask + (size_t)b * n;
   float* din = work + (size_t)b * 2 * n;
@@ -183,16 +183,23 @@ __global__ __launch_bounds__(kGeoThreads) void geodesic_weight_kernel(const floa
     double a = 0, c = 0, d = 0;
     for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { a += sred[0][k]; c += sred[1][k]; d += sred[2][k]; }
     int cx, cy;
-    if (centers) { cx = centers[2 * b]; cy = centers[2 * b + 1]; }
+    if (centers) { cx = centers[2 * (size_t)b * nc]; cy = centers[2 * (size_t)b * nc + 1]; }
     else { cx = (int)(a / d); cy = (int)(c / d); }                 // astype(np.int16): truncation (NaN for an empty mask -> 0)
     if (!(d > 0.0) && !centers) { cx = 0; cy = 0; }
     s_c[0] = cx; s_c[1] = cy;
     if (center_out) { center_out[2 * b] = cx; center_out[2 * b + 1] = cy; }
+    // geodesic.py:22-27: EVERY source must lie on the mask, else the map is all ones (several sources: geodesic_pt_list joints)
+    bool inside = true;
+    const int ncs = centers ? nc : 1;
+    for (int k = 0; k < ncs; ++k) {
+      const int x = centers ? centers[2 * ((size_t)b * nc + k)] : cx, y = centers ? centers[2 * ((size_t)b * nc + k) + 1] : cy;
+      inside = inside && (unsigned)x < (unsigned)P && (unsigned)y < (unsigned)P && m[y * P + x] != 0.f;
+    }
+    s_c[2] = inside ? 1 : 0;
   }
   __syncthreads();
   const int cx = s_c[0], cy = s_c[1];
-  const bool inside = (unsigned)cx < (unsigned)P && (unsigned)cy < (unsigned)P && m[cy * P + cx] != 0.f;
-  if (!inside) {                                       // geodesic.py:25-27: centre on the background -> weights of one
+  if (!s_c[2]) {                                       // geodesic.py:25-27: a source on the background -> weights of one
     for (int i = threadIdx.x; i < n; i += blockDim.x) o[i] = 1.0f;
     return;
   }
@@ -201,6 +208,10 @@ __global__ __launch_bounds__(kGeoThreads) void geodesic_weight_kernel(const floa
     dbg[i] = dm[i] ? 0.f : kInf;
   }
   __syncthreads();
+  if (centers && nc > 1) {                             // the other sources (geodesic.py:29-31: every centre is a zero of the level set)
+    for (int k = 1 + threadIdx.x; k < nc; k += blockDim.x) din[centers[2 * ((size_t)b * nc + k) + 1] * P + centers[2 * ((size_t)b * nc + k)]] = 0.f;
+    __syncthreads();
+  }
   eikonal_solve(din, dm, P, 4 * P);
   // background solve: every pixel is in the domain -> reuse `o` region? no: a second domain array of ones is implied
   {
@@ -283,8 +294,22 @@ extern "C" int xas_geodesic_weight(const float* mask, const int* centers, const 
               (double)params5[4]);
   float* work = reinterpret_cast<float*>(workspace);
   uint8_t* dom = reinterpret_cast<uint8_t*>(work + (size_t)B * 2 * P * P);
-  hipLaunchKernelGGL(geodesic_weight_kernel, dim3(B), dim3(kGeoThreads), 0, as_stream(stream), mask, centers, params5[0],
+  hipLaunchKernelGGL(geodesic_weight_kernel, dim3(B), dim3(kGeoThreads), 0, as_stream(stream), mask, centers, 1, params5[0],
                      params5[1], params5[2], params5[3], P, work, dom, out, center_out);
+  XAS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int xas_geodesic_weight_multi(const float* mask, const int* centers, int num_centers, const float* params5, int B, int P,
+                                         float* out, void* workspace, void* stream) {
+  XAS_REQUIRE(mask && centers && params5 && out && workspace && B > 0 && P >= 2 && P <= 1024 && num_centers >= 1 && num_centers <= 64,
+              "geodesic_weight_multi: bad arguments (B=%d P=%d centres=%d)", B, P, num_centers);
+  XAS_REQUIRE(params5[4] == 0.f, "geodesic_weight_multi: geodesic_param_list[4] = %g: only the shipped 0.0 (mask = zero level) is built",
+              (double)params5[4]);
+  float* work = reinterpret_cast<float*>(workspace);
+  uint8_t* dom = reinterpret_cast<uint8_t*>(work + (size_t)B * 2 * P * P);
+  hipLaunchKernelGGL(geodesic_weight_kernel, dim3(B), dim3(kGeoThreads), 0, as_stream(stream), mask, centers, num_centers, params5[0],
+                     params5[1], params5[2], params5[3], P, work, dom, out, (int*)nullptr);
   XAS_LAUNCH_CHECK();
   return 0;
 }

@@ -21,8 +21,8 @@ from xas_amd._lib import call, ptr, query
 
 
 def compute_geodesic_dis_batch(mask, geodesic_param_list, centers=None):
-    """mask [B,1,P,P] float device tensor (non-zero = foreground) -> (weights [B,1,P,P] float32, centres [B,2] int32 (x, y)).
-    centers: optional [B,2] integer tensor of source pixels (geodesic_pt_list joints); default: mask centroid."""
+    """mask [B,1,P,P] float device tensor (non-zero = foreground) -> (weights [B,1,P,P] float32, centres [B,2] or [B,n,2] int32 (x, y)).
+    centers: optional [B,2] or [B,n,2] integer tensor of source pixels (the geodesic_pt_list joints); default: mask centroid."""
     if mask.dim() != 4 or mask.shape[1] != 1 or mask.shape[2] != mask.shape[3]:
         raise RuntimeError('compute_geodesic_dis_batch expects a [B,1,P,P] mask batch')
     mask = mask.contiguous().float()
@@ -32,6 +32,11 @@ def compute_geodesic_dis_batch(mask, geodesic_param_list, centers=None):
     ws = torch.empty(query('xas_geodesic_workspace_bytes', B, P), device=mask.device, dtype=torch.uint8)
     params = (ctypes.c_float * 5)(*[float(v) for v in geodesic_param_list])
     c = centers.to(device=mask.device, dtype=torch.int32).contiguous() if centers is not None else None
+    if c is not None and c.dim() == 3:                 # several sources per image
+        if c.shape[0] != B or c.shape[2] != 2 or not 1 <= c.shape[1] <= 64:
+            raise RuntimeError('compute_geodesic_dis_batch: centres must be [B, n, 2] with 1 <= n <= 64')
+        call('xas_geodesic_weight_multi', ptr(mask), ptr(c), int(c.shape[1]), ctypes.cast(params, ctypes.c_void_p), B, P, ptr(out), ptr(ws))
+        return out, c
     call('xas_geodesic_weight', ptr(mask), ptr(c), ctypes.cast(params, ctypes.c_void_p), B, P, ptr(out), ptr(cen), ptr(ws))
     return out, cen
 
@@ -52,13 +57,15 @@ def _in_loader_worker():
 
 def compute_geodesic_dis(img, img_path, geodesic_param_list, centers=None, is_norm=True):
     """Reference signature (geodesic.py:14): img [1,H,W] numpy mask -> (weight map [1,H,W], centres [n,2] int16)."""
-    if (not is_norm or img.shape[-1] != img.shape[-2] or (centers is not None and len(centers) != 1) or _in_loader_worker()
+    if (not is_norm or img.shape[-1] != img.shape[-2] or (centers is not None and not 1 <= len(centers) <= 64) or _in_loader_worker()
             or not torch.cuda.is_available()):
         return __getattr__('compute_geodesic_dis')(img, img_path, geodesic_param_list, centers, is_norm)
     dev = torch.device('cuda', torch.cuda.current_device())
     m = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32)).to(dev)[None]
     # (a centre may carry a depth column - the reference indexes center[0], center[1] only, geodesic.py:23-24,30-31)
     c = None if centers is None else torch.as_tensor(np.ascontiguousarray(np.asarray(centers)[:, :2], dtype=np.int32))
+    if c is not None and len(c) > 1:
+        c = c[None]                                    # [1, n, 2]: several sources
     out, cen = compute_geodesic_dis_batch(m, geodesic_param_list, c)
     return out[0].cpu().numpy(), cen.cpu().numpy().astype(np.int16).reshape(-1, 2)
 

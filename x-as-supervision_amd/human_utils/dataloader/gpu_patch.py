@@ -86,7 +86,8 @@ def generate_patch_batch(samples, frames, masks, patch_width, patch_height, rect
     joints = torch.tensor(np.stack(joints_out), dtype=torch.float32, device=device)
     centers = None
     if geodesic_pts is not None and len(geodesic_pts):
-        raise NotImplementedError('geodesic_pt_list with several source joints (shipped configs use the centroid)')
+        # dataloader.py:189-191: the listed joints (patch pixels) are the sources; geodesic.py:19: astype(int16) truncates
+        centers = joints[:, [int(k) for k in geodesic_pts], :2].to(torch.int32).contiguous()
     geo, cen = compute_geodesic_dis_batch(out_mask, geodesic_param_list, centers)
     return {'img': out_img, 'mask': out_mask, 'geodesic_dis': geo, 'geodesic_center': cen, 'joints': joints,
             'trans_image': torch.tensor(np.stack(trans), dtype=torch.float32, device=device)}
