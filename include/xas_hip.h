@@ -413,11 +413,15 @@ int xas_patch_finish(const uint8_t* img_bgr, const uint8_t* mask, const float* c
 size_t xas_geodesic_workspace_bytes(int B, int P);
 int xas_geodesic_weight(const float* mask, const int* centers, const float* params5, int B, int P, float* out,
                         int* center_out, void* workspace, void* stream);
-/* The same with SEVERAL source pixels per image (geodesic_pt_list: the listed joints, dataloader.py:189-191): centers is
- * device [B][num_centers][2] ints (x, y), 1 <= num_centers <= 64; every centre is a zero of the inside solve; if ANY centre
- * of an image lies on the background that image's map is all ones (geodesic.py:22-27).  Workspace as above. */
-int xas_geodesic_weight_multi(const float* mask, const int* centers, int num_centers, const float* params5, int B, int P,
-                              float* out, void* workspace, void* stream);
+/* The general form: SEVERAL source pixels per image (geodesic_pt_list: the listed joints, dataloader.py:189-191) and the order
+ * of the upwind scheme.  centers: device [B][num_centers][2] ints (x, y), 1 <= num_centers <= 64, or NULL with num_centers = 1
+ * (centroid); every centre is a zero of the inside solve; if ANY centre of an image lies on the background that image's map is
+ * all ones (geodesic.py:22-27).  order: 2 = the second-order scheme scikit-fmm's `distance` runs by default (one-sided
+ * second-order differences where the second upwind neighbour is not larger, first order elsewhere; restated from the
+ * library's documented algorithm, parity unpinned), 1 = first order (what xas_geodesic_weight computes).  center_out: device
+ * [B][2] ints (first centre) or NULL.  Workspace as above. */
+int xas_geodesic_weight_multi(const float* mask, const int* centers, int num_centers, int order, const float* params5, int B, int P,
+                              float* out, int* center_out, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Mask losses (modules/base_losses/loss_func.py:4-16), fused clip * weight * MSE.

@@ -162,9 +162,16 @@ def compute_centroid(mask):
     return np.array([np.sum(grid[1] * mask) / np.sum(mask), np.sum(grid[0] * mask) / np.sum(mask)]).astype(np.int16)
 
 
-def fmm_distance(sources, domain):
-    """First-order fast marching on the unit grid: distance from the `sources` pixels (value 0) through `domain` pixels
-    (bool arrays [H,W]).  Pixels outside the domain (or unreachable) come back as 0, as scikit-fmm reports masked cells."""
+def fmm_distance(sources, domain, order=2):
+    """Fast marching on the unit grid: distance from the `sources` pixels (value 0) through `domain` pixels (bool arrays
+    [H,W]).  Pixels outside the domain (or unreachable) come back as 0, as scikit-fmm reports masked cells.
+
+    order = 2 (scikit-fmm's default, what `skfmm.distance(m)` of geodesic.py:35,39 runs): the published scheme of its
+    distance marcher - per axis the smaller FROZEN neighbour v1; if the next pixel in the same direction is frozen too and not
+    larger, the one-sided second-order difference (3u - 4 v1 + v2) / 2, i.e. the quadratic term 9/4 (u - (4 v1 - v2) / 3)^2,
+    else the first-order term (u - v1)^2; sum of the terms = 1, larger root.  A pixel's tentative value is RE-computed (not
+    min-ed) every time one of its neighbours is frozen.  Restated from the library's documented algorithm - the package is not
+    in the image (parity unpinned).  order = 1: the first-order scheme (the r03-r04 maps)."""
     H, W = domain.shape
     INF = np.inf
     u = np.full((H, W), INF)
@@ -175,7 +182,7 @@ def fmm_distance(sources, domain):
         heap.append((0.0, int(y), int(x)))
     heapq.heapify(heap)
 
-    def solve(y, x):
+    def solve1(y, x):
         a = min(u[y, x - 1] if x > 0 and domain[y, x - 1] else INF, u[y, x + 1] if x < W - 1 and domain[y, x + 1] else INF)
         b = min(u[y - 1, x] if y > 0 and domain[y - 1, x] else INF, u[y + 1, x] if y < H - 1 and domain[y + 1, x] else INF)
         lo, hi = min(a, b), max(a, b)
@@ -183,22 +190,63 @@ def fmm_distance(sources, domain):
             return lo + 1.0
         return 0.5 * (a + b + np.sqrt(2.0 - (a - b) ** 2))
 
-    while heap:
-        d, y, x = heapq.heappop(heap)
-        if done[y, x] or d > u[y, x]:
-            continue
-        done[y, x] = True
+    def frozen(y, x):
+        return 0 <= y < H and 0 <= x < W and domain[y, x] and done[y, x]
+
+    def solve2(y, x):
+        a = b = c = 0.0
+        for dy, dx in ((0, 1), (1, 0)):                        # the two axes
+            v1 = v2 = INF
+            for j in (-1, 1):                                  # both directions of the axis
+                y1, x1 = y + j * dy, x + j * dx
+                if frozen(y1, x1) and u[y1, x1] < v1:
+                    v1 = u[y1, x1]
+                    y2, x2 = y + 2 * j * dy, x + 2 * j * dx
+                    v2 = u[y2, x2] if frozen(y2, x2) and u[y2, x2] <= v1 else INF
+            if v2 < INF:
+                tp = (4.0 * v1 - v2) / 3.0
+                a += 2.25; b -= 2.0 * 2.25 * tp; c += 2.25 * tp * tp
+            elif v1 < INF:
+                a += 1.0; b -= 2.0 * v1; c += v1 * v1
+        if a == 0.0:
+            return INF
+        c -= 1.0
+        det = b * b - 4.0 * a * c
+        if det < 0.0:                                          # (not reached with frozen neighbours on the unit grid; first-order fallback)
+            return solve1(y, x)
+        return (-b + np.sqrt(det)) / (2.0 * a)
+
+    def relax_neighbours(y, x):
         for yy, xx in ((y, x - 1), (y, x + 1), (y - 1, x), (y + 1, x)):
             if 0 <= yy < H and 0 <= xx < W and domain[yy, xx] and not done[yy, xx]:
-                nu = solve(yy, xx)
-                if nu < u[yy, xx]:
-                    u[yy, xx] = nu
-                    heapq.heappush(heap, (nu, yy, xx))
+                if order == 2:
+                    nu = solve2(yy, xx)
+                    if nu != u[yy, xx]:
+                        u[yy, xx] = nu
+                        heapq.heappush(heap, (nu, yy, xx))
+                else:
+                    nu = solve1(yy, xx)
+                    if nu < u[yy, xx]:
+                        u[yy, xx] = nu
+                        heapq.heappush(heap, (nu, yy, xx))
+
+    if order == 2:                                             # the sources are frozen from the start (scikit-fmm: the zero level set),
+        seeds, heap = heap, []                                 # the narrow band starts as their neighbours
+        for _, y, x in seeds:
+            done[y, x] = True
+        for _, y, x in seeds:
+            relax_neighbours(y, x)
+    while heap:
+        d, y, x = heapq.heappop(heap)
+        if done[y, x] or d != u[y, x]:                         # stale entry
+            continue
+        done[y, x] = True
+        relax_neighbours(y, x)
     u[~np.isfinite(u)] = 0.0
     return u
 
 
-def compute_geodesic_dis(img, params, centers=None):
+def compute_geodesic_dis(img, params, centers=None, order=2):
     """geodesic.py:14-54 with is_norm=True: img [1,H,W] float mask -> (weight map [1,H,W] float64, centres [n,2])."""
     mask = np.bool_(img)
     centers = compute_centroid(mask).reshape(-1, 2) if centers is None else np.asarray(centers).copy().astype(np.int16)
@@ -208,8 +256,8 @@ def compute_geodesic_dis(img, params, centers=None):
     src = np.zeros(mask.shape[1:], dtype=bool)
     for c in centers:
         src[c[1], c[0]] = True
-    distance = fmm_distance(src, mask[0])
-    distance_bg = fmm_distance(mask[0], np.ones_like(mask[0]))
+    distance = fmm_distance(src, mask[0], order)
+    distance_bg = fmm_distance(mask[0], np.ones_like(mask[0]), order)
     distance = np.exp(params[0] * (distance / np.max(distance))) + params[1]
     distance_bg = params[2] * (distance_bg / np.max(distance_bg)) + params[3]
     return (distance + distance_bg)[None, ...], centers

@@ -91,14 +91,33 @@ def test_geodesic_weight_vs_fast_marching_oracle():
     ring = ((yy - 48) ** 2 + (xx - 48) ** 2 < 40 ** 2) & ((yy - 48) ** 2 + (xx - 48) ** 2 > 25 ** 2)
     m[3, 0][ring] = 1.0
     params = [2, 1, 3, 20, 0.0]
-    out, cen = compute_geodesic_dis(torch.from_numpy(m).cuda(), params)
-    out, cen = out.cpu().numpy(), cen.cpu().numpy()
-    for i in range(5):
-        ref, c = O.compute_geodesic_dis(m[i], params)
-        assert cen[i].tolist() == c[0].tolist(), i
-        # the iterative solver converges to the fixed point of the same first-order stencil the heap solver evaluates
-        assert np.abs(out[i] - ref.astype(np.float64)).max() < 2e-4 * np.abs(ref).max(), (i, np.abs(out[i] - ref).max())
-    assert (out[3] == 1.0).all()                                         # geodesic.py:25-27 early-out
+    for order in (2, 1):                                                 # 2: scikit-fmm's default scheme (the product default); 1: first order
+        out, cen = compute_geodesic_dis(torch.from_numpy(m).cuda(), params, order=order)
+        out, cen = out.cpu().numpy(), cen.cpu().numpy()
+        for i in range(5):
+            ref, c = O.compute_geodesic_dis(m[i], params, order=order)
+            assert cen[i].tolist() == c[0].tolist(), i
+            err = np.abs(out[i] - ref.astype(np.float64))
+            inside = m[i] != 0
+            # the sweeps converge to the values the heap solver computes for the same stencil.  Order 1 is a monotone scheme
+            # with ONE fixed point: tight everywhere.  Order 2 switches stencils on comparisons of neighbouring values, so where
+            # many pixels have EQUAL distance (the rings around the flat mask region of the background solve) the heap order /
+            # the last ulp decides which neighbours count - two correct solvers differ there by a few tenths of a pixel
+            # (measured between the float64 heap solver and float64 sweeps: 0.22 px): the background part gets that bar; the
+            # inside solve (point sources: ties are rare) is tight on at least 90 % of the mask pixels of every image - on two of
+            # the three blobs on ALL of them, 3e-6 - with the same loose bar for the wake of a flipped comparison.
+            tight = 2e-4 * np.abs(ref).max()
+            if order == 1 or (out[i] == 1.0).all():
+                assert err.max() < tight, (order, i, err.max())
+            else:
+                assert np.quantile(err[inside], 0.9) < tight and err[inside].max() < 3e-2, (order, i, err[inside].max())
+                assert err[~inside].max() < 3e-2 and np.median(err[~inside]) < 1e-2, (order, i, err[~inside].max())
+        assert (out[3] == 1.0).all()                                     # geodesic.py:25-27 early-out
+    out2, _ = compute_geodesic_dis(torch.from_numpy(m).cuda(), params)   # default = order 2
+    again, _ = compute_geodesic_dis(torch.from_numpy(m).cuda(), params)
+    assert torch.equal(out2, again)                                      # Jacobi sweeps: the same bits every run
+    assert np.abs(out2.cpu().numpy() - out).max() > 1e-3                  # (and it differs from the first-order map)
+    out = out2.cpu().numpy()
     assert out[0].min() >= 21.9 and out[0].max() <= np.exp(2.0) + 1 + 3 + 20 + 1e-3
 
 
@@ -122,8 +141,12 @@ def test_geodesic_weight_several_sources_vs_fast_marching_oracle():
     out = out.cpu().numpy()
     assert c.cpu().numpy().tolist() == cen.tolist()
     for i in range(4):
-        ref, _ = O.compute_geodesic_dis(m[i], params, centers=cen[i])
-        assert np.abs(out[i] - ref.astype(np.float64)).max() < 2e-4 * np.abs(ref).max(), (i, np.abs(out[i] - ref).max())
+        ref, _ = O.compute_geodesic_dis(m[i], params, centers=cen[i])                       # (order 2 on both sides)
+        err, inside = np.abs(out[i] - ref.astype(np.float64)), m[i] != 0
+        if (out[i] == 1.0).all():
+            assert err.max() == 0
+        else:                                                            # (bars: see test_geodesic_weight_vs_fast_marching_oracle)
+            assert np.quantile(err[inside], 0.9) < 2e-4 * np.abs(ref).max() and err.max() < 3e-2, (i, err[inside].max(), err[~inside].max())
     assert (out[2] == 1.0).all()
     # differs from the single-source map (the sources are really used)
     one, _ = compute_geodesic_dis_batch(torch.from_numpy(m).cuda(), params, torch.from_numpy(np.ascontiguousarray(cen[:, 0])))

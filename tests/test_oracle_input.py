@@ -67,13 +67,24 @@ def test_fast_marching_known_answers():
     dom = np.ones((21, 21), dtype=bool)
     src = np.zeros_like(dom)
     src[10, 10] = True
-    d = O.fmm_distance(src, dom)
+    d = O.fmm_distance(src, dom, order=1)
     assert d[10, 10] == 0 and d[10, 15] == 5.0 and d[3, 10] == 7.0                          # along the axes: exact
     assert abs(d[13, 14] - 5.0) < 0.7                                                       # first-order: overestimates diagonals
+    d2 = O.fmm_distance(src, dom)                                                           # order 2 (scikit-fmm's default)
+    assert d2[10, 10] == 0 and abs(d2[10, 15] - 5.0) < 1e-12 and abs(d2[3, 10] - 7.0) < 1e-12
+    yy, xx = np.mgrid[0:21, 0:21]
+    eu = np.hypot(yy - 10, xx - 10)
+    assert np.abs(d2 - eu).max() < 0.35 < np.abs(d - eu).max()                              # second order: closer to the Euclidean distance
+    assert np.abs(d2 - eu).mean() < 0.5 * np.abs(d - eu).mean()
+    # second upwind neighbour not larger -> (3u - 4 v1 + v2) / 2 = 1: two pixels from the source along an axis u = 4/3 + 2/3 = 2
+    line = np.ones((1, 9), dtype=bool)
+    s1 = np.zeros_like(line); s1[0, 0] = True
+    assert np.allclose(O.fmm_distance(s1, line)[0], np.arange(9.0), atol=1e-12)
     wall = dom.copy()
     wall[0:18, 12] = False                                                                  # obstacle: geodesic detour
-    dw = O.fmm_distance(src, wall)
-    assert dw[10, 14] > d[10, 14] + 10 and dw[0, 12] == 0.0                                 # masked cells report 0
+    for order in (1, 2):
+        dw = O.fmm_distance(src, wall, order)
+        assert dw[10, 14] > d[10, 14] + 10 and dw[0, 12] == 0.0                             # masked cells report 0
     mask = np.zeros((1, 32, 32), dtype=np.float32)
     mask[0, 8:24, 10:20] = 1.0
     w, c = O.compute_geodesic_dis(mask, [2, 1, 3, 20, 0.0])

@@ -140,6 +140,80 @@ __device__ void eikonal_solve(float* __restrict__ u, const uint8_t* __restrict__
   }
 }
 
+// ---- second order (what scikit-fmm's `distance` runs by default, order = 2).  Per axis: the smaller neighbour v1; when the
+// next pixel in the same direction is not larger (in fast marching: frozen before v1), the one-sided second-order difference
+// (3u - 4 v1 + v2) / 2 - the term 9/4 (u - t)^2 with t = v1 + (v1 - v2) / 3 - else the first-order term (u - v1)^2; the terms sum
+// to 1.  Solved relative to the smaller t (the textbook form b^2 - 4ac cancels catastrophically in fp32 at distances of
+// hundreds of pixels).  A neighbour larger than the result is not upwind and is dropped (fast marching: not frozen yet).
+// The scheme is not monotone in its neighbours (a smaller v2 RAISES t), so the sweeps ASSIGN the value instead of keeping the
+// minimum, until a sweep changes nothing: the values settle in causal order (every pixel depends on strictly smaller ones).
+// A neighbour counts as upwind only if it is smaller than the result by this margin: pixels of (nearly) EQUAL distance - the whole
+// first ring around a flat source region - must not take each other as upwind neighbours (fast marching breaks such ties by its
+// heap order; parallel sweeps would chase each other an ulp at a time).  The result is continuous across the switch (at
+// v = single-axis value both forms agree), so the margin moves values by O(1e-4) pixels.
+constexpr float kGeoCausal = 1e-4f;
+
+__device__ __forceinline__ float eikonal2_value(const float* __restrict__ u, const uint8_t* __restrict__ dom, int i, int P) {
+  const int y = i / P, x = i - y * P;
+  float t[2], w[2], v[2];
+#pragma unroll
+  for (int ax = 0; ax < 2; ++ax) {
+    const int step = ax ? P : 1, pos = ax ? y : x;
+    float v1 = kInf, v2 = kInf;
+#pragma unroll
+    for (int j = -1; j <= 1; j += 2) {
+      if ((unsigned)(pos + j) >= (unsigned)P) continue;
+      const int n1 = i + j * step;
+      if (dom && !dom[n1]) continue;
+      const float a = u[n1];
+      if (a < v1) {
+        v1 = a; v2 = kInf;
+        if ((unsigned)(pos + 2 * j) < (unsigned)P) {
+          const int n2 = i + 2 * j * step;
+          if (!dom || dom[n2]) { const float b = u[n2]; if (b <= a) v2 = b; }
+        }
+      }
+    }
+    v[ax] = v1;
+    if (v2 < kInf) { t[ax] = v1 + (v1 - v2) * (1.f / 3.f); w[ax] = 2.25f; }
+    else { t[ax] = v1; w[ax] = 1.f; }
+  }
+  const int lo = t[1] < t[0] ? 1 : 0, hi = 1 - lo;              // (kInf on an axis without a reached neighbour)
+  if (v[lo] >= kInf) return kInf;
+  const float single = t[lo] + (w[lo] > 1.f ? (2.f / 3.f) : 1.f);
+  if (v[hi] >= kInf) return single;
+  const float d = t[hi] - t[lo], sw = w[lo] + w[hi];
+  const float det = sw - w[lo] * w[hi] * d * d;
+  if (det < 0.f) return single;
+  const float r = t[lo] + (w[hi] * d + sqrtf(det)) / sw;
+  return r - kGeoCausal >= v[hi] ? r : single;
+}
+
+// u: sources 0, others kInf on entry; dom: 1 = pixel takes part (nullptr: all); tmp: a second field.  JACOBI sweeps (every
+// pixel from the PREVIOUS field): the result does not depend on the order in which the waves run - with in-place sweeps a
+// comparison of two nearly equal neighbours could go either way from run to run, and with it a stencil.
+__device__ void eikonal2_solve(float* __restrict__ u, float* __restrict__ tmp, const uint8_t* __restrict__ dom, int P, int max_sweeps) {
+  const int n = P * P;
+  float* src = u;
+  float* dst = tmp;
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    int changed = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const float cur = src[i];
+      float nu = cur;
+      if ((!dom || dom[i]) && cur != 0.f) nu = eikonal2_value(src, dom, i, P);
+      dst[i] = nu;
+      changed |= nu != cur;
+    }
+    float* t = src; src = dst; dst = t;                 // (uniform)
+    if (!__syncthreads_or(changed)) break;
+  }
+  if (src != u) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) u[i] = src[i];
+    __syncthreads();
+  }
+}
+
 __device__ float block_max(float v, float* red) {      // red: >= 33 floats; result valid in every thread
   v = wave_max(v);
   __syncthreads();
@@ -154,9 +228,9 @@ __device__ float block_max(float v, float* red) {      // red: >= 33 floats; res
   return red[32];
 }
 
-__global__ __launch_bounds__(kGeoThreads) void geodesic_weight_kernel(const float* __restrict__ mask, const int* __restrict__ centers, int nc,
+__global__ __launch_bounds__(kGeoThreads) void geodesic_weight_kernel(const float* __restrict__ mask, const int* __restrict__ centers, int nc, int order,
                                                                       float p0, float p1, float p2, float p3, int P,
-                                                                      float* __restrict__ work /*[B][2][P*P]*/,
+                                                                      float* __restrict__ work /*[B][3][P*P]*/,
                                                                       uint8_t* __restrict__ dom /*[B][P*P]*/,
                                                                       float* __restrict__ out, int* __restrict__ center_out) {
   __shared__ float red[33];
@@ -164,8 +238,9 @@ __global__ __launch_bounds__(kGeoThreads) void geodesic_weight_kernel(const floa
   __shared__ int s_c[3];
   const int b = blockIdx.x, n = P * P;
   const float* m = mask + (size_t)b * n;
-  float* din = work + (size_t)b * 2 * n;
+  float* din = work + (size_t)b * 3 * n;
   float* dbg = din + n;
+  float* tmp = dbg + n;                                // second field of the Jacobi sweeps (order 2)
   uint8_t* dm = dom + (size_t)b * n;
   float* o = out + (size_t)b * n;
   // centroid of the BOOLEAN mask (np.bool_(img): any non-zero value is foreground), truncated to int16 (geodesic.py:4-12,15)
@@ -212,13 +287,15 @@ __global__ __launch_bounds__(kGeoThreads) void geodesic_weight_kernel(const floa
     for (int k = 1 + threadIdx.x; k < nc; k += blockDim.x) din[centers[2 * ((size_t)b * nc + k) + 1] * P + centers[2 * ((size_t)b * nc + k)]] = 0.f;
     __syncthreads();
   }
-  eikonal_solve(din, dm, P, 4 * P);
-  // background solve: every pixel is in the domain -> reuse `o` region? no: a second domain array of ones is implied
-  {
-    const int nn = n;
+  if (order == 2) {
+    eikonal2_solve(din, tmp, dm, P, 8 * P);
+    eikonal2_solve(dbg, tmp, nullptr, P, 8 * P);
+  } else {
+    eikonal_solve(din, dm, P, 4 * P);
+    // background solve: every pixel is in the domain
     for (int sweep = 0; sweep < 4 * P; ++sweep) {
       int changed = 0;
-      for (int i = threadIdx.x; i < nn; i += blockDim.x) {
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const float cur = dbg[i];
         if (cur == 0.f) continue;
         const int y = i / P, x = i - y * P;
@@ -284,7 +361,7 @@ extern "C" int xas_patch_finish(const uint8_t* img_bgr, const uint8_t* mask, con
 
 extern "C" size_t xas_geodesic_workspace_bytes(int B, int P) {
   if (B <= 0 || P <= 0) return 0;
-  return (size_t)B * P * P * (2 * sizeof(float) + 1);
+  return (size_t)B * P * P * (3 * sizeof(float) + 1);
 }
 
 extern "C" int xas_geodesic_weight(const float* mask, const int* centers, const float* params5, int B, int P, float* out,
@@ -293,23 +370,24 @@ extern "C" int xas_geodesic_weight(const float* mask, const int* centers, const 
   XAS_REQUIRE(params5[4] == 0.f, "geodesic_weight: geodesic_param_list[4] = %g: only the shipped 0.0 (mask = zero level) is built",
               (double)params5[4]);
   float* work = reinterpret_cast<float*>(workspace);
-  uint8_t* dom = reinterpret_cast<uint8_t*>(work + (size_t)B * 2 * P * P);
-  hipLaunchKernelGGL(geodesic_weight_kernel, dim3(B), dim3(kGeoThreads), 0, as_stream(stream), mask, centers, 1, params5[0],
+  uint8_t* dom = reinterpret_cast<uint8_t*>(work + (size_t)B * 3 * P * P);
+  hipLaunchKernelGGL(geodesic_weight_kernel, dim3(B), dim3(kGeoThreads), 0, as_stream(stream), mask, centers, 1, 1, params5[0],
                      params5[1], params5[2], params5[3], P, work, dom, out, center_out);
   XAS_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int xas_geodesic_weight_multi(const float* mask, const int* centers, int num_centers, const float* params5, int B, int P,
-                                         float* out, void* workspace, void* stream) {
-  XAS_REQUIRE(mask && centers && params5 && out && workspace && B > 0 && P >= 2 && P <= 1024 && num_centers >= 1 && num_centers <= 64,
-              "geodesic_weight_multi: bad arguments (B=%d P=%d centres=%d)", B, P, num_centers);
+extern "C" int xas_geodesic_weight_multi(const float* mask, const int* centers, int num_centers, int order, const float* params5,
+                                         int B, int P, float* out, int* center_out, void* workspace, void* stream) {
+  XAS_REQUIRE(mask && params5 && out && workspace && B > 0 && P >= 2 && P <= 1024 && num_centers >= 1 && num_centers <= 64 &&
+              (centers || num_centers == 1) && (order == 1 || order == 2),
+              "geodesic_weight_multi: bad arguments (B=%d P=%d centres=%d order=%d)", B, P, num_centers, order);
   XAS_REQUIRE(params5[4] == 0.f, "geodesic_weight_multi: geodesic_param_list[4] = %g: only the shipped 0.0 (mask = zero level) is built",
               (double)params5[4]);
   float* work = reinterpret_cast<float*>(workspace);
-  uint8_t* dom = reinterpret_cast<uint8_t*>(work + (size_t)B * 2 * P * P);
-  hipLaunchKernelGGL(geodesic_weight_kernel, dim3(B), dim3(kGeoThreads), 0, as_stream(stream), mask, centers, num_centers, params5[0],
-                     params5[1], params5[2], params5[3], P, work, dom, out, (int*)nullptr);
+  uint8_t* dom = reinterpret_cast<uint8_t*>(work + (size_t)B * 3 * P * P);
+  hipLaunchKernelGGL(geodesic_weight_kernel, dim3(B), dim3(kGeoThreads), 0, as_stream(stream), mask, centers, num_centers, order,
+                     params5[0], params5[1], params5[2], params5[3], P, work, dom, out, center_out);
   XAS_LAUNCH_CHECK();
   return 0;
 }

@@ -20,11 +20,16 @@ import torch
 from xas_amd._lib import call, ptr, query
 
 
-def compute_geodesic_dis_batch(mask, geodesic_param_list, centers=None):
+FMM_ORDER = 2        # scikit-fmm's default (skfmm.distance(m), geodesic.py:35,39); 1: the first-order maps of rounds 3-4
+
+
+def compute_geodesic_dis_batch(mask, geodesic_param_list, centers=None, order=None):
     """mask [B,1,P,P] float device tensor (non-zero = foreground) -> (weights [B,1,P,P] float32, centres [B,2] or [B,n,2] int32 (x, y)).
-    centers: optional [B,2] or [B,n,2] integer tensor of source pixels (the geodesic_pt_list joints); default: mask centroid."""
+    centers: optional [B,2] or [B,n,2] integer tensor of source pixels (the geodesic_pt_list joints); default: mask centroid.
+    order: 1 / 2 = order of the upwind scheme of the two distance solves (default FMM_ORDER = 2, scikit-fmm's default)."""
     if mask.dim() != 4 or mask.shape[1] != 1 or mask.shape[2] != mask.shape[3]:
         raise RuntimeError('compute_geodesic_dis_batch expects a [B,1,P,P] mask batch')
+    order = FMM_ORDER if order is None else int(order)
     mask = mask.contiguous().float()
     B, _, P, _ = mask.shape
     out = torch.empty_like(mask)
@@ -32,13 +37,13 @@ def compute_geodesic_dis_batch(mask, geodesic_param_list, centers=None):
     ws = torch.empty(query('xas_geodesic_workspace_bytes', B, P), device=mask.device, dtype=torch.uint8)
     params = (ctypes.c_float * 5)(*[float(v) for v in geodesic_param_list])
     c = centers.to(device=mask.device, dtype=torch.int32).contiguous() if centers is not None else None
+    nc = 1
     if c is not None and c.dim() == 3:                 # several sources per image
         if c.shape[0] != B or c.shape[2] != 2 or not 1 <= c.shape[1] <= 64:
             raise RuntimeError('compute_geodesic_dis_batch: centres must be [B, n, 2] with 1 <= n <= 64')
-        call('xas_geodesic_weight_multi', ptr(mask), ptr(c), int(c.shape[1]), ctypes.cast(params, ctypes.c_void_p), B, P, ptr(out), ptr(ws))
-        return out, c
-    call('xas_geodesic_weight', ptr(mask), ptr(c), ctypes.cast(params, ctypes.c_void_p), B, P, ptr(out), ptr(cen), ptr(ws))
-    return out, cen
+        nc = int(c.shape[1])
+    call('xas_geodesic_weight_multi', ptr(mask), ptr(c), nc, order, ctypes.cast(params, ctypes.c_void_p), B, P, ptr(out), ptr(cen), ptr(ws))
+    return out, (c if nc > 1 else cen)
 
 
 def compute_centroid(mask):

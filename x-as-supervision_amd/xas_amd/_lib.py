@@ -93,7 +93,7 @@ SIGNATURES = {
     'xas_patch_finish': ('pppppiiippp', 'i'),
     'xas_geodesic_workspace_bytes': ('ii', 'z'),
     'xas_geodesic_weight': ('pppiipppp', 'i'),
-    'xas_geodesic_weight_multi': ('ppipiippp', 'i'),
+    'xas_geodesic_weight_multi': ('ppiipiipppp', 'i'),
     'xas_loss_nblk': ('l', 'i'),
     'xas_mask_loss_fwd': ('pppliPpp'.replace('P', 'p'), 'i'),
     'xas_mask_loss_bwd': ('pppliPppp'.replace('P', 'p'), 'i'),
