@@ -9,9 +9,10 @@ Third-party arithmetic, absent from this image and from /root/reference (require
     + `cv2.threshold`.  Restated from OpenCV 4.x's published algorithm (modules/imgproc/src/imgwarp.cpp: AB_BITS = 10,
     INTER_BITS = 5, INTER_REMAP_COEF_BITS = 15, BORDER_CONSTANT 0; smooth: fixed-point [1 4 6 4 1]/16 kernel,
     BORDER_REFLECT_101).  PARITY UNPINNED: no cv2 here to generate vectors from.
-  * scikit-fmm: `skfmm.distance` (fast marching).  Restated as a FIRST-ORDER upwind fast-marching solve with a heap
-    (scikit-fmm's default is order=2: its second-order stencil where two upwind neighbours are known).  PARITY UNPINNED,
-    and a known deviation: distances differ by a fraction of a pixel from the second-order solution.
+  * scikit-fmm: `skfmm.distance` (fast marching).  Restated as a heap fast-marching solve of the library's default
+    SECOND-order scheme (order=2: the one-sided second-order difference where the second upwind neighbour is frozen and not
+    larger, first order elsewhere; tentative values re-computed whenever a neighbour freezes), r05; order=1 (the r03-r04
+    restatement) is kept.  PARITY UNPINNED: the package is not in the image.
 The reference's own numpy-only helpers (rotate_2d, trans_point2d, trans_points_3d, fliplr_joints, norm_rot_angle,
 convert_cvimg_to_tensor, compute_centroid) ARE pinned by tests/golden/input_affine.npz (make_golden.py g_input)."""
 import heapq

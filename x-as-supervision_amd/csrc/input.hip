@@ -106,8 +106,9 @@ __global__ void patch_finish_kernel(const uint8_t* __restrict__ img, const uint8
 
 // ---------------------------------------------------------------- geodesic weight map
 // One workgroup per image.  Phase 1: centroid (geodesic.py:4-12, truncated to integers) or the given centre, early-out
-// flag (centre outside the mask -> map of ones, geodesic.py:25-27).  Phase 2: two first-order upwind Eikonal solves on the
-// pixel grid, iterated to their fixed point (the solution the fast-marching method computes for the same stencil):
+// flag (a centre outside the mask -> map of ones, geodesic.py:25-27).  Phase 2: two upwind Eikonal solves on the pixel grid -
+// scikit-fmm's default second-order scheme (order 2, r05) or first order - iterated to their fixed point (the solution the
+// fast-marching method computes for the same stencil):
 //   d_in : domain = mask pixels, source = centre pixel          (skfmm.distance of the masked array, geodesic.py:29-35)
 //   d_bg : domain = all pixels, sources = mask pixels (value 0) (skfmm.distance(m_bg), geodesic.py:37-39)
 // Phase 3: out = exp(p0 * d_in / max d_in) + p1 + p2 * d_bg / max d_bg + p3 (geodesic.py:45-52).
