@@ -13,6 +13,7 @@ reference's scikit-fmm implementation runs, exactly as without the mirror.  The 
 `gpu_patch` on whole device batches, not from this per-sample entry.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -20,7 +21,7 @@ import torch
 from xas_amd._lib import call, ptr, query
 
 
-FMM_ORDER = 2        # scikit-fmm's default (skfmm.distance(m), geodesic.py:35,39); 1: the first-order maps of rounds 3-4
+FMM_ORDER = int(os.environ.get('XAS_FMM_ORDER', '2'))   # 2: scikit-fmm's default scheme (skfmm.distance(m), geodesic.py:35,39); 1: the first-order maps of rounds 3-4
 
 
 def compute_geodesic_dis_batch(mask, geodesic_param_list, centers=None, order=None):

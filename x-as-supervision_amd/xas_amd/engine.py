@@ -116,8 +116,8 @@ class TrainStep:
         self.red_det = self.red_disc = None
         self._weights_checked = False
         self._range_polls = []      # [(event, pinned int32)]: xas_f16_weight_overflow_peek results in flight (read one step late)
-        opt_det.grad_arena                       # materialise the gradient arenas: conv weight gradients are
-        if opt_disc is not None:                 # accumulated straight into them on a side stream
+        opt_det.grad_arena                       # materialise the gradient arenas: the kernels accumulate weight, bias and
+        if opt_disc is not None:                 # norm-parameter gradients straight into them
             opt_disc.grad_arena
         if dp_active():
             f = opt_det
