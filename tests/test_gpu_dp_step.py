@@ -52,7 +52,7 @@ def _run2(opts=None):
     return ret[0], ret[1]
 
 
-@pytest.mark.parametrize('beside', [None, 1, 0])
+@pytest.mark.parametrize('beside', [None, pytest.param(1, marks=pytest.mark.multistream), 0])
 def test_two_rank_step_keeps_replicas_identical(beside):
     """beside = XAS_DISC_BESIDE_GEN: the discriminator update on the second stream next to the generator's detector passes
     (1, the single-GPU default) or on the main stream in program order (0; also what an unset variable means under data
@@ -65,6 +65,7 @@ def test_two_rank_step_keeps_replicas_identical(beside):
     assert a[4] != b[4]                           # in-block BatchNorm2d stays rank-local (different data)
 
 
+@pytest.mark.multistream
 @pytest.mark.parametrize('dedupe,cam_batch', [(False, 1), (True, 1), (True, 0)])
 def test_early_bucket_launch_equals_launch_at_finish(dedupe, cam_batch):
     """(XAS_DP_OVERLAP=1, the r02-r04 schedule - off by default since r05.)

@@ -289,6 +289,7 @@ def test_conv_beyond_2gib_splits_over_images():
     assert rel(dw.view(cout, cin), ref_dw.float()) < 1e-5
 
 
+@pytest.mark.multistream
 def test_two_chain_step_equals_single_stream_step(monkeypatch):
     """xas_amd.streams.chains: the real-image pass and the pseudo-image pass of the generator step on two streams (forward
     and backward; running statistics through the bookkeeping stream, norm-parameter gradients by hardware atomics, weight

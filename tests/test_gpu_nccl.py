@@ -52,7 +52,7 @@ def _worker(rank, world, mode):
     return res
 
 
-@pytest.mark.parametrize('mode', ['nccl', 'nccl_overlap'])
+@pytest.mark.parametrize('mode', ['nccl', pytest.param('nccl_overlap', marks=pytest.mark.multistream)])
 def test_nccl_world1_step_equals_plain_step(mode):
     a = run_ranks(_worker, 1, ('plain',))[0]
     b = run_ranks(_worker, 1, (mode,))[0]
