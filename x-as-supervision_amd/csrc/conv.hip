@@ -2016,7 +2016,7 @@ static void wgrad_plan(const xas_conv_shape* s, bool x6, int* bm, int* bn, int* 
   // chain of the step: shorter blocks hand the CUs over sooner, but every split costs a slab of dW to write and to reduce;
   // with the round-3 kernels the slab traffic weighs more (sweeps in the define below)
 #ifndef XAS_WGRAD_XTARGET
-#define XAS_WGRAD_XTARGET 512           // blocks per launch the pixel splits aim for (r03 sweeps, in-box: with the bf16x6 kernels 512..1024 were 1 ms/step better than 2048 - fewer slabs to write and reduce -, 256 / 384 and 4096 worse; with the f16x3 kernels 768 is 0.6 ms better than 1024, 512 another 0.4, 1536 0.8 worse)
+#define XAS_WGRAD_XTARGET 1024          // blocks per launch the pixel splits aim for.  r03 sweeps (weight gradients on a side stream, sharing the CUs): 512 best.  r05, ONE stream (the kernel has the chip to itself): 384 +3.2 ms/step, 512 +0.7, 768 +0.6, 1024 best, 1536 / 2048 +0.7, 3072 +2.2 (in-box, interleaved, 3 rounds)
 #endif
   const int xtarget = XAS_WGRAD_XTARGET;
   long sp = cdiv(x6 ? xtarget : 1024, tiles);
