@@ -132,10 +132,15 @@ def test_linear(rows, cin, cout):
     assert rel(m.weight.grad, wc.grad) < 3e-6 and rel(m.bias.grad, bc.grad) < 3e-6
 
 
+@pytest.mark.parametrize('lean', [False, True], ids=['shipped', 'lean_reduce'])
 @pytest.mark.parametrize('n,c,h,act,res', [(4, 64, 16, 1, False), (2, 256, 9, 1, True), (3, 32, 8, 2, False),
                                            (2, 2048, 4, 0, False), (2, 128, 7, 0, True)])
-def test_batch_norm_train(n, c, h, act, res):
+def test_batch_norm_train(n, c, h, act, res, lean, request):
+    """lean: the <= 64-register build of the backward sums (tuning bit 18; shipped in r04, kept as a variant)."""
     from xas_amd import layers as L
+    from xas_amd._lib import query
+    query('xas_set_tuning', (1 << 18) if lean else 0)
+    request.addfinalizer(lambda: query('xas_set_tuning', 0))
     g = torch.Generator().manual_seed(c + h)
     x = torch.randn(n, c, h, h, generator=g) * 2 + 3            # mean >> 0 exercises the pivoted variance
     r = torch.randn(n, c, h, h, generator=g) if res else None

@@ -387,8 +387,10 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs a) {
   col_reduce_body<MODE, 4, 4>(a);
 }
 
-// Same kernel compiled for at most 64 VGPRs (the shipped one for the backward sums): in the backward pass it runs beside two
-// weight-gradient blocks per CU, which leave 112 VGPRs per SIMD lane - room for two lean waves instead of one.
+// Same kernel compiled for at most 64 VGPRs: shipped for the backward sums in r04, when they ran beside two weight-gradient
+// blocks per CU (which leave 112 VGPRs per SIMD lane - room for two lean waves instead of one).  On ONE stream (r05) the
+// 86-register build above is 0.7 ms/step faster (in-box, interleaved, 5 rounds: 126.95 -> 126.24) and is the shipped one;
+// tune bit 18 selects this build.
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void col_reduce_lean_kernel(ColArgs a) {
@@ -1038,7 +1040,7 @@ extern "C" int xas_bn_bwd_reduce(const float* x, const float* y, const float* dy
               "bn_bwd_reduce: null buffer (an activation needs y, or x with gamma and beta)");
   XAS_REQUIRE(x || (act != 0 && y && gamma && beta), "bn_bwd_reduce: without x the layer needs an activation, y, gamma, beta");
   XAS_REQUIRE((dbeta_acc == nullptr) == (dgamma_acc == nullptr), "bn_bwd_reduce: gradient accumulators come in pairs");
-  const bool lean = (tune_flags() & 262144) == 0;      // shipped: the <= 64-VGPR build (tune bit18 selects the 86-VGPR one)
+  const bool lean = (tune_flags() & 262144) != 0;      // shipped: the 86-VGPR build (tune bit 18 selects the <= 64-VGPR one: see col_reduce_lean_kernel)
   ColArgs a{};
   if (col_args(&a, g, M, C, workspace)) return 1;
   a.dy = dy; a.mean = mean; a.var = var_biased; a.eps = eps; a.act = act;
