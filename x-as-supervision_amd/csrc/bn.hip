@@ -106,10 +106,12 @@ __device__ __forceinline__ float4 load_wt(__amdgpu_buffer_rsrc_t r, unsigned byt
   return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
 }
 
-// loads of the reduction passes: non-temporal like every streamed operand (XAS_BN_REDUCE_NT=0: plain loads, so that the
-// apply pass that re-reads the same tensors right afterwards may find them in the Infinity Cache - measured, see DESIGN)
+// loads of the reduction passes: PLAIN since r05.  r03/r04 shipped non-temporal loads here like for every streamed operand
+// (measured with the weight gradients sharing the chip); on ONE stream the apply kernel that follows reads
+// the same x and dy again and finds part of them in the caches when the reduction did not mark them for early eviction:
+// -0.7 ms/step (in-box, interleaved, 3 rounds: 124.8 -> 124.1).  XAS_BN_REDUCE_NT=1 brings the hint back.
 #ifndef XAS_BN_REDUCE_NT
-#define XAS_BN_REDUCE_NT 1
+#define XAS_BN_REDUCE_NT 0
 #endif
 __device__ __forceinline__ float4 red_load(const float4* p) { return XAS_BN_REDUCE_NT ? stream_load(p) : *p; }
 

@@ -1991,7 +1991,10 @@ extern "C" int xas_conv_dgrad_bn_bwd(const float* dy, const float* w_packed_t, c
                           nullptr, stream);
 }
 
-static inline unsigned slab_threads() { return 256u; }
+#ifndef XAS_SLAB_THREADS
+#define XAS_SLAB_THREADS 256
+#endif
+static inline unsigned slab_threads() { return XAS_SLAB_THREADS; }
 
 // does the weight gradient of this shape run on the bf16-split kernel (conv_x6.hip)?  32-bit byte offsets (tensors below
 // 2 GiB), whole float4s inside one filter tap, at most one carry per coordinate in the per-thread pixel decode
