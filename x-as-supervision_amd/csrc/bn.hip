@@ -568,7 +568,11 @@ __global__ __launch_bounds__(256) void bn_apply_stream_kernel(const float4* __re
       mask_out[goff + k] = (uint8_t)((o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u));
     o.x = act_fwd(o.x, ACT); o.y = act_fwd(o.y, ACT); o.z = act_fwd(o.z, ACT); o.w = act_fwd(o.w, ACT);
     amx = amax4(amx, o);
+#ifdef XAS_BN_APPLY_PLAIN_STORE
+    y[goff + k] = o;
+#else
     stream_store(y + goff + k, o);
+#endif
   };
   const float4 z4 = make_float4(0, 0, 0, 0);
   for (; i + 3 * stride < n4g; i += 4 * stride) {
@@ -631,7 +635,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(
     o.z = g.z * is.z * (dz.z - a.z * inv_count - xh.z * b.z * inv_count);
     o.w = g.w * is.w * (dz.w - a.w * inv_count - xh.w * b.w * inv_count);
     amx = fmaxf(fmaxf(amx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+#ifdef XAS_BN_BWD_PLAIN_STORE
+    dx[goff + k] = o;
+#else
     stream_store(dx + goff + k, o);
+#endif
   };
   const float4 z4 = make_float4(0, 0, 0, 0);
   constexpr bool NEEDX = XH || SIGN == 2, NEEDY = SIGN == 1 || !XH;
@@ -641,8 +649,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const long k = goff + i + u * stride;
+#ifdef XAS_BN_BWD_PLAIN_LOAD
+      dv[u] = dy[k];
+      xv[u] = NEEDX ? x[k] : z4;
+#else
       dv[u] = stream_load(dy + k);
       xv[u] = NEEDX ? stream_load(x + k) : z4;
+#endif
       yv[u] = NEEDY ? stream_load(y + k) : z4;
       mb[u] = SIGN == 3 ? mask[k] : 0u;
     }

@@ -484,7 +484,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
           v.x += (mb & 1u) ? o.x : 0.f; v.y += (mb & 2u) ? o.y : 0.f;
           v.z += (mb & 4u) ? o.z : 0.f; v.w += (mb & 8u) ? o.w : 0.f;
         }
+#ifdef XAS_CONV_ROWS_PLAIN_STORE
+        *reinterpret_cast<float4*>(p.out + orow * p.Cd + nn) = v;
+#else
         stream_store(reinterpret_cast<float4*>(p.out + orow * p.Cd + nn), v);
+#endif
       }
     }
     if constexpr (HEAD && MODE == 0 && BM == 64 && BNH == 64) {
