@@ -873,9 +873,12 @@ extern "C" size_t xas_bn_workspace_floats(long M, int C, int groups) {
   return (size_t)g.G * g.nslab * 2 * C + C;
 }
 
+#ifndef XAS_EW_CAP
+#define XAS_EW_CAP 8192                  // blocks of a streaming launch over all groups (r05 re-sweep on one stream, in-box: 2048 +0.9 ms/step, 4096 +0.3, 8192 best, 16384 +0.4)
+#endif
 static inline unsigned ew_grid_g(long n_per_group, int groups) {
   long b = cdiv(n_per_group, 256);
-  const long cap = groups > 1 ? cdiv(4096, groups) : 4096;
+  const long cap = groups > 1 ? cdiv(XAS_EW_CAP, groups) : XAS_EW_CAP;
   return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
