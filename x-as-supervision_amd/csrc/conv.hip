@@ -1113,6 +1113,7 @@ __global__ __launch_bounds__(256) void stem_fwd_f16_kernel(const float* __restri
         b0[pc] = *reinterpret_cast<const uint4*>(wp + i * STH_WROW);
         b1[pc] = *reinterpret_cast<const uint4*>(wp + (32 + i) * STH_WROW);
       }
+      frag_regs(a); frag_regs(b0); frag_regs(b1);
 #pragma unroll
       for (int t = 0; t < 3; ++t) {                    // a2 b1, a1 b2, a1 b1 (smallest first)
         const int pa = t == 0 ? 1 : 0, pb = t == 1 ? 1 : 0;

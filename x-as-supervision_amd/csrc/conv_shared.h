@@ -201,6 +201,37 @@ template <int P> struct Products;
 template <> struct Products<3> { static constexpr int N = 6; static constexpr int A[6] = {2, 0, 1, 1, 0, 0}; static constexpr int B[6] = {0, 2, 1, 0, 1, 0}; };
 template <> struct Products<2> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}; static constexpr int B[3] = {0, 1, 0}; };
 template <> struct Products<1> { static constexpr int N = 1; static constexpr int A[1] = {0}; static constexpr int B[1] = {0}; };
+// XAS_FRAG_AGPR (experiment, r05): a matrix-instruction operand fragment is moved to the ACCUMULATION half of the register file
+// once, where it is formed; the K-doubled matrix instructions then read their 128-bit A / B operands from there.  With the
+// operands read from AGPRs the multi-stream hazard of DESIGN.md section 5 did not show (0 / 500 steps on the three-stream schedule,
+// shipped build on the same lease 11 / 200: profiles/r05_hazard_census_agpr.txt).
+__device__ __forceinline__ uint4 frag_reg(uint4 v) {
+#ifdef XAS_FRAG_AGPR
+  typedef unsigned u32x4v_ __attribute__((ext_vector_type(4)));
+  u32x4v_ t = {v.x, v.y, v.z, v.w}, o;
+  asm("" : "=a"(o) : "0"(t));
+  return make_uint4(o[0], o[1], o[2], o[3]);
+#else
+  return v;
+#endif
+}
+template <int A_, int B_>
+__device__ __forceinline__ void frag_regs(uint4 (&f)[A_][B_]) {
+#ifdef XAS_FRAG_AGPR
+#pragma unroll
+  for (int i = 0; i < A_; ++i)
+#pragma unroll
+    for (int j = 0; j < B_; ++j) f[i][j] = frag_reg(f[i][j]);
+#endif
+}
+template <int A_>
+__device__ __forceinline__ void frag_regs(uint4 (&f)[A_]) {
+#ifdef XAS_FRAG_AGPR
+#pragma unroll
+  for (int i = 0; i < A_; ++i) f[i] = frag_reg(f[i]);
+#endif
+}
+
 template <int P>
 __device__ __forceinline__ f32x16 mfma_piece(uint4 a, uint4 b, f32x16 c) {
 #ifdef XAS_MFMA_X8
@@ -231,6 +262,19 @@ __device__ __forceinline__ f32x16 mfma_piece(uint4 a, uint4 b, f32x16 c) {
       c[4 * q] = t[0]; c[4 * q + 1] = t[1]; c[4 * q + 2] = t[2]; c[4 * q + 3] = t[3];
     }
     return c;
+  }
+#endif
+#ifdef XAS_MFMA_AGPR_OPERANDS
+  // diagnosis build: the A / B operands of the matrix instruction come from ACCUMULATION registers (the unified file's upper
+  // half; copied there by v_accvgpr_write): does the multi-stream hazard depend on where the K-doubled instruction reads its
+  // 128-bit operands from?  (A production form would load the fragments straight into AGPRs - ds_read / buffer_load can.)
+  {
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w}, aa, ab;
+    asm volatile("" : "=a"(aa) : "0"(av));
+    asm volatile("" : "=a"(ab) : "0"(bv));
+    a = make_uint4(aa[0], aa[1], aa[2], aa[3]);
+    b = make_uint4(ab[0], ab[1], ab[2], ab[3]);
   }
 #endif
 #ifdef XAS_MFMA_X16_TWICE

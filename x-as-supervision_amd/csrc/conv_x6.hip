@@ -312,13 +312,23 @@ __global__ __launch_bounds__(256, (P == 2 ? (BM == 64 && BN == 256 ? XAS_X6_WAVE
 #else
     (void)sb;
 #endif
+#ifdef XAS_FRAG_AGPR
+    uint4 gq[P][C::NI];
+#pragma unroll
+    for (int pc = 0; pc < P; ++pc)
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni) gq[pc][ni] = frag_reg(gb[pc][ni]);
+    frag_regs(fa);
+#else
+    const uint4 (&gq)[P][C::NI] = gb;
+#endif
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < C::NI; ++ni)
-          acc[mi][ni] = mfma_piece<P>(gb[Products<P>::B[t]][ni], fa[Products<P>::A[t]][mi], acc[mi][ni]);
+          acc[mi][ni] = mfma_piece<P>(gq[Products<P>::B[t]][ni], fa[Products<P>::A[t]][mi], acc[mi][ni]);
   };
   (void)NMF;
 #define SYNC() do { if (!(XAS_X6_ABL & 8)) __syncthreads(); } while (0)
@@ -461,13 +471,23 @@ __global__ __launch_bounds__(256, 3) void igemm_x6p_kernel(IgemmParams p) {
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
         fa[pc][mi] = *reinterpret_cast<const uint4*>(sb + pc * PLANE + (mi * 32 + i) * XLDH + xswz(i, hh));
+#ifdef XAS_FRAG_AGPR
+    uint4 gq[P][C::NI];
+#pragma unroll
+    for (int pc = 0; pc < P; ++pc)
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni) gq[pc][ni] = frag_reg(gb[pc][ni]);
+    frag_regs(fa);
+#else
+    const uint4 (&gq)[P][C::NI] = gb;
+#endif
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < C::NI; ++ni)
-          acc[mi][ni] = mfma_piece<P>(gb[Products<P>::B[t]][ni], fa[Products<P>::A[t]][mi], acc[mi][ni]);
+          acc[mi][ni] = mfma_piece<P>(gq[Products<P>::B[t]][ni], fa[Products<P>::A[t]][mi], acc[mi][ni]);
   };
   uint4 gb_0[P][C::NI], gb_1[P][C::NI];
   load_a(ra_0);                                          // tile 0: K-steps 0 and 1
@@ -660,7 +680,20 @@ __global__ __launch_bounds__(256, XAS_X6T_WAVES) void igemm_x6t_kernel(IgemmPara
       for (int mi = 0; mi < C::MI; ++mi)
         fa[pc][mi] = *reinterpret_cast<const uint4*>(S + pc * plane_b + fbase[mi] + tapoff);
   };
-  auto mfmas = [&](const uint4 (&fa)[P][C::MI], const uint4 (&gb)[P][C::NI]) {
+  auto mfmas = [&](const uint4 (&fa_)[P][C::MI], const uint4 (&gb_)[P][C::NI]) {
+#ifdef XAS_FRAG_AGPR
+    uint4 fa[P][C::MI], gb[P][C::NI];
+#pragma unroll
+    for (int pc = 0; pc < P; ++pc) {
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi) fa[pc][mi] = frag_reg(fa_[pc][mi]);
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni) gb[pc][ni] = frag_reg(gb_[pc][ni]);
+    }
+#else
+    const uint4 (&fa)[P][C::MI] = fa_;
+    const uint4 (&gb)[P][C::NI] = gb_;
+#endif
 #pragma unroll
     for (int t = 0; t < Products<P>::N; ++t)
 #pragma unroll
@@ -1064,6 +1097,8 @@ __global__ __launch_bounds__(256, (P == 2 ? XAS_WX6_WAVES2 : 2)) void wgrad_x6_k
         fb[pc][ni] = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
       }
     }
+    frag_regs(fa);
+    frag_regs(fb);
 #pragma unroll
     for (int t = 0; t < Products<P>::N; ++t)
 #pragma unroll
@@ -1260,6 +1295,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6t_kernel(WgradParams p) {
       const s16x4_t hi = tr_read(sb, fragA + pc * XH * SA + 4 * SA);
       fa[pc] = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     }
+    frag_regs(fa);
     // halo pixel of the slice's first pixel for tap (0, 0) offset: row ks (two rows 2 (ks & 3) of image ks >> 2 when 8-wide)
     const int wbase = tw == 16 ? (ks + 1) * hw + 1 : (ks >> 2) * npix_img + (2 * (ks & 3) + 1) * hw + 1;
 #pragma unroll
@@ -1275,6 +1311,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6t_kernel(WgradParams p) {
           const s16x4_t hi = tr_read(SX, xo + pc * xplane + 4 * XPB);
           fb[pc] = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
+        frag_regs(fb);
 #pragma unroll
         for (int k = 0; k < Products<P>::N; ++k)
           acc[ti] = mfma_piece<P>(fa[Products<P>::A[k]], fb[Products<P>::B[k]], acc[ti]);
