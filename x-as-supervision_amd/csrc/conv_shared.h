@@ -277,6 +277,17 @@ __device__ __forceinline__ f32x16 mfma_piece(uint4 a, uint4 b, f32x16 c) {
     b = make_uint4(ab[0], ab[1], ab[2], ab[3]);
   }
 #endif
+#ifdef XAS_MFMA_AGPR_DUMMY
+  // diagnosis control for XAS_MFMA_AGPR_OPERANDS: the same eight copies into accumulation registers before every matrix
+  // instruction, but the instruction still reads the ORIGINAL (vector-register) operands: is it the copies or the operand source?
+  {
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w}, aa, ab;
+    asm volatile("" : "=a"(aa) : "0"(av));
+    asm volatile("" : "=a"(ab) : "0"(bv));
+    asm volatile("" :: "a"(aa), "a"(ab));
+  }
+#endif
 #ifdef XAS_MFMA_X16_TWICE
   // diagnosis control for XAS_MFMA_X8: the K = 16 instruction issued TWICE (second result thrown away): the timing of the K = 8
   // build with the instruction of the shipped one
@@ -287,8 +298,18 @@ __device__ __forceinline__ f32x16 mfma_piece(uint4 a, uint4 b, f32x16 c) {
     asm volatile("" :: "v"(waste));
   }
 #endif
+#ifdef XAS_MFMA_NOP
+  // diagnosis build: XAS_MFMA_NOP idle issue slots of the wave after every matrix instruction (is it the issue density?)
+  if constexpr (P == 2) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop %0" :: "n"(XAS_MFMA_NOP));
+  __builtin_amdgcn_sched_barrier(0);
+  return c;
+#else
   if constexpr (P == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+#endif
 }
 
 // dgrad epilogue with the batch-norm backward reduction folded in (see IgemmParams::bnb_x).  Stride 1: output row = m.
