@@ -840,12 +840,16 @@ static int launch_igemm_x6t(const IgemmParams& p, int Mrows_max, hipStream_t st)
   return 0;
 }
 
-// pure GEMM with an even number of K-steps: what igemm_x6p_kernel is written for (tune bit 26: never; bit 27: any K).
+// pure GEMM with an even number of K-steps: what igemm_x6p_kernel is written for (tune bit 26: never).
 // Measured alone at 384 / 256 images (r05): K = 64: 505 -> 437 us forward (4.6 TB/s), 427 -> 362 us data gradient; K = 128:
-// -5 % / -9 %; K >= 256: +-2 % either way - the K loop is long enough to cover its own loads, so those keep the one-tile kernel.
+// -5 % / -9 %; K >= 256: +-2 % either way.  In the step (in-box, interleaved, 3 rounds) taking every K is 0.2-0.3 ms better
+// than stopping at 128: XAS_X6P_MAX_K bounds it for experiments.
+#ifndef XAS_X6P_MAX_K
+#define XAS_X6P_MAX_K 4096
+#endif
 static bool x6p_takes(const IgemmParams& p, int mode, int phases) {
   if (p.tune & (1 << 26)) return false;
-  if (p.Cs > 128 && !(p.tune & (1 << 27))) return false;
+  if (p.Cs > XAS_X6P_MAX_K && !(p.tune & (1 << 27))) return false;
   const int hr = mode == 0 ? p.Hrow : p.Hd, wr = mode == 0 ? p.Wrow : p.Wd;
   return p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && phases == 1 && p.Cs % (2 * BK) == 0 && p.Hs == hr && p.Ws == wr &&
          !p.t2d_tw && !p.bnb_x && p.a_amax != nullptr && (p.Cd & 3) == 0;
